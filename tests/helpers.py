@@ -1,0 +1,83 @@
+"""Shared test helpers: fixtures loading, instance generators, residual checks."""
+import glob
+import json
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))
+
+
+def load_golden(name=None):
+    files = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.json")))
+    out = []
+    for f in files:
+        d = json.load(open(f))
+        if name is None or d["name"] == name:
+            for k in ("A", "theta_inv", "regP", "regD", "xi_p", "xi_d", "dx", "dy"):
+                d[k] = np.array(d[k], dtype=np.float64)
+            d["A_csc"] = sp.csc_matrix(d["A"])
+            out.append(d)
+    return out
+
+
+def golden_tol(g):
+    """10*eps*cond(S), floor 1e-13, relative to the solution size (see test_oracle.py)."""
+    return max(1e-13, 10 * np.finfo(float).eps * g["cond_S"])
+
+
+def kkt_residuals(A, th, rp, rd, xp, xd, dx, dy):
+    """The two residual norms of /root/reference/src/KKT/Test/test.jl:39-43."""
+    r_p = A @ dx + rd * dy - xp
+    r_d = -dx * (th + rp) + A.T @ dy - xd
+    return float(np.abs(r_p).max(initial=0.0)), float(np.abs(r_d).max(initial=0.0))
+
+
+def random_lp_matrix(m, n, nnz_per_col, seed, slack=False):
+    """Random sparse m x n matrix (CSC), nnz_per_col distinct rows per column, N(0,1) values;
+    optionally [A0 I] (inequality rows -> slack columns, ipmdata.jl:90-96)."""
+    rng = np.random.default_rng(seed)
+    rows = np.concatenate([rng.choice(m, size=min(nnz_per_col, m), replace=False) for _ in range(n)])
+    k = min(nnz_per_col, m)
+    cols = np.repeat(np.arange(n), k)
+    vals = rng.standard_normal(n * k)
+    A = sp.csc_matrix((vals, (rows, cols)), shape=(m, n))
+    if slack:
+        A = sp.hstack([A, sp.identity(m, format="csc")], format="csc")
+    A.sort_indices()
+    return A
+
+
+def ipm_like_data(m, n, seed, regime="mid"):
+    rng = np.random.default_rng(seed)
+    if regime == "mid":
+        th = 10.0 ** rng.uniform(-3, 3, n); rp = np.full(n, 1e-4); rd = np.full(m, 1e-4)
+    elif regime == "late":
+        th = 10.0 ** rng.uniform(-8, 8, n); th[rng.random(n) < 0.05] = 0.0
+        rp = np.full(n, SQRT_EPS); rd = np.full(m, SQRT_EPS)
+    else:
+        th = np.ones(n); rp = np.ones(n); rd = np.ones(m)
+    return th, rp, rd, rng.standard_normal(m), rng.standard_normal(n)
+
+
+def block_angular(nblocks, mk, nk, m0, nnz_in, link_prob, seed):
+    """Block-angular A = [diag(A_1..A_K); B_1 .. B_K]:
+    A_k is mk x nk with nnz_in nonzeros per column, each column also hits one linking row
+    w.p. link_prob.  Returns (A csc, row_block) with row_block[i] = k for block rows and
+    -1 for the m0 linking rows (placed last)."""
+    blocks, links = [], []
+    for k in range(nblocks):
+        rng = np.random.default_rng(seed + k)
+        Ak = random_lp_matrix(mk, nk, nnz_in, seed + 1000 + k)
+        has = rng.random(nk) < link_prob
+        cols = np.nonzero(has)[0]
+        rows = rng.integers(0, max(m0, 1), size=cols.size)
+        Bk = sp.csc_matrix((rng.standard_normal(cols.size), (rows, cols)), shape=(m0, nk))
+        blocks.append(Ak); links.append(Bk)
+    top = sp.block_diag(blocks, format="csc")
+    A = sp.vstack([top, sp.hstack(links, format="csc")], format="csc") if m0 > 0 else top
+    A.sort_indices()
+    row_block = np.concatenate([np.repeat(np.arange(nblocks), mk), np.full(m0, -1)]).astype(np.int64)
+    return A, row_block

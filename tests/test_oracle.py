@@ -1,0 +1,110 @@
+"""Pin the CPU oracle (oracle/k1_oracle.c) before anything is compared against it:
+reference fixture, golden vectors, dense numpy solves, structural checks of S and L."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import SQRT_EPS, ipm_like_data, kkt_residuals, load_golden, random_lp_matrix
+from oracle_binding import OracleK1, OraclePosDefError
+
+
+def test_reference_fixture_run_ls_tests():
+    """/root/reference/test/KKT/Cholmod/cholmod.jl:3-16 through src/KKT/Test/test.jl:26-43."""
+    A = sp.csc_matrix(np.array([[1.0, 0, 1, 0], [0, 1, 0, 1]]))
+    o = OracleK1(A)
+    th = np.ones(4); rp = np.ones(4); rd = np.ones(2)
+    o.update(th, rp, rd)
+    dx, dy = o.solve(np.ones(2), np.ones(4))
+    rp_, rd_ = kkt_residuals(A, th, rp, rd, np.ones(2), np.ones(4), dx, dy)
+    assert rp_ <= SQRT_EPS and rd_ <= SQRT_EPS          # test.jl:41-42, atol = sqrt(eps)
+    np.testing.assert_allclose(dy, [1.0, 1.0], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(dx, np.zeros(4), rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("g", load_golden(), ids=lambda g: g["name"])
+def test_golden_vectors(g):
+    o = OracleK1(g["A_csc"])
+    o.update(g["theta_inv"], g["regP"], g["regD"])
+    dx, dy = o.solve(g["xi_p"], g["xi_d"])
+    scale = max(np.abs(g["dx"]).max(), np.abs(g["dy"]).max(), 1.0)
+    # Tolerance relative to the solution size.  The K1 reduction solves with S, so the
+    # attainable forward accuracy of ANY backward-stable Cholesky (the reference's CHOLMOD path
+    # included -- spd.jl has no refinement, spd.jl:68) is ~eps*cond(S); cond(S) is stored in the
+    # fixture.  Gate: 10*eps*cond(S), floor 1e-13.
+    tol = max(1e-13, 10 * np.finfo(float).eps * g["cond_S"])
+    assert np.abs(dx - g["dx"]).max() <= tol * scale
+    assert np.abs(dy - g["dy"]).max() <= tol * scale
+    if "cholS" in g:                                     # KAT-2: S and chol(S) themselves
+        S = o.get_S().toarray()
+        np.testing.assert_allclose(S, np.tril(np.array(g["S"])), rtol=1e-15, atol=0)
+        np.testing.assert_allclose(o.get_L().toarray(), np.array(g["cholS"]), rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("use_perm", [False, True])
+def test_random_vs_dense(seed, use_perm):
+    m, n = 40 + 7 * seed, 90 + 5 * seed
+    A = random_lp_matrix(m, n, 3, seed)
+    th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
+    perm = np.random.default_rng(seed).permutation(m) if use_perm else None
+    o = OracleK1(A, perm)
+    o.update(th, rp, rd)
+    dx, dy = o.solve(xp, xd)
+    Ad = A.toarray()
+    D = 1.0 / (th + rp)
+    S = Ad @ np.diag(D) @ Ad.T + np.diag(rd)
+    dy_ref = np.linalg.solve(S, xp + Ad @ (D * xd))
+    dx_ref = D * (Ad.T @ dy_ref - xd)
+    np.testing.assert_allclose(dy, dy_ref, rtol=1e-9, atol=1e-11 * np.abs(dy_ref).max())
+    np.testing.assert_allclose(dx, dx_ref, rtol=1e-9, atol=1e-11 * np.abs(dx_ref).max())
+    # S on the fixed pattern and L*L' = P S P'
+    P = np.arange(m) if perm is None else perm
+    Sp = S[np.ix_(P, P)]
+    np.testing.assert_allclose(o.get_S().toarray(), np.tril(Sp), rtol=1e-12, atol=1e-13)
+    L = o.get_L().toarray()
+    np.testing.assert_allclose(L @ L.T, Sp, rtol=1e-10, atol=1e-10 * np.abs(Sp).max())
+    assert o.nnzL >= o.nnzS
+
+
+def test_free_variables_and_stored_copies():
+    """theta_inv = 0 for free variables (HSD/step.jl:24-26) => D_j = 1/regP_j; update! copies
+    its inputs (spd.jl:36-38) so later mutation by the caller must not matter."""
+    m, n = 12, 30
+    A = random_lp_matrix(m, n, 3, 5)
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 5, "late")
+    th[:5] = 0.0
+    o = OracleK1(A)
+    th2, rp2, rd2 = th.copy(), rp.copy(), rd.copy()
+    o.update(th2, rp2, rd2)
+    th2[:] = 7.0; rp2[:] = 3.0; rd2[:] = 9.0
+    dx, dy = o.solve(xp, xd)
+    r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+    assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp).max(), np.abs(xd).max()) * 1e8)
+
+
+def test_not_posdef_is_reported_and_object_reusable():
+    """spd.jl:46-47 -> PosDefException; the IPM retries with larger regularisation
+    (HSD/step.jl:35-49) so the object must stay usable."""
+    A = sp.csc_matrix(np.array([[1.0, 2.0], [2.0, 4.0]]))          # rank-1 A A'
+    o = OracleK1(A)
+    with pytest.raises(OraclePosDefError):
+        o.update(np.ones(2), np.zeros(2), np.array([0.0, -1.0]))
+    o.update(np.ones(2), np.zeros(2), np.array([1e-3, 1e-3]))
+    dx, dy = o.solve(np.ones(2), np.ones(2))
+    assert np.isfinite(dx).all() and np.isfinite(dy).all()
+
+
+def test_empty_and_degenerate_shapes():
+    # a row of A that is structurally empty: S_ii = regD_i only
+    A = sp.csc_matrix(np.array([[1.0, 0.0, 2.0], [0.0, 0.0, 0.0]]))
+    o = OracleK1(A)
+    o.update(np.ones(3), np.ones(3), np.array([0.5, 0.25]))
+    dx, dy = o.solve(np.array([1.0, 1.0]), np.zeros(3))
+    assert dy[1] == pytest.approx(4.0)
+    # n = 0 columns
+    A0 = sp.csc_matrix((3, 0))
+    o = OracleK1(A0)
+    o.update(np.ones(0), np.ones(0), np.full(3, 2.0))
+    dx, dy = o.solve(np.ones(3), np.ones(0))
+    np.testing.assert_allclose(dy, 0.5)
+    assert dx.shape == (0,)
