@@ -1,0 +1,155 @@
+/*
+ * tlpk.h -- C ABI of libtlpk.so: the MI355X (gfx950) backend for Tulip's normal-equations
+ * Newton step.  This is the drop-in boundary: a Julia `HIPNormalEquations <: AbstractKKTSolver`
+ * (tulip.jl_amd/julia/hip.jl) binds these entry points with `ccall`.
+ *
+ * Reference interface replaced (citations into /root/reference):
+ *   tlpk_create   <-> KKT.setup(A, ::K1, backend)            src/KKT/KKT.jl:59, Cholmod/spd.jl:5-20
+ *   tlpk_update   <-> KKT.update!(kkt, θinv, regP, regD)      src/KKT/KKT.jl:65-83, Cholmod/spd.jl:22-50
+ *   tlpk_solve    <-> KKT.solve!(dx, dy, kkt, ξp, ξd)         src/KKT/KKT.jl:85-100, Cholmod/spd.jl:52-70
+ *   tlpk_backend_name / tlpk_system_name <-> KKT.backend / KKT.linear_system   KKT.jl:107-121
+ *   tlpk_destroy  <-> GC finalizer of the solver object
+ *
+ * Conventions: plain pointers and sizes only; every function returns a TLPK_* code and never
+ * throws, aborts or retains a host pointer after it returns.  Host-pointer entry points block
+ * until results are in host memory.  One handle is used by one thread at a time; several
+ * handles may coexist.  Numeric factorise + solves run on the device; the analyse phase
+ * (ordering, elimination tree, supernodes, schedules) runs on the host inside tlpk_create.
+ */
+#ifndef TLPK_H
+#define TLPK_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tlpk_handle tlpk_handle;
+
+/* return codes */
+#define TLPK_OK 0
+#define TLPK_NOT_POSDEF 1   /* -> PosDefException in the glue (spd.jl:47); handle stays usable */
+#define TLPK_BADARG 2       /* -> DimensionMismatch / ArgumentError (spd.jl:26-34) */
+#define TLPK_OOM 3          /* -> OutOfMemoryError (HSD.jl:327-329) */
+#define TLPK_HIPERR 4       /* HIP runtime error; tlpk_last_error() has the text */
+#define TLPK_NO_DEVICE 5    /* numeric call on an analyse-only handle, or no GPU visible */
+#define TLPK_TOO_LARGE 6    /* symbolic nnz(L) exceeds the memory budget (SURVEY.md App. C gate) */
+#define TLPK_NOT_FACTORED 7 /* solve before a successful update */
+#define TLPK_INTERNAL 8
+
+/* ordering selector */
+#define TLPK_ORDER_AMD 0
+#define TLPK_ORDER_NATURAL 1
+#define TLPK_ORDER_USER 2
+
+typedef struct tlpk_options {
+    int32_t struct_size;       /* = sizeof(tlpk_options); set by tlpk_default_options */
+    int32_t device;            /* HIP device ordinal; -1 = analyse only (no device is touched) */
+    int32_t ordering;          /* TLPK_ORDER_* */
+    int32_t relax;             /* supernode amalgamation: 0 = fundamental only, 1 = relaxed */
+    int32_t profile;           /* 1 = time every kernel class with HIP events (tlpk_kernel_times) */
+    int32_t rank, nranks;      /* block-angular sharding over ranks (nranks = 1: everything local) */
+    int32_t reserved0;
+    const int64_t *user_perm;  /* TLPK_ORDER_USER: perm[new] = old, in index_base, length m */
+    const int64_t *row_block;  /* block-angular hook (length m): block id >= 0, or -1 for a linking
+                                  row; NULL = general sparse.  Blocks are ordered independently,
+                                  linking rows last as one dense root supernode. */
+    int64_t mem_budget_bytes;  /* 0 = 90 % of the device's free memory (or unlimited if device=-1) */
+} tlpk_options;
+
+typedef struct tlpk_stats {
+    int64_t m, n, nnzA;
+    int64_t nnzS;              /* lower triangle of A*D*A' + Rd, incl. diagonal */
+    int64_t nnzL;              /* nnz of the Cholesky factor (incl. diagonal) */
+    int64_t nnzL_stored;       /* doubles stored in supernodal panels (>= nnzL) */
+    double  flops_chol;        /* sum_j l_j^2 (CHOLMOD `fl` convention) */
+    double  flops_panel;       /* flops executed by the dense panel kernels (incl. padding zeros) */
+    int64_t n_supernodes;
+    int64_t n_levels;          /* depth of the supernodal elimination tree */
+    int64_t max_front;         /* largest front order */
+    int64_t n_pairs;           /* products in the A*D*A' assembly lists */
+    int64_t device_bytes;      /* device memory held by this handle */
+    int64_t launches_update, launches_solve;
+    int64_t fail_col;          /* permuted column of the first non-positive pivot, or -1 */
+    double  ms_analyse;        /* host analyse time */
+    double  ms_last_update;    /* device time of the last update (HIP events, handle stream) */
+    double  ms_last_solve;     /* device time of the last solve */
+    int32_t n_local_blocks, n_blocks;
+    int64_t root_panel_len;    /* doubles in the root (linking) panel reduced across ranks */
+} tlpk_stats;
+
+/* per-kernel-class timing, filled when options.profile = 1 */
+#define TLPK_KC_ASSEMBLE 0
+#define TLPK_KC_EXTEND_ADD 1
+#define TLPK_KC_POTRF 2
+#define TLPK_KC_TRSM 3
+#define TLPK_KC_UPDATE 4     /* fp64-MFMA panel update (the dominant kernel) */
+#define TLPK_KC_SOLVE_FWD 5
+#define TLPK_KC_SOLVE_BWD 6
+#define TLPK_KC_SPMV 7
+#define TLPK_KC_COUNT 8
+typedef struct tlpk_kernel_times {
+    double  ms[TLPK_KC_COUNT];       /* summed duration of the class in the last update+solve */
+    int64_t launches[TLPK_KC_COUNT];
+} tlpk_kernel_times;
+
+void tlpk_default_options(tlpk_options *opt);
+
+/* A is m x n CSC with int64 indices (Julia SparseMatrixCSC{Float64,Int}); index_base in {0,1}.
+ * A is copied; nothing is retained.  Runs the whole analyse phase and uploads the symbolic
+ * structures.  Does NOT perform the throw-away numeric factorisation of spd.jl:14-17. */
+int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr,
+                const int64_t *rowval, const double *nzval, int index_base,
+                const tlpk_options *opt);
+void tlpk_destroy(tlpk_handle *h);
+
+/* Host-pointer entry points (what the Julia glue calls). */
+int tlpk_update(tlpk_handle *h, const double *theta_inv /*n*/, const double *regP /*n*/,
+                const double *regD /*m*/);
+int tlpk_solve(tlpk_handle *h, double *dx /*n*/, double *dy /*m*/, const double *xi_p /*m*/,
+               const double *xi_d /*n*/);
+
+/* Device-pointer entry points: same semantics, arguments are device pointers on the handle's
+ * device, work is enqueued on the handle's stream; tlpk_sync waits and returns the status
+ * (TLPK_NOT_POSDEF is reported by tlpk_update_device itself: it reads back one status word). */
+int tlpk_update_device(tlpk_handle *h, const double *d_theta_inv, const double *d_regP,
+                       const double *d_regD);
+int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xi_p,
+                      const double *d_xi_d);
+int tlpk_sync(tlpk_handle *h);
+void *tlpk_stream(tlpk_handle *h);           /* hipStream_t the kernels are launched on */
+
+/* Block-angular sharding (nranks > 1): split-phase calls so that the caller owns the
+ * collective (RCCL all-reduce over xGMI through whatever communicator it has).
+ *   update : tlpk_update_local -> allreduce(sum) of tlpk_root_panel -> tlpk_update_finish
+ *   solve  : tlpk_solve_local  -> allreduce(sum) of tlpk_root_rhs   -> tlpk_solve_finish
+ * With nranks = 1 the split calls compose to exactly tlpk_update_device / tlpk_solve_device. */
+int tlpk_update_local(tlpk_handle *h, const double *d_theta_inv, const double *d_regP,
+                      const double *d_regD);
+int tlpk_root_panel(tlpk_handle *h, double **d_ptr, int64_t *count);
+int tlpk_update_finish(tlpk_handle *h);
+int tlpk_solve_local(tlpk_handle *h, const double *d_xi_p, const double *d_xi_d);
+int tlpk_root_rhs(tlpk_handle *h, double **d_ptr, int64_t *count);
+int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xi_d);
+
+/* Introspection */
+int tlpk_info(const tlpk_handle *h, tlpk_stats *out);
+int tlpk_kernel_timing(const tlpk_handle *h, tlpk_kernel_times *out);
+int tlpk_get_perm(const tlpk_handle *h, int64_t *perm /*m, 0-based, perm[new] = old*/);
+/* Symbolic structures, for tests and tools.  `what` selects an array; returns its length and,
+ * if buf != NULL, copies min(len, cap) int64 entries. */
+int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, int64_t cap);
+int64_t tlpk_symbolic_get_f64(const tlpk_handle *h, const char *what, double *buf, int64_t cap);
+/* Copy the numeric factor panels (device -> host), nnzL_stored doubles. */
+int tlpk_get_factor(tlpk_handle *h, double *lval, int64_t cap);
+
+const char *tlpk_strerror(int code);
+const char *tlpk_last_error(const tlpk_handle *h);
+const char *tlpk_backend_name(void);         /* "HIP (gfx950)" */
+const char *tlpk_system_name(void);          /* "Normal equations (K1)" */
+int tlpk_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLPK_H */

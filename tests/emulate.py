@@ -1,0 +1,248 @@
+"""CPU emulation (numpy) of the device schedule of libtlpk, driven ONLY by the symbolic arrays
+and task lists the library exports (tlpk_symbolic_get).  It executes exactly what the HIP
+kernels execute -- assembly lists, extend-add, potrf/trsm/update tasks, forward/backward solve
+tasks, in launch order -- so the host analyse phase (ordering, supernodes, relative indices,
+schedules) can be validated in the CPU-only test run.  Test infrastructure: never imported by
+the product."""
+import numpy as np
+
+LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
+          BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9)
+
+
+class Emulator:
+    def __init__(self, kkt):
+        g = kkt.symbolic
+        self.kkt = kkt
+        self.m, self.n = kkt.m, kkt.n
+        self.perm = g("perm")
+        self.f = g("front_f"); self.ns = g("front_ns"); self.col0 = g("front_col0")
+        self.parent = g("front_parent"); self.loff = g("front_loff"); self.rowoff = g("front_rowoff")
+        self.reloff = g("front_reloff"); self.child_ptr = g("front_child_ptr"); self.nchild = g("front_nchild")
+        self.local = g("front_local")
+        self.rowidx = g("rowidx"); self.rel = g("rel"); self.children = g("children")
+        self.s_target = g("s_target"); self.s_diag_row = g("s_diag_row")
+        self.pair_ptr = g("pair_ptr"); self.pair_j = g("pair_j")
+        from tulip_jl_amd import _lib
+        self.pair_w = _lib.symbolic_array_f64(kkt._h, "pair_w")
+        self.tasks = {
+            LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 3),
+            LK["POTRF"]: g("potrf_tasks").reshape(-1, 3),
+            LK["TRSM"]: g("trsm_tasks").reshape(-1, 4),
+            LK["UPDATE"]: g("update_tasks").reshape(-1, 6),
+            LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 4),
+            LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 4),
+            LK["FWD_UPDATE"]: g("fwd_update_tasks").reshape(-1, 4),
+            LK["BWD_UPDATE"]: g("bwd_update_tasks").reshape(-1, 4),
+            LK["BWD_DIAG"]: g("bwd_diag_tasks").reshape(-1, 4),
+        }
+        self.factor_launches = g("factor_launches").reshape(-1, 3)
+        self.fwd_launches = g("fwd_launches").reshape(-1, 3)
+        self.bwd_launches = g("bwd_launches").reshape(-1, 3)
+        st = kkt.stats()
+        self.lval_len = st["nnzL_stored"]
+        self.Lval = np.zeros(max(self.lval_len, 1))
+        self.U = {}          # front -> rs x rs array (lower part meaningful)
+        self.fail_col = None
+
+    # views
+    def panel(self, s):
+        f, ns = int(self.f[s]), int(self.ns[s])
+        return self.Lval[self.loff[s]: self.loff[s] + f * ns].reshape((f, ns), order="F")
+
+    def rows(self, s):
+        return self.rowidx[self.rowoff[s]: self.rowoff[s] + self.f[s]]
+
+    def relidx(self, s):
+        rs = self.f[s] - self.ns[s]
+        return self.rel[self.reloff[s]: self.reloff[s] + rs]
+
+    def kids(self, s):
+        return self.children[self.child_ptr[s]: self.child_ptr[s] + self.nchild[s]]
+
+    def front_get(self, s, r, c):
+        ns = self.ns[s]
+        return self.panel(s)[r, c] if c < ns else self.U[s][r - ns, c - ns]
+
+    # ---- update! ----
+    def update(self, theta, regP, regD, stop_at_marker=False):
+        self.D = 1.0 / (theta + regP)
+        self.regD = np.asarray(regD, dtype=float)
+        self.Lval[:] = 0.0
+        contrib = self.pair_w * self.D[self.pair_j]
+        nent = len(self.s_target)
+        vals = np.add.reduceat(np.concatenate([contrib, [0.0]]), np.minimum(self.pair_ptr[:-1], len(contrib)))
+        vals[self.pair_ptr[:-1] == self.pair_ptr[1:]] = 0.0
+        for e in range(nent):
+            if self.s_target[e] < 0:
+                continue
+            v = vals[e]
+            if self.s_diag_row[e] >= 0:
+                v += self.regD[self.s_diag_row[e]]
+            self.Lval[self.s_target[e]] = v
+        self.U = {}
+        self.fail_col = None
+        return self._run(self.factor_launches, stop_at_marker)
+
+    def _run(self, launches, stop_at_marker=False, start=0):
+        for li in range(start, len(launches)):
+            kind, first, count = (int(x) for x in launches[li])
+            if kind == LK["ALLREDUCE"]:
+                if stop_at_marker:
+                    return li + 1
+                continue
+            T = self.tasks[kind][first: first + count]
+            getattr(self, "_k%d" % kind)(T)
+        return len(launches)
+
+    def _k0(self, T):      # extend-add
+        # group tasks by front: emulation processes whole columns ranges, children in order
+        for front, j0, j1 in T:
+            f, ns = int(self.f[front]), int(self.ns[front])
+            rs = f - ns
+            if front not in self.U:
+                self.U[front] = np.full((rs, rs), np.nan)       # NaN = never zeroed: catches missing tasks
+            Up = self.U[front]
+            for col in range(max(j0, ns), j1):
+                Up[col - ns:, col - ns] = 0.0
+            P = self.panel(front)
+            for c in self.kids(front):
+                relc = self.relidx(c)
+                rsc = len(relc)
+                Uc = self.U[c]
+                q0, q1 = np.searchsorted(relc, j0), np.searchsorted(relc, j1)
+                for q in range(q0, q1):
+                    tc = relc[q]
+                    src = Uc[q:, q]
+                    tr = relc[q:]
+                    if tc < ns:
+                        P[tr, tc] += src
+                    else:
+                        Up[tr - ns, tc - ns] += src
+
+    def _k1(self, T):      # potrf
+        for front, k0, nb in T:
+            P = self.panel(front)
+            blk = np.tril(P[k0:k0 + nb, k0:k0 + nb])
+            for j in range(nb):
+                d = blk[j, j]
+                if not d > 0:
+                    col = int(self.col0[front] + k0 + j)
+                    self.fail_col = col if self.fail_col is None else min(self.fail_col, col)
+                    d = 1.0
+                blk[j + 1:, j + 1:] -= np.tril(np.outer(blk[j + 1:, j], blk[j + 1:, j]) / d)
+                blk[j, j] = np.sqrt(d)
+                blk[j + 1:, j] /= blk[j, j]
+            P[k0:k0 + nb, k0:k0 + nb] = blk
+
+    def _k2(self, T):      # trsm
+        import scipy.linalg as sla
+        for front, k0, nb, row0 in T:
+            P = self.panel(front)
+            f = int(self.f[front])
+            r1 = min(row0 + 64, f)
+            L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
+            P[row0:r1, k0:k0 + nb] = sla.solve_triangular(L11, P[row0:r1, k0:k0 + nb].T, lower=True).T
+
+    def _k3(self, T):      # update
+        TILE = 128
+        for front, k0, kw, i0, j0, jlim in T:
+            P = self.panel(front)
+            f, ns = int(self.f[front]), int(self.ns[front])
+            i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)
+            if i1 <= i0 or j1 <= j0:
+                continue
+            G = P[i0:i1, k0:k0 + kw] @ P[j0:j1, k0:k0 + kw].T
+            rr = np.arange(i0, i1)[:, None]; cc = np.arange(j0, j1)[None, :]
+            mask = rr >= cc
+            for c in range(j0, j1):
+                rsel = np.arange(max(i0, c), i1)
+                if rsel.size == 0:
+                    continue
+                if c < ns:
+                    P[rsel, c] -= G[rsel - i0, c - j0]
+                else:
+                    self.U[front][rsel - ns, c - ns] -= G[rsel - i0, c - j0]
+            del mask
+
+    # ---- solve! ----
+    def solve(self, xi_p, xi_d, A):
+        xi = xi_p + A @ (self.D * xi_d)
+        self.xw = xi[self.perm].copy()
+        self.uc = {}
+        self._run(self.fwd_launches)
+        self._run(self.bwd_launches)
+        dy = np.empty(self.m)
+        dy[self.perm] = self.xw
+        dx = self.D * (A.T @ dy - xi_d)
+        return dx, dy
+
+    def _k4(self, T):      # fwd gather
+        for front, *_ in T:
+            ns = int(self.ns[front]); rs = int(self.f[front]) - ns
+            self.uc[front] = np.zeros(rs)
+            c0 = int(self.col0[front])
+            for c in self.kids(front):
+                relc = self.relidx(c)
+                src = self.uc[c]
+                pv = relc < ns
+                self.xw[c0 + relc[pv]] += src[pv]
+                self.uc[front][relc[~pv] - ns] += src[~pv]
+
+    def _k5(self, T):      # fwd diag
+        import scipy.linalg as sla
+        for front, k0, nb, _ in T:
+            P = self.panel(front); c0 = int(self.col0[front])
+            L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
+            self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11, self.xw[c0 + k0: c0 + k0 + nb], lower=True)
+
+    def _k6(self, T):      # fwd update
+        for front, k0, nb, row0 in T:
+            P = self.panel(front); c0 = int(self.col0[front])
+            f, ns = int(self.f[front]), int(self.ns[front])
+            r1 = min(row0 + 256, f)
+            acc = P[row0:r1, k0:k0 + nb] @ self.xw[c0 + k0: c0 + k0 + nb]
+            if front not in self.uc:
+                self.uc[front] = np.full(f - ns, np.nan)
+            for t, r in enumerate(range(row0, r1)):
+                if r < ns:
+                    self.xw[c0 + r] -= acc[t]
+                else:
+                    self.uc[front][r - ns] -= acc[t]
+
+    def _k7(self, T):      # bwd update
+        for front, k0, nb, row0 in T:
+            P = self.panel(front); c0 = int(self.col0[front])
+            f, ns = int(self.f[front]), int(self.ns[front])
+            rows = self.rows(front)
+            xf = np.concatenate([self.xw[c0: c0 + ns], self.xw[rows[ns:]]])
+            self.xw[c0 + k0: c0 + k0 + nb] -= P[row0:f, k0:k0 + nb].T @ xf[row0:f]
+
+    def _k8(self, T):      # bwd diag
+        import scipy.linalg as sla
+        for front, k0, nb, _ in T:
+            P = self.panel(front); c0 = int(self.col0[front])
+            L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
+            self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11.T, self.xw[c0 + k0: c0 + k0 + nb], lower=False)
+
+    # dense L in permuted numbering, from the panels
+    def dense_L(self):
+        L = np.zeros((self.m, self.m))
+        for s in range(len(self.f)):
+            if not self.local[s]:
+                continue
+            P = self.panel(s); rows = self.rows(s); ns = int(self.ns[s]); c0 = int(self.col0[s])
+            for c in range(ns):
+                L[rows[c:], c0 + c] = P[c:, c]
+        return L
+
+
+def panels_to_dense_L(kkt, lval):
+    """Dense L (permuted numbering) from panel storage copied off the device."""
+    em = Emulator.__new__(Emulator)
+    g = kkt.symbolic
+    em.m = kkt.m
+    em.f = g("front_f"); em.ns = g("front_ns"); em.col0 = g("front_col0"); em.loff = g("front_loff")
+    em.rowoff = g("front_rowoff"); em.rowidx = g("rowidx"); em.local = g("front_local")
+    em.Lval = lval
+    return em.dense_L()

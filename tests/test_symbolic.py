@@ -1,0 +1,172 @@
+"""Host analyse phase of libtlpk (no GPU needed): ordering, elimination tree, column counts,
+supernodes, assembly lists and launch schedules, validated by executing the exported schedule
+in numpy (tests/emulate.py) and comparing with the CPU oracle and dense algebra."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import tulip_jl_amd as tk
+from emulate import Emulator
+from helpers import block_angular, ipm_like_data, kkt_residuals, load_golden, random_lp_matrix
+from oracle_binding import OracleK1
+
+
+def analyse_only(A, **kw):
+    return tk.setup(A, tk.K1(), tk.Backend(device=-1, **kw))
+
+
+def check_against_oracle(A, kkt, seed=0, regime="mid", tol=1e-9):
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, seed, regime)
+    perm = kkt.perm()
+    assert sorted(perm.tolist()) == list(range(m))
+    orc = OracleK1(A, perm)
+    orc.update(th, rp, rd)
+    st = kkt.stats()
+    assert st["nnzL"] == orc.nnzL, "column counts disagree with the oracle's symbolic factorisation"
+    assert st["nnzS"] == orc.nnzS
+    assert abs(st["flops_chol"] - orc.flops) <= 1e-9 * orc.flops
+    em = Emulator(kkt)
+    em.update(th, rp, rd)
+    assert em.fail_col is None
+    L = em.dense_L()
+    Lo = orc.get_L().toarray()
+    scale = np.abs(Lo).max()
+    assert np.abs(L - Lo).max() <= tol * scale
+    dx, dy = em.solve(xp, xd, A)
+    dxo, dyo = orc.solve(xp, xd)
+    assert np.abs(dy - dyo).max() <= tol * max(1.0, np.abs(dyo).max())
+    assert np.abs(dx - dxo).max() <= tol * max(1.0, np.abs(dxo).max())
+    return em
+
+
+@pytest.mark.parametrize("g", load_golden(), ids=lambda g: g["name"])
+def test_golden_through_schedule(g):
+    kkt = analyse_only(g["A_csc"])
+    em = Emulator(kkt)
+    em.update(g["theta_inv"], g["regP"], g["regD"])
+    dx, dy = em.solve(g["xi_p"], g["xi_d"], g["A_csc"])
+    from helpers import golden_tol
+    scale = max(np.abs(g["dx"]).max(), np.abs(g["dy"]).max(), 1.0)
+    assert np.abs(dx - g["dx"]).max() <= golden_tol(g) * scale
+    assert np.abs(dy - g["dy"]).max() <= golden_tol(g) * scale
+
+
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("relax", [False, True])
+@pytest.mark.parametrize("ordering", ["amd", "natural"])
+def test_random_sparse(seed, relax, ordering):
+    m, n = 60 + 25 * seed, 150 + 40 * seed
+    A = random_lp_matrix(m, n, 3, 100 + seed)
+    kkt = analyse_only(A, relax=relax, ordering=ordering)
+    check_against_oracle(A, kkt, seed)
+
+
+def test_user_perm_and_slack_columns():
+    A = random_lp_matrix(80, 60, 4, 7, slack=True)
+    perm = np.random.default_rng(3).permutation(80)
+    kkt = analyse_only(A, ordering="user", user_perm=perm)
+    check_against_oracle(A, kkt, 1)
+    # the final permutation is the user's order up to an etree postorder: same fill
+    o_user = OracleK1(A, perm)
+    assert kkt.stats()["nnzL"] == o_user.nnzL
+
+
+def test_large_front_exercises_blocking():
+    """Fronts wider than NB_IN (64) and NB_OUT (256): multi-step potrf/trsm/update schedule."""
+    m, n = 420, 700
+    A = random_lp_matrix(m, n, 6, 11)           # dense-ish S -> one big trailing supernode
+    kkt = analyse_only(A)
+    assert kkt.symbolic("front_ns").max() > 256
+    check_against_oracle(A, kkt, 2, tol=1e-8)
+
+
+def test_late_ipm_regime():
+    A = random_lp_matrix(70, 200, 3, 21)
+    kkt = analyse_only(A)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 4, "late")
+    em = Emulator(kkt)
+    em.update(th, rp, rd)
+    dx, dy = em.solve(xp, xd, A)
+    orc = OracleK1(A, kkt.perm()); orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    # same ordering, different summation order: agreement limited by cond(S)
+    assert np.abs(dy - dyo).max() <= 1e-6 * max(1.0, np.abs(dyo).max())
+
+
+@pytest.mark.parametrize("relax", [False, True])
+def test_block_angular_structure(relax):
+    A, row_block = block_angular(nblocks=5, mk=40, nk=90, m0=12, nnz_in=3, link_prob=0.5, seed=5)
+    kkt = analyse_only(A, row_block=row_block, relax=relax)
+    st = kkt.stats()
+    assert st["n_blocks"] == 5
+    root = int(kkt.symbolic("root_front")[0])
+    ns, f, col0 = kkt.symbolic("front_ns"), kkt.symbolic("front_f"), kkt.symbolic("front_col0")
+    assert root == len(ns) - 1 and ns[root] == 12 and f[root] == 12 and col0[root] == A.shape[0] - 12
+    perm = kkt.perm()
+    assert set(perm[-12:].tolist()) == set(np.nonzero(row_block < 0)[0].tolist())
+    fb = kkt.symbolic("front_block")
+    assert fb[root] == -1 and (fb[:root] >= 0).all()
+    # blocks stay contiguous in the ordering
+    pb = row_block[perm[:-12]]
+    assert (np.diff(pb) >= 0).all()
+    check_against_oracle(A, kkt, 3)
+
+
+def test_block_angular_no_linking_rows():
+    A, row_block = block_angular(nblocks=3, mk=30, nk=50, m0=0, nnz_in=3, link_prob=0.0, seed=8)
+    kkt = analyse_only(A, row_block=row_block)
+    assert int(kkt.symbolic("root_front")[0]) == -1
+    check_against_oracle(A, kkt, 5)
+
+
+def test_bad_row_block_is_rejected():
+    A, row_block = block_angular(nblocks=3, mk=20, nk=30, m0=5, nnz_in=3, link_prob=0.5, seed=2)
+    bad = row_block.copy()
+    bad[0] = 2                                       # row 0 now claims another block
+    with pytest.raises(tk.DimensionMismatch):
+        analyse_only(A, row_block=bad)
+
+
+def test_amd_fill_is_competitive():
+    """Ordering quality: nnz(L) under our AMD vs SuperLU's MMD(A'+A) on S (SURVEY.md section 7:
+    'a poor ordering silently inflates sum l^2')."""
+    import scipy.sparse.linalg as spla
+    A = random_lp_matrix(600, 1500, 3, 33)
+    kkt = analyse_only(A)
+    S = (A @ A.T + sp.identity(600)).tocsc()
+    lu = spla.splu(S, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options={"SymmetricMode": True})
+    ours, theirs = kkt.stats()["nnzL"], lu.L.nnz
+    assert ours <= 1.25 * theirs, (ours, theirs)
+
+
+def test_degenerate_shapes():
+    # empty row, single column, 1x1
+    A = sp.csc_matrix(np.array([[1.0, 0.0, 2.0], [0.0, 0.0, 0.0], [0.0, 3.0, 0.0]]))
+    kkt = analyse_only(A)
+    check_against_oracle(A, kkt, 0, regime="ones")
+    A1 = sp.csc_matrix(np.array([[2.0]]))
+    check_against_oracle(A1, analyse_only(A1), 0, regime="ones")
+    # n = 0: S = diag(regD)
+    A0 = sp.csc_matrix((4, 0))
+    k0 = analyse_only(A0)
+    em = Emulator(k0)
+    em.update(np.ones(0), np.ones(0), np.full(4, 4.0))
+    dx, dy = em.solve(np.ones(4), np.ones(0), A0)
+    np.testing.assert_allclose(dy, 0.25)
+
+
+def test_memory_gate():
+    A = random_lp_matrix(200, 400, 4, 3)
+    with pytest.raises(tk.OutOfMemoryError):
+        tk.setup(A, tk.K1(), tk.Backend(device=-1, mem_budget_bytes=1024))
+
+
+def test_numeric_calls_fail_loudly_without_device():
+    A = random_lp_matrix(10, 20, 2, 1)
+    kkt = analyse_only(A)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        tk.update(kkt, np.ones(20), np.ones(20), np.ones(10))
+    with pytest.raises(tk.DimensionMismatch):
+        tk.update(kkt, np.ones(19), np.ones(20), np.ones(10))

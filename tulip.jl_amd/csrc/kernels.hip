@@ -1,0 +1,460 @@
+// kernels.hip -- gfx950 (CDNA4, wave64) device kernels of libtlpk: numeric phase of the
+// normal-equations Newton step.
+//
+//   update!  (/root/reference/src/KKT/Cholmod/spd.jl:22-50)
+//     k_compute_d     D = 1/(theta_inv + regP)                                  spd.jl:42
+//     k_assemble      S = A*D*A' + diag(regD) gathered straight into the supernodal panels  spd.jl:43
+//     k_extend_add    multifrontal assembly of the children's update matrices
+//     k_potrf / k_trsm / k_update   blocked dense partial Cholesky of every front; the rank-k
+//                     panel updates run on v_mfma_f64_16x16x4_f64                 spd.jl:46
+//   solve!   (spd.jl:52-70)
+//     k_rhs           xi = xi_p + A*(D.*xi_d), permuted                          spd.jl:56-57
+//     k_fwd_* / k_bwd_*  supernodal forward / backward substitution             spd.jl:61
+//     k_unpermute, k_dx  dy = P' x ;  dx = D.*(A'dy - xi_d)                      spd.jl:64-66
+//
+// Every kernel is deterministic (no floating-point atomics): sums that cross workgroups are
+// ordered by the static schedule built on the host (symbolic.cpp: build_schedule).
+#include <hip/hip_runtime.h>
+
+#include "tlpk_device.hpp"
+
+namespace tlpk {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double *front_u(const DevCtx &c, const FrontDesc &fd) {
+    return (fd.ubuf ? c.U1 : c.U0) + fd.uoff;
+}
+
+// ------------------------------------------------------------------------------------------
+// elementwise / sparse kernels
+// ------------------------------------------------------------------------------------------
+__global__ void k_compute_d(i64 n, const double *__restrict__ theta, const double *__restrict__ regP,
+                            double *__restrict__ D) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) D[j] = 1.0 / (theta[j] + regP[j]);
+}
+
+// One thread per stored entry of S (lower triangle): value = sum_t w_t * D[j_t] (+ regD[i] on the
+// diagonal), written to its slot in the panel storage.  Gather formulation: no atomics, fixed
+// summation order.
+__global__ void k_assemble(i64 nent, const i64 *__restrict__ target, const i32 *__restrict__ diag_row,
+                           const i64 *__restrict__ pptr, const double *__restrict__ pw,
+                           const i32 *__restrict__ pj, const double *__restrict__ D,
+                           const double *__restrict__ regD, double *__restrict__ Lval) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nent) return;
+    const i64 p0 = pptr[e], p1 = pptr[e + 1];
+    double s = 0.0;
+    for (i64 p = p0; p < p1; ++p) s += pw[p] * D[pj[p]];
+    const i32 dr = diag_row[e];
+    if (dr >= 0) s += regD[dr];
+    Lval[target[e]] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// extend-add: one workgroup owns parent columns [j0, j1); it zeroes the U part of those columns
+// and then adds, child after child, the child update-matrix columns that land in its range.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ tasks, DevCtx c) {
+    const EaTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns, rs = f - ns;
+    double *P = c.Lval + fd.loff;
+    double *Up = front_u(c, fd);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // zero the lower part of U columns in range
+    for (i32 col = max(t.j0, ns) + wave; col < t.j1; col += 4)
+        for (i32 r = col + lane; r < f; r += 64) Up[(i64)(r - ns) + (i64)(col - ns) * rs] = 0.0;
+    __syncthreads();
+    for (i32 ci = 0; ci < fd.nchild; ++ci) {
+        const FrontDesc cd = c.fronts[c.children[fd.child_ptr + ci]];
+        const i32 rsc = cd.f - cd.ns;
+        const double *Uc = front_u(c, cd);
+        const i32 *relc = c.rel + cd.reloff;
+        // child columns whose parent column lies in [j0, j1): rel is increasing -> binary search
+        i32 lo = 0, hi = rsc;
+        while (lo < hi) { const i32 mid = (lo + hi) >> 1; if (relc[mid] < t.j0) lo = mid + 1; else hi = mid; }
+        const i32 q0 = lo;
+        hi = rsc;
+        while (lo < hi) { const i32 mid = (lo + hi) >> 1; if (relc[mid] < t.j1) lo = mid + 1; else hi = mid; }
+        const i32 q1 = lo;
+        for (i32 q = q0 + wave; q < q1; q += 4) {
+            const i32 tc = relc[q];
+            const double *src = Uc + (i64)q * rsc;
+            if (tc < ns) {
+                double *dst = P + (i64)tc * f;
+                for (i32 r = q + lane; r < rsc; r += 64) dst[relc[r]] += src[r];
+            } else {
+                double *dst = Up + (i64)(tc - ns) * rs - ns;
+                for (i32 r = q + lane; r < rsc; r += 64) dst[relc[r]] += src[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// potrf: Cholesky of one nb x nb diagonal block (nb <= NB_IN) by one workgroup, in LDS.
+// Right-looking; one barrier per column.  A pivot that is <= 0 or NaN records its (permuted)
+// column in info[0] (min over all failures) and is replaced by 1 so that no NaN is produced;
+// the host then reports TLPK_NOT_POSDEF (spd.jl:46-47).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {
+    constexpr int LD = NB_IN + 1;
+    __shared__ double Ts[NB_IN * LD];
+    const PotrfTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, nb = t.nb;
+    double *P = c.Lval + fd.loff + (i64)t.k0 + (i64)t.k0 * f;
+    const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
+    for (i32 col = cg; col < nb; col += 4)
+        if (r < nb) Ts[col * LD + r] = (r >= col) ? P[(i64)r + (i64)col * f] : 0.0;
+    double inv_prev = 0.0, sq_prev = 0.0;
+    for (i32 j = 0; j < nb; ++j) {
+        __syncthreads();
+        // finish column j-1 (scale) -- disjoint from everything step j touches
+        if (j > 0 && cg == 0 && r < nb) {
+            if (r == j - 1) Ts[(j - 1) * LD + r] = sq_prev;
+            else if (r > j - 1) Ts[(j - 1) * LD + r] *= inv_prev;
+        }
+        double d = Ts[j * LD + j];
+        if (!(d > 0.0)) {
+            if (tid == 0) atomicMin(c.info, fd.col0 + t.k0 + j);
+            d = 1.0;
+        }
+        const double inv2 = 1.0 / d;
+        sq_prev = sqrt(d);
+        inv_prev = 1.0 / sq_prev;
+        if (r > j && r < nb) {
+            const double arj = Ts[j * LD + r] * inv2;
+            for (i32 col = j + 1 + cg; col <= r; col += 4) Ts[col * LD + r] -= arj * Ts[j * LD + col];
+        }
+    }
+    __syncthreads();
+    if (cg == 0 && r == nb - 1 && nb > 0) Ts[(nb - 1) * LD + r] = sq_prev;
+    __syncthreads();
+    for (i32 col = cg; col < nb; col += 4)
+        if (r < nb && r >= col) P[(i64)r + (i64)col * f] = Ts[col * LD + r];
+}
+
+// ------------------------------------------------------------------------------------------
+// trsm: X * L11' = B for TRSM_ROWS rows of the panel below a factored diagonal block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
+    constexpr int LD = NB_IN + 1;
+    __shared__ double Ls[NB_IN * LD];
+    __shared__ double Bs[NB_IN * LD];
+    const TrsmTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, nb = t.nb;
+    double *P = c.Lval + fd.loff;
+    const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
+    const i32 row = t.row0 + r;
+    const bool rok = row < f;
+    for (i32 col = cg; col < nb; col += 4) {
+        if (r < nb) Ls[col * LD + r] = (r >= col) ? P[(i64)(t.k0 + r) + (i64)(t.k0 + col) * f] : 0.0;
+        Bs[col * LD + r] = rok ? P[(i64)row + (i64)(t.k0 + col) * f] : 0.0;
+    }
+    __syncthreads();
+    for (i32 j = 0; j < nb; ++j) {
+        const double xj = Bs[j * LD + r] / Ls[j * LD + j];
+        for (i32 col = j + 1 + cg; col < nb; col += 4) Bs[col * LD + r] -= xj * Ls[j * LD + col];
+        if (cg == 0 && rok) P[(i64)row + (i64)(t.k0 + j) * f] = xj;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// update: T[I,J] -= P[I,K] * P[J,K]'  on the lower triangle, one TILE x TILE tile per workgroup,
+// on the fp64 matrix cores.  v_mfma_f64_16x16x4_f64: A operand lane l = A[l&15][l>>4], B operand
+// lane l = B[l>>4][l&15], result reg r of lane l = D[(l>>4)+4r][l&15]
+// (/opt/skills/guides/cdna_hip_programming.md section 3).  The MFMA "A" operand is fed from the
+// COLUMN tile (rows J of the panel) and "B" from the ROW tile so that D[i][j] = T[I0+j, J0+i]:
+// consecutive lanes then hold consecutive rows of one target column -> coalesced column-major
+// read-modify-write.
+// Targets with column < ns live in the panel, the others in the update matrix U.
+// ------------------------------------------------------------------------------------------
+constexpr int UPD_KT = 16;                 // K depth staged per LDS round
+constexpr int UPD_LD = TILE + 16;          // LDS row stride (doubles), == 16 mod 32: conflict-free b64 reads
+
+__global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double As[UPD_KT * UPD_LD];  // As[k][r] = P[i0 + r, k0 + kk + k]  (row tile)
+    __shared__ double Bs[UPD_KT * UPD_LD];  // Bs[k][r] = P[j0 + r, k0 + kk + k]  (column tile)
+    const UpdateTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns, rs = f - ns;
+    const double *P = c.Lval + fd.loff;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR, scalar branches
+    const int wr = wave >> 1, wc = wave & 1;        // 2 x 2 waves, each a 64 x 64 sub-tile
+    const i32 ibase = t.i0 + wr * 64;               // target rows of this wave
+    const i32 jbase = t.j0 + wc * 64;               // target cols of this wave
+    const bool diag_tile = (t.i0 == t.j0);
+
+    // which 16x16 blocks of the wave's sub-tile hold any target entry
+    bool valid[4][4];
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const i32 cb = jbase + a * 16, rb = ibase + b * 16;   // block columns [cb,cb+16), rows [rb,rb+16)
+            valid[a][b] = (rb < f) && (cb < t.jlim) && (rb + 15 >= cb);
+            any |= valid[a][b];
+        }
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    const int lr = lane & 15, lk = lane >> 4;
+    const int sr = tid & 127, sk0 = tid >> 7;       // staging: row sr, k = sk0 + 2*it
+    for (i32 kk = 0; kk < t.kw; kk += UPD_KT) {
+        // stage K-slab [kk, kk+16) of both tiles (zero-filled outside the front / K range)
+        {
+            const i32 ra = t.i0 + sr, rb = t.j0 + sr;
+#pragma unroll
+            for (int it = 0; it < UPD_KT / 2; ++it) {
+                const int k = sk0 + 2 * it;
+                const bool kok = (kk + k) < t.kw;
+                const i64 coff = (i64)(t.k0 + kk + k) * f;
+                As[k * UPD_LD + sr] = (kok && ra < f) ? P[coff + ra] : 0.0;
+                if (!diag_tile) Bs[k * UPD_LD + sr] = (kok && rb < f) ? P[coff + rb] : 0.0;
+            }
+        }
+        __syncthreads();
+        if (any) {
+            const double *Bt = diag_tile ? As : Bs;
+#pragma unroll
+            for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
+                double av[4], bv[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) av[a] = Bt[(k4 + lk) * UPD_LD + wc * 64 + a * 16 + lr];   // column tile rows
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bv[b] = As[(k4 + lk) * UPD_LD + wr * 64 + b * 16 + lr];   // row tile rows
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (valid[a][b])
+                            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (!any) return;
+    // epilogue: D[i][j] (reg q: i = lk + 4q, j = lr) = sum_k P[jbase+16a+i, k] * P[ibase+16b+j, k]
+    double *Pw = c.Lval + fd.loff;
+    double *Uw = front_u(c, fd);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (!valid[a][b]) continue;
+            const i32 row = ibase + b * 16 + lr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i32 col = jbase + a * 16 + lk + 4 * q;
+                if (row < f && col < t.jlim && row >= col) {
+                    double *dst = (col < ns) ? (Pw + (i64)row + (i64)col * f)
+                                             : (Uw + (i64)(row - ns) + (i64)(col - ns) * rs);
+                    *dst -= acc[a][b][q];
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// solve kernels
+// ------------------------------------------------------------------------------------------
+// xw[ii] = xi_p[i] + sum_j A[i,j] D_j xi_d[j],  i = perm[ii].  Sharded runs: a rank sums only its
+// own columns and only rank 0 adds xi_p on linking rows (the all-reduce completes the sum).
+__global__ void k_rhs(i64 m, const i32 *__restrict__ perm, const i64 *__restrict__ Tp,
+                      const i32 *__restrict__ Tj, const double *__restrict__ Tx,
+                      const double *__restrict__ D, const double *__restrict__ xi_p,
+                      const double *__restrict__ xi_d, const char *__restrict__ row_local,
+                      const char *__restrict__ col_local, int rank, double *__restrict__ xw) {
+    const i64 ii = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ii >= m) return;
+    const i32 i = perm[ii];
+    const char rl = row_local[i];
+    if (rl == 0) { xw[ii] = 0.0; return; }
+    double s = (rl == 2 && rank != 0) ? 0.0 : xi_p[i];
+    for (i64 q = Tp[i]; q < Tp[i + 1]; ++q) {
+        const i32 j = Tj[q];
+        if (col_local[j]) s += Tx[q] * (D[j] * xi_d[j]);
+    }
+    xw[ii] = s;
+}
+
+// forward gather: uc_s = 0; then children's contribution vectors are added into the front's
+// right-hand side (pivot rows: xw, rows below: uc_s).  One workgroup per front, children in order.
+__global__ __launch_bounds__(256) void k_fwd_gather(const SolveTask *__restrict__ tasks, DevCtx c) {
+    const SolveTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 ns = fd.ns, rs = fd.f - ns;
+    double *ucp = c.uc + fd.ucoff;
+    double *xs = c.xw + fd.col0;
+    for (i32 r = threadIdx.x; r < rs; r += 256) ucp[r] = 0.0;
+    __syncthreads();
+    for (i32 ci = 0; ci < fd.nchild; ++ci) {
+        const FrontDesc cd = c.fronts[c.children[fd.child_ptr + ci]];
+        const i32 rsc = cd.f - cd.ns;
+        const double *src = c.uc + cd.ucoff;
+        const i32 *relc = c.rel + cd.reloff;
+        for (i32 r = threadIdx.x; r < rsc; r += 256) {
+            const i32 tr = relc[r];
+            if (tr < ns) xs[tr] += src[r]; else ucp[tr - ns] += src[r];
+        }
+        __syncthreads();
+    }
+}
+
+// forward diagonal block: y = L11^{-1} y for one nb x nb block (one wave, y in registers).
+__global__ __launch_bounds__(64) void k_fwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
+    constexpr int LD = SOLVE_NB + 1;
+    __shared__ double Ls[SOLVE_NB * LD];
+    const SolveTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, nb = t.nb;
+    const double *P = c.Lval + fd.loff + (i64)t.k0 + (i64)t.k0 * f;
+    const int lane = threadIdx.x;
+    for (i32 col = 0; col < nb; ++col)
+        if (lane < nb && lane >= col) Ls[col * LD + lane] = P[(i64)lane + (i64)col * f];
+    double *xs = c.xw + fd.col0 + t.k0;
+    double y = (lane < nb) ? xs[lane] : 0.0;
+    __syncthreads();
+    for (i32 j = 0; j < nb; ++j) {
+        const double yj = __shfl(y, j) / Ls[j * LD + j];
+        if (lane == j) y = yj;
+        else if (lane > j && lane < nb) y -= Ls[j * LD + lane] * yj;
+    }
+    if (lane < nb) xs[lane] = y;
+}
+
+// forward update: rows below a solved block: rhs[r] -= sum_j L[r, k0+j] * y[j].
+__global__ __launch_bounds__(256) void k_fwd_update(const SolveTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double ys[SOLVE_NB];
+    const SolveTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns, nb = t.nb;
+    const double *P = c.Lval + fd.loff + (i64)t.k0 * f;
+    if (threadIdx.x < nb) ys[threadIdx.x] = c.xw[fd.col0 + t.k0 + threadIdx.x];
+    __syncthreads();
+    const i32 r = t.row0 + threadIdx.x;
+    if (r >= f) return;
+    double acc = 0.0;
+    for (i32 j = 0; j < nb; ++j) acc += P[(i64)r + (i64)j * f] * ys[j];
+    if (r < ns) c.xw[fd.col0 + r] -= acc;
+    else c.uc[fd.ucoff + (r - ns)] -= acc;
+}
+
+// backward update: x[k0+j] -= sum_{r >= row0} L[r, k0+j] * x_front[r]; one wave per column,
+// shuffle-tree reduction (fixed order).  blockDim = 256: wave w takes columns w, w+4, ...
+__global__ __launch_bounds__(256) void k_bwd_update(const SolveTask *__restrict__ tasks, DevCtx c) {
+    const SolveTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns, nb = t.nb;
+    const double *P = c.Lval + fd.loff + (i64)t.k0 * f;
+    const i32 *rows = c.rowidx + fd.rowoff;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (i32 j = wave; j < nb; j += 4) {
+        const double *col = P + (i64)j * f;
+        double acc = 0.0;
+        for (i32 r = t.row0 + lane; r < f; r += 64) {
+            const double xv = (r < ns) ? c.xw[fd.col0 + r] : c.xw[rows[r]];
+            acc += col[r] * xv;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) c.xw[fd.col0 + t.k0 + j] -= acc;
+    }
+}
+
+// backward diagonal block: x = L11^{-T} x (one wave).
+__global__ __launch_bounds__(64) void k_bwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
+    constexpr int LD = SOLVE_NB + 1;
+    __shared__ double Ls[SOLVE_NB * LD];
+    const SolveTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, nb = t.nb;
+    const double *P = c.Lval + fd.loff + (i64)t.k0 + (i64)t.k0 * f;
+    const int lane = threadIdx.x;
+    for (i32 col = 0; col < nb; ++col)
+        if (lane < nb && lane >= col) Ls[col * LD + lane] = P[(i64)lane + (i64)col * f];
+    double *xs = c.xw + fd.col0 + t.k0;
+    double x = (lane < nb) ? xs[lane] : 0.0;
+    __syncthreads();
+    for (i32 j = nb - 1; j >= 0; --j) {
+        const double xj = __shfl(x, j) / Ls[j * LD + j];
+        if (lane == j) x = xj;
+        else if (lane < j) x -= Ls[lane * LD + j] * xj;      // L[j][lane]
+    }
+    if (lane < nb) xs[lane] = x;
+}
+
+__global__ void k_unpermute(i64 m, const i32 *__restrict__ perm, const char *__restrict__ row_local,
+                            const double *__restrict__ xw, double *__restrict__ dy) {
+    const i64 ii = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ii >= m) return;
+    const i32 i = perm[ii];
+    dy[i] = row_local[i] ? xw[ii] : 0.0;
+}
+
+// dx_j = D_j (A[:,j]' dy - xi_d[j]);  columns of other ranks give 0.
+__global__ void k_dx(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ Ai,
+                     const double *__restrict__ Ax, const double *__restrict__ D,
+                     const double *__restrict__ dy, const double *__restrict__ xi_d,
+                     const char *__restrict__ col_local, double *__restrict__ dx) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (!col_local[j]) { dx[j] = 0.0; return; }
+    double s = 0.0;
+    for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) s += Ax[p] * dy[Ai[p]];
+    dx[j] = D[j] * (s - xi_d[j]);
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------
+static inline unsigned nblk(i64 n, int b) { return (unsigned)((n + b - 1) / b); }
+
+void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D) {
+    if (n > 0) hipLaunchKernelGGL(k_compute_d, dim3(nblk(n, 256)), dim3(256), 0, st, n, theta, regP, D);
+}
+void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD) {
+    if (a.n_asm > 0)
+        hipLaunchKernelGGL(k_assemble, dim3(nblk(a.n_asm, 256)), dim3(256), 0, st, a.n_asm, a.asm_target, a.asm_diag,
+                           a.asm_ptr, a.pair_w, a.pair_j, D, regD, a.ctx.Lval);
+}
+void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
+    if (L.count <= 0) return;
+    const dim3 g((unsigned)L.count);
+    switch (L.kind) {
+    case LK_EXTEND_ADD: hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, a.ea_tasks + L.first, a.ctx); break;
+    case LK_POTRF: hipLaunchKernelGGL(k_potrf, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
+    case LK_TRSM: hipLaunchKernelGGL(k_trsm, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
+    case LK_UPDATE: hipLaunchKernelGGL(k_update, g, dim3(256), 0, st, a.update_tasks + L.first, a.ctx); break;
+    case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;
+    case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(64), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
+    case LK_FWD_UPDATE: hipLaunchKernelGGL(k_fwd_update, g, dim3(256), 0, st, a.fwd_update_tasks + L.first, a.ctx); break;
+    case LK_BWD_UPDATE: hipLaunchKernelGGL(k_bwd_update, g, dim3(256), 0, st, a.bwd_update_tasks + L.first, a.ctx); break;
+    case LK_BWD_DIAG: hipLaunchKernelGGL(k_bwd_diag, g, dim3(64), 0, st, a.bwd_diag_tasks + L.first, a.ctx); break;
+    default: break;
+    }
+}
+void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank) {
+    if (a.m > 0)
+        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, D, xi_p, xi_d,
+                           a.row_local, a.col_local, rank, a.ctx.xw);
+}
+void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy) {
+    if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw, dy);
+}
+void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx) {
+    if (a.n > 0) hipLaunchKernelGGL(k_dx, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, D, dy, xi_d, a.col_local, dx);
+}
+
+}  // namespace tlpk

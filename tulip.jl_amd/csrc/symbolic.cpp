@@ -1,0 +1,701 @@
+// symbolic.cpp -- host analyse phase: pattern of S = A*A', fill-reducing ordering, elimination
+// tree, column counts, supernodes (fronts), relative indices, assembly lists for A*D*A' + Rd.
+//
+// Reference counterpart: the `cholesky(Symmetric(A*A' + I))` call in KKT.setup
+// (/root/reference/src/KKT/Cholmod/spd.jl:14-17), i.e. CHOLMOD's analyse [ext].  The pattern of S
+// is structural and constant over the IPM run (spd.jl:14,43), so everything computed here is
+// reused by every update!/solve!.
+#include "tlpk_host.hpp"
+#include "../../include/tlpk.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+namespace tlpk {
+
+namespace {
+
+// Liu's elimination-tree algorithm with path compression on a graph given in ORIGINAL labels
+// plus a labelling iperm (old -> new); returns parent in NEW labels.
+void etree_of(i32 m, const std::vector<i64> &xadj, const std::vector<i32> &adj, const std::vector<i32> &perm,
+              const std::vector<i32> &iperm, std::vector<i32> &parent) {
+    parent.assign(m, -1);
+    std::vector<i32> anc(m, -1);
+    for (i32 i = 0; i < m; ++i) {
+        const i32 old = perm[i];
+        for (i64 p = xadj[old]; p < xadj[old + 1]; ++p) {
+            i32 k = iperm[adj[p]];
+            while (k != -1 && k < i) {
+                const i32 nxt = anc[k];
+                anc[k] = i;
+                if (nxt == -1) parent[k] = i;
+                k = nxt;
+            }
+        }
+    }
+}
+
+// Postorder of a forest (children visited in increasing label order).  `skip[v]` nodes are cut
+// out of the forest (their children become roots) and are not emitted.
+void postorder_forest(i32 m, const std::vector<i32> &parent, const std::vector<char> *skip, std::vector<i32> &post) {
+    std::vector<i32> head(m, -1), next(m, -1), roots;
+    for (i32 v = m - 1; v >= 0; --v) {
+        if (skip && (*skip)[v]) continue;
+        const i32 p = parent[v];
+        if (p == -1 || (skip && (*skip)[p])) continue;
+        next[v] = head[p];
+        head[p] = v;
+    }
+    post.clear();
+    post.reserve(m);
+    std::vector<i32> stack;
+    for (i32 r = 0; r < m; ++r) {
+        if (skip && (*skip)[r]) continue;
+        const i32 p = parent[r];
+        if (!(p == -1 || (skip && (*skip)[p]))) continue;
+        stack.push_back(r);
+        while (!stack.empty()) {
+            const i32 v = stack.back();
+            const i32 c = head[v];
+            if (c != -1) { head[v] = next[c]; stack.push_back(c); }
+            else { post.push_back(v); stack.pop_back(); }
+        }
+    }
+}
+
+}  // namespace
+
+static int fail(Symbolic &S, int code, const std::string &msg) { S.error = msg; return code; }
+
+static void build_schedule(Symbolic &S);
+
+int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval, const double *nzval,
+            int base, const Options &opt) {
+    if (m64 < 0 || n64 < 0 || (base != 0 && base != 1) || !colptr) return fail(S, TLPK_BADARG, "bad dimensions or index base");
+    if (m64 >= (i64)1 << 31 || n64 >= (i64)1 << 31) return fail(S, TLPK_TOO_LARGE, "m or n exceeds int32");
+    const i64 nnz = colptr[n64] - base;
+    if (nnz < 0 || nnz >= (i64)1 << 31) return fail(S, TLPK_TOO_LARGE, "nnz(A) exceeds int32");
+    if (nnz > 0 && (!rowval || !nzval)) return fail(S, TLPK_BADARG, "null rowval/nzval");
+    const i32 m = (i32)m64, n = (i32)n64;
+    S.m = m; S.n = n; S.nnzA = nnz;
+    if (opt.nranks < 1 || opt.rank < 0 || opt.rank >= opt.nranks) return fail(S, TLPK_BADARG, "bad rank/nranks");
+    if (opt.nranks > 1 && !opt.row_block) return fail(S, TLPK_BADARG, "sharding needs row_block (general sparse LPs are single-GPU)");
+
+    // ---- 1. copy A (CSC) and build CSR ----
+    S.Ap.resize((size_t)n + 1); S.Ai.resize((size_t)nnz); S.Ax.resize((size_t)nnz); S.Acol.resize((size_t)nnz);
+    for (i32 j = 0; j <= n; ++j) {
+        S.Ap[j] = colptr[j] - base;
+        if (S.Ap[j] < 0 || S.Ap[j] > nnz || (j > 0 && S.Ap[j] < S.Ap[j - 1])) return fail(S, TLPK_BADARG, "colptr not monotone");
+    }
+    S.Tp.assign((size_t)m + 1, 0);
+    for (i32 j = 0; j < n; ++j)
+        for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
+            const i64 r = rowval[p] - base;
+            if (r < 0 || r >= m) return fail(S, TLPK_BADARG, "row index out of range");
+            S.Ai[p] = (i32)r; S.Ax[p] = nzval[p]; S.Acol[p] = j;
+            S.Tp[r + 1]++;
+        }
+    for (i32 i = 0; i < m; ++i) S.Tp[i + 1] += S.Tp[i];
+    S.Tj.resize((size_t)nnz); S.Tpos.resize((size_t)nnz);
+    {
+        std::vector<i64> cur(S.Tp.begin(), S.Tp.end() - 1);
+        for (i32 j = 0; j < n; ++j)
+            for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
+                const i64 q = cur[S.Ai[p]]++;
+                S.Tj[q] = j; S.Tpos[q] = (i32)p;
+            }
+    }
+
+    // ---- 2. block-angular structure (optional) ----
+    std::vector<i32> row_block, col_block;
+    i32 nblocks = 0, nlink = 0;
+    if (opt.row_block) {
+        row_block.resize(m);
+        for (i32 i = 0; i < m; ++i) {
+            const i64 b = opt.row_block[i];
+            if (b < -1 || b >= (i64)1 << 30) return fail(S, TLPK_BADARG, "row_block out of range");
+            row_block[i] = (i32)b;
+            if (b >= 0) nblocks = std::max(nblocks, (i32)b + 1); else ++nlink;
+        }
+        col_block.assign(n, -1);
+        for (i32 j = 0; j < n; ++j)
+            for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
+                const i32 b = row_block[S.Ai[p]];
+                if (b < 0) continue;
+                if (col_block[j] == -1) col_block[j] = b;
+                else if (col_block[j] != b) return fail(S, TLPK_BADARG, "row_block is not block-angular: a column spans two blocks");
+            }
+    }
+    S.nblocks = nblocks;
+
+    // ---- 3. adjacency graph of A*A' (original labels, no diagonal, both directions) ----
+    std::vector<i64> xadj((size_t)m + 1, 0);
+    std::vector<i32> adj;
+    {
+        std::vector<i32> mark(m, -1);
+        i64 est = 0;
+        for (i32 j = 0; j < n; ++j) { const i64 c = S.Ap[j + 1] - S.Ap[j]; est += c * (c - 1); }
+        adj.reserve((size_t)std::min<i64>(est, (i64)1 << 33));
+        for (i32 k = 0; k < m; ++k) {
+            mark[k] = k;
+            for (i64 q = S.Tp[k]; q < S.Tp[k + 1]; ++q) {
+                const i32 j = S.Tj[q];
+                for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
+                    const i32 i = S.Ai[p];
+                    if (mark[i] != k) { mark[i] = k; adj.push_back(i); }
+                }
+            }
+            xadj[k + 1] = (i64)adj.size();
+        }
+    }
+
+    // ---- 4. fill-reducing ordering ----
+    std::vector<i32> order0;
+    order0.reserve(m);
+    std::vector<char> is_link(m, 0);
+    if (opt.ordering == TLPK_ORDER_USER) {
+        if (!opt.user_perm) return fail(S, TLPK_BADARG, "user_perm is null");
+        std::vector<char> seen(m, 0);
+        for (i32 i = 0; i < m; ++i) {
+            const i64 v = opt.user_perm[i];
+            if (v < 0 || v >= m || seen[v]) return fail(S, TLPK_BADARG, "user_perm is not a permutation");
+            seen[v] = 1; order0.push_back((i32)v);
+        }
+        if (opt.row_block) return fail(S, TLPK_BADARG, "user_perm cannot be combined with row_block");
+    } else if (!opt.row_block) {
+        if (opt.ordering == TLPK_ORDER_NATURAL) { order0.resize(m); std::iota(order0.begin(), order0.end(), 0); }
+        else amd_order(m, xadj, adj, order0);
+    } else {
+        // each diagonal block on its own (blocks are mutually non-adjacent in S); linking rows last
+        std::vector<std::vector<i32>> members(nblocks);
+        for (i32 i = 0; i < m; ++i) if (row_block[i] >= 0) members[row_block[i]].push_back(i);
+        std::vector<i32> local(m, -1);
+        for (i32 b = 0; b < nblocks; ++b) {
+            const auto &mb = members[b];
+            const i32 nb = (i32)mb.size();
+            if (opt.ordering == TLPK_ORDER_NATURAL) { order0.insert(order0.end(), mb.begin(), mb.end()); continue; }
+            for (i32 t = 0; t < nb; ++t) local[mb[t]] = t;
+            std::vector<i64> bx((size_t)nb + 1, 0);
+            std::vector<i32> ba;
+            for (i32 t = 0; t < nb; ++t) {
+                const i32 v = mb[t];
+                for (i64 p = xadj[v]; p < xadj[v + 1]; ++p) {
+                    const i32 u = adj[p];
+                    if (row_block[u] == b) ba.push_back(local[u]);
+                }
+                bx[t + 1] = (i64)ba.size();
+            }
+            std::vector<i32> bo;
+            amd_order(nb, bx, ba, bo);
+            for (i32 t : bo) order0.push_back(mb[t]);
+        }
+        for (i32 i = 0; i < m; ++i) if (row_block[i] < 0) { order0.push_back(i); is_link[i] = 1; }
+    }
+    if ((i32)order0.size() != m) return fail(S, TLPK_INTERNAL, "ordering did not return a permutation");
+
+    // ---- 5. elimination tree, postorder ----
+    std::vector<i32> iperm0(m);
+    for (i32 i = 0; i < m; ++i) iperm0[order0[i]] = i;
+    std::vector<i32> parent0;
+    etree_of(m, xadj, adj, order0, iperm0, parent0);
+    // final order: postorder of the forest without the linking nodes, then the linking nodes
+    std::vector<char> skip(m, 0);
+    for (i32 i = 0; i < m; ++i) skip[i] = is_link[order0[i]];
+    std::vector<i32> post0;
+    postorder_forest(m, parent0, nlink ? &skip : nullptr, post0);
+    for (i32 i = 0; i < m; ++i) if (skip[i]) post0.push_back(i);
+    if ((i32)post0.size() != m) return fail(S, TLPK_INTERNAL, "postorder lost nodes");
+    S.perm.resize(m); S.iperm.resize(m);
+    std::vector<i32> relabel(m);               // order0-label -> final label
+    for (i32 k = 0; k < m; ++k) { S.perm[k] = order0[post0[k]]; relabel[post0[k]] = k; }
+    for (i32 k = 0; k < m; ++k) S.iperm[S.perm[k]] = k;
+    S.parent.assign(m, -1);
+    for (i32 v = 0; v < m; ++v) if (parent0[v] != -1) S.parent[relabel[v]] = relabel[parent0[v]];
+    for (i32 k = 0; k < m; ++k) if (S.parent[k] != -1 && S.parent[k] <= k) return fail(S, TLPK_INTERNAL, "etree not topological");
+    const i32 first_link = m - nlink;
+
+    // ---- 6. permuted lower pattern of S ----
+    S.Sp.assign((size_t)m + 1, 0);
+    for (i32 kk = 0; kk < m; ++kk) {
+        const i32 k = S.perm[kk];
+        i64 c = 1;
+        for (i64 p = xadj[k]; p < xadj[k + 1]; ++p) if (S.iperm[adj[p]] > kk) ++c;
+        S.Sp[kk + 1] = S.Sp[kk] + c;
+    }
+    S.nnzS = S.Sp[m];
+    S.Si.resize((size_t)S.nnzS);
+    for (i32 kk = 0; kk < m; ++kk) {
+        const i32 k = S.perm[kk];
+        i64 q = S.Sp[kk];
+        S.Si[q++] = kk;
+        for (i64 p = xadj[k]; p < xadj[k + 1]; ++p) { const i32 ii = S.iperm[adj[p]]; if (ii > kk) S.Si[q++] = ii; }
+        std::sort(S.Si.begin() + S.Sp[kk] + 1, S.Si.begin() + q);
+    }
+    { std::vector<i32>().swap(adj); std::vector<i64>().swap(xadj); }
+
+    // ---- 7. column counts (Gilbert, Ng & Peyton 1994: row-subtree leaves + LCA by union-find) ----
+    {
+        std::vector<i32> tpost;
+        postorder_forest(m, S.parent, nullptr, tpost);        // a true postorder of the final tree
+        std::vector<i32> pidx(m), first(m), delta(m, 0), maxfirst(m, -1), prevleaf(m, -1), anc(m);
+        for (i32 k = 0; k < m; ++k) pidx[tpost[k]] = k;
+        for (i32 v = 0; v < m; ++v) { first[v] = pidx[v]; anc[v] = v; }
+        for (i32 k = 0; k < m; ++k) {                          // first descendant, children before parents
+            const i32 v = tpost[k], p = S.parent[v];
+            if (p != -1) first[p] = std::min(first[p], first[v]);
+        }
+        for (i32 k = 0; k < m; ++k) {
+            const i32 j = tpost[k];
+            delta[j] += (first[j] == k) ? 1 : 0;               // j is a leaf of the etree
+            if (S.parent[j] != -1) delta[S.parent[j]]--;
+            for (i64 p = S.Sp[j] + 1; p < S.Sp[j + 1]; ++p) {
+                const i32 i = S.Si[p];                         // i is an ancestor of j, S[i,j] != 0
+                if (first[j] <= maxfirst[i]) continue;         // j is not a leaf of row subtree T^i
+                maxfirst[i] = first[j];
+                const i32 jprev = prevleaf[i];
+                prevleaf[i] = j;
+                delta[j]++;
+                if (jprev != -1) {
+                    i32 q = jprev;
+                    while (anc[q] != q) q = anc[q];
+                    for (i32 s = jprev; s != q;) { const i32 t = anc[s]; anc[s] = q; s = t; }
+                    delta[q]--;
+                }
+            }
+            if (S.parent[j] != -1) anc[j] = S.parent[j];
+        }
+        S.colcount.assign(m, 0);
+        for (i32 k = 0; k < m; ++k) {
+            const i32 j = tpost[k];
+            S.colcount[j] += delta[j];
+            if (S.parent[j] != -1) S.colcount[S.parent[j]] += S.colcount[j];
+        }
+    }
+    S.nnzL = 0; S.flops_chol = 0;
+    for (i32 j = 0; j < m; ++j) {
+        if (S.colcount[j] < 1) return fail(S, TLPK_INTERNAL, "column count < 1");
+        S.nnzL += S.colcount[j]; S.flops_chol += (double)S.colcount[j] * (double)S.colcount[j];
+    }
+
+    // ---- 8. supernodes ----
+    // start[s] = first column.  Fundamental rule: j joins j-1 when parent[j-1] == j and the
+    // structures nest exactly (count[j-1] == count[j] + 1).  Linking columns form one root front.
+    std::vector<i32> sn_start;
+    for (i32 j = 0; j < m; ++j) {
+        bool join = false;
+        if (j > 0) {
+            if (j > first_link) join = true;                                 // inside the forced root
+            else if (j == first_link) join = false;
+            else join = (S.parent[j - 1] == j && S.colcount[j - 1] == S.colcount[j] + 1);
+        }
+        if (!join) sn_start.push_back(j);
+    }
+    sn_start.push_back(m);
+    i32 ns_total = (i32)sn_start.size() - 1;
+
+    // relaxed amalgamation: merge a supernode into its parent when it is the parent's last child
+    // (columns adjacent) and the explicit zeros this introduces stay small.
+    std::vector<i32> sn_rows_count(ns_total);       // front order f of each supernode
+    for (i32 s = 0; s < ns_total; ++s) sn_rows_count[s] = S.colcount[sn_start[s]];
+    if (nlink) sn_rows_count[ns_total - 1] = nlink;
+    if (opt.relax && ns_total > 1) {
+        // process in order; keep a stack-free greedy pass: try to merge s into s+1 repeatedly
+        std::vector<i32> st, fr;                     // merged starts / front orders
+        std::vector<double> zeros;                   // explicit zeros accumulated in each merged node
+        for (i32 s = 0; s < ns_total; ++s) {
+            st.push_back(sn_start[s]); fr.push_back(sn_rows_count[s]); zeros.push_back(0.0);
+            // try merging the top of the stack into nothing yet; merging happens when the parent arrives
+            while (st.size() >= 2) {
+                const size_t c = st.size() - 2, p = st.size() - 1;
+                const i32 c0 = st[c], p0 = st[p];
+                const i32 p_end = sn_start[s + 1];
+                if (nlink && p0 >= first_link) break;                         // never merge into the root
+                if (S.parent[p0 - 1] < p0 || S.parent[p0 - 1] >= p_end) break;  // child's parent not in p
+                const i32 nc = p0 - c0, np = p_end - p0;
+                const double fc = fr[c], fp = fr[p];
+                // new front: columns nc+np, rows nc + fp
+                const double newz = zeros[c] + zeros[p] + (double)nc * ((double)nc + fp - fc);
+                const double total = ((double)nc + np) * ((double)nc + fp);
+                const i32 width = nc + np;
+                bool ok;
+                if (nc + fp - fc == 0) ok = true;                             // no new zeros at all
+                else if (width <= 4) ok = true;
+                else if (width <= 16) ok = newz <= 0.8 * total;
+                else if (width <= 48) ok = newz <= 0.1 * total;
+                else ok = newz <= 0.05 * total;
+                if (!ok) break;
+                fr[c] = (i32)(nc + fp); zeros[c] = newz;
+                st.pop_back(); fr.pop_back(); zeros.pop_back();
+                // merged node now spans [c0, p_end); continue trying with its new predecessor
+            }
+        }
+        st.push_back(m);
+        sn_start.swap(st);
+        ns_total = (i32)sn_start.size() - 1;
+    }
+    S.nsuper = ns_total;
+    S.sn_of_col.resize(m);
+    for (i32 s = 0; s < ns_total; ++s) for (i32 j = sn_start[s]; j < sn_start[s + 1]; ++j) S.sn_of_col[j] = s;
+
+    // ---- 9. supernodal tree and front row structures ----
+    S.fronts.assign(ns_total, FrontDesc{});
+    std::vector<i32> sparent(ns_total, -1);
+    for (i32 s = 0; s < ns_total; ++s) {
+        const i32 last = sn_start[s + 1] - 1;
+        // parent column of the supernode: the etree parent of its last column that lies outside it
+        i32 pc = S.parent[last];
+        sparent[s] = (pc == -1) ? -1 : S.sn_of_col[pc];
+        if (sparent[s] != -1 && sparent[s] <= s) return fail(S, TLPK_INTERNAL, "supernodal tree not topological");
+    }
+    // with relaxed merging a merged supernode may contain columns whose etree parent leaves the
+    // supernode before the last column does; the union construction below keeps rows correct
+    // because every column's structure is folded in explicitly.
+    std::vector<i32> nchild(ns_total, 0);
+    for (i32 s = 0; s < ns_total; ++s) if (sparent[s] != -1) nchild[sparent[s]]++;
+    {
+        i32 acc = 0;
+        for (i32 s = 0; s < ns_total; ++s) { S.fronts[s].child_ptr = acc; S.fronts[s].nchild = 0; acc += nchild[s]; }
+        S.children.assign(acc, -1);
+        for (i32 s = 0; s < ns_total; ++s) if (sparent[s] != -1) {
+            FrontDesc &p = S.fronts[sparent[s]];
+            S.children[p.child_ptr + p.nchild++] = s;
+        }
+    }
+    {
+        std::vector<i32> mark(m, -1), tmp;
+        std::vector<i64> rowoff(ns_total + 1, 0);
+        S.rowidx.clear();
+        for (i32 s = 0; s < ns_total; ++s) {
+            const i32 j0 = sn_start[s], j1 = sn_start[s + 1] - 1;
+            tmp.clear();
+            for (i32 j = j0; j <= j1; ++j)
+                for (i64 p = S.Sp[j] + 1; p < S.Sp[j + 1]; ++p) {
+                    const i32 i = S.Si[p];
+                    if (i > j1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
+                }
+            const FrontDesc &fd = S.fronts[s];
+            for (i32 t = 0; t < fd.nchild; ++t) {
+                const i32 c = S.children[fd.child_ptr + t];
+                const FrontDesc &cd = S.fronts[c];
+                for (i64 q = cd.rowoff + cd.ns; q < cd.rowoff + cd.f; ++q) {
+                    const i32 i = S.rowidx[q];
+                    if (i > j1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
+                }
+            }
+            std::sort(tmp.begin(), tmp.end());
+            FrontDesc &w = S.fronts[s];
+            w.rowoff = (i64)S.rowidx.size();
+            w.ns = j1 - j0 + 1;
+            w.f = w.ns + (i32)tmp.size();
+            w.col0 = j0;
+            w.parent = sparent[s];
+            for (i32 j = j0; j <= j1; ++j) S.rowidx.push_back(j);
+            S.rowidx.insert(S.rowidx.end(), tmp.begin(), tmp.end());
+            if (w.f < S.colcount[j0]) return fail(S, TLPK_INTERNAL, "front smaller than its first column count");
+            if (!tmp.empty() && sparent[s] == -1) return fail(S, TLPK_INTERNAL, "root front with rows below");
+            if (!tmp.empty() && S.sn_of_col[tmp[0]] != sparent[s]) {
+                // the first below-row must belong to the parent front
+                return fail(S, TLPK_INTERNAL, "first below-row is not in the parent front");
+            }
+            S.max_front = std::max<i64>(S.max_front, w.f);
+        }
+    }
+
+    // ---- 10. depths, levels ----
+    S.depth.assign(ns_total, 0);
+    for (i32 s = ns_total - 1; s >= 0; --s) S.depth[s] = (sparent[s] == -1) ? 0 : S.depth[sparent[s]] + 1;
+    S.nlevels = 0;
+    for (i32 s = 0; s < ns_total; ++s) S.nlevels = std::max(S.nlevels, S.depth[s] + 1);
+    S.level_ptr.assign((size_t)S.nlevels + 1, 0);
+    for (i32 s = 0; s < ns_total; ++s) S.level_ptr[S.depth[s] + 1]++;
+    for (i32 d = 0; d < S.nlevels; ++d) S.level_ptr[d + 1] += S.level_ptr[d];
+    S.level_fronts.resize(ns_total);
+    {
+        std::vector<i32> cur(S.level_ptr.begin(), S.level_ptr.end() - 1);
+        for (i32 s = 0; s < ns_total; ++s) S.level_fronts[cur[S.depth[s]]++] = s;
+    }
+
+    // ---- 11. ownership (block-angular sharding) ----
+    S.front_block.assign(ns_total, -1);
+    S.front_local.assign(ns_total, 1);
+    S.root_front = (nlink > 0) ? ns_total - 1 : -1;
+    std::vector<i32> block_owner(std::max(nblocks, 1), 0);
+    if (opt.row_block) {
+        std::vector<double> bflops(nblocks, 0.0);
+        for (i32 s = 0; s < ns_total; ++s) {
+            const i32 b = row_block[S.perm[S.fronts[s].col0]];
+            S.front_block[s] = b;
+            if (b >= 0) {
+                const double f = S.fronts[s].f, k = S.fronts[s].ns;
+                bflops[b] += k * f * f;     // proportional weight
+                if (S.fronts[s].parent != -1 && S.front_block[s] < 0) return fail(S, TLPK_INTERNAL, "linking front below the root");
+            } else if (s != S.root_front) return fail(S, TLPK_INTERNAL, "linking column outside the root front");
+        }
+        // contiguous block ranges balanced by weight: block b goes to the rank whose share of
+        // the cumulative weight contains b's midpoint; never more ranks than blocks in use
+        double total = 0; for (double f : bflops) total += f;
+        double acc = 0;
+        for (i32 b = 0; b < nblocks; ++b) {
+            i32 r = (total > 0) ? (i32)((acc + 0.5 * bflops[b]) / total * opt.nranks) : (i32)((i64)b * opt.nranks / nblocks);
+            r = std::max(0, std::min(r, opt.nranks - 1));
+            if (b > 0) r = std::max(r, block_owner[b - 1]);
+            block_owner[b] = r;
+            acc += bflops[b];
+        }
+        S.n_local_blocks = 0;
+        for (i32 b = 0; b < nblocks; ++b) if (block_owner[b] == opt.rank) S.n_local_blocks++;
+        for (i32 s = 0; s < ns_total; ++s) {
+            const i32 b = S.front_block[s];
+            S.front_local[s] = (b < 0) || (block_owner[b] == opt.rank);
+        }
+    }
+
+    S.col_local.assign(n, 1);
+    S.row_local.assign(m, 1);
+    if (opt.row_block && opt.nranks > 1) {
+        for (i32 j = 0; j < n; ++j) {
+            const i32 b = col_block[j];
+            S.col_local[j] = (b < 0) ? (opt.rank == 0) : (block_owner[b] == opt.rank);
+        }
+        for (i32 i = 0; i < m; ++i) {
+            const i32 b = row_block[i];
+            S.row_local[i] = (b < 0) ? 2 : (block_owner[b] == opt.rank);   // 2 = linking (replicated)
+        }
+    } else if (opt.row_block) {
+        for (i32 i = 0; i < m; ++i) if (row_block[i] < 0) S.row_local[i] = 2;
+    }
+
+    // ---- 12. storage offsets (local fronts only) ----
+    S.lval_len = 0; S.uc_len = 0; S.ubuf_len[0] = S.ubuf_len[1] = 0;
+    for (i32 s = 0; s < ns_total; ++s) {
+        FrontDesc &w = S.fronts[s];
+        w.ubuf = S.depth[s] & 1;
+        if (!S.front_local[s]) { w.loff = -1; w.uoff = -1; w.ucoff = -1; continue; }
+        w.loff = S.lval_len; S.lval_len += (i64)w.f * w.ns;
+        w.ucoff = S.uc_len; S.uc_len += (w.f - w.ns);
+    }
+    for (i32 d = 0; d < S.nlevels; ++d) {
+        i64 off = 0;
+        for (i32 t = S.level_ptr[d]; t < S.level_ptr[d + 1]; ++t) {
+            FrontDesc &w = S.fronts[S.level_fronts[t]];
+            if (!S.front_local[S.level_fronts[t]]) continue;
+            const i64 rs = w.f - w.ns;
+            w.uoff = off; off += rs * rs;
+        }
+        S.ubuf_len[d & 1] = std::max(S.ubuf_len[d & 1], off);
+    }
+    S.flops_panel = 0;
+    for (i32 s = 0; s < ns_total; ++s) {
+        const double f = S.fronts[s].f, k = S.fronts[s].ns;
+        // potrf k^3/3 + trsm (f-k)k^2 + syrk (f-k)^2 k, in flops (multiply-add = 2)
+        S.flops_panel += k * k * k / 3.0 + (f - k) * k * k + (f - k) * (f - k) * k;
+    }
+
+    // ---- 13. relative indices (below-rows of each front -> position in the parent front) ----
+    S.rel.clear();
+    for (i32 s = 0; s < ns_total; ++s) {
+        FrontDesc &w = S.fronts[s];
+        w.reloff = (i64)S.rel.size();
+        if (w.parent == -1) continue;
+        const FrontDesc &p = S.fronts[w.parent];
+        i64 qp = p.rowoff;
+        const i64 qend = p.rowoff + p.f;
+        for (i64 q = w.rowoff + w.ns; q < w.rowoff + w.f; ++q) {
+            const i32 r = S.rowidx[q];
+            while (qp < qend && S.rowidx[qp] < r) ++qp;
+            if (qp == qend || S.rowidx[qp] != r) return fail(S, TLPK_INTERNAL, "child row missing from parent front");
+            S.rel.push_back((i32)(qp - p.rowoff));
+        }
+    }
+
+    // ---- 14. assembly lists: S[ii,kk] = sum_j A[i,j] D_j A[k,j] (+ regD on the diagonal) ----
+    {
+        S.s_target.assign((size_t)S.nnzS, -1);
+        S.s_diag_row.assign((size_t)S.nnzS, -1);
+        S.s_local.assign((size_t)S.nnzS, 0);
+        S.pair_ptr.assign((size_t)S.nnzS + 1, 0);
+        std::vector<i32> pos_in_front(m, -1);
+        std::vector<i64> epos(m, -1);
+        auto col_is_mine = [&](i32 j) -> bool {
+            if (opt.nranks == 1 || !opt.row_block) return true;
+            const i32 b = col_block[j];
+            return (b < 0) ? (opt.rank == 0) : (block_owner[b] == opt.rank);
+        };
+        // pass 1: targets + counts, pass 2: fill
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<i64> cursor;
+            if (pass) {
+                for (i64 e = 0; e < S.nnzS; ++e) S.pair_ptr[e + 1] += S.pair_ptr[e];
+                S.pair_w.resize((size_t)S.pair_ptr[S.nnzS]); S.pair_j.resize((size_t)S.pair_ptr[S.nnzS]);
+                cursor.assign(S.pair_ptr.begin(), S.pair_ptr.end() - 1);
+            }
+            for (i32 s = 0; s < ns_total; ++s) {
+                if (!S.front_local[s]) continue;
+                const FrontDesc &w = S.fronts[s];
+                const bool is_root = (s == S.root_front);
+                if (!pass) for (i32 t = 0; t < w.f; ++t) pos_in_front[S.rowidx[w.rowoff + t]] = t;
+                for (i32 kk = w.col0; kk < w.col0 + w.ns; ++kk) {
+                    const i32 k = S.perm[kk];
+                    for (i64 e = S.Sp[kk]; e < S.Sp[kk + 1]; ++e) epos[S.Si[e]] = e;
+                    if (!pass) {
+                        for (i64 e = S.Sp[kk]; e < S.Sp[kk + 1]; ++e) {
+                            const i32 ii = S.Si[e];
+                            S.s_target[e] = w.loff + pos_in_front[ii] + (i64)(kk - w.col0) * w.f;
+                            S.s_local[e] = 1;
+                        }
+                        if (!is_root || opt.rank == 0) S.s_diag_row[S.Sp[kk]] = k;
+                    }
+                    for (i64 q = S.Tp[k]; q < S.Tp[k + 1]; ++q) {
+                        const i32 j = S.Tj[q];
+                        if (is_root && !col_is_mine(j)) continue;
+                        const double akj = S.Ax[S.Tpos[q]];
+                        for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
+                            const i32 ii = S.iperm[S.Ai[p]];
+                            if (ii < kk) continue;
+                            const i64 e = epos[ii];
+                            if (!pass) S.pair_ptr[e + 1]++;
+                            else { const i64 c = cursor[e]++; S.pair_w[c] = akj * S.Ax[p]; S.pair_j[c] = j; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    build_schedule(S);
+    return TLPK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch schedules.  All task lists are static for the lifetime of the handle: one IPM run
+// replays them once per update! (factor) and 2..6 times per Newton step (solves).
+// ---------------------------------------------------------------------------------------------
+static void build_schedule(Symbolic &S) {
+    const i32 slots_per_outer = (NB_OUT / NB_IN) * 3;
+    auto push_launch = [](std::vector<Launch> &L, i32 kind, i64 first, i64 count) {
+        if (count > 0) L.push_back(Launch{kind, 0, first, count});
+    };
+    // ---------------- factorisation ----------------
+    for (i32 d = S.nlevels - 1; d >= 0; --d) {
+        const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
+        const bool root_level = (d == 0 && S.root_front >= 0);
+        // (a) extend-add: zero U, add children's update matrices
+        {
+            const i64 first = (i64)S.ea_tasks.size();
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (!S.front_local[s]) continue;
+                const FrontDesc &w = S.fronts[s];
+                if (w.f == w.ns && w.nchild == 0) continue;
+                // columns with any work: all of [0,f) when children exist, else only U's columns
+                const i32 jbeg = (w.nchild > 0) ? 0 : w.ns;
+                for (i32 j = jbeg; j < w.f; j += EA_COLS) S.ea_tasks.push_back(EaTask{s, j, std::min(j + EA_COLS, w.f), 0});
+            }
+            push_launch(S.factor_launches, LK_EXTEND_ADD, first, (i64)S.ea_tasks.size() - first);
+        }
+        if (root_level) S.factor_launches.push_back(Launch{LK_ALLREDUCE_ROOT, 0, 0, 0});
+        // (b) blocked partial factorisation, slot by slot
+        i32 max_ns = 0;
+        for (i32 t = t0; t < t1; ++t) if (S.front_local[S.level_fronts[t]]) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
+        const i32 nouter = (max_ns + NB_OUT - 1) / NB_OUT;
+        for (i32 slot = 0; slot < nouter * slots_per_outer; ++slot) {
+            const i32 io = slot / slots_per_outer, r = slot % slots_per_outer, ii = r / 3, kind = r % 3;
+            const i32 ko = io * NB_OUT, ki = ko + ii * NB_IN;
+            const i64 f_potrf = (i64)S.potrf_tasks.size(), f_trsm = (i64)S.trsm_tasks.size(), f_upd = (i64)S.update_tasks.size();
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (!S.front_local[s]) continue;
+                const FrontDesc &w = S.fronts[s];
+                if (ko >= w.ns) continue;
+                const i32 no = std::min(NB_OUT, w.ns - ko);
+                const bool last_inner = (ii == NB_OUT / NB_IN - 1);
+                if (ki < ko + no) {
+                    const i32 ni = std::min(NB_IN, ko + no - ki);
+                    if (kind == 0) S.potrf_tasks.push_back(PotrfTask{s, ki, ni, 0});
+                    else if (kind == 1) {
+                        for (i32 r0 = ki + ni; r0 < w.f; r0 += TRSM_ROWS) S.trsm_tasks.push_back(TrsmTask{s, ki, ni, r0});
+                    } else {
+                        // inner update: columns [ki+ni, ko+no), K = [ki, ki+ni)
+                        const i32 c0 = ki + ni, c1 = ko + no;
+                        if (c0 < c1) {
+                            for (i32 j0 = c0; j0 < c1; j0 += TILE)
+                                for (i32 i0 = j0; i0 < w.f; i0 += TILE)
+                                    S.update_tasks.push_back(UpdateTask{s, ki, ni, i0, j0, c1, 0, 0});
+                        }
+                    }
+                }
+                if (kind == 2 && last_inner) {
+                    // outer (trailing) update: columns [ko+no, f), K = [ko, ko+no)
+                    const i32 c0 = ko + no;
+                    for (i32 j0 = c0; j0 < w.f; j0 += TILE)
+                        for (i32 i0 = j0; i0 < w.f; i0 += TILE)
+                            S.update_tasks.push_back(UpdateTask{s, ko, no, i0, j0, w.f, 0, 0});
+                }
+            }
+            push_launch(S.factor_launches, LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
+            push_launch(S.factor_launches, LK_TRSM, f_trsm, (i64)S.trsm_tasks.size() - f_trsm);
+            push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
+        }
+    }
+    // ---------------- forward solve: deepest level first ----------------
+    for (i32 d = S.nlevels - 1; d >= 0; --d) {
+        const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
+        const bool root_level = (d == 0 && S.root_front >= 0);
+        {
+            const i64 first = (i64)S.fwd_gather_tasks.size();
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (!S.front_local[s]) continue;
+                const FrontDesc &w = S.fronts[s];
+                if (w.nchild == 0 && w.f == w.ns) continue;
+                S.fwd_gather_tasks.push_back(SolveTask{s, 0, 0, 0});
+            }
+            push_launch(S.fwd_launches, LK_FWD_GATHER, first, (i64)S.fwd_gather_tasks.size() - first);
+        }
+        if (root_level) S.fwd_launches.push_back(Launch{LK_ALLREDUCE_ROOT, 0, 0, 0});
+        i32 max_ns = 0;
+        for (i32 t = t0; t < t1; ++t) if (S.front_local[S.level_fronts[t]]) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
+        for (i32 kb = 0; kb < max_ns; kb += SOLVE_NB) {
+            const i64 f_diag = (i64)S.fwd_diag_tasks.size(), f_upd = (i64)S.fwd_update_tasks.size();
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (!S.front_local[s]) continue;
+                const FrontDesc &w = S.fronts[s];
+                if (kb >= w.ns) continue;
+                const i32 nb = std::min(SOLVE_NB, w.ns - kb);
+                S.fwd_diag_tasks.push_back(SolveTask{s, kb, nb, 0});
+                for (i32 r0 = kb + nb; r0 < w.f; r0 += SOLVE_ROWS) S.fwd_update_tasks.push_back(SolveTask{s, kb, nb, r0});
+            }
+            push_launch(S.fwd_launches, LK_FWD_DIAG, f_diag, (i64)S.fwd_diag_tasks.size() - f_diag);
+            push_launch(S.fwd_launches, LK_FWD_UPDATE, f_upd, (i64)S.fwd_update_tasks.size() - f_upd);
+        }
+    }
+    // ---------------- backward solve: root level first ----------------
+    for (i32 d = 0; d < S.nlevels; ++d) {
+        const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
+        i32 max_ns = 0;
+        for (i32 t = t0; t < t1; ++t) if (S.front_local[S.level_fronts[t]]) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
+        const i32 nblk = (max_ns + SOLVE_NB - 1) / SOLVE_NB;
+        // fronts are right-aligned: step b handles each front's block (its_nblk - 1 - b) so that
+        // every front walks its own blocks from last to first
+        for (i32 b = 0; b < nblk; ++b) {
+            const i64 f_upd = (i64)S.bwd_update_tasks.size(), f_diag = (i64)S.bwd_diag_tasks.size();
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (!S.front_local[s]) continue;
+                const FrontDesc &w = S.fronts[s];
+                const i32 my_nblk = (w.ns + SOLVE_NB - 1) / SOLVE_NB;
+                if (b >= my_nblk) continue;
+                const i32 kb = (my_nblk - 1 - b) * SOLVE_NB;
+                const i32 nb = std::min(SOLVE_NB, w.ns - kb);
+                if (kb + nb < w.f) S.bwd_update_tasks.push_back(SolveTask{s, kb, nb, kb + nb});
+                S.bwd_diag_tasks.push_back(SolveTask{s, kb, nb, 0});
+            }
+            push_launch(S.bwd_launches, LK_BWD_UPDATE, f_upd, (i64)S.bwd_update_tasks.size() - f_upd);
+            push_launch(S.bwd_launches, LK_BWD_DIAG, f_diag, (i64)S.bwd_diag_tasks.size() - f_diag);
+        }
+    }
+}
+
+}  // namespace tlpk

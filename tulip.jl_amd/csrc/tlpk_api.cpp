@@ -1,0 +1,584 @@
+// tlpk_api.cpp -- the C ABI of libtlpk.so (include/tlpk.h): handle life cycle, uploads, and
+// the replay of the static launch schedules on the handle's HIP stream.
+//
+// Mirrors the solver object of the reference backend
+// (/root/reference/src/KKT/Cholmod/cholmod.jl:46-60: m, n, A, theta, regP, regD, K, F, xi) with
+// device-resident state: A (CSC+CSR), stored copies of theta/regP/regD, the supernodal factor.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/tlpk.h"
+#include "tlpk_device.hpp"
+
+using namespace tlpk;
+
+struct tlpk_handle {
+    Symbolic S;
+    Options opt;
+    std::vector<i64> row_block_copy, user_perm_copy;
+    int device = -1;
+    bool has_device = false;
+    bool profile = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_class;            // class of each recorded pair in the current call
+    size_t ev_used = 0;
+    DevArrays d;
+    std::vector<void *> allocs;
+    i64 device_bytes = 0;
+    double *d_theta = nullptr, *d_regP = nullptr, *d_regD = nullptr, *d_D = nullptr;
+    double *d_xip = nullptr, *d_xid = nullptr, *d_dx = nullptr, *d_dy = nullptr;
+    int *h_info = nullptr;
+    bool factored = false, local_done = false;
+    i64 fail_col = -1;
+    double ms_analyse = 0, ms_update = 0, ms_solve = 0;
+    tlpk_kernel_times kt{};
+    size_t factor_marker = 0, fwd_marker = 0;   // index of the LK_ALLREDUCE_ROOT launch (or size)
+    i64 first_link = 0, nlink = 0;
+    std::string last_error;
+};
+
+namespace {
+
+int hip_fail(tlpk_handle *h, hipError_t e, const char *what) {
+    h->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return (e == hipErrorOutOfMemory) ? TLPK_OOM : TLPK_HIPERR;
+}
+#define HIPCHK(h, call)                                                   \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return hip_fail((h), e_, #call);            \
+    } while (0)
+
+template <class T>
+int dev_alloc(tlpk_handle *h, T **out, i64 count) {
+    *out = nullptr;
+    const size_t bytes = (size_t)std::max<i64>(count, 1) * sizeof(T);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return hip_fail(h, e, "hipMalloc");
+    h->allocs.push_back(p);
+    h->device_bytes += (i64)bytes;
+    *out = (T *)p;
+    return TLPK_OK;
+}
+template <class T>
+int dev_upload(tlpk_handle *h, T **out, const std::vector<T> &v) {
+    int rc = dev_alloc(h, out, (i64)v.size());
+    if (rc != TLPK_OK) return rc;
+    if (!v.empty()) HIPCHK(h, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return TLPK_OK;
+}
+
+int kind_class(i32 kind) {
+    switch (kind) {
+    case LK_EXTEND_ADD: return TLPK_KC_EXTEND_ADD;
+    case LK_POTRF: return TLPK_KC_POTRF;
+    case LK_TRSM: return TLPK_KC_TRSM;
+    case LK_UPDATE: return TLPK_KC_UPDATE;
+    case LK_FWD_GATHER: case LK_FWD_DIAG: case LK_FWD_UPDATE: return TLPK_KC_SOLVE_FWD;
+    default: return TLPK_KC_SOLVE_BWD;
+    }
+}
+
+// profile helpers: record an event pair around one launch
+struct ProfScope {
+    tlpk_handle *h; bool on; size_t idx;
+    ProfScope(tlpk_handle *h_, int cls) : h(h_), on(h_->profile), idx(0) {
+        if (!on) return;
+        if (h->ev_used + 2 > h->ev_pool.size()) {
+            const size_t old = h->ev_pool.size();
+            h->ev_pool.resize(old + 512);
+            for (size_t i = old; i < h->ev_pool.size(); ++i) hipEventCreate(&h->ev_pool[i]);
+        }
+        idx = h->ev_used; h->ev_used += 2;
+        h->ev_class.push_back(cls);
+        hipEventRecord(h->ev_pool[idx], h->stream);
+    }
+    ~ProfScope() { if (on) hipEventRecord(h->ev_pool[idx + 1], h->stream); }
+};
+void prof_begin(tlpk_handle *h, bool reset) {
+    if (!h->profile) return;
+    h->ev_used = 0; h->ev_class.clear();
+    if (reset) std::memset(&h->kt, 0, sizeof(h->kt));
+}
+void prof_collect(tlpk_handle *h) {          // stream must be synchronised
+    if (!h->profile) return;
+    for (size_t i = 0; i < h->ev_class.size(); ++i) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]);
+        h->kt.ms[h->ev_class[i]] += ms;
+        h->kt.launches[h->ev_class[i]] += 1;
+    }
+    h->ev_used = 0; h->ev_class.clear();
+}
+
+void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, size_t to) {
+    for (size_t i = from; i < to; ++i) {
+        if (L[i].kind == LK_ALLREDUCE_ROOT) continue;
+        ProfScope ps(h, kind_class(L[i].kind));
+        launch_tasks(h->stream, h->d, L[i]);
+    }
+}
+
+int upload_all(tlpk_handle *h) {
+    Symbolic &S = h->S;
+    DevArrays &d = h->d;
+    d.m = S.m; d.n = S.n;
+    int rc;
+#define UP(dst, vec) if ((rc = dev_upload(h, &(dst), (vec))) != TLPK_OK) return rc
+    UP(d.Ap, S.Ap); UP(d.Ai, S.Ai); UP(d.Ax, S.Ax);
+    UP(d.Tp, S.Tp); UP(d.Tj, S.Tj);
+    {
+        std::vector<double> Tx(S.Tpos.size());
+        for (size_t q = 0; q < Tx.size(); ++q) Tx[q] = S.Ax[S.Tpos[q]];
+        UP(d.Tx, Tx);
+    }
+    UP(d.perm, S.perm);
+    UP(d.row_local, S.row_local); UP(d.col_local, S.col_local);
+    {
+        // compact the assembly lists to the entries this rank owns
+        std::vector<i64> tgt, ptr; std::vector<i32> diag;
+        tgt.reserve((size_t)S.nnzS); diag.reserve((size_t)S.nnzS); ptr.reserve((size_t)S.nnzS + 1);
+        std::vector<double> pw; std::vector<i32> pj;
+        const bool all_local = (S.pair_ptr[(size_t)S.nnzS] == (i64)S.pair_w.size());
+        i64 np = 0;
+        ptr.push_back(0);
+        for (i64 e = 0; e < S.nnzS; ++e) {
+            if (!S.s_local[e]) continue;
+            tgt.push_back(S.s_target[e]); diag.push_back(S.s_diag_row[e]);
+            np += S.pair_ptr[e + 1] - S.pair_ptr[e];
+            ptr.push_back(np);
+        }
+        d.n_asm = (i64)tgt.size();
+        // pairs of local entries are contiguous per entry; entries of non-local fronts have none,
+        // so the pair arrays are already compact and in the same order.
+        (void)all_local;
+        UP(d.asm_target, tgt); UP(d.asm_diag, diag); UP(d.asm_ptr, ptr);
+        UP(d.pair_w, S.pair_w); UP(d.pair_j, S.pair_j);
+        if (np != (i64)S.pair_w.size()) { h->last_error = "assembly list compaction mismatch"; return TLPK_INTERNAL; }
+    }
+    const FrontDesc *fr = nullptr; const i32 *ri = nullptr, *re = nullptr, *ch = nullptr;
+    { FrontDesc *p; UP(p, S.fronts); fr = p; }
+    { i32 *p; UP(p, S.rowidx); ri = p; }
+    { i32 *p; UP(p, S.rel); re = p; }
+    { i32 *p; UP(p, S.children); ch = p; }
+    d.ctx.fronts = fr; d.ctx.rowidx = ri; d.ctx.rel = re; d.ctx.children = ch;
+    UP(d.ea_tasks, S.ea_tasks); UP(d.potrf_tasks, S.potrf_tasks); UP(d.trsm_tasks, S.trsm_tasks);
+    UP(d.update_tasks, S.update_tasks);
+    UP(d.fwd_gather_tasks, S.fwd_gather_tasks); UP(d.fwd_diag_tasks, S.fwd_diag_tasks);
+    UP(d.fwd_update_tasks, S.fwd_update_tasks); UP(d.bwd_update_tasks, S.bwd_update_tasks);
+    UP(d.bwd_diag_tasks, S.bwd_diag_tasks);
+#undef UP
+#define AL(dst, cnt) if ((rc = dev_alloc(h, &(dst), (cnt))) != TLPK_OK) return rc
+    AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
+    AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4);
+    AL(h->d_theta, S.n); AL(h->d_regP, S.n); AL(h->d_regD, S.m); AL(h->d_D, S.n);
+    AL(h->d_xip, S.m); AL(h->d_xid, S.n); AL(h->d_dx, S.n); AL(h->d_dy, S.m);
+#undef AL
+    HIPCHK(h, hipHostMalloc((void **)&h->h_info, 4 * sizeof(int), hipHostMallocDefault));
+    // free host-side copies that are only needed on the device
+    std::vector<double>().swap(S.pair_w); std::vector<i32>().swap(S.pair_j);
+    return TLPK_OK;
+}
+
+void find_markers(tlpk_handle *h) {
+    h->factor_marker = h->S.factor_launches.size();
+    h->fwd_marker = h->S.fwd_launches.size();
+    for (size_t i = 0; i < h->S.factor_launches.size(); ++i)
+        if (h->S.factor_launches[i].kind == LK_ALLREDUCE_ROOT) h->factor_marker = i;
+    for (size_t i = 0; i < h->S.fwd_launches.size(); ++i)
+        if (h->S.fwd_launches[i].kind == LK_ALLREDUCE_ROOT) h->fwd_marker = i;
+}
+
+}  // namespace
+
+extern "C" {
+
+void tlpk_default_options(tlpk_options *opt) {
+    if (!opt) return;
+    std::memset(opt, 0, sizeof(*opt));
+    opt->struct_size = (int32_t)sizeof(tlpk_options);
+    opt->device = 0;
+    opt->ordering = TLPK_ORDER_AMD;
+    opt->relax = 1;
+    opt->nranks = 1;
+}
+
+int tlpk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                const double *nzval, int index_base, const tlpk_options *uopt) {
+    if (!out) return TLPK_BADARG;
+    *out = nullptr;
+    tlpk_options def;
+    tlpk_default_options(&def);
+    if (uopt) {
+        if (uopt->struct_size != (int32_t)sizeof(tlpk_options)) return TLPK_BADARG;
+        def = *uopt;
+    }
+    tlpk_handle *h = new (std::nothrow) tlpk_handle();
+    if (!h) return TLPK_OOM;
+    int rc = TLPK_OK;
+    try {
+        h->opt.ordering = def.ordering; h->opt.relax = def.relax;
+        h->opt.rank = def.rank; h->opt.nranks = def.nranks < 1 ? 1 : def.nranks;
+        if (def.row_block && m > 0) {
+            h->row_block_copy.assign(def.row_block, def.row_block + m);
+            h->opt.row_block = h->row_block_copy.data();
+        }
+        if (def.ordering == TLPK_ORDER_USER && def.user_perm && m > 0) {
+            h->user_perm_copy.resize((size_t)m);
+            for (i64 i = 0; i < m; ++i) h->user_perm_copy[(size_t)i] = def.user_perm[i] - index_base;
+            h->opt.user_perm = h->user_perm_copy.data();
+        }
+        h->profile = def.profile != 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = analyse(h->S, m, n, colptr, rowval, nzval, index_base, h->opt);
+        h->ms_analyse = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        h->last_error = h->S.error;
+        if (rc == TLPK_OK) {
+            find_markers(h);
+            h->nlink = (h->S.root_front >= 0) ? h->S.fronts[h->S.root_front].ns : 0;
+            h->first_link = h->S.m - h->nlink;
+        }
+        if (rc == TLPK_OK && def.device >= 0) {
+            int ndev = 0;
+            if (hipGetDeviceCount(&ndev) != hipSuccess || def.device >= ndev) {
+                h->last_error = "no HIP device " + std::to_string(def.device) + " visible";
+                rc = TLPK_NO_DEVICE;
+            } else {
+                h->device = def.device;
+                hipError_t e = hipSetDevice(h->device);
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+                if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+                if (e != hipSuccess) rc = hip_fail(h, e, "device init");
+                if (rc == TLPK_OK) {
+                    // memory gate: refuse before allocating
+                    size_t free_b = 0, total_b = 0;
+                    hipMemGetInfo(&free_b, &total_b);
+                    const double budget = def.mem_budget_bytes > 0 ? (double)def.mem_budget_bytes : 0.9 * (double)free_b;
+                    const double need = 8.0 * ((double)h->S.lval_len + (double)h->S.ubuf_len[0] + (double)h->S.ubuf_len[1]) +
+                                        12.0 * (double)h->S.pair_w.size() + 20.0 * (double)h->S.nnzS + 40.0 * (double)h->S.nnzA;
+                    if (need > budget) {
+                        h->last_error = "factor needs " + std::to_string(need / 1e9) + " GB, budget " + std::to_string(budget / 1e9) + " GB";
+                        rc = TLPK_TOO_LARGE;
+                    }
+                }
+                if (rc == TLPK_OK) rc = upload_all(h);
+                if (rc == TLPK_OK) h->has_device = true;
+            }
+        } else if (rc == TLPK_OK && def.mem_budget_bytes > 0) {
+            const double need = 8.0 * ((double)h->S.lval_len + (double)h->S.ubuf_len[0] + (double)h->S.ubuf_len[1]);
+            if (need > (double)def.mem_budget_bytes) { h->last_error = "factor exceeds mem_budget_bytes"; rc = TLPK_TOO_LARGE; }
+        }
+    } catch (const std::bad_alloc &) {
+        rc = TLPK_OOM; h->last_error = "host out of memory during analyse";
+    } catch (...) {
+        rc = TLPK_INTERNAL; h->last_error = "unexpected exception";
+    }
+    // a failed create still returns the handle when it carries useful diagnostics (TOO_LARGE)
+    if (rc != TLPK_OK && rc != TLPK_TOO_LARGE) { tlpk_destroy(h); return rc; }
+    *out = h;
+    return rc;
+}
+
+void tlpk_destroy(tlpk_handle *h) {
+    if (!h) return;
+    if (h->device >= 0) {
+        hipSetDevice(h->device);
+        if (h->stream) hipStreamSynchronize(h->stream);
+        for (void *p : h->allocs) hipFree(p);
+        if (h->h_info) hipHostFree(h->h_info);
+        for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+        if (h->ev0) hipEventDestroy(h->ev0);
+        if (h->ev1) hipEventDestroy(h->ev1);
+        if (h->stream) hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+// ---- update ----
+int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_regP, const double *d_regD) {
+    if (!h || !d_theta || !d_regP || !d_regD) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    HIPCHK(h, hipSetDevice(h->device));
+    const Symbolic &S = h->S;
+    h->factored = false; h->local_done = false; h->fail_col = -1;
+    prof_begin(h, true);
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    // stored copies (spd.jl:36-38): the caller may mutate its vectors right after the call
+    if (d_theta != h->d_theta) HIPCHK(h, hipMemcpyAsync(h->d_theta, d_theta, (size_t)S.n * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (d_regP != h->d_regP) HIPCHK(h, hipMemcpyAsync(h->d_regP, d_regP, (size_t)S.n * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (d_regD != h->d_regD) HIPCHK(h, hipMemcpyAsync(h->d_regD, d_regD, (size_t)S.m * 8, hipMemcpyDeviceToDevice, h->stream));
+    h->h_info[0] = INT_MAX;
+    HIPCHK(h, hipMemcpyAsync(h->d.ctx.info, h->h_info, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    { ProfScope ps(h, TLPK_KC_ASSEMBLE); launch_compute_d(h->stream, S.n, h->d_theta, h->d_regP, h->d_D); }
+    {
+        ProfScope ps(h, TLPK_KC_ASSEMBLE);
+        if (S.lval_len > 0) HIPCHK(h, hipMemsetAsync(h->d.ctx.Lval, 0, (size_t)S.lval_len * 8, h->stream));
+        launch_assemble(h->stream, h->d, h->d_D, h->d_regD);
+    }
+    run_launches(h, S.factor_launches, 0, h->factor_marker);
+    HIPCHK(h, hipGetLastError());
+    h->local_done = true;
+    return TLPK_OK;
+}
+
+int tlpk_root_panel(tlpk_handle *h, double **d_ptr, int64_t *count) {
+    if (!h || !d_ptr || !count) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (h->S.root_front < 0) { *d_ptr = nullptr; *count = 0; return TLPK_OK; }
+    const FrontDesc &fd = h->S.fronts[h->S.root_front];
+    *d_ptr = h->d.ctx.Lval + fd.loff;
+    *count = (i64)fd.f * fd.ns;
+    return TLPK_OK;
+}
+
+int tlpk_update_finish(tlpk_handle *h) {
+    if (!h) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (!h->local_done) return TLPK_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const Symbolic &S = h->S;
+    run_launches(h, S.factor_launches, h->factor_marker, S.factor_launches.size());
+    HIPCHK(h, hipMemcpyAsync(h->h_info, h->d.ctx.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->ms_update = ms;
+    prof_collect(h);
+    h->local_done = false;
+    if (h->h_info[0] != INT_MAX) { h->fail_col = h->h_info[0]; return TLPK_NOT_POSDEF; }
+    h->factored = true;
+    return TLPK_OK;
+}
+
+int tlpk_update_device(tlpk_handle *h, const double *d_theta, const double *d_regP, const double *d_regD) {
+    int rc = tlpk_update_local(h, d_theta, d_regP, d_regD);
+    if (rc != TLPK_OK) return rc;
+    return tlpk_update_finish(h);
+}
+
+int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
+    if (!h || !theta || !regP || !regD) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    HIPCHK(h, hipSetDevice(h->device));
+    const Symbolic &S = h->S;
+    HIPCHK(h, hipMemcpyAsync(h->d_theta, theta, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_regP, regP, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_regD, regD, (size_t)S.m * 8, hipMemcpyHostToDevice, h->stream));
+    return tlpk_update_device(h, h->d_theta, h->d_regP, h->d_regD);
+}
+
+// ---- solve ----
+int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
+    if (!h || !d_xip || !d_xid) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (!h->factored) return TLPK_NOT_FACTORED;
+    HIPCHK(h, hipSetDevice(h->device));
+    prof_begin(h, false);
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    { ProfScope ps(h, TLPK_KC_SPMV); launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank); }
+    run_launches(h, h->S.fwd_launches, 0, h->fwd_marker);
+    HIPCHK(h, hipGetLastError());
+    return TLPK_OK;
+}
+
+int tlpk_root_rhs(tlpk_handle *h, double **d_ptr, int64_t *count) {
+    if (!h || !d_ptr || !count) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    *d_ptr = h->nlink ? h->d.ctx.xw + h->first_link : nullptr;
+    *count = h->nlink;
+    return TLPK_OK;
+}
+
+int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xid) {
+    if (!h || !d_dx || !d_dy || !d_xid) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (!h->factored) return TLPK_NOT_FACTORED;
+    HIPCHK(h, hipSetDevice(h->device));
+    run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size());
+    run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size());
+    { ProfScope ps(h, TLPK_KC_SPMV); launch_unpermute(h->stream, h->d, d_dy); }
+    { ProfScope ps(h, TLPK_KC_SPMV); launch_dx(h->stream, h->d, h->d_D, d_dy, d_xid, d_dx); }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipGetLastError());
+    return TLPK_OK;
+}
+
+int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xip, const double *d_xid) {
+    int rc = tlpk_solve_local(h, d_xip, d_xid);
+    if (rc != TLPK_OK) return rc;
+    return tlpk_solve_finish(h, d_dx, d_dy, d_xid);
+}
+
+int tlpk_sync(tlpk_handle *h) {
+    if (!h) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->ms_solve = ms;
+    prof_collect(h);
+    return TLPK_OK;
+}
+
+void *tlpk_stream(tlpk_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const double *xi_d) {
+    if (!h || !dx || !dy || !xi_p || !xi_d) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (!h->factored) return TLPK_NOT_FACTORED;
+    HIPCHK(h, hipSetDevice(h->device));
+    const Symbolic &S = h->S;
+    HIPCHK(h, hipMemcpyAsync(h->d_xip, xi_p, (size_t)S.m * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_xid, xi_d, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = tlpk_solve_device(h, h->d_dx, h->d_dy, h->d_xip, h->d_xid);
+    if (rc != TLPK_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(dx, h->d_dx, (size_t)S.n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dy, h->d_dy, (size_t)S.m * 8, hipMemcpyDeviceToHost, h->stream));
+    return tlpk_sync(h);
+}
+
+// ---- introspection ----
+int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
+    if (!h || !out) return TLPK_BADARG;
+    const Symbolic &S = h->S;
+    std::memset(out, 0, sizeof(*out));
+    out->m = S.m; out->n = S.n; out->nnzA = S.nnzA; out->nnzS = S.nnzS; out->nnzL = S.nnzL;
+    out->nnzL_stored = S.lval_len; out->flops_chol = S.flops_chol; out->flops_panel = S.flops_panel;
+    out->n_supernodes = S.nsuper; out->n_levels = S.nlevels; out->max_front = S.max_front;
+    out->n_pairs = S.pair_ptr.empty() ? 0 : S.pair_ptr.back();
+    out->device_bytes = h->device_bytes;
+    for (const Launch &L : S.factor_launches) if (L.kind != LK_ALLREDUCE_ROOT) out->launches_update++;
+    out->launches_update += 3;
+    for (const Launch &L : S.fwd_launches) if (L.kind != LK_ALLREDUCE_ROOT) out->launches_solve++;
+    out->launches_solve += (i64)S.bwd_launches.size() + 3;
+    out->fail_col = h->fail_col;
+    out->ms_analyse = h->ms_analyse; out->ms_last_update = h->ms_update; out->ms_last_solve = h->ms_solve;
+    out->n_local_blocks = S.n_local_blocks; out->n_blocks = S.nblocks;
+    out->root_panel_len = (S.root_front >= 0) ? (i64)S.fronts[S.root_front].f * S.fronts[S.root_front].ns : 0;
+    return TLPK_OK;
+}
+
+int tlpk_kernel_timing(const tlpk_handle *h, tlpk_kernel_times *out) {
+    if (!h || !out) return TLPK_BADARG;
+    *out = h->kt;
+    return TLPK_OK;
+}
+
+int tlpk_get_perm(const tlpk_handle *h, int64_t *perm) {
+    if (!h || !perm) return TLPK_BADARG;
+    for (i64 i = 0; i < h->S.m; ++i) perm[i] = h->S.perm[(size_t)i];
+    return TLPK_OK;
+}
+
+int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, int64_t cap) {
+    if (!h || !what) return -1;
+    const Symbolic &S = h->S;
+    std::vector<i64> tmp;
+    const std::string w(what);
+    auto from32 = [&](const std::vector<i32> &v) { tmp.assign(v.begin(), v.end()); };
+    auto field = [&](auto getter) { tmp.resize(S.fronts.size()); for (size_t s = 0; s < S.fronts.size(); ++s) tmp[s] = (i64)getter(S.fronts[s]); };
+    if (w == "perm") from32(S.perm);
+    else if (w == "etree") from32(S.parent);
+    else if (w == "colcount") from32(S.colcount);
+    else if (w == "s_colptr") tmp = S.Sp;
+    else if (w == "s_rowidx") from32(S.Si);
+    else if (w == "s_target") tmp = S.s_target;
+    else if (w == "s_diag_row") from32(S.s_diag_row);
+    else if (w == "pair_ptr") tmp = S.pair_ptr;
+    else if (w == "pair_j") from32(S.pair_j);
+    else if (w == "rowidx") from32(S.rowidx);
+    else if (w == "rel") from32(S.rel);
+    else if (w == "children") from32(S.children);
+    else if (w == "depth") from32(S.depth);
+    else if (w == "front_block") from32(S.front_block);
+    else if (w == "front_local") tmp.assign(S.front_local.begin(), S.front_local.end());
+    else if (w == "col_local") tmp.assign(S.col_local.begin(), S.col_local.end());
+    else if (w == "row_local") tmp.assign(S.row_local.begin(), S.row_local.end());
+    else if (w == "front_f") field([](const FrontDesc &f) { return f.f; });
+    else if (w == "front_ns") field([](const FrontDesc &f) { return f.ns; });
+    else if (w == "front_col0") field([](const FrontDesc &f) { return f.col0; });
+    else if (w == "front_parent") field([](const FrontDesc &f) { return f.parent; });
+    else if (w == "front_loff") field([](const FrontDesc &f) { return f.loff; });
+    else if (w == "front_rowoff") field([](const FrontDesc &f) { return f.rowoff; });
+    else if (w == "front_reloff") field([](const FrontDesc &f) { return f.reloff; });
+    else if (w == "front_child_ptr") field([](const FrontDesc &f) { return f.child_ptr; });
+    else if (w == "front_nchild") field([](const FrontDesc &f) { return f.nchild; });
+    else if (w == "root_front") tmp.assign(1, S.root_front);
+    else if (w == "potrf_tasks") { for (auto &t : S.potrf_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); } }
+    else if (w == "trsm_tasks") { for (auto &t : S.trsm_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); } }
+    else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); } }
+    else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); } }
+    else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks" || w == "bwd_diag_tasks") {
+        const std::vector<SolveTask> &v = (w == "fwd_gather_tasks") ? S.fwd_gather_tasks : (w == "fwd_diag_tasks") ? S.fwd_diag_tasks :
+                                          (w == "fwd_update_tasks") ? S.fwd_update_tasks : (w == "bwd_update_tasks") ? S.bwd_update_tasks : S.bwd_diag_tasks;
+        for (auto &t : v) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); }
+    }
+    else if (w == "front_ucoff") field([](const FrontDesc &f) { return f.ucoff; });
+    else if (w == "front_uoff") field([](const FrontDesc &f) { return f.uoff; });
+    else if (w == "front_ubuf") field([](const FrontDesc &f) { return f.ubuf; });
+    else if (w == "factor_launches") { for (auto &L : S.factor_launches) { tmp.push_back(L.kind); tmp.push_back(L.first); tmp.push_back(L.count); } }
+    else if (w == "fwd_launches") { for (auto &L : S.fwd_launches) { tmp.push_back(L.kind); tmp.push_back(L.first); tmp.push_back(L.count); } }
+    else if (w == "bwd_launches") { for (auto &L : S.bwd_launches) { tmp.push_back(L.kind); tmp.push_back(L.first); tmp.push_back(L.count); } }
+    else return -1;
+    const i64 len = (i64)tmp.size();
+    if (buf) std::copy(tmp.begin(), tmp.begin() + std::min(len, cap), buf);
+    return len;
+}
+
+int64_t tlpk_symbolic_get_f64(const tlpk_handle *h, const char *what, double *buf, int64_t cap) {
+    if (!h || !what) return -1;
+    const std::string w(what);
+    const std::vector<double> *v = nullptr;
+    if (w == "pair_w") v = &h->S.pair_w;
+    else return -1;
+    const i64 len = (i64)v->size();
+    if (buf) std::copy(v->begin(), v->begin() + std::min(len, cap), buf);
+    return len;
+}
+
+int tlpk_get_factor(tlpk_handle *h, double *lval, int64_t cap) {
+    if (!h || !lval) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (cap < h->S.lval_len) return TLPK_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(lval, h->d.ctx.Lval, (size_t)h->S.lval_len * 8, hipMemcpyDeviceToHost));
+    return TLPK_OK;
+}
+
+const char *tlpk_strerror(int code) {
+    switch (code) {
+    case TLPK_OK: return "ok";
+    case TLPK_NOT_POSDEF: return "matrix is not positive definite";
+    case TLPK_BADARG: return "bad argument / dimension mismatch";
+    case TLPK_OOM: return "out of memory";
+    case TLPK_HIPERR: return "HIP runtime error";
+    case TLPK_NO_DEVICE: return "no HIP device (analyse-only handle or no GPU visible)";
+    case TLPK_TOO_LARGE: return "factor does not fit the memory budget";
+    case TLPK_NOT_FACTORED: return "solve called before a successful update";
+    case TLPK_INTERNAL: return "internal error";
+    default: return "unknown error";
+    }
+}
+const char *tlpk_last_error(const tlpk_handle *h) { return h ? h->last_error.c_str() : ""; }
+const char *tlpk_backend_name(void) { return "HIP (gfx950)"; }
+const char *tlpk_system_name(void) { return "Normal equations (K1)"; }
+
+}  // extern "C"

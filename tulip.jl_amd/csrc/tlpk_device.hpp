@@ -1,0 +1,48 @@
+// tlpk_device.hpp -- device-side views shared by kernels.hip and tlpk_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tlpk_host.hpp"
+
+namespace tlpk {
+
+// passed by value to every front kernel
+struct DevCtx {
+    const FrontDesc *fronts;
+    const i32 *rowidx;
+    const i32 *rel;
+    const i32 *children;
+    double *Lval;       // supernodal panels of L
+    double *U0, *U1;    // ping-pong update-matrix buffers (by tree depth parity)
+    double *uc;         // solve contribution vectors
+    double *xw;         // permuted right-hand side / solution
+    int *info;          // info[0] = smallest failing pivot column (INT_MAX = none)
+};
+
+struct DevArrays {
+    DevCtx ctx{};
+    i64 m = 0, n = 0;
+    // A (CSC + CSR)
+    i64 *Ap = nullptr; i32 *Ai = nullptr; double *Ax = nullptr;
+    i64 *Tp = nullptr; i32 *Tj = nullptr; double *Tx = nullptr;
+    i32 *perm = nullptr;
+    char *row_local = nullptr, *col_local = nullptr;
+    // assembly lists (local entries only)
+    i64 n_asm = 0;
+    i64 *asm_target = nullptr; i32 *asm_diag = nullptr; i64 *asm_ptr = nullptr;
+    double *pair_w = nullptr; i32 *pair_j = nullptr;
+    // task arrays
+    EaTask *ea_tasks = nullptr; PotrfTask *potrf_tasks = nullptr; TrsmTask *trsm_tasks = nullptr;
+    UpdateTask *update_tasks = nullptr;
+    SolveTask *fwd_gather_tasks = nullptr, *fwd_diag_tasks = nullptr, *fwd_update_tasks = nullptr,
+              *bwd_update_tasks = nullptr, *bwd_diag_tasks = nullptr;
+};
+
+void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D);
+void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD);
+void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L);
+void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank);
+void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy);
+void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx);
+
+}  // namespace tlpk

@@ -1,0 +1,114 @@
+// tlpk_host.hpp -- host-side analyse phase of libtlpk (ordering, elimination tree, supernodes,
+// assembly maps, launch schedules).  Everything here runs once per KKT.setup
+// (/root/reference/src/KKT/Cholmod/spd.jl:5-20 does the same work through CHOLMOD's analyse) and
+// is amortised over the IPM iterations; the numeric work is in kernels.hip.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace tlpk {
+
+using i32 = int32_t;
+using i64 = int64_t;
+
+// ---- tunables of the dense front kernels (shared by the scheduler and kernels.hip) ----
+constexpr int NB_IN = 64;     // diagonal-block / triangular-solve width (potrf + trsm kernels)
+constexpr int NB_OUT = 256;   // outer panel width: trailing updates run with K = NB_OUT
+constexpr int TILE = 128;     // update-kernel tile (TILE x TILE per workgroup)
+constexpr int TRSM_ROWS = 64; // rows per trsm workgroup
+constexpr int EA_COLS = 16;   // parent columns per extend-add workgroup
+constexpr int SOLVE_NB = 64;  // block width of the triangular-solve kernels
+constexpr int SOLVE_ROWS = 256; // rows per forward-update workgroup
+
+// ---- device-visible descriptors (plain structs, uploaded as arrays) ----
+struct FrontDesc {
+    i64 loff;      // offset of the panel (f x ns, ld = f, column-major) in Lval
+    i64 uoff;      // offset of the update matrix (rs x rs, ld = rs) in its ping-pong buffer
+    i64 rowoff;    // offset into rowidx (f entries, first ns are the pivot columns)
+    i64 reloff;    // offset into rel (rs entries: position of each below-row in the parent front)
+    i64 ucoff;     // offset of the rs-vector of solve contributions
+    i32 f, ns;
+    i32 col0;      // first pivot column (permuted numbering)
+    i32 ubuf;      // which ping-pong buffer holds U (depth & 1)
+    i32 parent;    // parent front or -1
+    i32 child_ptr, nchild;   // children in `children[child_ptr .. child_ptr+nchild)`
+    i32 pad;
+};
+static_assert(sizeof(FrontDesc) == 72, "FrontDesc layout");
+
+struct PotrfTask { i32 front, k0, nb, pad; };
+struct TrsmTask  { i32 front, k0, nb, row0; };
+struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, pad0, pad1; };   // tile rows i0.., cols j0..<jlim
+struct EaTask    { i32 front, j0, j1, pad; };                        // parent columns [j0, j1)
+struct SolveTask { i32 front, k0, nb, row0; };
+
+enum LaunchKind : i32 {
+    LK_EXTEND_ADD = 0, LK_POTRF, LK_TRSM, LK_UPDATE,
+    LK_FWD_GATHER, LK_FWD_DIAG, LK_FWD_UPDATE, LK_BWD_UPDATE, LK_BWD_DIAG,
+    LK_ALLREDUCE_ROOT   // marker: everything after this belongs to the replicated root front
+};
+struct Launch { i32 kind; i32 pad; i64 first; i64 count; };   // tasks[first .. first+count) of that kind
+
+struct Options {
+    i32 ordering = 0, relax = 1, rank = 0, nranks = 1;
+    const i64 *user_perm = nullptr;   // 0-based here
+    const i64 *row_block = nullptr;
+};
+
+struct Symbolic {
+    i64 m = 0, n = 0, nnzA = 0;
+    // A, CSC and CSR (0-based, int32 indices); csr_pos[q] = CSC position of the CSR entry q
+    std::vector<i64> Ap; std::vector<i32> Ai; std::vector<double> Ax;
+    std::vector<i64> Tp; std::vector<i32> Tj; std::vector<i32> Tpos;
+    std::vector<i32> Acol;                 // column of each CSC entry
+    // ordering
+    std::vector<i32> perm, iperm;          // perm[new] = old
+    // permuted lower-triangular pattern of S (diagonal first in each column)
+    std::vector<i64> Sp; std::vector<i32> Si;
+    std::vector<i32> parent;               // column elimination tree (postordered numbering)
+    std::vector<i32> colcount;             // nnz(L[:,j]) incl. diagonal
+    // supernodes / fronts
+    i32 nsuper = 0;
+    std::vector<FrontDesc> fronts;
+    std::vector<i32> sn_of_col;
+    std::vector<i32> rowidx;               // concatenated front row lists (permuted indices)
+    std::vector<i32> rel;                  // concatenated relative indices
+    std::vector<i32> children;             // concatenated child lists
+    std::vector<i32> depth;                // depth of each front (roots = 0)
+    i32 nlevels = 0;
+    std::vector<i32> level_ptr, level_fronts;   // level d: level_fronts[level_ptr[d]..level_ptr[d+1])
+    // block-angular structure
+    i32 nblocks = 0;
+    std::vector<i32> front_block;          // block of each front, -1 for the root/linking front
+    std::vector<char> front_local;         // processed by this rank
+    std::vector<char> col_local;           // column of A handled by this rank
+    std::vector<char> row_local;           // 0 = other rank's block row, 1 = local block row, 2 = linking row
+    i32 root_front = -1;                   // the replicated linking front (or -1)
+    i32 n_local_blocks = 0;
+    // assembly of S = A*D*A' + Rd into the panels
+    std::vector<i64> s_target;             // per S entry: position in Lval
+    std::vector<i32> s_diag_row;           // per S entry: original row index if diagonal, else -1
+    std::vector<i64> pair_ptr;             // per S entry: range of products
+    std::vector<double> pair_w;            // A[i,j]*A[k,j]
+    std::vector<i32> pair_j;               // j
+    std::vector<char> s_local;             // entry assembled by this rank
+    // sizes
+    i64 nnzS = 0, nnzL = 0, lval_len = 0, ubuf_len[2] = {0, 0}, uc_len = 0, max_front = 0;
+    double flops_chol = 0, flops_panel = 0;
+    // schedules
+    std::vector<PotrfTask> potrf_tasks; std::vector<TrsmTask> trsm_tasks;
+    std::vector<UpdateTask> update_tasks; std::vector<EaTask> ea_tasks;
+    std::vector<SolveTask> fwd_gather_tasks, fwd_diag_tasks, fwd_update_tasks, bwd_update_tasks, bwd_diag_tasks;
+    std::vector<Launch> factor_launches, fwd_launches, bwd_launches;
+    std::string error;
+};
+
+// amd.cpp
+void amd_order(i32 n, const std::vector<i64> &xadj, const std::vector<i32> &adj, std::vector<i32> &order);
+
+// symbolic.cpp : returns a TLPK_* code
+int analyse(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
+            int index_base, const Options &opt);
+
+}  // namespace tlpk

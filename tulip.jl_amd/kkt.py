@@ -1,0 +1,249 @@
+"""Host-side mirror of Tulip's KKT interface for the HIP normal-equations backend.
+
+Same names, argument meaning and error behaviour as the reference
+(/root/reference/src/KKT/KKT.jl:59-121, src/KKT/Cholmod/spd.jl:5-70); Julia's `update!` /
+`solve!` are `update` / `solve` here.  The Julia glue with the same semantics is
+tulip.jl_amd/julia/hip.jl.  All numeric work happens in libtlpk.so on the GPU; this module only
+validates arguments and maps return codes to exceptions.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))
+
+
+class K1:
+    """Normal-equations system, /root/reference/src/KKT/systems.jl:34-54."""
+
+
+class DimensionMismatch(ValueError):
+    """Julia's DimensionMismatch (spd.jl:26-34)."""
+
+
+class PosDefException(ArithmeticError):
+    """Julia's PosDefException (spd.jl:47); caught by the IPM to bump regularisations
+    (/root/reference/src/IPM/HSD/step.jl:39-48)."""
+
+    def __init__(self, info=0):
+        super().__init__(f"matrix is not positive definite; Cholesky factorization failed (column {info})")
+        self.info = info
+
+
+class OutOfMemoryError(MemoryError):
+    """Julia's OutOfMemoryError -> Trm_MemoryLimit (/root/reference/src/IPM/HSD/HSD.jl:327-329)."""
+
+
+class Backend:
+    """`TlpHIP.Backend`: selects the HIP solver, the analogue of `TlpCholmod.Backend`
+    (/root/reference/src/KKT/Cholmod/cholmod.jl:18).
+
+    row_block: optional block-angular structure (length m; block id >= 0 or -1 for a linking
+    row) -- Tulip's structured-matrix hook (parameters.jl:11 MatrixFactory -> KKT.setup dispatch).
+    """
+
+    def __init__(self, device=0, ordering="amd", relax=True, row_block=None, user_perm=None,
+                 profile=False, rank=0, nranks=1, mem_budget_bytes=0):
+        self.device = device
+        self.ordering = {"amd": _lib.ORDER_AMD, "natural": _lib.ORDER_NATURAL, "user": _lib.ORDER_USER}[ordering]
+        self.relax = bool(relax)
+        self.row_block = None if row_block is None else np.ascontiguousarray(row_block, dtype=np.int64)
+        self.user_perm = None if user_perm is None else np.ascontiguousarray(user_perm, dtype=np.int64)
+        self.profile = bool(profile)
+        self.rank, self.nranks = int(rank), int(nranks)
+        self.mem_budget_bytes = int(mem_budget_bytes)
+
+
+def _raise_for(code, handle=None, what=""):
+    if code == _lib.OK:
+        return
+    msg = _lib.strerror(code)
+    if handle:
+        detail = _lib.lib().tlpk_last_error(handle).decode()
+        if detail:
+            msg = f"{msg}: {detail}"
+    if code == _lib.NOT_POSDEF:
+        raise PosDefException(0)
+    if code == _lib.BADARG:
+        raise DimensionMismatch(f"{what}{msg}")
+    if code in (_lib.OOM, _lib.TOO_LARGE):
+        raise OutOfMemoryError(msg)
+    raise RuntimeError(f"{what}{msg} (code {code})")
+
+
+class HIPNormalEquations:
+    """`HIPNormalEquations <: AbstractKKTSolver{Float64}` -- the counterpart of
+    `CholmodSolver{Float64,K1}` (/root/reference/src/KKT/Cholmod/cholmod.jl:46-60)."""
+
+    def __init__(self, A, backend_):
+        import scipy.sparse as sp
+        if not sp.issparse(A):
+            A = sp.csc_matrix(np.asarray(A, dtype=np.float64))     # cholmod.jl:65 convert(SparseMatrixCSC, A)
+        A = A.tocsc()
+        A.sort_indices()
+        self.m, self.n = A.shape
+        self.A = A                                                # stored by reference, never mutated
+        L = _lib.lib()
+        opt = _lib.Options()
+        L.tlpk_default_options(C.byref(opt))
+        opt.device = backend_.device
+        opt.ordering = backend_.ordering
+        opt.relax = int(backend_.relax)
+        opt.profile = int(backend_.profile)
+        opt.rank, opt.nranks = backend_.rank, backend_.nranks
+        opt.mem_budget_bytes = backend_.mem_budget_bytes
+        self._keep = []
+        if backend_.row_block is not None:
+            if backend_.row_block.shape != (self.m,):
+                raise DimensionMismatch(f"length(row_block)={backend_.row_block.shape[0]} but A has m={self.m}")
+            opt.row_block = _lib.as_p64(backend_.row_block)
+            self._keep.append(backend_.row_block)
+        if backend_.user_perm is not None:
+            opt.user_perm = _lib.as_p64(backend_.user_perm)
+            self._keep.append(backend_.user_perm)
+        colptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(A.indices, dtype=np.int64)
+        nzval = np.ascontiguousarray(A.data, dtype=np.float64)
+        self._h = C.c_void_p()
+        rc = L.tlpk_create(C.byref(self._h), self.m, self.n, _lib.as_p64(colptr), _lib.as_p64(rowval),
+                           _lib.as_pd(nzval), 0, C.byref(opt))
+        if rc != _lib.OK:
+            h = self._h if self._h else None
+            try:
+                _raise_for(rc, h, "KKT.setup: ")
+            finally:
+                if self._h:
+                    L.tlpk_destroy(self._h)
+                    self._h = C.c_void_p()
+        self.backend_options = backend_
+
+    # -- introspection --
+    def stats(self):
+        st = _lib.Stats()
+        _lib.lib().tlpk_info(self._h, C.byref(st))
+        return st.as_dict()
+
+    def kernel_times(self):
+        kt = _lib.KernelTimes()
+        _lib.lib().tlpk_kernel_timing(self._h, C.byref(kt))
+        return kt.as_dict()
+
+    def perm(self):
+        p = np.empty(self.m, dtype=np.int64)
+        _lib.lib().tlpk_get_perm(self._h, _lib.as_p64(p))
+        return p
+
+    def symbolic(self, what):
+        return _lib.symbolic_array(self._h, what)
+
+    def factor_panels(self):
+        st = self.stats()
+        buf = np.empty(max(st["nnzL_stored"], 1))
+        _raise_for(_lib.lib().tlpk_get_factor(self._h, _lib.as_pd(buf), buf.size), self._h)
+        return buf[:st["nnzL_stored"]]
+
+    # -- device-pointer entry points (arguments: integer device addresses) --
+    def update_device(self, d_theta, d_regP, d_regD):
+        _raise_for(_lib.lib().tlpk_update_device(self._h, d_theta, d_regP, d_regD), self._h)
+
+    def solve_device(self, d_dx, d_dy, d_xip, d_xid, sync=True):
+        _raise_for(_lib.lib().tlpk_solve_device(self._h, d_dx, d_dy, d_xip, d_xid), self._h)
+        if sync:
+            _raise_for(_lib.lib().tlpk_sync(self._h), self._h)
+
+    def sync(self):
+        _raise_for(_lib.lib().tlpk_sync(self._h), self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().tlpk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):                       # the Julia glue does this in a finalizer
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def setup(A, system=None, backend_=None):
+    """KKT.setup(A, ::K1, ::TlpHIP.Backend)  (KKT.jl:59, spd.jl:5-20).  Runs the analyse phase on
+    the host and uploads the symbolic structures; skips the throw-away numeric factorisation of
+    spd.jl:14-17."""
+    if system is not None and not isinstance(system, K1) and system is not K1:
+        raise TypeError("the HIP backend solves the normal equations (K1) only")
+    return HIPNormalEquations(A, backend_ or Backend())
+
+
+def _vec(x, name, length, what):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if a.ndim != 1 or a.shape[0] != length[1]:
+        raise DimensionMismatch(f"length({name})={a.shape[0] if a.ndim == 1 else a.shape} "
+                                f"but KKT solver has {length[0]}={length[1]}{what}")
+    return a
+
+
+def update(kkt, theta_inv, regP, regD):
+    """KKT.update!(kkt, θinv, regP, regD) -> nothing  (KKT.jl:65-83, spd.jl:22-50).
+    Raises DimensionMismatch (spd.jl:26-34) or PosDefException (spd.jl:47)."""
+    th = _vec(theta_inv, "θ", ("n", kkt.n), ".")
+    rp = _vec(regP, "regP", ("n", kkt.n), "")
+    rd = _vec(regD, "regD", ("m", kkt.m), "")
+    rc = _lib.lib().tlpk_update(kkt._h, _lib.as_pd(th), _lib.as_pd(rp), _lib.as_pd(rd))
+    _raise_for(rc, kkt._h, "KKT.update!: ")
+    return None
+
+
+def solve(dx, dy, kkt, xi_p, xi_d):
+    """KKT.solve!(dx, dy, kkt, ξp, ξd) -> nothing  (KKT.jl:85-100, spd.jl:52-70).
+    dx, dy are overwritten in place; ξp, ξd are read-only."""
+    if not (isinstance(dx, np.ndarray) and isinstance(dy, np.ndarray) and dx.dtype == np.float64
+            and dy.dtype == np.float64 and dx.flags.c_contiguous and dy.flags.c_contiguous):
+        raise TypeError("dx, dy must be contiguous float64 numpy vectors (modified in place)")
+    if dx.shape != (kkt.n,):
+        raise DimensionMismatch(f"length(dx)={dx.shape[0]} but KKT solver has n={kkt.n}")
+    if dy.shape != (kkt.m,):
+        raise DimensionMismatch(f"length(dy)={dy.shape[0]} but KKT solver has m={kkt.m}")
+    xp = _vec(xi_p, "ξp", ("m", kkt.m), "")
+    xd = _vec(xi_d, "ξd", ("n", kkt.n), "")
+    rc = _lib.lib().tlpk_solve(kkt._h, _lib.as_pd(dx), _lib.as_pd(dy), _lib.as_pd(xp), _lib.as_pd(xd))
+    _raise_for(rc, kkt._h, "KKT.solve!: ")
+    return None
+
+
+def arithmetic(kkt):
+    """KKT.arithmetic (KKT.jl:107)."""
+    return np.float64
+
+
+def backend(kkt):
+    """KKT.backend (KKT.jl:114) -- printed in the IPM log banner (HSD.jl:227-229)."""
+    return _lib.lib().tlpk_backend_name().decode()
+
+
+def linear_system(kkt):
+    """KKT.linear_system (KKT.jl:121; spd.jl:3)."""
+    return _lib.lib().tlpk_system_name().decode()
+
+
+def run_ls_tests(A, kkt, atol=SQRT_EPS):
+    """The reference's conformance routine for a KKT backend, restated
+    (/root/reference/src/KKT/Test/test.jl:9-47): update! with all-ones, solve! with all-ones,
+    both residual infinity-norms <= atol.  Returns (rp_norm, rd_norm)."""
+    import scipy.sparse as sp
+    assert callable(update) and callable(solve)          # test.jl:19-20 hasmethod checks
+    Ad = A if sp.issparse(A) else sp.csc_matrix(np.asarray(A, dtype=np.float64))
+    m, n = Ad.shape
+    th = np.ones(n); rp = np.ones(n); rd = np.ones(m)
+    update(kkt, th, rp, rd)                              # test.jl:26-29
+    xp = np.ones(m); xd = np.ones(n)
+    dx = np.zeros(n); dy = np.zeros(m)
+    solve(dx, dy, kkt, xp, xd)                           # test.jl:32-36
+    r_p = Ad @ dx + rd * dy - xp                         # test.jl:39
+    r_d = -dx * (th + rp) + Ad.T @ dy - xd               # test.jl:40
+    np_, nd_ = float(np.abs(r_p).max(initial=0.0)), float(np.abs(r_d).max(initial=0.0))
+    if not (np_ <= atol and nd_ <= atol):
+        raise AssertionError(f"run_ls_tests residuals {np_:.3e}, {nd_:.3e} exceed atol={atol:.3e}")
+    return np_, nd_
