@@ -76,6 +76,8 @@ typedef struct tlpk_stats {
     double  ms_last_solve;     /* device time of the last solve */
     int32_t n_local_blocks, n_blocks;
     int64_t root_panel_len;    /* doubles in the root (linking) panel reduced across ranks */
+    double  flops_update;      /* algorithmic flops of the fp64-MFMA update kernel per factorisation:
+                                  2*K*(lower-triangle target entries), summed over its launches */
 } tlpk_stats;
 
 /* per-kernel-class timing, filled when options.profile = 1 */
@@ -135,6 +137,7 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
 /* Introspection */
 int tlpk_info(const tlpk_handle *h, tlpk_stats *out);
 int tlpk_kernel_timing(const tlpk_handle *h, tlpk_kernel_times *out);
+int tlpk_set_profile(tlpk_handle *h, int on);   /* toggle per-launch HIP-event timing at run time */
 int tlpk_get_perm(const tlpk_handle *h, int64_t *perm /*m, 0-based, perm[new] = old*/);
 /* Symbolic structures, for tests and tools.  `what` selects an array; returns its length and,
  * if buf != NULL, copies min(len, cap) int64 entries. */

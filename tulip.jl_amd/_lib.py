@@ -35,7 +35,7 @@ class Stats(C.Structure):
                 ("launches_update", C.c_int64), ("launches_solve", C.c_int64),
                 ("fail_col", C.c_int64), ("ms_analyse", C.c_double), ("ms_last_update", C.c_double),
                 ("ms_last_solve", C.c_double), ("n_local_blocks", C.c_int32), ("n_blocks", C.c_int32),
-                ("root_panel_len", C.c_int64)]
+                ("root_panel_len", C.c_int64), ("flops_update", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -55,7 +55,7 @@ EXPORTS = [
     "tlpk_update_device", "tlpk_solve_device", "tlpk_sync", "tlpk_stream", "tlpk_update_local",
     "tlpk_root_panel", "tlpk_update_finish", "tlpk_solve_local", "tlpk_root_rhs",
     "tlpk_solve_finish", "tlpk_info", "tlpk_kernel_timing", "tlpk_get_perm", "tlpk_symbolic_get",
-    "tlpk_symbolic_get_f64", "tlpk_get_factor", "tlpk_strerror", "tlpk_last_error",
+    "tlpk_symbolic_get_f64", "tlpk_set_profile", "tlpk_get_factor", "tlpk_strerror", "tlpk_last_error",
     "tlpk_backend_name", "tlpk_system_name", "tlpk_device_count",
 ]
 
@@ -91,6 +91,8 @@ def lib():
     L.tlpk_solve_finish.argtypes = [vp, vp, vp, vp]
     L.tlpk_info.argtypes = [vp, C.POINTER(Stats)]
     L.tlpk_kernel_timing.argtypes = [vp, C.POINTER(KernelTimes)]
+    L.tlpk_set_profile.argtypes = [vp, C.c_int]
+    L.tlpk_set_profile.restype = C.c_int
     L.tlpk_get_perm.argtypes = [vp, p64]
     L.tlpk_symbolic_get.argtypes = [vp, C.c_char_p, p64, C.c_int64]
     L.tlpk_symbolic_get.restype = C.c_int64

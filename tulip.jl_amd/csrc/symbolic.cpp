@@ -619,6 +619,7 @@ static void build_schedule(Symbolic &S) {
                         // inner update: columns [ki+ni, ko+no), K = [ki, ki+ni)
                         const i32 c0 = ki + ni, c1 = ko + no;
                         if (c0 < c1) {
+                            for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * ni * (double)(w.f - cc);
                             for (i32 j0 = c0; j0 < c1; j0 += TILE)
                                 for (i32 i0 = j0; i0 < w.f; i0 += TILE)
                                     S.update_tasks.push_back(UpdateTask{s, ki, ni, i0, j0, c1, 0, 0});
@@ -628,6 +629,7 @@ static void build_schedule(Symbolic &S) {
                 if (kind == 2 && last_inner) {
                     // outer (trailing) update: columns [ko+no, f), K = [ko, ko+no)
                     const i32 c0 = ko + no;
+                    { const double t = (double)(w.f - c0); S.flops_update += 2.0 * no * t * (t + 1.0) * 0.5; }
                     for (i32 j0 = c0; j0 < w.f; j0 += TILE)
                         for (i32 i0 = j0; i0 < w.f; i0 += TILE)
                             S.update_tasks.push_back(UpdateTask{s, ko, no, i0, j0, w.f, 0, 0});

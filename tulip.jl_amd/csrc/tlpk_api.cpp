@@ -471,6 +471,7 @@ int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
     out->fail_col = h->fail_col;
     out->ms_analyse = h->ms_analyse; out->ms_last_update = h->ms_update; out->ms_last_solve = h->ms_solve;
     out->n_local_blocks = S.n_local_blocks; out->n_blocks = S.nblocks;
+    out->flops_update = S.flops_update;
     out->root_panel_len = (S.root_front >= 0) ? (i64)S.fronts[S.root_front].f * S.fronts[S.root_front].ns : 0;
     return TLPK_OK;
 }
@@ -478,6 +479,14 @@ int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
 int tlpk_kernel_timing(const tlpk_handle *h, tlpk_kernel_times *out) {
     if (!h || !out) return TLPK_BADARG;
     *out = h->kt;
+    return TLPK_OK;
+}
+
+int tlpk_set_profile(tlpk_handle *h, int on) {
+    if (!h) return TLPK_BADARG;
+    h->profile = on != 0;
+    h->ev_used = 0; h->ev_class.clear();
+    std::memset(&h->kt, 0, sizeof(h->kt));
     return TLPK_OK;
 }
 

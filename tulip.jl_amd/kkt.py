@@ -130,6 +130,33 @@ class HIPNormalEquations:
         _lib.lib().tlpk_kernel_timing(self._h, C.byref(kt))
         return kt.as_dict()
 
+    def set_profile(self, on):
+        _lib.lib().tlpk_set_profile(self._h, int(bool(on)))
+
+    # -- split-phase entry points for block-angular sharding (include/tlpk.h) --
+    def update_local(self, d_theta, d_regP, d_regD):
+        _raise_for(_lib.lib().tlpk_update_local(self._h, d_theta, d_regP, d_regD), self._h)
+
+    def update_finish(self):
+        _raise_for(_lib.lib().tlpk_update_finish(self._h), self._h)
+
+    def solve_local(self, d_xip, d_xid):
+        _raise_for(_lib.lib().tlpk_solve_local(self._h, d_xip, d_xid), self._h)
+
+    def solve_finish(self, d_dx, d_dy, d_xid):
+        _raise_for(_lib.lib().tlpk_solve_finish(self._h, d_dx, d_dy, d_xid), self._h)
+
+    def root_panel(self):
+        """(device address, count) of the root (linking) panel to all-reduce after update_local."""
+        p = C.c_void_p(); n = C.c_int64()
+        _raise_for(_lib.lib().tlpk_root_panel(self._h, C.byref(p), C.byref(n)), self._h)
+        return (p.value or 0), n.value
+
+    def root_rhs(self):
+        p = C.c_void_p(); n = C.c_int64()
+        _raise_for(_lib.lib().tlpk_root_rhs(self._h, C.byref(p), C.byref(n)), self._h)
+        return (p.value or 0), n.value
+
     def perm(self):
         p = np.empty(self.m, dtype=np.int64)
         _lib.lib().tlpk_get_perm(self._h, _lib.as_p64(p))

@@ -1,0 +1,53 @@
+"""Synthetic LP constraint matrices for bench.py and the tests (BASELINE.json `configs`,
+SURVEY.md section 8d).  Pure numpy/scipy, seeded, no reference code involved."""
+import numpy as np
+import scipy.sparse as sp
+
+SEED = 20260927
+
+
+def sparse_columns(m, n, nnz_per_col, rng):
+    """m x n CSC, ~nnz_per_col N(0,1) entries per column at uniform rows (vectorised; the rare
+    duplicate row inside a column is summed, so a column may have one entry fewer)."""
+    k = min(nnz_per_col, m)
+    rows = rng.integers(0, m, size=(n, k)).ravel()
+    cols = np.repeat(np.arange(n), k)
+    A = sp.csc_matrix((rng.standard_normal(n * k), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+def block_angular_lp(nblocks=64, mk=5000, nk=10000, m0=1000, nnz_in=4, link_prob=0.5, seed=SEED,
+                     blocks=None):
+    """Config C4: `nblocks` diagonal blocks A_k (mk x nk, nnz_in per column, equality rows) and
+    m0 linking rows; each column touches one linking row w.p. link_prob (SURVEY.md 8d proposal,
+    seed + k per block).  `blocks` restricts generation to a subset of block ids (same content
+    per block as in the full problem).  Returns (A csc, row_block) with linking rows last."""
+    ids = list(range(nblocks)) if blocks is None else list(blocks)
+    diag, link = [], []
+    for k in ids:
+        rng = np.random.default_rng(seed + k)
+        Ak = sparse_columns(mk, nk, nnz_in, rng)
+        cols = np.nonzero(rng.random(nk) < link_prob)[0]
+        rows = rng.integers(0, max(m0, 1), size=cols.size)
+        vals = rng.standard_normal(cols.size)
+        Bk = sp.csc_matrix((vals, (rows, cols)), shape=(m0, nk)) if m0 > 0 else None
+        diag.append(Ak); link.append(Bk)
+    top = sp.block_diag(diag, format="csc")
+    A = sp.vstack([top, sp.hstack(link, format="csc")], format="csc") if m0 > 0 else top
+    A.sort_indices()
+    row_block = np.concatenate([np.repeat(np.arange(len(ids)), mk), np.full(m0, -1)]).astype(np.int64)
+    return A, row_block
+
+
+def kernel_inputs(m, n, seed=7, regime="mid"):
+    """Kernel-level benchmark inputs: theta_inv = 10^U(-3,3), regP = regD = 1e-4
+    ('mid-IPM'), or 10^U(-8,8) with 5 % exact zeros and regs = sqrt(eps) ('late')."""
+    rng = np.random.default_rng(seed)
+    if regime == "mid":
+        th = 10.0 ** rng.uniform(-3, 3, n); rp = np.full(n, 1e-4); rd = np.full(m, 1e-4)
+    else:
+        th = 10.0 ** rng.uniform(-8, 8, n); th[rng.random(n) < 0.05] = 0.0
+        e = float(np.sqrt(np.finfo(float).eps)); rp = np.full(n, e); rd = np.full(m, e)
+    return th, rp, rd, rng.standard_normal(m), rng.standard_normal(n)
