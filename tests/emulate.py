@@ -30,11 +30,11 @@ class Emulator:
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 3),
             LK["TRSM"]: g("trsm_tasks").reshape(-1, 4),
             LK["UPDATE"]: g("update_tasks").reshape(-1, 6),
-            LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 4),
-            LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 4),
-            LK["FWD_UPDATE"]: g("fwd_update_tasks").reshape(-1, 4),
-            LK["BWD_UPDATE"]: g("bwd_update_tasks").reshape(-1, 4),
-            LK["BWD_DIAG"]: g("bwd_diag_tasks").reshape(-1, 4),
+            LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 6),
+            LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 6),
+            LK["FWD_UPDATE"]: g("fwd_update_tasks").reshape(-1, 6),
+            LK["BWD_UPDATE"]: g("bwd_update_tasks").reshape(-1, 6),
+            LK["BWD_DIAG"]: g("bwd_diag_tasks").reshape(-1, 6),
         }
         self.factor_launches = g("factor_launches").reshape(-1, 3)
         self.fwd_launches = g("fwd_launches").reshape(-1, 3)
@@ -191,13 +191,13 @@ class Emulator:
 
     def _k5(self, T):      # fwd diag
         import scipy.linalg as sla
-        for front, k0, nb, _ in T:
+        for front, k0, nb, *_ in T:
             P = self.panel(front); c0 = int(self.col0[front])
             L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
             self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11, self.xw[c0 + k0: c0 + k0 + nb], lower=True)
 
     def _k6(self, T):      # fwd update
-        for front, k0, nb, row0 in T:
+        for front, k0, nb, row0, *_ in T:
             P = self.panel(front); c0 = int(self.col0[front])
             f, ns = int(self.f[front]), int(self.ns[front])
             r1 = min(row0 + 256, f)
@@ -210,20 +210,26 @@ class Emulator:
                 else:
                     self.uc[front][r - ns] -= acc[t]
 
-    def _k7(self, T):      # bwd update
-        for front, k0, nb, row0 in T:
+    def _k7(self, T):      # bwd update: partial sums per row chunk
+        if not hasattr(self, "bpart"):
+            self.bpart = {}
+        for front, k0, nb, row0, slot, _ in T:
             P = self.panel(front); c0 = int(self.col0[front])
             f, ns = int(self.f[front]), int(self.ns[front])
             rows = self.rows(front)
             xf = np.concatenate([self.xw[c0: c0 + ns], self.xw[rows[ns:]]])
-            self.xw[c0 + k0: c0 + k0 + nb] -= P[row0:f, k0:k0 + nb].T @ xf[row0:f]
+            r1 = min(row0 + 256, f)
+            self.bpart[int(slot)] = P[row0:r1, k0:k0 + nb].T @ xf[row0:r1]
 
     def _k8(self, T):      # bwd diag
         import scipy.linalg as sla
-        for front, k0, nb, _ in T:
+        for front, k0, nb, _, slot, nslot in T:
             P = self.panel(front); c0 = int(self.col0[front])
             L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
-            self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11.T, self.xw[c0 + k0: c0 + k0 + nb], lower=False)
+            x = self.xw[c0 + k0: c0 + k0 + nb].copy()
+            for sl in range(int(slot), int(slot) + int(nslot)):
+                x -= self.bpart.pop(sl)          # pop: every slot is consumed exactly once
+            self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11.T, x, lower=False)
 
     # dense L in permuted numbering, from the panels
     def dense_L(self):

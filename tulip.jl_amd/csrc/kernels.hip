@@ -177,10 +177,12 @@ __global__ __launch_bounds__(256) void k_trsm(const TrsmTask *__restrict__ tasks
 // ------------------------------------------------------------------------------------------
 constexpr int UPD_KT = 16;                 // K depth staged per LDS round
 constexpr int UPD_LD = TILE + 16;          // LDS row stride (doubles), == 16 mod 32: conflict-free b64 reads
+constexpr int UPD_NLD = UPD_KT / 2;        // staging loads per thread per operand per round
 
 __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict__ tasks, DevCtx c) {
-    __shared__ double As[UPD_KT * UPD_LD];  // As[k][r] = P[i0 + r, k0 + kk + k]  (row tile)
-    __shared__ double Bs[UPD_KT * UPD_LD];  // Bs[k][r] = P[j0 + r, k0 + kk + k]  (column tile)
+    // double-buffered K-slabs: slab t+1 travels global -> registers while slab t is multiplied
+    __shared__ double As[2][UPD_KT * UPD_LD];  // As[.][k][r] = P[i0 + r, k0 + kk + k]  (row tile)
+    __shared__ double Bs[2][UPD_KT * UPD_LD];  // Bs[.][k][r] = P[j0 + r, k0 + kk + k]  (column tile)
     const UpdateTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
@@ -211,29 +213,46 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
 
     const int lr = lane & 15, lk = lane >> 4;
     const int sr = tid & 127, sk0 = tid >> 7;       // staging: row sr, k = sk0 + 2*it
-    for (i32 kk = 0; kk < t.kw; kk += UPD_KT) {
-        // stage K-slab [kk, kk+16) of both tiles (zero-filled outside the front / K range)
-        {
-            const i32 ra = t.i0 + sr, rb = t.j0 + sr;
+    const i32 ra = t.i0 + sr, rb_ = t.j0 + sr;
+    const bool raok = ra < f, rbok = (rb_ < f) && !diag_tile;
+    double pa[UPD_NLD], pb[UPD_NLD];
+
+    auto load_slab = [&](i32 kk) {
 #pragma unroll
-            for (int it = 0; it < UPD_KT / 2; ++it) {
-                const int k = sk0 + 2 * it;
-                const bool kok = (kk + k) < t.kw;
-                const i64 coff = (i64)(t.k0 + kk + k) * f;
-                As[k * UPD_LD + sr] = (kok && ra < f) ? P[coff + ra] : 0.0;
-                if (!diag_tile) Bs[k * UPD_LD + sr] = (kok && rb < f) ? P[coff + rb] : 0.0;
-            }
+        for (int it = 0; it < UPD_NLD; ++it) {
+            const int k = sk0 + 2 * it;
+            const bool kok = (kk + k) < t.kw;
+            const i64 coff = (i64)(t.k0 + kk + k) * f;
+            pa[it] = (kok && raok) ? P[coff + ra] : 0.0;
+            pb[it] = (kok && rbok) ? P[coff + rb_] : 0.0;
         }
-        __syncthreads();
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < UPD_NLD; ++it) {
+            const int k = sk0 + 2 * it;
+            As[buf][k * UPD_LD + sr] = pa[it];
+            if (!diag_tile) Bs[buf][k * UPD_LD + sr] = pb[it];
+        }
+    };
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    int cur = 0;
+    for (i32 kk = 0; kk < t.kw; kk += UPD_KT) {
+        const bool more = (kk + UPD_KT) < t.kw;
+        if (more) load_slab(kk + UPD_KT);           // in flight during the MFMA block below
         if (any) {
-            const double *Bt = diag_tile ? As : Bs;
+            const double *At = As[cur];
+            const double *Bt = diag_tile ? As[cur] : Bs[cur];
 #pragma unroll
             for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
                 double av[4], bv[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) av[a] = Bt[(k4 + lk) * UPD_LD + wc * 64 + a * 16 + lr];   // column tile rows
 #pragma unroll
-                for (int b = 0; b < 4; ++b) bv[b] = As[(k4 + lk) * UPD_LD + wr * 64 + b * 16 + lr];   // row tile rows
+                for (int b = 0; b < 4; ++b) bv[b] = At[(k4 + lk) * UPD_LD + wr * 64 + b * 16 + lr];   // row tile rows
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -242,7 +261,9 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
                             acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
             }
         }
+        if (more) store_slab(cur ^ 1);
         __syncthreads();
+        cur ^= 1;
     }
     if (!any) return;
     // epilogue: D[i][j] (reg q: i = lk + 4q, j = lr) = sum_k P[jbase+16a+i, k] * P[ibase+16b+j, k]
@@ -271,22 +292,27 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
 // ------------------------------------------------------------------------------------------
 // xw[ii] = xi_p[i] + sum_j A[i,j] D_j xi_d[j],  i = perm[ii].  Sharded runs: a rank sums only its
 // own columns and only rank 0 adds xi_p on linking rows (the all-reduce completes the sum).
-__global__ void k_rhs(i64 m, const i32 *__restrict__ perm, const i64 *__restrict__ Tp,
+__global__ __launch_bounds__(256) void k_rhs(i64 m, const i32 *__restrict__ perm, const i64 *__restrict__ Tp,
                       const i32 *__restrict__ Tj, const double *__restrict__ Tx,
                       const double *__restrict__ D, const double *__restrict__ xi_p,
                       const double *__restrict__ xi_d, const char *__restrict__ row_local,
                       const char *__restrict__ col_local, int rank, double *__restrict__ xw) {
-    const i64 ii = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per row (linking rows are long); fixed shuffle-tree reduction
+    const i64 ii = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (ii >= m) return;
     const i32 i = perm[ii];
     const char rl = row_local[i];
-    if (rl == 0) { xw[ii] = 0.0; return; }
-    double s = (rl == 2 && rank != 0) ? 0.0 : xi_p[i];
-    for (i64 q = Tp[i]; q < Tp[i + 1]; ++q) {
-        const i32 j = Tj[q];
-        if (col_local[j]) s += Tx[q] * (D[j] * xi_d[j]);
+    double s = 0.0;
+    if (rl != 0) {
+        for (i64 q = Tp[i] + lane; q < Tp[i + 1]; q += 64) {
+            const i32 j = Tj[q];
+            if (col_local[j]) s += Tx[q] * (D[j] * xi_d[j]);
+        }
     }
-    xw[ii] = s;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) xw[ii] = (rl == 0) ? 0.0 : (((rl == 2 && rank != 0) ? 0.0 : xi_p[i]) + s);
 }
 
 // forward gather: uc_s = 0; then children's contribution vectors are added into the front's
@@ -312,20 +338,22 @@ __global__ __launch_bounds__(256) void k_fwd_gather(const SolveTask *__restrict_
     }
 }
 
-// forward diagonal block: y = L11^{-1} y for one nb x nb block (one wave, y in registers).
-__global__ __launch_bounds__(64) void k_fwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
+// forward diagonal block: y = L11^{-1} y for one nb x nb block.  All four waves stage the block
+// into LDS, wave 0 runs the substitution with y held one entry per lane.
+__global__ __launch_bounds__(256) void k_fwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
     constexpr int LD = SOLVE_NB + 1;
     __shared__ double Ls[SOLVE_NB * LD];
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, nb = t.nb;
     const double *P = c.Lval + fd.loff + (i64)t.k0 + (i64)t.k0 * f;
-    const int lane = threadIdx.x;
-    for (i32 col = 0; col < nb; ++col)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (i32 col = wave; col < nb; col += 4)
         if (lane < nb && lane >= col) Ls[col * LD + lane] = P[(i64)lane + (i64)col * f];
+    __syncthreads();
+    if (wave != 0) return;
     double *xs = c.xw + fd.col0 + t.k0;
     double y = (lane < nb) ? xs[lane] : 0.0;
-    __syncthreads();
     for (i32 j = 0; j < nb; ++j) {
         const double yj = __shfl(y, j) / Ls[j * LD + j];
         if (lane == j) y = yj;
@@ -351,42 +379,53 @@ __global__ __launch_bounds__(256) void k_fwd_update(const SolveTask *__restrict_
     else c.uc[fd.ucoff + (r - ns)] -= acc;
 }
 
-// backward update: x[k0+j] -= sum_{r >= row0} L[r, k0+j] * x_front[r]; one wave per column,
-// shuffle-tree reduction (fixed order).  blockDim = 256: wave w takes columns w, w+4, ...
+// backward update: partial sums  part[slot][j] = sum_{r in chunk} L[r, k0+j] * x_front[r]  for one
+// chunk of BWD_ROWS rows below the block; wave w takes columns w, w+4, ...; shuffle-tree
+// reduction (fixed order).  The diagonal task adds the chunks' partials in slot order.
 __global__ __launch_bounds__(256) void k_bwd_update(const SolveTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double xs[BWD_ROWS];
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, nb = t.nb;
-    const double *P = c.Lval + fd.loff + (i64)t.k0 * f;
     const i32 *rows = c.rowidx + fd.rowoff;
+    const i32 nr = min(BWD_ROWS, f - t.row0);
+    for (i32 i = threadIdx.x; i < nr; i += 256) {
+        const i32 r = t.row0 + i;
+        xs[i] = (r < ns) ? c.xw[fd.col0 + r] : c.xw[rows[r]];
+    }
+    __syncthreads();
+    const double *P = c.Lval + fd.loff + (i64)t.k0 * f + t.row0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *part = c.bpart + (i64)t.slot * SOLVE_NB;
     for (i32 j = wave; j < nb; j += 4) {
         const double *col = P + (i64)j * f;
         double acc = 0.0;
-        for (i32 r = t.row0 + lane; r < f; r += 64) {
-            const double xv = (r < ns) ? c.xw[fd.col0 + r] : c.xw[rows[r]];
-            acc += col[r] * xv;
-        }
+        for (i32 i = lane; i < nr; i += 64) acc += col[i] * xs[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-        if (lane == 0) c.xw[fd.col0 + t.k0 + j] -= acc;
+        if (lane == 0) part[j] = acc;
     }
 }
 
-// backward diagonal block: x = L11^{-T} x (one wave).
-__global__ __launch_bounds__(64) void k_bwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
+// backward diagonal block: x = L11^{-T} (x - sum of the chunks' partial sums).
+__global__ __launch_bounds__(256) void k_bwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
     constexpr int LD = SOLVE_NB + 1;
     __shared__ double Ls[SOLVE_NB * LD];
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, nb = t.nb;
     const double *P = c.Lval + fd.loff + (i64)t.k0 + (i64)t.k0 * f;
-    const int lane = threadIdx.x;
-    for (i32 col = 0; col < nb; ++col)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (i32 col = wave; col < nb; col += 4)
         if (lane < nb && lane >= col) Ls[col * LD + lane] = P[(i64)lane + (i64)col * f];
+    __syncthreads();
+    if (wave != 0) return;
     double *xs = c.xw + fd.col0 + t.k0;
     double x = (lane < nb) ? xs[lane] : 0.0;
-    __syncthreads();
+    if (lane < nb) {
+        const double *part = c.bpart + (i64)t.slot * SOLVE_NB + lane;
+        for (i32 s = 0; s < t.nslot; ++s) x -= part[(i64)s * SOLVE_NB];
+    }
     for (i32 j = nb - 1; j >= 0; --j) {
         const double xj = __shfl(x, j) / Ls[j * LD + j];
         if (lane == j) x = xj;
@@ -438,16 +477,16 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     case LK_TRSM: hipLaunchKernelGGL(k_trsm, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
     case LK_UPDATE: hipLaunchKernelGGL(k_update, g, dim3(256), 0, st, a.update_tasks + L.first, a.ctx); break;
     case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;
-    case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(64), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
+    case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(256), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
     case LK_FWD_UPDATE: hipLaunchKernelGGL(k_fwd_update, g, dim3(256), 0, st, a.fwd_update_tasks + L.first, a.ctx); break;
     case LK_BWD_UPDATE: hipLaunchKernelGGL(k_bwd_update, g, dim3(256), 0, st, a.bwd_update_tasks + L.first, a.ctx); break;
-    case LK_BWD_DIAG: hipLaunchKernelGGL(k_bwd_diag, g, dim3(64), 0, st, a.bwd_diag_tasks + L.first, a.ctx); break;
+    case LK_BWD_DIAG: hipLaunchKernelGGL(k_bwd_diag, g, dim3(256), 0, st, a.bwd_diag_tasks + L.first, a.ctx); break;
     default: break;
     }
 }
 void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank) {
     if (a.m > 0)
-        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, D, xi_p, xi_d,
+        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 64, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, D, xi_p, xi_d,
                            a.row_local, a.col_local, rank, a.ctx.xw);
 }
 void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy) {

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -216,24 +217,26 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     for (i32 k = 0; k < m; ++k) if (S.parent[k] != -1 && S.parent[k] <= k) return fail(S, TLPK_INTERNAL, "etree not topological");
     const i32 first_link = m - nlink;
 
-    // ---- 6. permuted lower pattern of S ----
-    S.Sp.assign((size_t)m + 1, 0);
-    for (i32 kk = 0; kk < m; ++kk) {
-        const i32 k = S.perm[kk];
-        i64 c = 1;
-        for (i64 p = xadj[k]; p < xadj[k + 1]; ++p) if (S.iperm[adj[p]] > kk) ++c;
-        S.Sp[kk + 1] = S.Sp[kk] + c;
-    }
-    S.nnzS = S.Sp[m];
-    S.Si.resize((size_t)S.nnzS);
-    for (i32 kk = 0; kk < m; ++kk) {
-        const i32 k = S.perm[kk];
-        i64 q = S.Sp[kk];
-        S.Si[q++] = kk;
-        for (i64 p = xadj[k]; p < xadj[k + 1]; ++p) { const i32 ii = S.iperm[adj[p]]; if (ii > kk) S.Si[q++] = ii; }
-        std::sort(S.Si.begin() + S.Sp[kk] + 1, S.Si.begin() + q);
-    }
-    { std::vector<i32>().swap(adj); std::vector<i64>().swap(xadj); }
+    // ---- 6. permuted lower pattern of S (rebuilt if the amalgamation re-orders columns) ----
+    auto build_pattern = [&]() {
+        S.Sp.assign((size_t)m + 1, 0);
+        for (i32 kk = 0; kk < m; ++kk) {
+            const i32 k = S.perm[kk];
+            i64 c = 1;
+            for (i64 p = xadj[k]; p < xadj[k + 1]; ++p) if (S.iperm[adj[p]] > kk) ++c;
+            S.Sp[kk + 1] = S.Sp[kk] + c;
+        }
+        S.nnzS = S.Sp[m];
+        S.Si.resize((size_t)S.nnzS);
+        for (i32 kk = 0; kk < m; ++kk) {
+            const i32 k = S.perm[kk];
+            i64 q = S.Sp[kk];
+            S.Si[q++] = kk;
+            for (i64 p = xadj[k]; p < xadj[k + 1]; ++p) { const i32 ii = S.iperm[adj[p]]; if (ii > kk) S.Si[q++] = ii; }
+            std::sort(S.Si.begin() + S.Sp[kk] + 1, S.Si.begin() + q);
+        }
+    };
+    build_pattern();
 
     // ---- 7. column counts (Gilbert, Ng & Peyton 1994: row-subtree leaves + LCA by union-find) ----
     {
@@ -279,9 +282,9 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         S.nnzL += S.colcount[j]; S.flops_chol += (double)S.colcount[j] * (double)S.colcount[j];
     }
 
-    // ---- 8. supernodes ----
-    // start[s] = first column.  Fundamental rule: j joins j-1 when parent[j-1] == j and the
-    // structures nest exactly (count[j-1] == count[j] + 1).  Linking columns form one root front.
+    // ---- 8. fundamental supernodes ----
+    // start[s] = first column.  j joins j-1 when parent[j-1] == j and the structures nest exactly
+    // (count[j-1] == count[j] + 1).  Linking columns form one forced root front.
     std::vector<i32> sn_start;
     for (i32 j = 0; j < m; ++j) {
         bool join = false;
@@ -293,68 +296,25 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         if (!join) sn_start.push_back(j);
     }
     sn_start.push_back(m);
-    i32 ns_total = (i32)sn_start.size() - 1;
+    i32 ns_total = 0;
+    std::vector<i32> sparent;
 
-    // relaxed amalgamation: merge a supernode into its parent when it is the parent's last child
-    // (columns adjacent) and the explicit zeros this introduces stay small.
-    std::vector<i32> sn_rows_count(ns_total);       // front order f of each supernode
-    for (i32 s = 0; s < ns_total; ++s) sn_rows_count[s] = S.colcount[sn_start[s]];
-    if (nlink) sn_rows_count[ns_total - 1] = nlink;
-    if (opt.relax && ns_total > 1) {
-        // process in order; keep a stack-free greedy pass: try to merge s into s+1 repeatedly
-        std::vector<i32> st, fr;                     // merged starts / front orders
-        std::vector<double> zeros;                   // explicit zeros accumulated in each merged node
-        for (i32 s = 0; s < ns_total; ++s) {
-            st.push_back(sn_start[s]); fr.push_back(sn_rows_count[s]); zeros.push_back(0.0);
-            // try merging the top of the stack into nothing yet; merging happens when the parent arrives
-            while (st.size() >= 2) {
-                const size_t c = st.size() - 2, p = st.size() - 1;
-                const i32 c0 = st[c], p0 = st[p];
-                const i32 p_end = sn_start[s + 1];
-                if (nlink && p0 >= first_link) break;                         // never merge into the root
-                if (S.parent[p0 - 1] < p0 || S.parent[p0 - 1] >= p_end) break;  // child's parent not in p
-                const i32 nc = p0 - c0, np = p_end - p0;
-                const double fc = fr[c], fp = fr[p];
-                // new front: columns nc+np, rows nc + fp
-                const double newz = zeros[c] + zeros[p] + (double)nc * ((double)nc + fp - fc);
-                const double total = ((double)nc + np) * ((double)nc + fp);
-                const i32 width = nc + np;
-                bool ok;
-                if (nc + fp - fc == 0) ok = true;                             // no new zeros at all
-                else if (width <= 4) ok = true;
-                else if (width <= 16) ok = newz <= 0.8 * total;
-                else if (width <= 48) ok = newz <= 0.1 * total;
-                else ok = newz <= 0.05 * total;
-                if (!ok) break;
-                fr[c] = (i32)(nc + fp); zeros[c] = newz;
-                st.pop_back(); fr.pop_back(); zeros.pop_back();
-                // merged node now spans [c0, p_end); continue trying with its new predecessor
-            }
-        }
-        st.push_back(m);
-        sn_start.swap(st);
+    // ---- 9. supernodal tree and front row structures (for a given column partition) ----
+    auto build_fronts = [&]() -> int {
         ns_total = (i32)sn_start.size() - 1;
-    }
-    S.nsuper = ns_total;
-    S.sn_of_col.resize(m);
-    for (i32 s = 0; s < ns_total; ++s) for (i32 j = sn_start[s]; j < sn_start[s + 1]; ++j) S.sn_of_col[j] = s;
-
-    // ---- 9. supernodal tree and front row structures ----
-    S.fronts.assign(ns_total, FrontDesc{});
-    std::vector<i32> sparent(ns_total, -1);
-    for (i32 s = 0; s < ns_total; ++s) {
-        const i32 last = sn_start[s + 1] - 1;
-        // parent column of the supernode: the etree parent of its last column that lies outside it
-        i32 pc = S.parent[last];
-        sparent[s] = (pc == -1) ? -1 : S.sn_of_col[pc];
-        if (sparent[s] != -1 && sparent[s] <= s) return fail(S, TLPK_INTERNAL, "supernodal tree not topological");
-    }
-    // with relaxed merging a merged supernode may contain columns whose etree parent leaves the
-    // supernode before the last column does; the union construction below keeps rows correct
-    // because every column's structure is folded in explicitly.
-    std::vector<i32> nchild(ns_total, 0);
-    for (i32 s = 0; s < ns_total; ++s) if (sparent[s] != -1) nchild[sparent[s]]++;
-    {
+        S.nsuper = ns_total;
+        S.sn_of_col.resize(m);
+        for (i32 s = 0; s < ns_total; ++s) for (i32 j = sn_start[s]; j < sn_start[s + 1]; ++j) S.sn_of_col[j] = s;
+        S.fronts.assign(ns_total, FrontDesc{});
+        sparent.assign(ns_total, -1);
+        for (i32 s = 0; s < ns_total; ++s) {
+            // parent front: the one holding the etree parent of the supernode's last column
+            const i32 pc = S.parent[sn_start[s + 1] - 1];
+            sparent[s] = (pc == -1) ? -1 : S.sn_of_col[pc];
+            if (sparent[s] != -1 && sparent[s] <= s) return fail(S, TLPK_INTERNAL, "supernodal tree not topological");
+        }
+        std::vector<i32> nchild(ns_total, 0);
+        for (i32 s = 0; s < ns_total; ++s) if (sparent[s] != -1) nchild[sparent[s]]++;
         i32 acc = 0;
         for (i32 s = 0; s < ns_total; ++s) { S.fronts[s].child_ptr = acc; S.fronts[s].nchild = 0; acc += nchild[s]; }
         S.children.assign(acc, -1);
@@ -362,11 +322,11 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
             FrontDesc &p = S.fronts[sparent[s]];
             S.children[p.child_ptr + p.nchild++] = s;
         }
-    }
-    {
+        // rows(s) = cols(s) ++ sorted union of the below-diagonal structure of every column of s
+        // and of the children's rows; merged (relaxed) supernodes carry explicit zeros.
         std::vector<i32> mark(m, -1), tmp;
-        std::vector<i64> rowoff(ns_total + 1, 0);
         S.rowidx.clear();
+        S.max_front = 0;
         for (i32 s = 0; s < ns_total; ++s) {
             const i32 j0 = sn_start[s], j1 = sn_start[s + 1] - 1;
             tmp.clear();
@@ -377,8 +337,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
                 }
             const FrontDesc &fd = S.fronts[s];
             for (i32 t = 0; t < fd.nchild; ++t) {
-                const i32 c = S.children[fd.child_ptr + t];
-                const FrontDesc &cd = S.fronts[c];
+                const FrontDesc &cd = S.fronts[S.children[fd.child_ptr + t]];
                 for (i64 q = cd.rowoff + cd.ns; q < cd.rowoff + cd.f; ++q) {
                     const i32 i = S.rowidx[q];
                     if (i > j1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
@@ -395,13 +354,97 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
             S.rowidx.insert(S.rowidx.end(), tmp.begin(), tmp.end());
             if (w.f < S.colcount[j0]) return fail(S, TLPK_INTERNAL, "front smaller than its first column count");
             if (!tmp.empty() && sparent[s] == -1) return fail(S, TLPK_INTERNAL, "root front with rows below");
-            if (!tmp.empty() && S.sn_of_col[tmp[0]] != sparent[s]) {
-                // the first below-row must belong to the parent front
-                return fail(S, TLPK_INTERNAL, "first below-row is not in the parent front");
-            }
+            if (!tmp.empty() && S.sn_of_col[tmp[0]] != sparent[s]) return fail(S, TLPK_INTERNAL, "first below-row is not in the parent front");
             S.max_front = std::max<i64>(S.max_front, w.f);
         }
+        return TLPK_OK;
+    };
+    { const int rc = build_fronts(); if (rc != TLPK_OK) return rc; }
+
+    // ---- 9b. relaxed amalgamation (any child, not only the adjacent one) ----
+    // A child front c is merged into its parent p when either the explicit zeros stay small
+    // (CHOLMOD-style width classes) or -- the multifrontal criterion -- padding c's ns_c columns
+    // to the parent's rows costs fewer flops than shipping its rs_c x rs_c update matrix through
+    // HBM would cost in time (extra_flops < GAMMA * rs_c^2, GAMMA ~ flop rate x bytes per entry /
+    // bandwidth) without growing memory.  Merged members become contiguous by re-ordering the
+    // columns with another topological order of the same elimination tree (identical fill).
+    if (opt.relax && ns_total > 1) {
+        double GAMMA = 25.0;
+        if (const char *e = std::getenv("TLPK_RELAX_GAMMA")) GAMMA = std::atof(e);    // tuning knob
+        const i32 forced_root = nlink ? ns_total - 1 : -1;
+        std::vector<i32> into(ns_total, -1);
+        std::vector<double> cns(ns_total), cf(ns_total), cz(ns_total, 0.0);
+        std::vector<std::vector<i32>> kids(ns_total);
+        for (i32 s = 0; s < ns_total; ++s) {
+            cns[s] = S.fronts[s].ns; cf[s] = S.fronts[s].f;
+            if (sparent[s] != -1) kids[sparent[s]].push_back(s);
+        }
+        bool any_merge = false;
+        for (i32 p = 0; p < ns_total; ++p) {
+            if (p == forced_root || kids[p].empty()) continue;
+            std::vector<i32> cand = kids[p], keep;
+            std::sort(cand.begin(), cand.end(), [&](i32 a, i32 b) { return (cf[a] - cns[a]) > (cf[b] - cns[b]); });
+            for (size_t idx = 0; idx < cand.size(); ++idx) {
+                const i32 c = cand[idx];
+                const double nc = cns[c], fc = cf[c], np = cns[p], fp = cf[p];
+                const double rsc = fc - nc, fnew = nc + fp;
+                const double extra_zeros = nc * (fnew - fc);
+                const double newz = cz[c] + cz[p] + extra_zeros;
+                const double total = (nc + np) * fnew;
+                const double width = nc + np;
+                const bool rule_a = extra_zeros == 0 || width <= 4 || (width <= 16 && newz <= 0.8 * total) ||
+                                    (width <= 48 && newz <= 0.1 * total) || newz <= 0.05 * total;
+                const double extra_flops = nc * (fnew * fnew - fc * fc);
+                const bool rule_b = extra_flops < GAMMA * rsc * rsc && extra_zeros < 0.5 * rsc * rsc;
+                if (rule_a || rule_b) {
+                    into[c] = p; cns[p] += nc; cf[p] = fnew; cz[p] = newz; any_merge = true;
+                    for (i32 g : kids[c]) cand.push_back(g);      // grandchildren now hang off p
+                } else {
+                    keep.push_back(c);
+                }
+            }
+            kids[p].swap(keep);
+        }
+        if (any_merge) {
+            auto root_of = [&](i32 s) { while (into[s] != -1) s = into[s]; return s; };
+            std::vector<std::vector<i32>> members(ns_total);
+            for (i32 s = 0; s < ns_total; ++s) members[root_of(s)].push_back(s);
+            // post-order over the group tree (children groups before the group's own columns)
+            std::vector<i32> newpos(m, -1), new_start;
+            i32 counter = 0;
+            std::vector<std::pair<i32, size_t>> stack;
+            for (i32 r = 0; r < ns_total; ++r) {
+                if (into[r] != -1 || sparent[r] != -1) continue;     // group roots without a parent
+                stack.emplace_back(r, 0);
+                while (!stack.empty()) {
+                    auto &top = stack.back();
+                    const i32 g = top.first;
+                    if (top.second < kids[g].size()) { const i32 ch = kids[g][top.second++]; stack.emplace_back(ch, 0); continue; }
+                    new_start.push_back(counter);
+                    for (i32 mem : members[g])
+                        for (i32 j = sn_start[mem]; j < sn_start[mem + 1]; ++j) newpos[j] = counter++;
+                    stack.pop_back();
+                }
+            }
+            if (counter != m) return fail(S, TLPK_INTERNAL, "amalgamation re-ordering lost columns");
+            new_start.push_back(m);
+            std::vector<i32> perm2(m), parent2(m, -1), cc2(m);
+            for (i32 k = 0; k < m; ++k) {
+                perm2[newpos[k]] = S.perm[k];
+                cc2[newpos[k]] = S.colcount[k];
+                if (S.parent[k] != -1) parent2[newpos[k]] = newpos[S.parent[k]];
+            }
+            S.perm.swap(perm2); S.parent.swap(parent2); S.colcount.swap(cc2);
+            for (i32 k = 0; k < m; ++k) S.iperm[S.perm[k]] = k;
+            for (i32 k = 0; k < m; ++k) if (S.parent[k] != -1 && S.parent[k] <= k) return fail(S, TLPK_INTERNAL, "re-ordered etree not topological");
+            if (nlink) for (i32 k = first_link; k < m; ++k) if (!is_link[S.perm[k]]) return fail(S, TLPK_INTERNAL, "linking rows moved");
+            sn_start.swap(new_start);
+            build_pattern();
+            const int rc = build_fronts();
+            if (rc != TLPK_OK) return rc;
+        }
     }
+    { std::vector<i32>().swap(adj); std::vector<i64>().swap(xadj); }
 
     // ---- 10. depths, levels ----
     S.depth.assign(ns_total, 0);
@@ -651,7 +694,7 @@ static void build_schedule(Symbolic &S) {
                 if (!S.front_local[s]) continue;
                 const FrontDesc &w = S.fronts[s];
                 if (w.nchild == 0 && w.f == w.ns) continue;
-                S.fwd_gather_tasks.push_back(SolveTask{s, 0, 0, 0});
+                S.fwd_gather_tasks.push_back(SolveTask{s, 0, 0, 0, 0, 0, 0, 0});
             }
             push_launch(S.fwd_launches, LK_FWD_GATHER, first, (i64)S.fwd_gather_tasks.size() - first);
         }
@@ -666,14 +709,15 @@ static void build_schedule(Symbolic &S) {
                 const FrontDesc &w = S.fronts[s];
                 if (kb >= w.ns) continue;
                 const i32 nb = std::min(SOLVE_NB, w.ns - kb);
-                S.fwd_diag_tasks.push_back(SolveTask{s, kb, nb, 0});
-                for (i32 r0 = kb + nb; r0 < w.f; r0 += SOLVE_ROWS) S.fwd_update_tasks.push_back(SolveTask{s, kb, nb, r0});
+                S.fwd_diag_tasks.push_back(SolveTask{s, kb, nb, 0, 0, 0, 0, 0});
+                for (i32 r0 = kb + nb; r0 < w.f; r0 += SOLVE_ROWS) S.fwd_update_tasks.push_back(SolveTask{s, kb, nb, r0, 0, 0, 0, 0});
             }
             push_launch(S.fwd_launches, LK_FWD_DIAG, f_diag, (i64)S.fwd_diag_tasks.size() - f_diag);
             push_launch(S.fwd_launches, LK_FWD_UPDATE, f_upd, (i64)S.fwd_update_tasks.size() - f_upd);
         }
     }
     // ---------------- backward solve: root level first ----------------
+    i64 slot_cursor = 0;
     for (i32 d = 0; d < S.nlevels; ++d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
         i32 max_ns = 0;
@@ -691,13 +735,20 @@ static void build_schedule(Symbolic &S) {
                 if (b >= my_nblk) continue;
                 const i32 kb = (my_nblk - 1 - b) * SOLVE_NB;
                 const i32 nb = std::min(SOLVE_NB, w.ns - kb);
-                if (kb + nb < w.f) S.bwd_update_tasks.push_back(SolveTask{s, kb, nb, kb + nb});
-                S.bwd_diag_tasks.push_back(SolveTask{s, kb, nb, 0});
+                // rows below the block are cut into chunks; each chunk writes SOLVE_NB partial sums
+                // into its own slot, the diagonal task adds the slots in order (deterministic)
+                const i32 slot0 = (i32)slot_cursor;
+                i32 nsl = 0;
+                for (i32 r0 = kb + nb; r0 < w.f; r0 += BWD_ROWS, ++nsl)
+                    S.bwd_update_tasks.push_back(SolveTask{s, kb, nb, r0, slot0 + nsl, 0, 0, 0});
+                slot_cursor += nsl;
+                S.bwd_diag_tasks.push_back(SolveTask{s, kb, nb, 0, slot0, nsl, 0, 0});
             }
             push_launch(S.bwd_launches, LK_BWD_UPDATE, f_upd, (i64)S.bwd_update_tasks.size() - f_upd);
             push_launch(S.bwd_launches, LK_BWD_DIAG, f_diag, (i64)S.bwd_diag_tasks.size() - f_diag);
         }
     }
+    S.bpart_len = slot_cursor * SOLVE_NB;
 }
 
 }  // namespace tlpk

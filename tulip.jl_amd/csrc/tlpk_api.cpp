@@ -107,8 +107,9 @@ struct ProfScope {
 };
 void prof_begin(tlpk_handle *h, bool reset) {
     if (!h->profile) return;
-    h->ev_used = 0; h->ev_class.clear();
-    if (reset) std::memset(&h->kt, 0, sizeof(h->kt));
+    // pending (not yet collected) event pairs of earlier async solves stay queued: the pool grows
+    // until the next prof_collect, which runs after a stream synchronisation
+    if (reset) { std::memset(&h->kt, 0, sizeof(h->kt)); h->ev_used = 0; h->ev_class.clear(); }
 }
 void prof_collect(tlpk_handle *h) {          // stream must be synchronised
     if (!h->profile) return;
@@ -180,7 +181,7 @@ int upload_all(tlpk_handle *h) {
 #undef UP
 #define AL(dst, cnt) if ((rc = dev_alloc(h, &(dst), (cnt))) != TLPK_OK) return rc
     AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
-    AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4);
+    AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4); AL(d.ctx.bpart, S.bpart_len);
     AL(h->d_theta, S.n); AL(h->d_regP, S.n); AL(h->d_regD, S.m); AL(h->d_D, S.n);
     AL(h->d_xip, S.m); AL(h->d_xid, S.n); AL(h->d_dx, S.n); AL(h->d_dy, S.m);
 #undef AL
@@ -537,7 +538,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks" || w == "bwd_diag_tasks") {
         const std::vector<SolveTask> &v = (w == "fwd_gather_tasks") ? S.fwd_gather_tasks : (w == "fwd_diag_tasks") ? S.fwd_diag_tasks :
                                           (w == "fwd_update_tasks") ? S.fwd_update_tasks : (w == "bwd_update_tasks") ? S.bwd_update_tasks : S.bwd_diag_tasks;
-        for (auto &t : v) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); }
+        for (auto &t : v) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.slot); tmp.push_back(t.nslot); }
     }
     else if (w == "front_ucoff") field([](const FrontDesc &f) { return f.ucoff; });
     else if (w == "front_uoff") field([](const FrontDesc &f) { return f.uoff; });

@@ -16,6 +16,7 @@ struct DevCtx {
     double *U0, *U1;    // ping-pong update-matrix buffers (by tree depth parity)
     double *uc;         // solve contribution vectors
     double *xw;         // permuted right-hand side / solution
+    double *bpart;      // backward-solve partial sums (SOLVE_NB doubles per slot)
     int *info;          // info[0] = smallest failing pivot column (INT_MAX = none)
 };
 

@@ -20,6 +20,7 @@ constexpr int TRSM_ROWS = 64; // rows per trsm workgroup
 constexpr int EA_COLS = 16;   // parent columns per extend-add workgroup
 constexpr int SOLVE_NB = 64;  // block width of the triangular-solve kernels
 constexpr int SOLVE_ROWS = 256; // rows per forward-update workgroup
+constexpr int BWD_ROWS = 256;   // rows per backward-update workgroup (partial sums, reduced in fixed order)
 
 // ---- device-visible descriptors (plain structs, uploaded as arrays) ----
 struct FrontDesc {
@@ -41,7 +42,7 @@ struct PotrfTask { i32 front, k0, nb, pad; };
 struct TrsmTask  { i32 front, k0, nb, row0; };
 struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, pad0, pad1; };   // tile rows i0.., cols j0..<jlim
 struct EaTask    { i32 front, j0, j1, pad; };                        // parent columns [j0, j1)
-struct SolveTask { i32 front, k0, nb, row0; };
+struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };  // slot: partial-sum slots (backward)
 
 enum LaunchKind : i32 {
     LK_EXTEND_ADD = 0, LK_POTRF, LK_TRSM, LK_UPDATE,
@@ -94,7 +95,7 @@ struct Symbolic {
     std::vector<i32> pair_j;               // j
     std::vector<char> s_local;             // entry assembled by this rank
     // sizes
-    i64 nnzS = 0, nnzL = 0, lval_len = 0, ubuf_len[2] = {0, 0}, uc_len = 0, max_front = 0;
+    i64 nnzS = 0, nnzL = 0, lval_len = 0, ubuf_len[2] = {0, 0}, uc_len = 0, max_front = 0, bpart_len = 0;
     double flops_chol = 0, flops_panel = 0, flops_update = 0;
     // schedules
     std::vector<PotrfTask> potrf_tasks; std::vector<TrsmTask> trsm_tasks;
