@@ -1,0 +1,72 @@
+"""One rank of the GPU sharding test: several ranks share ONE GPU (gpurun boxes have a single
+MI355X), run the real HIP split-phase path, and all-reduce the root panel / rhs through gloo on
+host copies (RCCL refuses two ranks on one device; bench.py uses backend nccl on real multi-GPU
+nodes).  python dist_gpu_worker.py RANK WORLD PORT SEED OUT.npz"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PROBLEM = dict(nblocks=6, mk=300, nk=600, m0=70, nnz_in=3, link_prob=0.5)
+
+
+class _Wrap:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def main():
+    rank, world, port, seed, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import tulip_jl_amd as tk
+    from helpers import block_angular, ipm_like_data
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        A, row_block = block_angular(seed=seed, **PROBLEM)
+        m, n = A.shape
+        th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=row_block, rank=rank, nranks=world))
+        d = [torch.from_numpy(v).to(dev) for v in (th, rp, rd, xp, xd)]
+        d_dx = torch.empty(n, dtype=torch.float64, device=dev)
+        d_dy = torch.empty(m, dtype=torch.float64, device=dev)
+        P = lambda t: t.data_ptr()   # noqa: E731
+
+        def allreduce_device(ptr_count):
+            ptr, count = ptr_count
+            if not count:
+                return
+            t = torch.as_tensor(_Wrap(ptr, count), device=dev)
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h.to(dev))
+            torch.cuda.synchronize()
+
+        kkt.update_local(P(d[0]), P(d[1]), P(d[2]))
+        kkt.sync()
+        allreduce_device(kkt.root_panel())
+        kkt.update_finish()
+        kkt.solve_local(P(d[3]), P(d[4]))
+        kkt.sync()
+        allreduce_device(kkt.root_rhs())
+        kkt.solve_finish(P(d_dx), P(d_dy), P(d[4]))
+        kkt.sync()
+        dx, dy = d_dx.cpu(), d_dy.cpu()
+        link = torch.from_numpy(row_block < 0)
+        dy_link = dy[link].numpy().copy()
+        dy = torch.where(link, dy / world, dy)
+        dist.all_reduce(dx); dist.all_reduce(dy)
+        np.savez(out, dx=dx.numpy(), dy=dy.numpy(), dy_link=dy_link, nloc=kkt.stats()["n_local_blocks"])
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""One rank of the CPU (gloo) sharding test -- launched by tests/test_distributed.py as a plain
+subprocess:  python dist_worker.py RANK WORLD PORT SEED OUT.npz"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PROBLEM = dict(nblocks=5, mk=40, nk=90, m0=14, nnz_in=3, link_prob=0.6)
+
+
+def main():
+    rank, world, port, seed, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # the container hostname may not resolve
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import tulip_jl_amd as tk
+    from emulate import Emulator
+    from helpers import block_angular, ipm_like_data
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A, row_block = block_angular(seed=seed, **PROBLEM)
+        m, n = A.shape
+        th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=-1, row_block=row_block, rank=rank, nranks=world))
+        em = Emulator(kkt)
+        # --- update: local subtrees + partial root panel, all-reduce, root factorisation ---
+        em.update(th, rp, rd, stop_at_marker=True)
+        panel = torch.from_numpy(em.root_panel())          # shares memory with the emulator's Lval
+        dist.all_reduce(panel)
+        em.update_finish()
+        assert em.fail_col is None
+        # --- solve ---
+        em.solve_local(xp, xd, A)
+        rhs = torch.from_numpy(em.root_rhs())
+        dist.all_reduce(rhs)
+        dx, dy = em.solve_finish(xd, A)
+        # assemble the global solution: block rows/cols from their owner, linking rows replicated
+        tdx = torch.from_numpy(dx.copy()); dist.all_reduce(tdx)
+        link = row_block < 0
+        dy_sh = dy.copy(); dy_sh[link] /= world
+        tdy = torch.from_numpy(dy_sh); dist.all_reduce(tdy)
+        own = torch.from_numpy(np.concatenate([(kkt.symbolic("col_local") != 0).astype(np.int64),
+                                               (kkt.symbolic("row_local") == 1).astype(np.int64)]))
+        dist.all_reduce(own)
+        st = kkt.stats()
+        np.savez(out, dx=tdx.numpy(), dy=tdy.numpy(), own=own.numpy(), nloc=st["n_local_blocks"],
+                 rlen=st["root_panel_len"], dy_link=dy[link])
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

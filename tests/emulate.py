@@ -20,6 +20,9 @@ class Emulator:
         self.parent = g("front_parent"); self.loff = g("front_loff"); self.rowoff = g("front_rowoff")
         self.reloff = g("front_reloff"); self.child_ptr = g("front_child_ptr"); self.nchild = g("front_nchild")
         self.local = g("front_local")
+        self.row_local = g("row_local"); self.col_local = g("col_local")
+        self.root_front = int(g("root_front")[0])
+        self.rank = kkt.backend_options.rank
         self.rowidx = g("rowidx"); self.rel = g("rel"); self.children = g("children")
         self.s_target = g("s_target"); self.s_diag_row = g("s_diag_row")
         self.pair_ptr = g("pair_ptr"); self.pair_j = g("pair_j")
@@ -82,7 +85,19 @@ class Emulator:
             self.Lval[self.s_target[e]] = v
         self.U = {}
         self.fail_col = None
-        return self._run(self.factor_launches, stop_at_marker)
+        self._resume = self._run(self.factor_launches, True)
+        if not stop_at_marker:
+            self.update_finish()
+
+    def root_panel(self):
+        """View of the root (linking) panel: what tlpk_root_panel exposes for the all-reduce."""
+        s = self.root_front
+        if s < 0:
+            return self.Lval[:0]
+        return self.Lval[self.loff[s]: self.loff[s] + self.f[s] * self.ns[s]]
+
+    def update_finish(self):
+        self._run(self.factor_launches, False, start=self._resume)
 
     def _run(self, launches, stop_at_marker=False, start=0):
         for li in range(start, len(launches)):
@@ -166,16 +181,34 @@ class Emulator:
             del mask
 
     # ---- solve! ----
-    def solve(self, xi_p, xi_d, A):
-        xi = xi_p + A @ (self.D * xi_d)
+    def solve_local(self, xi_p, xi_d, A):
+        # k_rhs: a rank sums only its own columns; only rank 0 adds xi_p on linking rows
+        Aloc = A @ __import__("scipy.sparse").sparse.diags(self.col_local.astype(float))
+        xi = Aloc @ (self.D * xi_d)
+        rl = self.row_local
+        xi = np.where(rl == 0, 0.0, xi + np.where((rl == 2) & (self.rank != 0), 0.0, xi_p))
         self.xw = xi[self.perm].copy()
         self.uc = {}
-        self._run(self.fwd_launches)
+        self._resume_fwd = self._run(self.fwd_launches, True)
+
+    def root_rhs(self):
+        s = self.root_front
+        if s < 0:
+            return self.xw[:0]
+        return self.xw[self.col0[s]: self.col0[s] + self.ns[s]]
+
+    def solve_finish(self, xi_d, A):
+        self._run(self.fwd_launches, False, start=self._resume_fwd)
         self._run(self.bwd_launches)
-        dy = np.empty(self.m)
+        dy = np.zeros(self.m)
         dy[self.perm] = self.xw
-        dx = self.D * (A.T @ dy - xi_d)
+        dy[self.row_local == 0] = 0.0
+        dx = np.where(self.col_local != 0, self.D * (A.T @ dy - xi_d), 0.0)
         return dx, dy
+
+    def solve(self, xi_p, xi_d, A):
+        self.solve_local(xi_p, xi_d, A)
+        return self.solve_finish(xi_d, A)
 
     def _k4(self, T):      # fwd gather
         for front, *_ in T:

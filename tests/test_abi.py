@@ -1,0 +1,91 @@
+"""The C-ABI library loads on a CPU-only machine and exports every symbol include/tlpk.h declares
+(no compute calls here).  Also: the product package never imports or links the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import tulip_jl_amd as tk
+from tulip_jl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "tlpk.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b(tlpk_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
+
+
+def test_every_declared_symbol_is_exported():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), f"libtlpk.so does not export {n}"
+    # and the Python binding knows about all of them
+    assert set(names) <= set(_lib.EXPORTS), set(names) - set(_lib.EXPORTS)
+
+
+def test_struct_layouts_match_header():
+    opt = _lib.Options()
+    _lib.lib().tlpk_default_options(ctypes.byref(opt))
+    assert opt.struct_size == ctypes.sizeof(_lib.Options)        # the library checks this on create
+    assert opt.nranks == 1 and opt.relax == 1 and opt.ordering == _lib.ORDER_AMD
+
+
+def test_strings_and_error_text():
+    assert tk.backend(None) == "HIP (gfx950)"
+    assert tk.linear_system(None) == "Normal equations (K1)"
+    assert "positive definite" in _lib.strerror(_lib.NOT_POSDEF)
+    assert _lib.lib().tlpk_device_count() >= 0
+
+
+def test_product_does_not_reference_the_oracle():
+    """No CPU fallback: the product sources never mention the oracle, and libtlpk.so does not
+    link it."""
+    pkg = os.path.join(ROOT, "tulip.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".jl")):
+                src = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "k1o_" not in src and "libk1oracle" not in src and "oracle_binding" not in src, fn
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "k1oracle" not in out
+    assert "amdhip64" in out
+
+
+def test_null_and_bad_arguments_return_codes():
+    L = _lib.lib()
+    assert L.tlpk_update(None, None, None, None) == _lib.BADARG
+    h = ctypes.c_void_p()
+    colptr = np.array([0, 1], dtype=np.int64)
+    rowval = np.array([5], dtype=np.int64)              # row index out of range for m = 2
+    nz = np.array([1.0])
+    opt = _lib.Options(); L.tlpk_default_options(ctypes.byref(opt)); opt.device = -1
+    rc = L.tlpk_create(ctypes.byref(h), 2, 1, _lib.as_p64(colptr), _lib.as_p64(rowval), _lib.as_pd(nz), 0, ctypes.byref(opt))
+    assert rc == _lib.BADARG and not h
+    opt.struct_size = 3
+    rc = L.tlpk_create(ctypes.byref(h), 2, 1, _lib.as_p64(colptr), _lib.as_p64(rowval), _lib.as_pd(nz), 0, ctypes.byref(opt))
+    assert rc == _lib.BADARG
+
+
+def test_one_based_indices_like_julia():
+    import scipy.sparse as sp
+    from helpers import random_lp_matrix
+    A = random_lp_matrix(30, 50, 3, 3)
+    k0 = tk.setup(A, tk.K1(), tk.Backend(device=-1))
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    colptr = (A.indptr.astype(np.int64) + 1); rowval = (A.indices.astype(np.int64) + 1)
+    opt = _lib.Options(); L.tlpk_default_options(ctypes.byref(opt)); opt.device = -1
+    rc = L.tlpk_create(ctypes.byref(h), 30, 50, _lib.as_p64(colptr), _lib.as_p64(rowval), _lib.as_pd(A.data), 1, ctypes.byref(opt))
+    assert rc == _lib.OK
+    p = np.empty(30, dtype=np.int64)
+    L.tlpk_get_perm(h, _lib.as_p64(p))
+    assert (p == k0.perm()).all()
+    L.tlpk_destroy(h)

@@ -1,0 +1,65 @@
+"""N > 1 path of the block-angular sharding, on CPU: world_size-2 (and 3) `gloo` processes.
+
+Each rank (tests/dist_worker.py) runs the library's host analyse with its (rank, nranks), then
+executes ITS OWN exported schedule in numpy (tests/emulate.py -- the same task lists the HIP
+kernels replay) up to the all-reduce marker, all-reduces the root panel / root right-hand side
+with torch.distributed, and finishes.  Checked: every rank ends with the oracle's solution of
+the whole LP; ownership is a partition; the split-phase sequence is the one bench.py uses."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_newton_step_matches_oracle(world, tmp_path):
+    from dist_worker import PROBLEM
+    from helpers import block_angular, ipm_like_data
+    from oracle_binding import OracleK1
+    seed = 11
+    port = str(_free_port())
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port,
+                               str(seed), outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("distributed worker timed out")
+        logs.append(out.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    A, row_block = block_angular(seed=seed, **PROBLEM)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
+    orc = OracleK1(A)
+    orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    nloc = []
+    for r in range(world):
+        z = np.load(outs[r])
+        assert np.abs(z["dx"] - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max())
+        assert np.abs(z["dy"] - dyo).max() <= 1e-9 * max(1, np.abs(dyo).max())
+        assert (z["own"] == 1).sum() == n + (row_block >= 0).sum()      # ownership is a partition
+        assert int(z["rlen"]) == PROBLEM["m0"] ** 2
+        assert np.abs(z["dy_link"] - dyo[row_block < 0]).max() <= 1e-9 * max(1, np.abs(dyo).max())  # replicated
+        nloc.append(int(z["nloc"]))
+    assert sum(nloc) == PROBLEM["nblocks"] and all(v >= 1 for v in nloc)

@@ -192,3 +192,44 @@ def test_c4_block_scale_property():
     r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
     scale = 1 + max(np.abs(xp).max(), np.abs(xd).max())
     assert r1 <= 1e-8 * scale * max(1.0, np.abs(dy).max()) and r2 <= 1e-8 * scale * max(1.0, np.abs(dx).max())
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_split_phase_on_device(world, tmp_path):
+    """The multi-rank device path (local subtrees, partial root panel, rank-aware rhs) with
+    `world` ranks sharing this box's single GPU; the collective goes through gloo on host copies
+    (tests/dist_gpu_worker.py).  Every rank must end with the oracle's solution."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from dist_gpu_worker import PROBLEM
+    here = os.path.dirname(os.path.abspath(__file__))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    seed = 13
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "dist_gpu_worker.py"), str(r), str(world), port,
+                               str(seed), outs[r]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("distributed GPU worker timed out")
+        logs.append(o.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    A, row_block = block_angular(seed=seed, **PROBLEM)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
+    orc = OracleK1(A)
+    orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    for r in range(world):
+        z = np.load(outs[r])
+        assert np.abs(z["dx"] - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max())
+        assert np.abs(z["dy"] - dyo).max() <= 1e-9 * max(1, np.abs(dyo).max())
+        assert np.abs(z["dy_link"] - dyo[row_block < 0]).max() <= 1e-9 * max(1, np.abs(dyo).max())

@@ -495,6 +495,18 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         }
     }
 
+    // a rank only ever walks its own children: drop the other ranks' block roots from the
+    // (replicated) root front's child list
+    if (opt.nranks > 1)
+        for (i32 s = 0; s < ns_total; ++s) {
+            FrontDesc &w = S.fronts[s];
+            i32 kept = 0;
+            for (i32 t = 0; t < w.nchild; ++t) {
+                const i32 c = S.children[w.child_ptr + t];
+                if (S.front_local[c]) S.children[w.child_ptr + kept++] = c;
+            }
+            w.nchild = kept;
+        }
     S.col_local.assign(n, 1);
     S.row_local.assign(m, 1);
     if (opt.row_block && opt.nranks > 1) {

@@ -1,0 +1,77 @@
+# libtlpk.jl -- ccall shim over the C ABI of libtlpk.so (include/tlpk.h).
+#
+# Where it goes in Tulip: `src/LinearAlgebra/libtlpk.jl`, included from
+# `src/LinearAlgebra/LinearAlgebra.jl` (reference file: /root/reference/src/LinearAlgebra/LinearAlgebra.jl:1-33).
+# Nothing here touches src/IPM.  No CUDA.jl / AMDGPU.jl: plain `ccall` on a C-ABI shared library.
+#
+# NOTE: Julia is not available in the build or GPU images of this project, so this file has been
+# reviewed by eye against include/tlpk.h but never executed.  It is deliberately mechanical.
+module LibTLPK
+
+using Libdl
+
+const libtlpk = Ref{String}(get(ENV, "TULIP_LIBTLPK", "libtlpk.so"))
+
+# return codes (include/tlpk.h)
+const TLPK_OK = Cint(0)
+const TLPK_NOT_POSDEF = Cint(1)
+const TLPK_BADARG = Cint(2)
+const TLPK_OOM = Cint(3)
+const TLPK_HIPERR = Cint(4)
+const TLPK_NO_DEVICE = Cint(5)
+const TLPK_TOO_LARGE = Cint(6)
+const TLPK_NOT_FACTORED = Cint(7)
+
+# mirror of `tlpk_options` (field order and types must match include/tlpk.h)
+Base.@kwdef mutable struct Options
+    struct_size::Int32 = 0
+    device::Int32 = 0
+    ordering::Int32 = 0          # TLPK_ORDER_AMD
+    relax::Int32 = 1
+    profile::Int32 = 0
+    rank::Int32 = 0
+    nranks::Int32 = 1
+    reserved0::Int32 = 0
+    user_perm::Ptr{Int64} = C_NULL
+    row_block::Ptr{Int64} = C_NULL
+    mem_budget_bytes::Int64 = 0
+end
+
+strerror(code::Integer) = unsafe_string(ccall((:tlpk_strerror, libtlpk[]), Cstring, (Cint,), code))
+last_error(h::Ptr{Cvoid}) = unsafe_string(ccall((:tlpk_last_error, libtlpk[]), Cstring, (Ptr{Cvoid},), h))
+backend_name() = unsafe_string(ccall((:tlpk_backend_name, libtlpk[]), Cstring, ()))
+system_name() = unsafe_string(ccall((:tlpk_system_name, libtlpk[]), Cstring, ()))
+
+"""
+    create(A; device, row_block) -> Ptr{Cvoid}
+
+`tlpk_create`: host analyse (ordering, elimination tree, supernodes) + upload.  `A` is passed
+with its 1-based `colptr`/`rowval` (index_base = 1); the library copies everything.
+"""
+function create(m::Int, n::Int, colptr::Vector{Int}, rowval::Vector{Int}, nzval::Vector{Float64};
+                device::Integer=0, row_block::Union{Nothing,Vector{Int}}=nothing)
+    opt = Options()
+    opt.struct_size = Int32(sizeof(Options))
+    opt.device = Int32(device)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rb = row_block === nothing ? Int[] : row_block
+    rc = GC.@preserve colptr rowval nzval rb opt begin
+        row_block === nothing || (opt.row_block = pointer(rb))
+        ccall((:tlpk_create, libtlpk[]), Cint,
+              (Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Ref{Options}),
+              h, m, n, colptr, rowval, nzval, 1, opt)
+    end
+    return rc, h[]
+end
+
+destroy(h::Ptr{Cvoid}) = ccall((:tlpk_destroy, libtlpk[]), Cvoid, (Ptr{Cvoid},), h)
+
+update(h::Ptr{Cvoid}, θinv::Vector{Float64}, regP::Vector{Float64}, regD::Vector{Float64}) =
+    GC.@preserve θinv regP regD ccall((:tlpk_update, libtlpk[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h, θinv, regP, regD)
+
+solve(h::Ptr{Cvoid}, dx::Vector{Float64}, dy::Vector{Float64}, ξp::Vector{Float64}, ξd::Vector{Float64}) =
+    GC.@preserve dx dy ξp ξd ccall((:tlpk_solve, libtlpk[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h, dx, dy, ξp, ξd)
+
+end  # module
