@@ -108,14 +108,20 @@ def main():
     P = lambda t: t.data_ptr()   # noqa: E731
 
     root_t = rhs_t = None
-    if world > 1:
-        class _Wrap:                      # view library memory as a torch tensor for the collective
-            def __init__(self, ptr, count):
-                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-        p, c = kkt.root_panel()
-        root_t = torch.as_tensor(_Wrap(p, c), device=dev) if c else None
-        p, c = kkt.root_rhs()
-        rhs_t = torch.as_tensor(_Wrap(p, c), device=dev) if c else None
+    if world > 1:                         # torch-owned buffers for the two collectives
+        _, c = kkt.root_panel()
+        root_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
+        _, c = kkt.root_rhs()
+        rhs_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
+
+    def reduce_root(which, buf):
+        if buf is None:
+            return
+        kkt.root_copy(which, "out", P(buf))
+        kkt.sync()
+        dist.all_reduce(buf)
+        torch.cuda.current_stream().synchronize()
+        kkt.root_copy(which, "in", P(buf))
 
     def newton_step():
         if world == 1:
@@ -125,17 +131,11 @@ def main():
             kkt.sync()
         else:
             kkt.update_local(P(d_th), P(d_rp), P(d_rd))
-            kkt.sync()
-            if root_t is not None:
-                dist.all_reduce(root_t)
-                torch.cuda.current_stream().synchronize()
+            reduce_root("panel", root_t)
             kkt.update_finish()
             for _ in range(args.solves):
                 kkt.solve_local(P(d_xp), P(d_xd))
-                kkt.sync()
-                if rhs_t is not None:
-                    dist.all_reduce(rhs_t)
-                    torch.cuda.current_stream().synchronize()
+                reduce_root("rhs", rhs_t)
                 kkt.solve_finish(P(d_dx), P(d_dy), P(d_xd))
             kkt.sync()
 

@@ -133,6 +133,10 @@ int tlpk_update_finish(tlpk_handle *h);
 int tlpk_solve_local(tlpk_handle *h, const double *d_xi_p, const double *d_xi_d);
 int tlpk_root_rhs(tlpk_handle *h, double **d_ptr, int64_t *count);
 int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xi_d);
+/* Copy the root panel (which = 0) or root rhs (which = 1) out of (dir = 0) / into (dir = 1) a
+ * caller-owned device buffer, on the handle's stream -- for callers whose communicator wants to
+ * own the memory it reduces (torch.distributed tensors). */
+int tlpk_root_copy(tlpk_handle *h, int which, int dir, double *d_buf);
 
 /* Introspection */
 int tlpk_info(const tlpk_handle *h, tlpk_stats *out);

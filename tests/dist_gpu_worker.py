@@ -12,11 +12,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PROBLEM = dict(nblocks=6, mk=300, nk=600, m0=70, nnz_in=3, link_prob=0.5)
 
 
-class _Wrap:
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-
 def main():
     rank, world, port, seed, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,23 +34,28 @@ def main():
         d_dy = torch.empty(m, dtype=torch.float64, device=dev)
         P = lambda t: t.data_ptr()   # noqa: E731
 
-        def allreduce_device(ptr_count):
-            ptr, count = ptr_count
+        def allreduce_device(which, count):
+            # torch-owned staging tensor <- library (D2D on the library stream), reduce over gloo on
+            # a host copy (several ranks share this GPU, RCCL needs one device per rank), copy back
             if not count:
                 return
-            t = torch.as_tensor(_Wrap(ptr, count), device=dev)
-            h = t.cpu()
+            buf = torch.empty(count, dtype=torch.float64, device=dev)
+            kkt.root_copy(which, "out", P(buf))
+            kkt.sync()
+            h = buf.cpu()
             dist.all_reduce(h)
-            t.copy_(h.to(dev))
+            buf.copy_(h)
             torch.cuda.synchronize()
+            kkt.root_copy(which, "in", P(buf))
+            kkt.sync()
 
         kkt.update_local(P(d[0]), P(d[1]), P(d[2]))
         kkt.sync()
-        allreduce_device(kkt.root_panel())
+        allreduce_device("panel", kkt.root_panel()[1])
         kkt.update_finish()
         kkt.solve_local(P(d[3]), P(d[4]))
         kkt.sync()
-        allreduce_device(kkt.root_rhs())
+        allreduce_device("rhs", kkt.root_rhs()[1])
         kkt.solve_finish(P(d_dx), P(d_dy), P(d[4]))
         kkt.sync()
         dx, dy = d_dx.cpu(), d_dy.cpu()

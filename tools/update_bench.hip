@@ -1,0 +1,61 @@
+// update_bench.hip -- isolates k_update (the fp64-MFMA panel update) on the shape that dominates
+// config C4: 64 fronts of order f = 4525 with ns = 3530 pivots, trailing update after the first
+// 256-column outer panel.  Build variants with -DUPD_VARIANT=n (see kernels.hip) to ablate.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tulip.jl_amd/csrc tools/update_bench.hip -o tools/update_bench
+#include "../tulip.jl_amd/csrc/kernels.hip"
+#include <cstdio>
+#include <vector>
+using namespace tlpk;
+
+int main(int argc, char **argv) {
+    const int nfronts = argc > 1 ? atoi(argv[1]) : 64;
+    const i32 f = argc > 2 ? atoi(argv[2]) : 4525, ns = argc > 3 ? atoi(argv[3]) : 3530;
+    const i32 k0 = 0, kw = argc > 4 ? atoi(argv[4]) : 256;
+    const i32 rs = f - ns;
+    std::vector<FrontDesc> fr(nfronts);
+    i64 loff = 0, uoff = 0;
+    for (int s = 0; s < nfronts; ++s) {
+        fr[s] = FrontDesc{};
+        fr[s].loff = loff; fr[s].uoff = uoff; fr[s].f = f; fr[s].ns = ns; fr[s].ubuf = 0; fr[s].parent = -1;
+        loff += (i64)f * ns; uoff += (i64)rs * rs;
+    }
+    std::vector<UpdateTask> tasks;
+    double flops = 0;
+    for (int s = 0; s < nfronts; ++s) {
+        const i32 c0 = k0 + kw;
+        const double t = (double)(f - c0);
+        flops += 2.0 * kw * t * (t + 1.0) * 0.5;
+        for (i32 j0 = c0; j0 < f; j0 += TILE)
+            for (i32 i0 = j0; i0 < f; i0 += TILE) tasks.push_back(UpdateTask{s, k0, kw, i0, j0, f, 0, 0});
+    }
+    DevCtx c{};
+    FrontDesc *dfr; UpdateTask *dt; double *L, *U; int *info;
+    hipMalloc(&dfr, sizeof(FrontDesc) * nfronts); hipMemcpy(dfr, fr.data(), sizeof(FrontDesc) * nfronts, hipMemcpyHostToDevice);
+    hipMalloc(&dt, sizeof(UpdateTask) * tasks.size()); hipMemcpy(dt, tasks.data(), sizeof(UpdateTask) * tasks.size(), hipMemcpyHostToDevice);
+    hipMalloc(&L, sizeof(double) * loff); hipMalloc(&U, sizeof(double) * (uoff + 1)); hipMalloc(&info, 16);
+    {   // random-ish fill (not zeros: DVFS) via a tiny kernel-free host pattern
+        std::vector<double> h((size_t)1 << 22);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = ((double)((i * 2654435761u) % 2001) - 1000.0) * 1e-3;
+        for (i64 off = 0; off < loff; off += (i64)h.size())
+            hipMemcpy(L + off, h.data(), sizeof(double) * std::min<i64>((i64)h.size(), loff - off), hipMemcpyHostToDevice);
+        hipMemset(U, 0, sizeof(double) * (uoff + 1));
+    }
+    c.fronts = dfr; c.Lval = L; c.U0 = U; c.U1 = U; c.info = info;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_update, dim3((unsigned)tasks.size()), dim3(256), 0, 0, dt, c);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;
+    }
+    printf("variant %d: fronts=%d f=%d ns=%d kw=%d tiles=%zu : %.3f ms  %.2f TFLOP/s (algorithmic)\n",
+#ifdef UPD_VARIANT
+           UPD_VARIANT,
+#else
+           0,
+#endif
+           nfronts, f, ns, kw, tasks.size(), best, flops / best / 1e9);
+    return 0;
+}

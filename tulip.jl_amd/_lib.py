@@ -55,7 +55,7 @@ EXPORTS = [
     "tlpk_update_device", "tlpk_solve_device", "tlpk_sync", "tlpk_stream", "tlpk_update_local",
     "tlpk_root_panel", "tlpk_update_finish", "tlpk_solve_local", "tlpk_root_rhs",
     "tlpk_solve_finish", "tlpk_info", "tlpk_kernel_timing", "tlpk_get_perm", "tlpk_symbolic_get",
-    "tlpk_symbolic_get_f64", "tlpk_set_profile", "tlpk_get_factor", "tlpk_strerror", "tlpk_last_error",
+    "tlpk_symbolic_get_f64", "tlpk_set_profile", "tlpk_root_copy", "tlpk_get_factor", "tlpk_strerror", "tlpk_last_error",
     "tlpk_backend_name", "tlpk_system_name", "tlpk_device_count",
 ]
 
@@ -89,6 +89,8 @@ def lib():
     L.tlpk_solve_local.argtypes = [vp, vp, vp]
     L.tlpk_root_rhs.argtypes = [vp, C.POINTER(vp), p64]
     L.tlpk_solve_finish.argtypes = [vp, vp, vp, vp]
+    L.tlpk_root_copy.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.tlpk_root_copy.restype = C.c_int
     L.tlpk_info.argtypes = [vp, C.POINTER(Stats)]
     L.tlpk_kernel_timing.argtypes = [vp, C.POINTER(KernelTimes)]
     L.tlpk_set_profile.argtypes = [vp, C.c_int]

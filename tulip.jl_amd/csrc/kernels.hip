@@ -179,32 +179,34 @@ constexpr int UPD_KT = 16;                 // K depth staged per LDS round
 constexpr int UPD_LD = TILE + 16;          // LDS row stride (doubles), == 16 mod 32: conflict-free b64 reads
 constexpr int UPD_NLD = UPD_KT / 2;        // staging loads per thread per operand per round
 
-__global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict__ tasks, DevCtx c) {
-    // double-buffered K-slabs: slab t+1 travels global -> registers while slab t is multiplied
-    __shared__ double As[2][UPD_KT * UPD_LD];  // As[.][k][r] = P[i0 + r, k0 + kk + k]  (row tile)
-    __shared__ double Bs[2][UPD_KT * UPD_LD];  // Bs[.][k][r] = P[j0 + r, k0 + kk + k]  (column tile)
-    const UpdateTask t = tasks[blockIdx.x];
-    const FrontDesc fd = c.fronts[t.front];
+// FULL = interior tile: all 128 rows of both operand tiles exist, the tile lies strictly below
+// the diagonal and inside the column limit, so every 16x16 block is a target and no load needs a
+// guard except the K tail.  The hot loop is then straight-line code: 16 unguarded staging loads,
+// 4 x (8 LDS reads + 16 MFMAs).  Edge and diagonal tiles take the guarded generic path.
+template <bool FULL>
+__device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc &fd, const DevCtx &c,
+                                            double (*As)[UPD_KT * UPD_LD], double (*Bs)[UPD_KT * UPD_LD]) {
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
     const double *P = c.Lval + fd.loff;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR, scalar branches
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int wr = wave >> 1, wc = wave & 1;        // 2 x 2 waves, each a 64 x 64 sub-tile
     const i32 ibase = t.i0 + wr * 64;               // target rows of this wave
     const i32 jbase = t.j0 + wc * 64;               // target cols of this wave
-    const bool diag_tile = (t.i0 == t.j0);
+    const bool diag_tile = !FULL && (t.i0 == t.j0);
 
-    // which 16x16 blocks of the wave's sub-tile hold any target entry
     bool valid[4][4];
-    bool any = false;
+    bool any = FULL;
+    if constexpr (!FULL) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const i32 cb = jbase + a * 16, rb = ibase + b * 16;   // block columns [cb,cb+16), rows [rb,rb+16)
-            valid[a][b] = (rb < f) && (cb < t.jlim) && (rb + 15 >= cb);
-            any |= valid[a][b];
-        }
+            for (int b = 0; b < 4; ++b) {
+                const i32 cb = jbase + a * 16, rb = ibase + b * 16;   // block columns [cb,cb+16), rows [rb,rb+16)
+                valid[a][b] = (rb < f) && (cb < t.jlim) && (rb + 15 >= cb);
+                any |= valid[a][b];
+            }
+    }
     v4f64 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -214,17 +216,25 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
     const int lr = lane & 15, lk = lane >> 4;
     const int sr = tid & 127, sk0 = tid >> 7;       // staging: row sr, k = sk0 + 2*it
     const i32 ra = t.i0 + sr, rb_ = t.j0 + sr;
-    const bool raok = ra < f, rbok = (rb_ < f) && !diag_tile;
+    const bool raok = FULL || (ra < f), rbok = FULL || ((rb_ < f) && !diag_tile);
+    const double *Pa = P + (i64)(t.k0 + sk0) * f + ra;
+    const double *Pb = P + (i64)(t.k0 + sk0) * f + rb_;
     double pa[UPD_NLD], pb[UPD_NLD];
 
-    auto load_slab = [&](i32 kk) {
+    auto load_slab = [&](i32 kk, bool full_k) {
+        if (FULL && full_k) {
 #pragma unroll
-        for (int it = 0; it < UPD_NLD; ++it) {
-            const int k = sk0 + 2 * it;
-            const bool kok = (kk + k) < t.kw;
-            const i64 coff = (i64)(t.k0 + kk + k) * f;
-            pa[it] = (kok && raok) ? P[coff + ra] : 0.0;
-            pb[it] = (kok && rbok) ? P[coff + rb_] : 0.0;
+            for (int it = 0; it < UPD_NLD; ++it) {
+                pa[it] = Pa[(i64)(kk + 2 * it) * f];
+                pb[it] = Pb[(i64)(kk + 2 * it) * f];
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < UPD_NLD; ++it) {
+                const bool kok = (kk + sk0 + 2 * it) < t.kw;
+                pa[it] = (kok && raok) ? Pa[(i64)(kk + 2 * it) * f] : 0.0;
+                pb[it] = (kok && rbok) ? Pb[(i64)(kk + 2 * it) * f] : 0.0;
+            }
         }
     };
     auto store_slab = [&](int buf) {
@@ -232,40 +242,57 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
         for (int it = 0; it < UPD_NLD; ++it) {
             const int k = sk0 + 2 * it;
             As[buf][k * UPD_LD + sr] = pa[it];
-            if (!diag_tile) Bs[buf][k * UPD_LD + sr] = pb[it];
+            if (FULL || !diag_tile) Bs[buf][k * UPD_LD + sr] = pb[it];
         }
     };
 
-    load_slab(0);
+    load_slab(0, UPD_KT <= t.kw);
     store_slab(0);
     __syncthreads();
     int cur = 0;
     for (i32 kk = 0; kk < t.kw; kk += UPD_KT) {
         const bool more = (kk + UPD_KT) < t.kw;
-        if (more) load_slab(kk + UPD_KT);           // in flight during the MFMA block below
+#if defined(UPD_VARIANT) && (UPD_VARIANT == 1 || UPD_VARIANT == 6)      /* ablation: no global loads in the loop */
+        if (more && kk < 0) load_slab(kk + UPD_KT, true);
+#else
+        if (more) load_slab(kk + UPD_KT, (kk + 2 * UPD_KT) <= t.kw);   // in flight during the MFMA block
+#endif
         if (any) {
-            const double *At = As[cur];
-            const double *Bt = diag_tile ? As[cur] : Bs[cur];
+            const double *At = As[cur] + wr * 64 + lr + lk * UPD_LD;
+            const double *Bt = (diag_tile ? As[cur] : Bs[cur]) + wc * 64 + lr + lk * UPD_LD;
 #pragma unroll
             for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
                 double av[4], bv[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) av[a] = Bt[(k4 + lk) * UPD_LD + wc * 64 + a * 16 + lr];   // column tile rows
+                for (int a = 0; a < 4; ++a) av[a] = Bt[k4 * UPD_LD + a * 16];   // column-tile rows
 #pragma unroll
-                for (int b = 0; b < 4; ++b) bv[b] = At[(k4 + lk) * UPD_LD + wr * 64 + b * 16 + lr];   // row tile rows
+                for (int b = 0; b < 4; ++b) bv[b] = At[k4 * UPD_LD + b * 16];   // row-tile rows
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if (valid[a][b])
+                    for (int b = 0; b < 4; ++b) {
+                        if constexpr (FULL) {
                             acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+                        } else {
+                            if (valid[a][b]) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+                        }
+                    }
             }
         }
         if (more) store_slab(cur ^ 1);
+#if !(defined(UPD_VARIANT) && (UPD_VARIANT == 4 || UPD_VARIANT == 6))   /* ablation 4/6: no barrier in the loop */
         __syncthreads();
+#endif
         cur ^= 1;
     }
     if (!any) return;
+#if defined(UPD_VARIANT) && (UPD_VARIANT == 2 || UPD_VARIANT == 6)   /* ablation: no epilogue read-modify-write */
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(acc[a][b]));
+    return;
+#endif
     // epilogue: D[i][j] (reg q: i = lk + 4q, j = lr) = sum_k P[jbase+16a+i, k] * P[ibase+16b+j, k]
     double *Pw = c.Lval + fd.loff;
     double *Uw = front_u(c, fd);
@@ -273,18 +300,36 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            if (!valid[a][b]) continue;
+            if constexpr (!FULL) { if (!valid[a][b]) continue; }
             const i32 row = ibase + b * 16 + lr;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const i32 col = jbase + a * 16 + lk + 4 * q;
-                if (row < f && col < t.jlim && row >= col) {
+                if (FULL || (row < f && col < t.jlim && row >= col)) {
                     double *dst = (col < ns) ? (Pw + (i64)row + (i64)col * f)
                                              : (Uw + (i64)(row - ns) + (i64)(col - ns) * rs);
                     *dst -= acc[a][b][q];
                 }
             }
         }
+}
+
+__global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict__ tasks, DevCtx c) {
+    // double-buffered K-slabs: slab t+1 travels global -> registers while slab t is multiplied
+    __shared__ double As[2][UPD_KT * UPD_LD];  // As[.][k][r] = P[i0 + r, k0 + kk + k]  (row tile)
+    __shared__ double Bs[2][UPD_KT * UPD_LD];  // Bs[.][k][r] = P[j0 + r, k0 + kk + k]  (column tile)
+#if defined(UPD_VARIANT) && UPD_VARIANT == 3      /* ablation: XCD-contiguous block remap */
+    const unsigned nb_ = gridDim.x, per_ = (nb_ + 7) / 8;
+    const unsigned rb_ = (blockIdx.x % 8) * per_ + blockIdx.x / 8;
+    if (rb_ >= nb_) return;
+    const UpdateTask t = tasks[rb_];
+#else
+    const UpdateTask t = tasks[blockIdx.x];
+#endif
+    const FrontDesc fd = c.fronts[t.front];
+    const bool full = (t.i0 + TILE <= fd.f) && (t.j0 + TILE <= t.jlim) && (t.i0 >= t.j0 + TILE);
+    if (full) update_tile<true>(t, fd, c, As, Bs);
+    else update_tile<false>(t, fd, c, As, Bs);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -650,49 +650,62 @@ static void build_schedule(Symbolic &S) {
             push_launch(S.factor_launches, LK_EXTEND_ADD, first, (i64)S.ea_tasks.size() - first);
         }
         if (root_level) S.factor_launches.push_back(Launch{LK_ALLREDUCE_ROOT, 0, 0, 0});
-        // (b) blocked partial factorisation, slot by slot
+        // (b) blocked partial factorisation.  Outer level LEFT-looking: before the 256-wide block
+        // column `io` of a front is factorised, one MFMA update accumulates the contribution of
+        // ALL previous columns [0, ko) in registers and writes each target entry once (the
+        // right-looking variant re-wrote the whole trailing matrix every 256 columns and was
+        // HBM-bound on that read-modify-write).  The update matrix U gets a single update with
+        // K = [0, ns) after the last block column.  Inside a block column: right-looking with
+        // 64-wide steps (potrf, trsm, update of the remaining columns of the block column).
         i32 max_ns = 0;
         for (i32 t = t0; t < t1; ++t) if (S.front_local[S.level_fronts[t]]) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         const i32 nouter = (max_ns + NB_OUT - 1) / NB_OUT;
-        for (i32 slot = 0; slot < nouter * slots_per_outer; ++slot) {
-            const i32 io = slot / slots_per_outer, r = slot % slots_per_outer, ii = r / 3, kind = r % 3;
-            const i32 ko = io * NB_OUT, ki = ko + ii * NB_IN;
-            const i64 f_potrf = (i64)S.potrf_tasks.size(), f_trsm = (i64)S.trsm_tasks.size(), f_upd = (i64)S.update_tasks.size();
-            for (i32 t = t0; t < t1; ++t) {
-                const i32 s = S.level_fronts[t];
-                if (!S.front_local[s]) continue;
-                const FrontDesc &w = S.fronts[s];
-                if (ko >= w.ns) continue;
-                const i32 no = std::min(NB_OUT, w.ns - ko);
-                const bool last_inner = (ii == NB_OUT / NB_IN - 1);
-                if (ki < ko + no) {
+        auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1) {
+            if (kw <= 0 || c0 >= c1) return;
+            for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * kw * (double)(w.f - cc);
+            for (i32 j0 = c0; j0 < c1; j0 += TILE)
+                for (i32 i0 = j0; i0 < w.f; i0 += TILE)
+                    S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, 0, 0});
+        };
+        for (i32 io = 0; io <= nouter; ++io) {
+            const i32 ko = io * NB_OUT;
+            // left-looking update of block column io (or of U when the front has no column left)
+            {
+                const i64 f_upd = (i64)S.update_tasks.size();
+                for (i32 t = t0; t < t1; ++t) {
+                    const i32 s = S.level_fronts[t];
+                    if (!S.front_local[s]) continue;
+                    const FrontDesc &w = S.fronts[s];
+                    const i32 my_nouter = (w.ns + NB_OUT - 1) / NB_OUT;
+                    if (io < my_nouter) push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns));
+                    else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f);
+                }
+                push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
+            }
+            if (io == nouter) break;
+            for (i32 r = 0; r < slots_per_outer; ++r) {
+                const i32 ii = r / 3, kind = r % 3;
+                const i32 ki = ko + ii * NB_IN;
+                const i64 f_potrf = (i64)S.potrf_tasks.size(), f_trsm = (i64)S.trsm_tasks.size(), f_upd = (i64)S.update_tasks.size();
+                for (i32 t = t0; t < t1; ++t) {
+                    const i32 s = S.level_fronts[t];
+                    if (!S.front_local[s]) continue;
+                    const FrontDesc &w = S.fronts[s];
+                    if (ko >= w.ns) continue;
+                    const i32 no = std::min(NB_OUT, w.ns - ko);
+                    if (ki >= ko + no) continue;
                     const i32 ni = std::min(NB_IN, ko + no - ki);
                     if (kind == 0) S.potrf_tasks.push_back(PotrfTask{s, ki, ni, 0});
                     else if (kind == 1) {
                         for (i32 r0 = ki + ni; r0 < w.f; r0 += TRSM_ROWS) S.trsm_tasks.push_back(TrsmTask{s, ki, ni, r0});
                     } else {
-                        // inner update: columns [ki+ni, ko+no), K = [ki, ki+ni)
-                        const i32 c0 = ki + ni, c1 = ko + no;
-                        if (c0 < c1) {
-                            for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * ni * (double)(w.f - cc);
-                            for (i32 j0 = c0; j0 < c1; j0 += TILE)
-                                for (i32 i0 = j0; i0 < w.f; i0 += TILE)
-                                    S.update_tasks.push_back(UpdateTask{s, ki, ni, i0, j0, c1, 0, 0});
-                        }
+                        push_update_region(s, w, ki, ni, ki + ni, ko + no);   // rest of this block column
                     }
                 }
-                if (kind == 2 && last_inner) {
-                    // outer (trailing) update: columns [ko+no, f), K = [ko, ko+no)
-                    const i32 c0 = ko + no;
-                    { const double t = (double)(w.f - c0); S.flops_update += 2.0 * no * t * (t + 1.0) * 0.5; }
-                    for (i32 j0 = c0; j0 < w.f; j0 += TILE)
-                        for (i32 i0 = j0; i0 < w.f; i0 += TILE)
-                            S.update_tasks.push_back(UpdateTask{s, ko, no, i0, j0, w.f, 0, 0});
-                }
+                push_launch(S.factor_launches, LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
+                push_launch(S.factor_launches, LK_TRSM, f_trsm, (i64)S.trsm_tasks.size() - f_trsm);
+                push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
             }
-            push_launch(S.factor_launches, LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
-            push_launch(S.factor_launches, LK_TRSM, f_trsm, (i64)S.trsm_tasks.size() - f_trsm);
-            push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
         }
     }
     // ---------------- forward solve: deepest level first ----------------

@@ -37,7 +37,7 @@ struct tlpk_handle {
     double *d_theta = nullptr, *d_regP = nullptr, *d_regD = nullptr, *d_D = nullptr;
     double *d_xip = nullptr, *d_xid = nullptr, *d_dx = nullptr, *d_dy = nullptr;
     int *h_info = nullptr;
-    bool factored = false, local_done = false;
+    bool factored = false, local_done = false, solve_timed = false;
     i64 fail_col = -1;
     double ms_analyse = 0, ms_update = 0, ms_solve = 0;
     tlpk_kernel_times kt{};
@@ -318,7 +318,7 @@ int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_reg
     if (!h->has_device) return TLPK_NO_DEVICE;
     HIPCHK(h, hipSetDevice(h->device));
     const Symbolic &S = h->S;
-    h->factored = false; h->local_done = false; h->fail_col = -1;
+    h->factored = false; h->local_done = false; h->fail_col = -1; h->solve_timed = false;
     prof_begin(h, true);
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     // stored copies (spd.jl:36-38): the caller may mutate its vectors right after the call
@@ -346,6 +346,17 @@ int tlpk_root_panel(tlpk_handle *h, double **d_ptr, int64_t *count) {
     const FrontDesc &fd = h->S.fronts[h->S.root_front];
     *d_ptr = h->d.ctx.Lval + fd.loff;
     *count = (i64)fd.f * fd.ns;
+    return TLPK_OK;
+}
+
+int tlpk_root_copy(tlpk_handle *h, int which, int dir, double *d_buf) {
+    if (!h || !d_buf || (which != 0 && which != 1) || (dir != 0 && dir != 1)) return TLPK_BADARG;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    double *p = nullptr; int64_t n = 0;
+    int rc = which == 0 ? tlpk_root_panel(h, &p, &n) : tlpk_root_rhs(h, &p, &n);
+    if (rc != TLPK_OK || n == 0) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(dir == 0 ? d_buf : p, dir == 0 ? p : d_buf, (size_t)n * 8, hipMemcpyDeviceToDevice, h->stream));
     return TLPK_OK;
 }
 
@@ -392,6 +403,7 @@ int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
     if (!h->factored) return TLPK_NOT_FACTORED;
     HIPCHK(h, hipSetDevice(h->device));
     prof_begin(h, false);
+    h->solve_timed = false;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     { ProfScope ps(h, TLPK_KC_SPMV); launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank); }
     run_launches(h, h->S.fwd_launches, 0, h->fwd_marker);
@@ -418,6 +430,7 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     { ProfScope ps(h, TLPK_KC_SPMV); launch_dx(h->stream, h->d, h->d_D, d_dy, d_xid, d_dx); }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
+    h->solve_timed = true;
     return TLPK_OK;
 }
 
@@ -432,8 +445,12 @@ int tlpk_sync(tlpk_handle *h) {
     if (!h->has_device) return TLPK_NO_DEVICE;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->ms_solve = ms;
+    if (h->solve_timed) {               // ev0/ev1 bracket a complete solve only then
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->ms_solve = ms;
+        h->solve_timed = false;
+    }
+    (void)hipGetLastError();
     prof_collect(h);
     return TLPK_OK;
 }

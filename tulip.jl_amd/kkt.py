@@ -152,6 +152,11 @@ class HIPNormalEquations:
         _raise_for(_lib.lib().tlpk_root_panel(self._h, C.byref(p), C.byref(n)), self._h)
         return (p.value or 0), n.value
 
+    def root_copy(self, which, direction, d_buf):
+        """which: 'panel' | 'rhs'; direction: 'out' (library -> d_buf) | 'in'; async on the stream."""
+        rc = _lib.lib().tlpk_root_copy(self._h, 0 if which == "panel" else 1, 0 if direction == "out" else 1, d_buf)
+        _raise_for(rc, self._h)
+
     def root_rhs(self):
         p = C.c_void_p(); n = C.c_int64()
         _raise_for(_lib.lib().tlpk_root_rhs(self._h, C.byref(p), C.byref(n)), self._h)
