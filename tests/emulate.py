@@ -155,7 +155,7 @@ class Emulator:
         for front, k0, nb, row0 in T:
             P = self.panel(front)
             f = int(self.f[front])
-            r1 = min(row0 + 64, f)
+            r1 = min(row0 + 128, f)
             L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
             P[row0:r1, k0:k0 + nb] = sla.solve_triangular(L11, P[row0:r1, k0:k0 + nb].T, lower=True).T
 

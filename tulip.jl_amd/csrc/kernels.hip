@@ -95,21 +95,33 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
 }
 
 // ------------------------------------------------------------------------------------------
-// potrf: Cholesky of one nb x nb diagonal block (nb <= NB_IN) by one workgroup, in LDS.
+// potrf: Cholesky of one nb x nb diagonal block (nb <= NB_IN) by one workgroup, in LDS, followed
+// by the inverse of the triangular block (used by the MFMA trsm and by the solve kernels).
 // Right-looking; one barrier per column.  A pivot that is <= 0 or NaN records its (permuted)
 // column in info[0] (min over all failures) and is replaced by 1 so that no NaN is produced;
 // the host then reports TLPK_NOT_POSDEF (spd.jl:46-47).
+// The inverse comes from applying the same row eliminations to an identity block (all 256
+// threads, no extra barriers): that yields L~^{-1} of the unit-lower factor, then rows are scaled
+// by 1/L_ii.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double *front_dinv(const DevCtx &c, const FrontDesc &fd, i32 k0) {
+    return c.dinv + fd.dinvoff + (i64)(k0 / NB_IN) * (NB_IN * NB_IN);
+}
+
 __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {
     constexpr int LD = NB_IN + 1;
-    __shared__ double Ts[NB_IN * LD];
+    __shared__ double Ts[NB_IN * LD];      // the block, column-major
+    __shared__ double Ys[NB_IN * LD];      // the same eliminations applied to I: ends as L~^{-1} (unit lower)
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, nb = t.nb;
     double *P = c.Lval + fd.loff + (i64)t.k0 + (i64)t.k0 * f;
     const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
     for (i32 col = cg; col < nb; col += 4)
-        if (r < nb) Ts[col * LD + r] = (r >= col) ? P[(i64)r + (i64)col * f] : 0.0;
+        if (r < nb) {
+            Ts[col * LD + r] = (r >= col) ? P[(i64)r + (i64)col * f] : 0.0;
+            Ys[col * LD + r] = (r == col) ? 1.0 : 0.0;
+        }
     double inv_prev = 0.0, sq_prev = 0.0;
     for (i32 j = 0; j < nb; ++j) {
         __syncthreads();
@@ -127,42 +139,89 @@ __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tas
         sq_prev = sqrt(d);
         inv_prev = 1.0 / sq_prev;
         if (r > j && r < nb) {
-            const double arj = Ts[j * LD + r] * inv2;
+            const double arj = Ts[j * LD + r] * inv2;          // multiplier L~[r][j]
             for (i32 col = j + 1 + cg; col <= r; col += 4) Ts[col * LD + r] -= arj * Ts[j * LD + col];
+            // the same row operation on the identity part: W[r][0..j] -= arj * W[j][0..j]
+            for (i32 col = cg; col <= j; col += 4) Ys[col * LD + r] -= arj * Ys[col * LD + j];
         }
     }
     __syncthreads();
     if (cg == 0 && r == nb - 1 && nb > 0) Ts[(nb - 1) * LD + r] = sq_prev;
     __syncthreads();
+    double *W = front_dinv(c, fd, t.k0);          // column-major nb x nb, ld = nb, upper part zero
     for (i32 col = cg; col < nb; col += 4)
-        if (r < nb && r >= col) P[(i64)r + (i64)col * f] = Ts[col * LD + r];
+        if (r < nb) {
+            if (r >= col) P[(i64)r + (i64)col * f] = Ts[col * LD + r];
+            // L^{-1} = diag(1/L_ii) * L~^{-1}
+            W[(i64)r + (i64)col * nb] = (r >= col) ? Ys[col * LD + r] / Ts[r * LD + r] : 0.0;
+        }
 }
 
 // ------------------------------------------------------------------------------------------
-// trsm: X * L11' = B for TRSM_ROWS rows of the panel below a factored diagonal block.
+// trsm on the matrix cores: X = B * L11^{-T} as the product with the inverted diagonal block,
+// computed transposed (D[c][r] = sum_k Linv[c][k] * B[r][k]) so that consecutive lanes write
+// consecutive panel rows.  One workgroup = 128 rows, one wave = 32 rows x all nb columns: the
+// wave loads its own B fragments straight from HBM into registers (each element is needed by
+// exactly one lane), Linv is shared through LDS.  In place: a wave only overwrites its own rows,
+// after all of its loads.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
-    constexpr int LD = NB_IN + 1;
-    __shared__ double Ls[NB_IN * LD];
-    __shared__ double Bs[NB_IN * LD];
+    constexpr int LDW = NB_IN + 16;                 // == 16 mod 32: conflict-free ds_read_b64
+    __shared__ double Ws[NB_IN * LDW];              // Ws[k*LDW + c] = Linv[c][k]
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, nb = t.nb;
     double *P = c.Lval + fd.loff;
-    const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
-    const i32 row = t.row0 + r;
-    const bool rok = row < f;
-    for (i32 col = cg; col < nb; col += 4) {
-        if (r < nb) Ls[col * LD + r] = (r >= col) ? P[(i64)(t.k0 + r) + (i64)(t.k0 + col) * f] : 0.0;
-        Bs[col * LD + r] = rok ? P[(i64)row + (i64)(t.k0 + col) * f] : 0.0;
+    const double *W = front_dinv(c, fd, t.k0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
+        const int cc = idx & (NB_IN - 1), k = idx >> 6;
+        Ws[k * LDW + cc] = (cc < nb && k < nb) ? W[(i64)cc + (i64)k * nb] : 0.0;
+    }
+    const int lr = lane & 15, lk = lane >> 4;
+    const i32 rbase = t.row0 + wave * 32;
+    // B fragments: bf[b][ks] = B[rbase + 16b + lr][k0 + 4ks + lk]
+    double bf[2][16];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const i32 row = rbase + b * 16 + lr;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const i32 k = 4 * ks + lk;
+            bf[b][ks] = (row < f && k < nb) ? P[(i64)row + (i64)(t.k0 + k) * f] : 0.0;
+        }
     }
     __syncthreads();
-    for (i32 j = 0; j < nb; ++j) {
-        const double xj = Bs[j * LD + r] / Ls[j * LD + j];
-        for (i32 col = j + 1 + cg; col < nb; col += 4) Bs[col * LD + r] -= xj * Ls[j * LD + col];
-        if (cg == 0 && rok) P[(i64)row + (i64)(t.k0 + j) * f] = xj;
-        __syncthreads();
+    if (rbase >= f) return;
+    v4f64 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (4 * ks > 16 * a + 15) continue;       // Linv[c][k] = 0 for k > c: whole block is zero
+            const double wv = Ws[(4 * ks + lk) * LDW + a * 16 + lr];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, bf[b][ks], acc[a][b], 0, 0, 0);
+        }
     }
+    // D[i][j] (reg q: i = lk + 4q -> column c = 16a + i ; j = lr -> row)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const i32 row = rbase + b * 16 + lr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i32 cc = a * 16 + lk + 4 * q;
+                if (row < f && cc < nb) P[(i64)row + (i64)(t.k0 + cc) * f] = acc[a][b][q];
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -383,28 +442,22 @@ __global__ __launch_bounds__(256) void k_fwd_gather(const SolveTask *__restrict_
     }
 }
 
-// forward diagonal block: y = L11^{-1} y for one nb x nb block.  All four waves stage the block
-// into LDS, wave 0 runs the substitution with y held one entry per lane.
-__global__ __launch_bounds__(256) void k_fwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
-    constexpr int LD = SOLVE_NB + 1;
-    __shared__ double Ls[SOLVE_NB * LD];
+// forward diagonal block: y = L11^{-1} b as a product with the inverted block written by k_potrf
+// (one wave; lane c accumulates row c of Linv against b, fixed order k = 0..c).
+__global__ __launch_bounds__(64) void k_fwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double bs[SOLVE_NB];
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, nb = t.nb;
-    const double *P = c.Lval + fd.loff + (i64)t.k0 + (i64)t.k0 * f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (i32 col = wave; col < nb; col += 4)
-        if (lane < nb && lane >= col) Ls[col * LD + lane] = P[(i64)lane + (i64)col * f];
-    __syncthreads();
-    if (wave != 0) return;
+    const i32 nb = t.nb;
+    const double *W = front_dinv(c, fd, t.k0);
+    const int lane = threadIdx.x;
     double *xs = c.xw + fd.col0 + t.k0;
-    double y = (lane < nb) ? xs[lane] : 0.0;
-    for (i32 j = 0; j < nb; ++j) {
-        const double yj = __shfl(y, j) / Ls[j * LD + j];
-        if (lane == j) y = yj;
-        else if (lane > j && lane < nb) y -= Ls[j * LD + lane] * yj;
-    }
-    if (lane < nb) xs[lane] = y;
+    if (lane < nb) bs[lane] = xs[lane];
+    __syncthreads();
+    if (lane >= nb) return;
+    double y = 0.0;
+    for (i32 k = 0; k <= lane; ++k) y += W[(i64)lane + (i64)k * nb] * bs[k];
+    xs[lane] = y;
 }
 
 // forward update: rows below a solved block: rhs[r] -= sum_j L[r, k0+j] * y[j].
@@ -452,31 +505,32 @@ __global__ __launch_bounds__(256) void k_bwd_update(const SolveTask *__restrict_
     }
 }
 
-// backward diagonal block: x = L11^{-T} (x - sum of the chunks' partial sums).
+// backward diagonal block: x = L11^{-T} (x - sum of the chunks' partial sums), with the inverted
+// block: x[c] = sum_{k >= c} Linv[k][c] * t[k].  The block is staged through LDS so that the
+// transposed access is conflict-free.
 __global__ __launch_bounds__(256) void k_bwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
     constexpr int LD = SOLVE_NB + 1;
-    __shared__ double Ls[SOLVE_NB * LD];
+    __shared__ double Ws[SOLVE_NB * LD];
+    __shared__ double ts[SOLVE_NB];
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, nb = t.nb;
-    const double *P = c.Lval + fd.loff + (i64)t.k0 + (i64)t.k0 * f;
+    const i32 nb = t.nb;
+    const double *W = front_dinv(c, fd, t.k0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (i32 col = wave; col < nb; col += 4)
-        if (lane < nb && lane >= col) Ls[col * LD + lane] = P[(i64)lane + (i64)col * f];
-    __syncthreads();
-    if (wave != 0) return;
+        if (lane < nb && lane >= col) Ws[col * LD + lane] = W[(i64)lane + (i64)col * nb];   // Linv[lane][col]
     double *xs = c.xw + fd.col0 + t.k0;
-    double x = (lane < nb) ? xs[lane] : 0.0;
-    if (lane < nb) {
+    if (wave == 0 && lane < nb) {
+        double x = xs[lane];
         const double *part = c.bpart + (i64)t.slot * SOLVE_NB + lane;
         for (i32 s = 0; s < t.nslot; ++s) x -= part[(i64)s * SOLVE_NB];
+        ts[lane] = x;
     }
-    for (i32 j = nb - 1; j >= 0; --j) {
-        const double xj = __shfl(x, j) / Ls[j * LD + j];
-        if (lane == j) x = xj;
-        else if (lane < j) x -= Ls[lane * LD + j] * xj;      // L[j][lane]
-    }
-    if (lane < nb) xs[lane] = x;
+    __syncthreads();
+    if (wave != 0 || lane >= nb) return;
+    double x = 0.0;
+    for (i32 k = lane; k < nb; ++k) x += Ws[lane * LD + k] * ts[k];       // Linv[k][lane]
+    xs[lane] = x;
 }
 
 __global__ void k_unpermute(i64 m, const i32 *__restrict__ perm, const char *__restrict__ row_local,
@@ -522,7 +576,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     case LK_TRSM: hipLaunchKernelGGL(k_trsm, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
     case LK_UPDATE: hipLaunchKernelGGL(k_update, g, dim3(256), 0, st, a.update_tasks + L.first, a.ctx); break;
     case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;
-    case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(256), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
+    case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(64), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
     case LK_FWD_UPDATE: hipLaunchKernelGGL(k_fwd_update, g, dim3(256), 0, st, a.fwd_update_tasks + L.first, a.ctx); break;
     case LK_BWD_UPDATE: hipLaunchKernelGGL(k_bwd_update, g, dim3(256), 0, st, a.bwd_update_tasks + L.first, a.ctx); break;
     case LK_BWD_DIAG: hipLaunchKernelGGL(k_bwd_diag, g, dim3(256), 0, st, a.bwd_diag_tasks + L.first, a.ctx); break;

@@ -523,13 +523,15 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     }
 
     // ---- 12. storage offsets (local fronts only) ----
-    S.lval_len = 0; S.uc_len = 0; S.ubuf_len[0] = S.ubuf_len[1] = 0;
+    S.lval_len = 0; S.uc_len = 0; S.ubuf_len[0] = S.ubuf_len[1] = 0; S.dinv_len = 0;
     for (i32 s = 0; s < ns_total; ++s) {
         FrontDesc &w = S.fronts[s];
         w.ubuf = S.depth[s] & 1;
-        if (!S.front_local[s]) { w.loff = -1; w.uoff = -1; w.ucoff = -1; continue; }
+        if (!S.front_local[s]) { w.loff = -1; w.uoff = -1; w.ucoff = -1; w.dinvoff = -1; continue; }
         w.loff = S.lval_len; S.lval_len += (i64)w.f * w.ns;
         w.ucoff = S.uc_len; S.uc_len += (w.f - w.ns);
+        w.dinvoff = S.dinv_len;
+        S.dinv_len += (w.ns >= NB_IN) ? (i64)((w.ns + NB_IN - 1) / NB_IN) * NB_IN * NB_IN : (i64)w.ns * w.ns;
     }
     for (i32 d = 0; d < S.nlevels; ++d) {
         i64 off = 0;

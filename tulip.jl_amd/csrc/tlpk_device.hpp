@@ -17,6 +17,7 @@ struct DevCtx {
     double *uc;         // solve contribution vectors
     double *xw;         // permuted right-hand side / solution
     double *bpart;      // backward-solve partial sums (SOLVE_NB doubles per slot)
+    double *dinv;       // inverses of the NB_IN x NB_IN diagonal blocks of L (written by k_potrf)
     int *info;          // info[0] = smallest failing pivot column (INT_MAX = none)
 };
 

@@ -16,7 +16,7 @@ using i64 = int64_t;
 constexpr int NB_IN = 64;     // diagonal-block / triangular-solve width (potrf + trsm kernels)
 constexpr int NB_OUT = 256;   // outer panel width: trailing updates run with K = NB_OUT
 constexpr int TILE = 128;     // update-kernel tile (TILE x TILE per workgroup)
-constexpr int TRSM_ROWS = 64; // rows per trsm workgroup
+constexpr int TRSM_ROWS = 128; // rows per trsm workgroup (4 waves x 32 rows)
 constexpr int EA_COLS = 16;   // parent columns per extend-add workgroup
 constexpr int SOLVE_NB = 64;  // block width of the triangular-solve kernels
 constexpr int SOLVE_ROWS = 256; // rows per forward-update workgroup
@@ -29,6 +29,7 @@ struct FrontDesc {
     i64 rowoff;    // offset into rowidx (f entries, first ns are the pivot columns)
     i64 reloff;    // offset into rel (rs entries: position of each below-row in the parent front)
     i64 ucoff;     // offset of the rs-vector of solve contributions
+    i64 dinvoff;   // offset of the inverted diagonal blocks: block b (NB_IN columns) at dinvoff + b*NB_IN*NB_IN, ld = its nb
     i32 f, ns;
     i32 col0;      // first pivot column (permuted numbering)
     i32 ubuf;      // which ping-pong buffer holds U (depth & 1)
@@ -36,7 +37,7 @@ struct FrontDesc {
     i32 child_ptr, nchild;   // children in `children[child_ptr .. child_ptr+nchild)`
     i32 pad;
 };
-static_assert(sizeof(FrontDesc) == 72, "FrontDesc layout");
+static_assert(sizeof(FrontDesc) == 80, "FrontDesc layout");
 
 struct PotrfTask { i32 front, k0, nb, pad; };
 struct TrsmTask  { i32 front, k0, nb, row0; };
@@ -95,7 +96,7 @@ struct Symbolic {
     std::vector<i32> pair_j;               // j
     std::vector<char> s_local;             // entry assembled by this rank
     // sizes
-    i64 nnzS = 0, nnzL = 0, lval_len = 0, ubuf_len[2] = {0, 0}, uc_len = 0, max_front = 0, bpart_len = 0;
+    i64 nnzS = 0, nnzL = 0, lval_len = 0, ubuf_len[2] = {0, 0}, uc_len = 0, max_front = 0, bpart_len = 0, dinv_len = 0;
     double flops_chol = 0, flops_panel = 0, flops_update = 0;
     // schedules
     std::vector<PotrfTask> potrf_tasks; std::vector<TrsmTask> trsm_tasks;
