@@ -109,52 +109,83 @@ __device__ __forceinline__ double *front_dinv(const DevCtx &c, const FrontDesc &
 }
 
 __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {
-    constexpr int LD = NB_IN + 1;
-    __shared__ double Ts[NB_IN * LD];      // the block, column-major
-    __shared__ double Ys[NB_IN * LD];      // the same eliminations applied to I: ends as L~^{-1} (unit lower)
+    // Register-resident: thread (r, cg) owns A[r][col] and W[r][col] for col = cg + 4q, q = 0..15.
+    // Per step only the pivot column of A and the pivot row of W go through LDS (double-buffered
+    // by step parity => one barrier per column and no dependent LDS read-modify-write chains).
+    __shared__ double colbuf[2][NB_IN];
+    __shared__ double rowbuf[2][NB_IN];
+    __shared__ double dg[NB_IN];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, nb = t.nb;
     double *P = c.Lval + fd.loff + (i64)t.k0 + (i64)t.k0 * f;
     const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
-    for (i32 col = cg; col < nb; col += 4)
-        if (r < nb) {
-            Ts[col * LD + r] = (r >= col) ? P[(i64)r + (i64)col * f] : 0.0;
-            Ys[col * LD + r] = (r == col) ? 1.0 : 0.0;
-        }
-    double inv_prev = 0.0, sq_prev = 0.0;
+    const bool rok = r < nb;
+    double av[16], wv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const i32 col = cg + 4 * q;
+        av[q] = (rok && col < nb && r >= col) ? P[(i64)r + (i64)col * f] : 0.0;
+        wv[q] = (r == col) ? 1.0 : 0.0;
+    }
     for (i32 j = 0; j < nb; ++j) {
-        __syncthreads();
-        // finish column j-1 (scale) -- disjoint from everything step j touches
-        if (j > 0 && cg == 0 && r < nb) {
-            if (r == j - 1) Ts[(j - 1) * LD + r] = sq_prev;
-            else if (r > j - 1) Ts[(j - 1) * LD + r] *= inv_prev;
+        const int pb = j & 1, jq = j >> 2;
+        if (cg == (j & 3)) {
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v = (q == jq) ? av[q] : v;
+            colbuf[pb][r] = v;                               // A[r][j]
         }
-        double d = Ts[j * LD + j];
+        if (r == j) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rowbuf[pb][cg + 4 * q] = wv[q];   // W[j][:]
+        }
+        __syncthreads();
+        double d = colbuf[pb][j];
         if (!(d > 0.0)) {
             if (tid == 0) atomicMin(c.info, fd.col0 + t.k0 + j);
             d = 1.0;
         }
-        const double inv2 = 1.0 / d;
-        sq_prev = sqrt(d);
-        inv_prev = 1.0 / sq_prev;
-        if (r > j && r < nb) {
-            const double arj = Ts[j * LD + r] * inv2;          // multiplier L~[r][j]
-            for (i32 col = j + 1 + cg; col <= r; col += 4) Ts[col * LD + r] -= arj * Ts[j * LD + col];
-            // the same row operation on the identity part: W[r][0..j] -= arj * W[j][0..j]
-            for (i32 col = cg; col <= j; col += 4) Ys[col * LD + r] -= arj * Ys[col * LD + j];
+        const double inv2 = 1.0 / d, sq = sqrt(d), isq = 1.0 / sq;
+        const double arj = (rok && r > j) ? colbuf[pb][r] * inv2 : 0.0;    // multiplier L~[r][j]
+        // all LDS reads first (independent), then branch-free predicated updates
+        double cv[16], rv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { cv[q] = colbuf[pb][cg + 4 * q]; rv[q] = rowbuf[pb][cg + 4 * q]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const i32 col = cg + 4 * q;
+            const double m1 = (col > j && col <= r) ? arj : 0.0;
+            const double m2 = (col <= j) ? arj : 0.0;
+            av[q] = fma(-m1, cv[q], av[q]);
+            wv[q] = fma(-m2, rv[q], wv[q]);
+        }
+        if (cg == (j & 3)) {                                  // finish column j: L[r][j]
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q == jq) av[q] = (r == j) ? sq : ((r > j) ? av[q] * isq : av[q]);
         }
     }
-    __syncthreads();
-    if (cg == 0 && r == nb - 1 && nb > 0) Ts[(nb - 1) * LD + r] = sq_prev;
+    // diagonal of L for the row scaling of the inverse
+    if (rok && cg == (r & 3)) {
+        double v = 1.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v = (q == (r >> 2)) ? av[q] : v;
+        dg[r] = v;
+    }
     __syncthreads();
     double *W = front_dinv(c, fd, t.k0);          // column-major nb x nb, ld = nb, upper part zero
-    for (i32 col = cg; col < nb; col += 4)
-        if (r < nb) {
-            if (r >= col) P[(i64)r + (i64)col * f] = Ts[col * LD + r];
-            // L^{-1} = diag(1/L_ii) * L~^{-1}
-            W[(i64)r + (i64)col * nb] = (r >= col) ? Ys[col * LD + r] / Ts[r * LD + r] : 0.0;
+    if (rok) {
+        const double idg = 1.0 / dg[r];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const i32 col = cg + 4 * q;
+            if (col < nb) {
+                if (r >= col) P[(i64)r + (i64)col * f] = av[q];
+                W[(i64)r + (i64)col * nb] = (r >= col) ? wv[q] * idg : 0.0;   // L^{-1} = diag(1/L_ii) L~^{-1}
+            }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
