@@ -526,13 +526,32 @@ __global__ __launch_bounds__(256) void k_bwd_update(const SolveTask *__restrict_
     const double *P = c.Lval + fd.loff + (i64)t.k0 * f + t.row0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *part = c.bpart + (i64)t.slot * SOLVE_NB;
-    for (i32 j = wave; j < nb; j += 4) {
-        const double *col = P + (i64)j * f;
-        double acc = 0.0;
-        for (i32 i = lane; i < nr; i += 64) acc += col[i] * xs[i];
+    // each lane keeps its (up to 4) x values in registers; a wave takes 4 columns at a time so
+    // that 16 independent loads are in flight before the shuffle reductions start
+    double xr[BWD_ROWS / 64];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-        if (lane == 0) part[j] = acc;
+    for (int u = 0; u < BWD_ROWS / 64; ++u) xr[u] = (lane + 64 * u < nr) ? xs[lane + 64 * u] : 0.0;
+    for (i32 j0 = wave * 4; j0 < nb; j0 += 16) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const i32 j = j0 + jj;
+            if (j < nb) {
+                const double *col = P + (i64)j * f;
+#pragma unroll
+                for (int u = 0; u < BWD_ROWS / 64; ++u)
+                    if (lane + 64 * u < nr) acc[jj] += col[lane + 64 * u] * xr[u];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[jj] += __shfl_down(acc[jj], off);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) if (j0 + jj < nb) part[j0 + jj] = acc[jj];
+        }
     }
 }
 
