@@ -1,0 +1,489 @@
+"""IPM harness: the CALLER of the KKT backend, restated so that "iterations, objective, residuals"
+can be produced without Julia.
+
+Test infrastructure only.  It restates, as a driver of the three-function KKT interface:
+  * free-format MPS reading (what /root/reference/src/Interfaces/tulip_julia_api.jl:18-39 gets
+    from QPSReader.readqps(mpsformat=:free)),
+  * the standard-form conversion of /root/reference/src/IPM/ipmdata.jl:64-173,
+  * the homogeneous self-dual loop of /root/reference/src/IPM/HSD/HSD.jl:203-350 and
+    /root/reference/src/IPM/HSD/step.jl:10-401 (Mehrotra predictor-corrector + Gondzio's multiple
+    centrality corrections, regularisation schedule and the PosDefException retry loop),
+with Tulip's defaults (/root/reference/src/IPM/options.jl:1-25).  No presolve and no scaling
+(Presolve_Level = 0 semantics; src/Presolve is out of scope).
+
+A backend is anything with update(theta_inv, regP, regD) / solve(dx, dy, xi_p, xi_d) that raises
+PosDef on a failed factorisation: the HIP library (HipBackend) or the CPU oracle (OracleBackend).
+"""
+import math
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))
+INF = float("inf")
+
+
+class PosDef(ArithmeticError):
+    pass
+
+
+# ------------------------------------------------------------------------------------------------
+# LP container + free MPS reader
+# ------------------------------------------------------------------------------------------------
+class LP:
+    def __init__(self, A, obj, obj0, lcon, ucon, lvar, uvar, objsense_min=True, name=""):
+        self.A = sp.csc_matrix(A)
+        self.obj = np.asarray(obj, float); self.obj0 = float(obj0)
+        self.lcon = np.asarray(lcon, float); self.ucon = np.asarray(ucon, float)
+        self.lvar = np.asarray(lvar, float); self.uvar = np.asarray(uvar, float)
+        self.objsense_min = objsense_min
+        self.name = name
+
+
+def read_free_mps(path):
+    rows, row_type, cols = {}, [], {}
+    entries = []                      # (row idx, col idx, value) ; objective in `objc`
+    objc, rhs, ranges = {}, {}, {}
+    lo, up = {}, {}
+    obj_row, obj0, sense_min, name = None, 0.0, True, ""
+    section = None
+    col_order = []
+    with open(path) as fh:
+        for raw in fh:
+            line = raw.rstrip("\n")
+            if not line.strip() or line.lstrip().startswith("*"):
+                continue
+            if not line[0].isspace():
+                tok = line.split()
+                section = tok[0].upper()
+                if section == "NAME" and len(tok) > 1:
+                    name = tok[1]
+                if section == "OBJSENSE" and len(tok) > 1:
+                    sense_min = not tok[1].upper().startswith("MAX")
+                if section == "ENDATA":
+                    break
+                continue
+            tok = line.split()
+            if section == "OBJSENSE":
+                sense_min = not tok[0].upper().startswith("MAX")
+            elif section == "ROWS":
+                t, r = tok[0].upper(), tok[1]
+                if t == "N":
+                    if obj_row is None:
+                        obj_row = r
+                else:
+                    rows[r] = len(row_type); row_type.append(t)
+            elif section == "COLUMNS":
+                if len(tok) >= 3 and tok[1].upper() == "'MARKER'":
+                    continue
+                c = tok[0]
+                if c not in cols:
+                    cols[c] = len(col_order); col_order.append(c)
+                for r, v in zip(tok[1::2], tok[2::2]):
+                    if r == obj_row:
+                        objc[cols[c]] = objc.get(cols[c], 0.0) + float(v)
+                    elif r in rows:
+                        entries.append((rows[r], cols[c], float(v)))
+            elif section == "RHS":
+                pairs = tok[1:] if len(tok) % 2 == 1 else tok
+                for r, v in zip(pairs[0::2], pairs[1::2]):
+                    if r == obj_row:
+                        obj0 = -float(v)
+                    elif r in rows:
+                        rhs[rows[r]] = float(v)
+            elif section == "RANGES":
+                pairs = tok[1:] if len(tok) % 2 == 1 else tok
+                for r, v in zip(pairs[0::2], pairs[1::2]):
+                    if r in rows:
+                        ranges[rows[r]] = float(v)
+            elif section == "BOUNDS":
+                t = tok[0].upper()
+                if t in ("FR", "MI", "PL", "BV"):
+                    c = tok[2] if len(tok) >= 3 else tok[1]
+                    v = None
+                else:
+                    c, v = (tok[2], float(tok[3])) if len(tok) >= 4 else (tok[1], float(tok[2]))
+                j = cols[c]
+                if t == "UP":
+                    up[j] = v
+                    if v < 0 and j not in lo:
+                        lo[j] = -INF
+                elif t == "LO":
+                    lo[j] = v
+                elif t == "FX":
+                    lo[j] = up[j] = v
+                elif t == "FR":
+                    lo[j], up[j] = -INF, INF
+                elif t == "MI":
+                    lo[j] = -INF
+                elif t == "PL":
+                    up[j] = INF
+                elif t == "BV":
+                    lo[j], up[j] = 0.0, 1.0
+    m, n = len(row_type), len(col_order)
+    lcon, ucon = np.empty(m), np.empty(m)
+    for i, t in enumerate(row_type):
+        b = rhs.get(i, 0.0)
+        if t == "E":
+            lcon[i] = ucon[i] = b
+            if i in ranges:
+                r = ranges[i]
+                lcon[i], ucon[i] = (b, b + abs(r)) if r >= 0 else (b - abs(r), b)
+        elif t == "L":
+            lcon[i], ucon[i] = -INF, b
+            if i in ranges:
+                lcon[i] = b - abs(ranges[i])
+        elif t == "G":
+            lcon[i], ucon[i] = b, INF
+            if i in ranges:
+                ucon[i] = b + abs(ranges[i])
+    lvar = np.array([lo.get(j, 0.0) for j in range(n)])
+    uvar = np.array([up.get(j, INF) for j in range(n)])
+    obj = np.array([objc.get(j, 0.0) for j in range(n)])
+    if entries:
+        ri, ci, vv = zip(*entries)
+        A = sp.csc_matrix((vv, (ri, ci)), shape=(m, n))
+    else:
+        A = sp.csc_matrix((m, n))
+    return LP(A, obj, obj0, lcon, ucon, lvar, uvar, sense_min, name)
+
+
+# ------------------------------------------------------------------------------------------------
+# standard form: ipmdata.jl:64-173
+# ------------------------------------------------------------------------------------------------
+class IPMData:
+    pass
+
+
+def standard_form(lp):
+    m, n = lp.A.shape
+    b = np.zeros(m)
+    sind, sval, lslack, uslack = [], [], [], []
+    for i, (lb, ub) in enumerate(zip(lp.lcon, lp.ucon)):
+        if lb == ub:
+            b[i] = lb
+        elif lb == -INF and ub == INF:
+            sind.append(i); sval.append(1.0); lslack.append(-INF); uslack.append(INF); b[i] = 0.0
+        elif lb == -INF and math.isfinite(ub):
+            sind.append(i); sval.append(1.0); lslack.append(0.0); uslack.append(INF); b[i] = ub
+        elif math.isfinite(lb) and ub == INF:
+            sind.append(i); sval.append(-1.0); lslack.append(0.0); uslack.append(INF); b[i] = lb
+        elif math.isfinite(lb) and math.isfinite(ub):
+            sind.append(i); sval.append(1.0); lslack.append(0.0); uslack.append(ub - lb); b[i] = ub
+        else:
+            raise ValueError(f"Invalid bounds for row {i}: [{lb}, {ub}]")
+    ns = len(sind)
+    slack = sp.csc_matrix((sval, (sind, np.arange(ns))), shape=(m, ns))
+    d = IPMData()
+    d.A = sp.hstack([lp.A, slack], format="csc") if ns else lp.A.copy()
+    d.A.sort_indices()
+    d.b = b
+    d.objsense = lp.objsense_min
+    d.c = np.concatenate([lp.obj, np.zeros(ns)]); d.c0 = lp.obj0
+    if not lp.objsense_min:
+        d.c = -d.c; d.c0 = -d.c0
+    d.l = np.concatenate([lp.lvar, lslack]); d.u = np.concatenate([lp.uvar, uslack])
+    d.lflag = np.isfinite(d.l); d.uflag = np.isfinite(d.u)
+    d.lz = np.where(d.lflag, d.l, 0.0); d.uz = np.where(d.uflag, d.u, 0.0)     # l .* lflag, u .* uflag
+    d.nrow, d.ncol, d.nvar = m, n + ns, n
+    return d
+
+
+# ------------------------------------------------------------------------------------------------
+# backends
+# ------------------------------------------------------------------------------------------------
+class HipBackend:
+    """KKT.setup/update!/solve! through libtlpk.so (tulip.jl_amd/kkt.py)."""
+
+    def __init__(self, A, **backend_kw):
+        import tulip_jl_amd as tk
+        self.tk = tk
+        self.kkt = tk.setup(A, tk.K1(), tk.Backend(**backend_kw))
+        self.name = f"{tk.backend(self.kkt)} / {tk.linear_system(self.kkt)}"
+
+    def update(self, th, rp, rd):
+        try:
+            self.tk.update(self.kkt, th, rp, rd)
+        except self.tk.PosDefException as e:
+            raise PosDef(str(e))
+
+    def solve(self, dx, dy, xp, xd):
+        self.tk.solve(dx, dy, self.kkt, xp, xd)
+
+
+class OracleBackend:
+    """The CPU oracle behind the same three calls (plumbing config C1, CPU-side comparator)."""
+
+    def __init__(self, A, perm=None):
+        from oracle_binding import OracleK1
+        self.o = OracleK1(A, perm)
+        self.name = "CPU oracle (left-looking Cholesky) / Normal equations (K1)"
+
+    def update(self, th, rp, rd):
+        from oracle_binding import OraclePosDefError
+        try:
+            self.o.update(th, rp, rd)
+        except OraclePosDefError as e:
+            raise PosDef(str(e))
+
+    def solve(self, dx, dy, xp, xd):
+        ddx, ddy = self.o.solve(xp, xd)
+        dx[:] = ddx; dy[:] = ddy
+
+
+# ------------------------------------------------------------------------------------------------
+# HSD
+# ------------------------------------------------------------------------------------------------
+class Options:
+    IterationsLimit = 100
+    TimeLimit = INF
+    TolerancePFeas = ToleranceDFeas = ToleranceRGap = ToleranceIFeas = SQRT_EPS
+    CorrectionLimit = 3
+    StepDampFactor = 0.9995
+    GammaMin = 0.1
+    CentralityOutlierThreshold = 0.1
+    PRegMin = DRegMin = SQRT_EPS
+    OutputLevel = 0
+
+
+class Point:
+    def __init__(self, m, n, p):
+        self.m, self.n, self.p = m, n, p
+        self.x = np.zeros(n); self.xl = np.zeros(n); self.xu = np.zeros(n)
+        self.y = np.zeros(m); self.zl = np.zeros(n); self.zu = np.zeros(n)
+        self.tau = 1.0; self.kappa = 1.0; self.mu = 1.0
+
+    def update_mu(self):                       # point.jl:45-48 (hflag = true)
+        self.mu = (self.xl @ self.zl + self.xu @ self.zu + self.tau * self.kappa) / (self.p + 1)
+
+
+def _max_step_vec(x, dx):                      # step.jl:274-287
+    neg = dx < 0
+    return float(np.min(-x[neg] / dx[neg])) if neg.any() else INF
+
+
+def _max_step(pt, d):                          # step.jl:294-306
+    at = (-pt.tau / d.tau) if d.tau < 0 else 1.0
+    ak = (-pt.kappa / d.kappa) if d.kappa < 0 else 1.0
+    return min(1.0, _max_step_vec(pt.xl, d.xl), _max_step_vec(pt.xu, d.xu),
+               _max_step_vec(pt.zl, d.zl), _max_step_vec(pt.zu, d.zu), at, ak)
+
+
+class HSD:
+    def __init__(self, dat, backend, options=None):
+        self.dat, self.kkt, self.opt = dat, backend, options or Options()
+        m, n = dat.nrow, dat.ncol
+        self.p = int(dat.lflag.sum() + dat.uflag.sum())
+        self.pt = Point(m, n, self.p)
+        self.regP = np.ones(n); self.regD = np.ones(m); self.regG = 1.0     # HSD.jl:50-52
+        self.niter = 0
+        self.status = "Trm_Unknown"
+        self.primal_status = self.dual_status = "Sln_Unknown"
+        self.timers = {"Factorization": 0.0, "KKT": 0.0, "n_update": 0, "n_solve": 0, "n_bump": 0}
+        self.log = []
+
+    # HSD.jl:77-128
+    def compute_residuals(self):
+        pt, d = self.pt, self.dat
+        self.rp = pt.tau * d.b - d.A @ pt.x
+        self.rl = (-pt.x + pt.xl + pt.tau * d.lz) * d.lflag
+        self.ru = (-pt.x - pt.xu + pt.tau * d.uz) * d.uflag
+        self.rd = pt.tau * d.c - d.A.T @ pt.y + pt.zu * d.uflag - pt.zl * d.lflag
+        dualsum = d.b @ pt.y + d.lz @ pt.zl - d.uz @ pt.zu
+        self.rg = pt.kappa + (d.c @ pt.x - dualsum)
+        nrm = lambda v: float(np.abs(v).max(initial=0.0))    # noqa: E731
+        self.rp_nrm, self.rl_nrm, self.ru_nrm, self.rd_nrm = nrm(self.rp), nrm(self.rl), nrm(self.ru), nrm(self.rd)
+        self.rg_nrm = abs(self.rg)
+        self.primal_objective = d.c @ pt.x / pt.tau + d.c0
+        self.dual_objective = dualsum / pt.tau + d.c0
+
+    # HSD.jl:136-196
+    def update_solver_status(self):
+        o, pt, d = self.opt, self.pt, self.dat
+        nrm = lambda v: float(np.abs(v).max(initial=0.0))    # noqa: E731
+        self.status = "Trm_Unknown"
+        rho_p = max(self.rp_nrm / (pt.tau * (1 + nrm(d.b))), self.rl_nrm / (pt.tau * (1 + nrm(d.lz))),
+                    self.ru_nrm / (pt.tau * (1 + nrm(d.uz))))
+        rho_d = self.rd_nrm / (pt.tau * (1 + nrm(d.c)))
+        rho_g = abs(self.primal_objective - self.dual_objective) / (1 + abs(self.dual_objective))
+        self.rho = (rho_p, rho_d, rho_g)
+        self.primal_status = "Sln_FeasiblePoint" if rho_p <= o.TolerancePFeas else "Sln_Unknown"
+        self.dual_status = "Sln_FeasiblePoint" if rho_d <= o.ToleranceDFeas else "Sln_Unknown"
+        if rho_p <= o.TolerancePFeas and rho_d <= o.ToleranceDFeas and rho_g <= o.ToleranceRGap:
+            self.primal_status = self.dual_status = "Sln_Optimal"
+            self.status = "Trm_Optimal"
+            return
+        if max(nrm(d.A @ pt.x), nrm((pt.x - pt.xl) * d.lflag), nrm((pt.x + pt.xu) * d.uflag)) * \
+                (nrm(d.c) / max(1.0, nrm(d.b))) < -o.ToleranceIFeas * (d.c @ pt.x):
+            self.primal_status = "Sln_InfeasibilityCertificate"
+            self.status = "Trm_DualInfeasible"
+            return
+        delta = d.A.T @ pt.y + pt.zl * d.lflag - pt.zu * d.uflag
+        if nrm(delta) * max(nrm(d.lz), nrm(d.uz), nrm(d.b)) / max(1.0, nrm(d.c)) < \
+                (d.b @ pt.y + d.lz @ pt.zl - d.uz @ pt.zu) * o.ToleranceIFeas:
+            self.dual_status = "Sln_InfeasibilityCertificate"
+            self.status = "Trm_PrimalInfeasible"
+
+    def _kkt_solve(self, dx, dy, xp, xd):
+        t0 = time.perf_counter()
+        self.kkt.solve(dx, dy, np.ascontiguousarray(xp), np.ascontiguousarray(xd))
+        self.timers["KKT"] += time.perf_counter() - t0
+        self.timers["n_solve"] += 1
+
+    # step.jl:198-266
+    def solve_newton_system(self, D, hx, hy, h0, xi_p, xi_l, xi_u, xi_d, xi_g, xi_xzl, xi_xzu, xi_tk):
+        pt, d = self.pt, self.dat
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tl = np.where(d.lflag, (xi_xzl + pt.zl * xi_l) / pt.xl, 0.0)
+            tu = np.where(d.uflag, (xi_xzu - pt.zu * xi_u) / pt.xu, 0.0)
+            zxl = np.where(d.lflag, pt.zl / pt.xl, 0.0); zxu = np.where(d.uflag, pt.zu / pt.xu, 0.0)
+            ixl = np.where(d.lflag, xi_xzl / pt.xl, 0.0); ixu = np.where(d.uflag, xi_xzu / pt.xu, 0.0)
+        xi_d_ = xi_d - tl + tu
+        self._kkt_solve(D.x, D.y, xi_p, xi_d_)
+        xi_g_ = (xi_g + xi_tk / pt.tau - ixl @ d.lz + ixu @ d.uz - (zxl * xi_l) @ d.lz - (zxu * xi_u) @ d.uz)
+        D.tau = (xi_g_ + (d.c + zxl * d.lz + zxu * d.uz) @ D.x - d.b @ D.y) / h0
+        D.x += D.tau * hx
+        D.y += D.tau * hy
+        D.xl = (-xi_l + D.x - D.tau * d.lz) * d.lflag
+        D.xu = (xi_u - D.x + D.tau * d.uz) * d.uflag
+        with np.errstate(divide="ignore", invalid="ignore"):
+            D.zl = np.where(d.lflag, (xi_xzl - pt.zl * D.xl) / pt.xl, 0.0)
+            D.zu = np.where(d.uflag, (xi_xzu - pt.zu * D.xu) / pt.xu, 0.0)
+        D.kappa = (xi_tk - pt.kappa * D.tau) / pt.tau
+
+    # step.jl:325-401
+    def compute_higher_corrector(self, Dc, gamma, hx, hy, h0, D, alpha, beta):
+        pt, d = self.pt, self.dat
+        a_ = min(1.0, 2.0 * alpha)
+        vl = ((pt.xl + a_ * D.xl) * (pt.zl + a_ * D.zl)) * d.lflag
+        vu = ((pt.xu + a_ * D.xu) * (pt.zu + a_ * D.zu)) * d.uflag
+        vt = (pt.tau + a_ * D.tau) * (pt.kappa + a_ * D.kappa)
+        mu_l, mu_u = beta * pt.mu * gamma, gamma * pt.mu / beta
+
+        def target(v, flag):
+            out = np.where(v < mu_l, mu_l - v, np.where(v > mu_u, mu_u - v, 0.0))
+            return np.where(flag, out, v)
+        vl = target(vl, d.lflag); vu = target(vu, d.uflag)
+        vt = mu_l - vt if vt < mu_l else (mu_u - vt if vt > mu_u else 0.0)
+        delta = (vl.sum() + vu.sum() + vt) / (pt.p + 1)
+        vl = vl - delta; vu = vu - delta; vt -= delta
+        z_m, z_n = np.zeros(pt.m), np.zeros(pt.n)
+        self.solve_newton_system(Dc, hx, hy, h0, z_m, z_n, z_n, z_n, 0.0, vl, vu, vt)
+        Dc.x += D.x; Dc.xl += D.xl; Dc.xu += D.xu; Dc.y += D.y; Dc.zl += D.zl; Dc.zu += D.zu
+        Dc.tau += D.tau; Dc.kappa += D.kappa
+        return _max_step(pt, Dc)
+
+    # step.jl:10-151
+    def compute_step(self):
+        o, pt, d = self.opt, self.pt, self.dat
+        with np.errstate(divide="ignore", invalid="ignore"):
+            th_l = np.where(d.lflag, pt.zl / pt.xl, 0.0)
+            th_u = np.where(d.uflag, pt.zu / pt.xu, 0.0)
+        theta_inv = th_l + th_u                       # exactly 0 for free variables
+        self.regP = np.maximum(o.PRegMin, self.regP / 10)
+        self.regD = np.maximum(o.DRegMin, self.regD / 10)
+        self.regG = max(o.PRegMin, self.regG / 10)
+        nbump = 0
+        while nbump <= 3:
+            try:
+                t0 = time.perf_counter()
+                self.kkt.update(theta_inv, self.regP, self.regD)
+                self.timers["Factorization"] += time.perf_counter() - t0
+                self.timers["n_update"] += 1
+                break
+            except PosDef:
+                self.regD *= 100; self.regP *= 100; self.regG *= 100
+                nbump += 1
+                self.timers["n_bump"] += 1
+        if not nbump < 3:                              # step.jl:51 (the reference's off-by-one is kept)
+            raise PosDef("factorization could not be saved")
+        D, Dc = Point(pt.m, pt.n, pt.p), Point(pt.m, pt.n, pt.p)
+        hx, hy = np.zeros(pt.n), np.zeros(pt.m)
+        xi_ = d.c - th_l * d.lz - th_u * d.uz
+        self._kkt_solve(hx, hy, d.b, xi_)              # xi_p aliases dat.b: inputs must be const
+        h0 = (d.lz @ (d.lz * th_l) + d.uz @ (d.uz * th_u) - (d.c + th_l * d.lz + th_u * d.uz) @ hx
+              + d.b @ hy + pt.kappa / pt.tau + self.regG)
+        self.solve_newton_system(D, hx, hy, h0, self.rp, self.rl, self.ru, self.rd, self.rg,
+                                 -(pt.xl * pt.zl) * d.lflag, -(pt.xu * pt.zu) * d.uflag, -pt.tau * pt.kappa)
+        alpha = _max_step(pt, D)
+        gamma = (1 - alpha) ** 2 * min(1 - alpha, o.GammaMin)
+        eta = 1 - gamma
+        self.solve_newton_system(D, hx, hy, h0, eta * self.rp, eta * self.rl, eta * self.ru, eta * self.rd,
+                                 eta * self.rg,
+                                 (-pt.xl * pt.zl + gamma * pt.mu - D.xl * D.zl) * d.lflag,
+                                 (-pt.xu * pt.zu + gamma * pt.mu - D.xu * D.zu) * d.uflag,
+                                 -pt.tau * pt.kappa + gamma * pt.mu - D.tau * D.kappa)
+        alpha = _max_step(pt, D)
+        ncor = 0
+        while ncor < o.CorrectionLimit and alpha < 0.999:
+            a_ = alpha
+            ncor += 1
+            ac = self.compute_higher_corrector(Dc, gamma, hx, hy, h0, D, a_, o.CentralityOutlierThreshold)
+            if ac > a_:
+                for k in ("x", "xl", "xu", "y", "zl", "zu"):
+                    setattr(D, k, getattr(Dc, k).copy())
+                D.tau, D.kappa = Dc.tau, Dc.kappa
+                alpha = ac
+            if ac < 1.1 * a_:
+                break
+        alpha *= o.StepDampFactor
+        pt.x += alpha * D.x; pt.xl += alpha * D.xl; pt.xu += alpha * D.xu
+        pt.y += alpha * D.y; pt.zl += alpha * D.zl; pt.zu += alpha * D.zu
+        pt.tau += alpha * D.tau; pt.kappa += alpha * D.kappa
+        pt.update_mu()
+
+    # HSD.jl:203-350
+    def optimize(self):
+        o, pt, d = self.opt, self.pt, self.dat
+        tstart = time.perf_counter()
+        self.niter = 0
+        pt.x[:] = 0; pt.xl[:] = 1.0 * d.lflag; pt.xu[:] = 1.0 * d.uflag
+        pt.y[:] = 0; pt.zl[:] = 1.0 * d.lflag; pt.zu[:] = 1.0 * d.uflag
+        pt.tau = pt.kappa = 1.0
+        pt.update_mu()
+        while True:
+            self.compute_residuals()
+            pt.update_mu()
+            eps_ = 1.0 if d.objsense else -1.0
+            self.log.append((self.niter, eps_ * self.primal_objective, eps_ * self.dual_objective,
+                             max(self.rp_nrm, self.ru_nrm), self.rd_nrm, self.rg_nrm, pt.mu))
+            if o.OutputLevel > 0:
+                print("%4d  %+14.7e  %+14.7e  %8.2e %8.2e %8.2e  %7.1e" % self.log[-1])
+            self.update_solver_status()
+            if self.status in ("Trm_Optimal", "Trm_PrimalInfeasible", "Trm_DualInfeasible"):
+                break
+            if self.niter >= o.IterationsLimit:
+                self.status = "Trm_IterationLimit"; break
+            if time.perf_counter() - tstart >= o.TimeLimit:
+                self.status = "Trm_TimeLimit"; break
+            try:
+                self.compute_step()
+            except PosDef:
+                self.status = "Trm_NumericalProblem"; break
+            except MemoryError:
+                self.status = "Trm_MemoryLimit"; break
+            self.niter += 1
+        return self
+
+    # model.jl:156-215 (the part the examples assert on)
+    def solution(self):
+        pt, d = self.pt, self.dat
+        ray = "Sln_InfeasibilityCertificate" in (self.primal_status, self.dual_status)
+        t_ = 1.0 if ray else 1.0 / pt.tau
+        n = d.nvar
+        x = pt.x[:n] * t_
+        s = (pt.zl[:n] - pt.zu[:n]) * t_
+        y = pt.y * t_
+        sgn = 1.0 if d.objsense else -1.0
+        return {"status": self.status, "niter": self.niter, "x": x, "y": y, "s": s,
+                "z_primal": sgn * self.primal_objective, "z_dual": sgn * self.dual_objective,
+                "primal_status": self.primal_status, "dual_status": self.dual_status, "rho": self.rho}
+
+
+def solve_lp(lp, backend_factory, options=None):
+    """load -> standard form -> KKT.setup -> HSD -> solution (optimize! without presolve)."""
+    dat = standard_form(lp)
+    be = backend_factory(dat.A)
+    hsd = HSD(dat, be, options).optimize()
+    return hsd, hsd.solution()
