@@ -100,6 +100,8 @@ def random_feasible_lp(m, n, seed, ineq=False):
     A = (A + sp.csc_matrix((np.ones(m), (np.arange(m), rng.integers(0, n, m))), shape=(m, n))).tocsc()
     x0 = rng.uniform(0.5, 1.5, n)
     y0 = rng.standard_normal(m); z0 = rng.uniform(0.1, 1.0, n)
+    if ineq:
+        y0 = -np.abs(y0)            # rows "a'x <= b" need multipliers <= 0 for a bounded LP
     c = A.T @ y0 + z0
     if ineq:
         s0 = rng.uniform(0.1, 1.0, m)
