@@ -251,7 +251,7 @@ class Emulator:
             f, ns = int(self.f[front]), int(self.ns[front])
             rows = self.rows(front)
             xf = np.concatenate([self.xw[c0: c0 + ns], self.xw[rows[ns:]]])
-            r1 = min(row0 + 256, f)
+            r1 = min(row0 + 128, f)
             self.bpart[int(slot)] = P[row0:r1, k0:k0 + nb].T @ xf[row0:r1]
 
     def _k8(self, T):      # bwd diag

@@ -10,7 +10,10 @@ using namespace tlpk;
 int main(int argc, char **argv) {
     const int nfronts = argc > 1 ? atoi(argv[1]) : 64;
     const i32 f = argc > 2 ? atoi(argv[2]) : 4525, ns = argc > 3 ? atoi(argv[3]) : 3530;
+    // mode "right": trailing update after the first kw columns (K = kw, all trailing columns);
+    // mode "left" (5th arg = 1): left-looking update of the block column [kw, kw+256) with K = [0, kw)
     const i32 k0 = 0, kw = argc > 4 ? atoi(argv[4]) : 256;
+    const bool left = argc > 5 && atoi(argv[5]) == 1;
     const i32 rs = f - ns;
     std::vector<FrontDesc> fr(nfronts);
     i64 loff = 0, uoff = 0;
@@ -22,11 +25,10 @@ int main(int argc, char **argv) {
     std::vector<UpdateTask> tasks;
     double flops = 0;
     for (int s = 0; s < nfronts; ++s) {
-        const i32 c0 = k0 + kw;
-        const double t = (double)(f - c0);
-        flops += 2.0 * kw * t * (t + 1.0) * 0.5;
-        for (i32 j0 = c0; j0 < f; j0 += TILE)
-            for (i32 i0 = j0; i0 < f; i0 += TILE) tasks.push_back(UpdateTask{s, k0, kw, i0, j0, f, 0, 0});
+        const i32 c0 = k0 + kw, c1 = left ? std::min(c0 + 256, ns) : f;
+        for (i32 cc = c0; cc < c1; ++cc) flops += 2.0 * kw * (double)(f - cc);
+        for (i32 j0 = c0; j0 < c1; j0 += TILE)
+            for (i32 i0 = j0; i0 < f; i0 += TILE) tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, 0, 0});
     }
     DevCtx c{};
     FrontDesc *dfr; UpdateTask *dt; double *L, *U; int *info;
@@ -42,6 +44,37 @@ int main(int argc, char **argv) {
     }
     c.fronts = dfr; c.Lval = L; c.U0 = U; c.U1 = U; c.info = info;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    // optional 6th arg: number of streams the fronts are split over (concurrent-kernel test)
+    const int nstreams = argc > 6 ? atoi(argv[6]) : 1;
+    if (nstreams > 1) {
+        std::vector<hipStream_t> st(nstreams);
+        for (auto &x : st) hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
+        std::vector<hipEvent_t> done(nstreams);
+        for (auto &x : done) hipEventCreate(&x);
+        // tasks are front-major: split into contiguous chunks of fronts
+        std::vector<size_t> cut(nstreams + 1, 0);
+        for (int g = 1; g <= nstreams; ++g) {
+            const int fcut = (int)((long long)nfronts * g / nstreams);
+            size_t i = cut[g - 1];
+            while (i < tasks.size() && tasks[i].front < fcut) ++i;
+            cut[g] = i;
+        }
+        float bestm = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            hipDeviceSynchronize();
+            hipEventRecord(e0, st[0]);
+            for (int g = 1; g < nstreams; ++g) hipStreamWaitEvent(st[g], e0, 0);
+            for (int g = 0; g < nstreams; ++g) {
+                hipLaunchKernelGGL(k_update, dim3((unsigned)(cut[g + 1] - cut[g])), dim3(256), 0, st[g], dt + cut[g], c);
+                hipEventRecord(done[g], st[g]);
+            }
+            for (int g = 1; g < nstreams; ++g) hipStreamWaitEvent(st[0], done[g], 0);
+            hipEventRecord(e1, st[0]); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms < bestm) bestm = ms;
+        }
+        printf("  %d streams: %.3f ms  %.2f TFLOP/s\n", nstreams, bestm, flops / bestm / 1e9);
+    }
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
@@ -50,12 +83,12 @@ int main(int argc, char **argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep > 0 && ms < best) best = ms;
     }
-    printf("variant %d: fronts=%d f=%d ns=%d kw=%d tiles=%zu : %.3f ms  %.2f TFLOP/s (algorithmic)\n",
+    printf("variant %d%s: fronts=%d f=%d ns=%d kw=%d tiles=%zu : %.3f ms  %.2f TFLOP/s (algorithmic)\n",
 #ifdef UPD_VARIANT
            UPD_VARIANT,
 #else
            0,
 #endif
-           nfronts, f, ns, kw, tasks.size(), best, flops / best / 1e9);
+           left ? " (left-looking)" : "", nfronts, f, ns, kw, tasks.size(), best, flops / best / 1e9);
     return 0;
 }

@@ -57,16 +57,20 @@ __global__ void k_assemble(i64 nent, const i64 *__restrict__ target, const i32 *
 // and then adds, child after child, the child update-matrix columns that land in its range.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ tasks, DevCtx c) {
+    // Parent column tc of the range is owned by wave (tc - j0) & 3 for the whole kernel: every
+    // contribution to a column is applied by the same wave in child order (deterministic) and the
+    // four waves never need a barrier.
     const EaTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
     double *P = c.Lval + fd.loff;
     double *Up = front_u(c, fd);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // zero the lower part of U columns in range
-    for (i32 col = max(t.j0, ns) + wave; col < t.j1; col += 4)
-        for (i32 r = col + lane; r < f; r += 64) Up[(i64)(r - ns) + (i64)(col - ns) * rs] = 0.0;
-    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // zero the lower part of the U columns this wave owns
+    for (i32 col = t.j0 + wave; col < t.j1; col += 4)
+        if (col >= ns)
+            for (i32 r = col + lane; r < f; r += 64) Up[(i64)(r - ns) + (i64)(col - ns) * rs] = 0.0;
     for (i32 ci = 0; ci < fd.nchild; ++ci) {
         const FrontDesc cd = c.fronts[c.children[fd.child_ptr + ci]];
         const i32 rsc = cd.f - cd.ns;
@@ -79,8 +83,9 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
         hi = rsc;
         while (lo < hi) { const i32 mid = (lo + hi) >> 1; if (relc[mid] < t.j1) lo = mid + 1; else hi = mid; }
         const i32 q1 = lo;
-        for (i32 q = q0 + wave; q < q1; q += 4) {
+        for (i32 q = q0; q < q1; ++q) {
             const i32 tc = relc[q];
+            if (((tc - t.j0) & 3) != wave) continue;
             const double *src = Uc + (i64)q * rsc;
             if (tc < ns) {
                 double *dst = P + (i64)tc * f;
@@ -90,7 +95,6 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
                 for (i32 r = q + lane; r < rsc; r += 64) dst[relc[r]] += src[r];
             }
         }
-        __syncthreads();
     }
 }
 
@@ -473,22 +477,57 @@ __global__ __launch_bounds__(256) void k_fwd_gather(const SolveTask *__restrict_
     }
 }
 
-// forward diagonal block: y = L11^{-1} b as a product with the inverted block written by k_potrf
-// (one wave; lane c accumulates row c of Linv against b, fixed order k = 0..c).
-__global__ __launch_bounds__(64) void k_fwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
+// 64-long dot products split over the 4 waves (16 terms each), partials combined in fixed order.
+// which: 0 -> W lower-tri row i (k <= i), 1 -> full row (L21), 2 -> transposed lower-tri (k >= i)
+template <int WHICH>
+__device__ __forceinline__ double dot4(const double *M, i64 ldm, const double *v, int i, int part, int n, int nk,
+                                       double (*ps)[NB_IN]) {
+    double s = 0.0;
+    if (i < n) {
+        const int k0 = part * 16, k1 = min(k0 + 16, nk);
+        for (int k = k0; k < k1; ++k) {
+            if (WHICH == 0 && k > i) break;
+            if (WHICH == 2 && k < i) continue;
+            const double mv = (WHICH == 2) ? M[(i64)k + (i64)i * ldm] : M[(i64)i + (i64)k * ldm];
+            s += mv * v[k];
+        }
+        ps[part][i] = s;
+    }
+    __syncthreads();
+    double r = 0.0;
+    if (i < n && part == 0) r = ((ps[0][i] + ps[1][i]) + ps[2][i]) + ps[3][i];
+    __syncthreads();
+    return r;
+}
+
+// forward diagonal block (nb <= SOLVE_NB = 2 sub-blocks of NB_IN): with the inverted sub-blocks
+// written by k_potrf,  y1 = Wa b1 ;  y2 = Wb (b2 - L21 y1).  Fixed summation order.
+__global__ __launch_bounds__(256) void k_fwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
     __shared__ double bs[SOLVE_NB];
+    __shared__ double ys[SOLVE_NB];
+    __shared__ double ps[4][NB_IN];
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    const i32 nb = t.nb;
-    const double *W = front_dinv(c, fd, t.k0);
-    const int lane = threadIdx.x;
+    const i32 f = fd.f, nb = t.nb, na = min(nb, NB_IN), nb2 = nb - na;
+    const double *Wa = front_dinv(c, fd, t.k0);
+    const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
     double *xs = c.xw + fd.col0 + t.k0;
-    if (lane < nb) bs[lane] = xs[lane];
+    if (tid < nb) bs[tid] = xs[tid];
     __syncthreads();
-    if (lane >= nb) return;
-    double y = 0.0;
-    for (i32 k = 0; k <= lane; ++k) y += W[(i64)lane + (i64)k * nb] * bs[k];
-    xs[lane] = y;
+    double y = dot4<0>(Wa, na, bs, i, part, na, na, ps);
+    if (part == 0 && i < na) ys[i] = y;
+    __syncthreads();
+    if (nb2 > 0) {
+        const double *L21 = c.Lval + fd.loff + (i64)(t.k0 + NB_IN) + (i64)t.k0 * f;     // rows k0+64.., cols k0..
+        const double s = dot4<1>(L21, f, ys, i, part, nb2, NB_IN, ps);
+        if (part == 0 && i < nb2) bs[NB_IN + i] -= s;
+        __syncthreads();
+        const double *Wb = front_dinv(c, fd, t.k0 + NB_IN);
+        y = dot4<0>(Wb, nb2, bs + NB_IN, i, part, nb2, nb2, ps);
+        if (part == 0 && i < nb2) ys[NB_IN + i] = y;
+        __syncthreads();
+    }
+    if (tid < nb) xs[tid] = ys[tid];
 }
 
 // forward update: rows below a solved block: rhs[r] -= sum_j L[r, k0+j] * y[j].
@@ -555,32 +594,46 @@ __global__ __launch_bounds__(256) void k_bwd_update(const SolveTask *__restrict_
     }
 }
 
-// backward diagonal block: x = L11^{-T} (x - sum of the chunks' partial sums), with the inverted
-// block: x[c] = sum_{k >= c} Linv[k][c] * t[k].  The block is staged through LDS so that the
-// transposed access is conflict-free.
+// backward diagonal block (nb <= SOLVE_NB): t = x - sum of the chunks' partial sums, then with the
+// inverted sub-blocks  x2 = Wb' t2 ;  x1 = Wa' (t1 - L21' x2).
 __global__ __launch_bounds__(256) void k_bwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
-    constexpr int LD = SOLVE_NB + 1;
-    __shared__ double Ws[SOLVE_NB * LD];
     __shared__ double ts[SOLVE_NB];
+    __shared__ double xo[SOLVE_NB];
+    __shared__ double ps[4][NB_IN];
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    const i32 nb = t.nb;
-    const double *W = front_dinv(c, fd, t.k0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (i32 col = wave; col < nb; col += 4)
-        if (lane < nb && lane >= col) Ws[col * LD + lane] = W[(i64)lane + (i64)col * nb];   // Linv[lane][col]
+    const i32 f = fd.f, nb = t.nb, na = min(nb, NB_IN), nb2 = nb - na;
+    const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
     double *xs = c.xw + fd.col0 + t.k0;
-    if (wave == 0 && lane < nb) {
-        double x = xs[lane];
-        const double *part = c.bpart + (i64)t.slot * SOLVE_NB + lane;
-        for (i32 s = 0; s < t.nslot; ++s) x -= part[(i64)s * SOLVE_NB];
-        ts[lane] = x;
+    if (tid < nb) {
+        double x = xs[tid];
+        const double *pp = c.bpart + (i64)t.slot * SOLVE_NB + tid;
+        for (i32 s = 0; s < t.nslot; ++s) x -= pp[(i64)s * SOLVE_NB];
+        ts[tid] = x;
     }
     __syncthreads();
-    if (wave != 0 || lane >= nb) return;
-    double x = 0.0;
-    for (i32 k = lane; k < nb; ++k) x += Ws[lane * LD + k] * ts[k];       // Linv[k][lane]
-    xs[lane] = x;
+    if (nb2 > 0) {
+        const double *Wb = front_dinv(c, fd, t.k0 + NB_IN);
+        const double *L21 = c.Lval + fd.loff + (i64)(t.k0 + NB_IN) + (i64)t.k0 * f;
+        const double x2 = dot4<2>(Wb, nb2, ts + NB_IN, i, part, nb2, nb2, ps);          // sum_k Wb[k][i] t2[k]
+        if (part == 0 && i < nb2) xo[NB_IN + i] = x2;
+        __syncthreads();
+        // t1[i] -= sum_k L21[k][i] x2[k] : column i of L21, contiguous in k
+        double s = 0.0;
+        if (i < na) {
+            const int k0 = part * 16, k1 = min(k0 + 16, (int)nb2);
+            for (int k = k0; k < k1; ++k) s += L21[(i64)k + (i64)i * f] * xo[NB_IN + k];
+            ps[part][i] = s;
+        }
+        __syncthreads();
+        if (part == 0 && i < na) ts[i] -= ((ps[0][i] + ps[1][i]) + ps[2][i]) + ps[3][i];
+        __syncthreads();
+    }
+    const double *Wa = front_dinv(c, fd, t.k0);
+    const double x1 = dot4<2>(Wa, na, ts, i, part, na, na, ps);
+    if (part == 0 && i < na) xo[i] = x1;
+    __syncthreads();
+    if (tid < nb) xs[tid] = xo[tid];
 }
 
 __global__ void k_unpermute(i64 m, const i32 *__restrict__ perm, const char *__restrict__ row_local,
@@ -626,7 +679,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     case LK_TRSM: hipLaunchKernelGGL(k_trsm, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
     case LK_UPDATE: hipLaunchKernelGGL(k_update, g, dim3(256), 0, st, a.update_tasks + L.first, a.ctx); break;
     case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;
-    case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(64), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
+    case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(256), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
     case LK_FWD_UPDATE: hipLaunchKernelGGL(k_fwd_update, g, dim3(256), 0, st, a.fwd_update_tasks + L.first, a.ctx); break;
     case LK_BWD_UPDATE: hipLaunchKernelGGL(k_bwd_update, g, dim3(256), 0, st, a.bwd_update_tasks + L.first, a.ctx); break;
     case LK_BWD_DIAG: hipLaunchKernelGGL(k_bwd_diag, g, dim3(256), 0, st, a.bwd_diag_tasks + L.first, a.ctx); break;

@@ -18,9 +18,9 @@ constexpr int NB_OUT = 256;   // outer panel width: trailing updates run with K 
 constexpr int TILE = 128;     // update-kernel tile (TILE x TILE per workgroup)
 constexpr int TRSM_ROWS = 128; // rows per trsm workgroup (4 waves x 32 rows)
 constexpr int EA_COLS = 16;   // parent columns per extend-add workgroup
-constexpr int SOLVE_NB = 64;  // block width of the triangular-solve kernels
+constexpr int SOLVE_NB = 128; // block width of the triangular-solve kernels (two NB_IN sub-blocks)
 constexpr int SOLVE_ROWS = 256; // rows per forward-update workgroup
-constexpr int BWD_ROWS = 256;   // rows per backward-update workgroup (partial sums, reduced in fixed order)
+constexpr int BWD_ROWS = 128;   // rows per backward-update workgroup (partial sums, reduced in fixed order)
 
 // ---- device-visible descriptors (plain structs, uploaded as arrays) ----
 struct FrontDesc {
