@@ -30,8 +30,8 @@ class Emulator:
         self.pair_w = _lib.symbolic_array_f64(kkt._h, "pair_w")
         self.tasks = {
             LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 3),
-            LK["POTRF"]: g("potrf_tasks").reshape(-1, 3),
-            LK["TRSM"]: g("trsm_tasks").reshape(-1, 4),
+            LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
+            LK["TRSM"]: g("trsm_tasks").reshape(-1, 5),
             LK["UPDATE"]: g("update_tasks").reshape(-1, 6),
             LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 6),
             LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 6),
@@ -136,9 +136,12 @@ class Emulator:
                         Up[tr - ns, tc - ns] += src
 
     def _k1(self, T):      # potrf
-        for front, k0, nb in T:
+        for front, k0, nb, kprev in T:
             P = self.panel(front)
             blk = np.tril(P[k0:k0 + nb, k0:k0 + nb])
+            if k0 > kprev:      # columns [kprev, k0) of this block column, applied inside the kernel
+                X = P[k0:k0 + nb, kprev:k0]
+                blk = blk - np.tril(X @ X.T)
             for j in range(nb):
                 d = blk[j, j]
                 if not d > 0:
@@ -152,11 +155,13 @@ class Emulator:
 
     def _k2(self, T):      # trsm
         import scipy.linalg as sla
-        for front, k0, nb, row0 in T:
+        for front, k0, nb, row0, kprev in T:
             P = self.panel(front)
             f = int(self.f[front])
             r1 = min(row0 + 128, f)
             L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
+            if k0 > kprev:
+                P[row0:r1, k0:k0 + nb] -= P[row0:r1, kprev:k0] @ P[k0:k0 + nb, kprev:k0].T
             P[row0:r1, k0:k0 + nb] = sla.solve_triangular(L11, P[row0:r1, k0:k0 + nb].T, lower=True).T
 
     def _k3(self, T):      # update

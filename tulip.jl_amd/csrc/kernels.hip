@@ -126,10 +126,40 @@ __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tas
     const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
     const bool rok = r < nb;
     double av[16], wv[16];
+    // Left-looking inside the block column: subtract X X' where X = L[k0.., kprev..k0) are the
+    // already factored 64-wide steps of this block column.  Wave w computes the 16 x 64 row strip
+    // w of the 64 x 64 product on the matrix cores (operands straight from L2), the result goes
+    // through LDS into the per-thread layout.
+    __shared__ double Ds[NB_IN * (NB_IN + 1)];
+    const i32 Kp = t.k0 - t.kprev;
+    if (Kp > 0) {
+        const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+        const double *X = c.Lval + fd.loff + (i64)t.k0 + (i64)t.kprev * f;     // X[rr][k] = X[rr + k*f]
+        v4f64 dacc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) dacc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        const i32 rrow = 16 * cg + lr;                                           // this wave's rows
+        for (i32 ks = 0; ks < Kp; ks += 4) {
+            const double bvv = (rrow < nb) ? X[(i64)rrow + (i64)(ks + lk) * f] : 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const i32 crow = 16 * a + lr;
+                const double avv = (crow < nb) ? X[(i64)crow + (i64)(ks + lk) * f] : 0.0;
+                dacc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(avv, bvv, dacc[a], 0, 0, 0);
+            }
+        }
+        // D[i][j]: i = lk + 4q -> column 16a + i, j = lr -> row 16*cg + lr
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ds[(16 * a + lk + 4 * q) * (NB_IN + 1) + rrow] = dacc[a][q];
+    }
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const i32 col = cg + 4 * q;
         av[q] = (rok && col < nb && r >= col) ? P[(i64)r + (i64)col * f] : 0.0;
+        if (Kp > 0 && rok && col < nb && r >= col) av[q] -= Ds[col * (NB_IN + 1) + r];
         wv[q] = (r == col) ? 1.0 : 0.0;
     }
     for (i32 j = 0; j < nb; ++j) {
@@ -200,9 +230,9 @@ __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tas
 // exactly one lane), Linv is shared through LDS.  In place: a wave only overwrites its own rows,
 // after all of its loads.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
+__global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
     constexpr int LDW = NB_IN + 16;                 // == 16 mod 32: conflict-free ds_read_b64
-    __shared__ double Ws[NB_IN * LDW];              // Ws[k*LDW + c] = Linv[c][k]
+    __shared__ double Ws[NB_IN * LDW];              // staged operand: Ws[k*LDW + c]
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, nb = t.nb;
@@ -210,12 +240,9 @@ __global__ __launch_bounds__(256) void k_trsm(const TrsmTask *__restrict__ tasks
     const double *W = front_dinv(c, fd, t.k0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
-        const int cc = idx & (NB_IN - 1), k = idx >> 6;
-        Ws[k * LDW + cc] = (cc < nb && k < nb) ? W[(i64)cc + (i64)k * nb] : 0.0;
-    }
     const int lr = lane & 15, lk = lane >> 4;
     const i32 rbase = t.row0 + wave * 32;
+    const bool active = rbase < f;
     // B fragments: bf[b][ks] = B[rbase + 16b + lr][k0 + 4ks + lk]
     double bf[2][16];
 #pragma unroll
@@ -227,9 +254,57 @@ __global__ __launch_bounds__(256) void k_trsm(const TrsmTask *__restrict__ tasks
             bf[b][ks] = (row < f && k < nb) ? P[(i64)row + (i64)(t.k0 + k) * f] : 0.0;
         }
     }
-    __syncthreads();
-    if (rbase >= f) return;
     v4f64 acc[4][2];
+    // ---- left-looking inside the block column: B -= X_prev * L[k0.., kprev..k0)'  ----
+    // (transposed: D[c][r] = sum_k L[k0+c][k] * X[r][k]); the accumulator layout of D coincides
+    // lane by lane with the operand layout of bf: element (a, q) <-> bf[.][4a + q].
+    const i32 Kp = t.k0 - t.kprev;
+    for (i32 c0 = 0; c0 < Kp; c0 += NB_IN) {
+        __syncthreads();
+        for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
+            const int cc = idx & (NB_IN - 1), k = idx >> 6;
+            Ws[k * LDW + cc] = (cc < nb) ? P[(i64)(t.k0 + cc) + (i64)(t.kprev + c0 + k) * f] : 0.0;
+        }
+        __syncthreads();
+        if (active) {
+            double xf[2][16];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const i32 row = rbase + b * 16 + lr;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    xf[b][ks] = (row < f) ? P[(i64)row + (i64)(t.kprev + c0 + 4 * ks + lk) * f] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const double wv = Ws[(4 * ks + lk) * LDW + a * 16 + lr];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, xf[b][ks], acc[a][b], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bf[b][4 * a + q] -= acc[a][b][q];
+        }
+    }
+    // ---- X = B * L11^{-T} with the inverted diagonal block ----
+    __syncthreads();
+    for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
+        const int cc = idx & (NB_IN - 1), k = idx >> 6;
+        Ws[k * LDW + cc] = (cc < nb && k < nb) ? W[(i64)cc + (i64)k * nb] : 0.0;
+    }
+    __syncthreads();
+    if (!active) return;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll

@@ -657,8 +657,8 @@ static void build_schedule(Symbolic &S) {
         // ALL previous columns [0, ko) in registers and writes each target entry once (the
         // right-looking variant re-wrote the whole trailing matrix every 256 columns and was
         // HBM-bound on that read-modify-write).  The update matrix U gets a single update with
-        // K = [0, ns) after the last block column.  Inside a block column: right-looking with
-        // 64-wide steps (potrf, trsm, update of the remaining columns of the block column).
+        // K = [0, ns) after the last block column.  Inside a block column: 64-wide steps, each
+        // potrf/trsm first applying the block column's previous 64-wide steps (left-looking too).
         i32 max_ns = 0;
         for (i32 t = t0; t < t1; ++t) if (S.front_local[S.level_fronts[t]]) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         const i32 nouter = (max_ns + NB_OUT - 1) / NB_OUT;
@@ -697,11 +697,11 @@ static void build_schedule(Symbolic &S) {
                     const i32 no = std::min(NB_OUT, w.ns - ko);
                     if (ki >= ko + no) continue;
                     const i32 ni = std::min(NB_IN, ko + no - ki);
-                    if (kind == 0) S.potrf_tasks.push_back(PotrfTask{s, ki, ni, 0});
+                    // the columns [ko, ki) of this block column are applied inside k_potrf (to the
+                    // diagonal block) and k_trsm (to the rows below): no separate inner update pass
+                    if (kind == 0) S.potrf_tasks.push_back(PotrfTask{s, ki, ni, ko});
                     else if (kind == 1) {
-                        for (i32 r0 = ki + ni; r0 < w.f; r0 += TRSM_ROWS) S.trsm_tasks.push_back(TrsmTask{s, ki, ni, r0});
-                    } else {
-                        push_update_region(s, w, ki, ni, ki + ni, ko + no);   // rest of this block column
+                        for (i32 r0 = ki + ni; r0 < w.f; r0 += TRSM_ROWS) S.trsm_tasks.push_back(TrsmTask{s, ki, ni, r0, ko, 0, 0, 0});
                     }
                 }
                 push_launch(S.factor_launches, LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
