@@ -31,7 +31,7 @@ class Emulator:
         self.tasks = {
             LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 3),
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
-            LK["TRSM"]: g("trsm_tasks").reshape(-1, 5),
+            LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),
             LK["UPDATE"]: g("update_tasks").reshape(-1, 6),
             LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 6),
             LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 6),
@@ -155,7 +155,7 @@ class Emulator:
 
     def _k2(self, T):      # trsm
         import scipy.linalg as sla
-        for front, k0, nb, row0, kprev in T:
+        for front, k0, nb, row0, kprev, fuse_nb in T:
             P = self.panel(front)
             f = int(self.f[front])
             r1 = min(row0 + 128, f)
@@ -163,6 +163,9 @@ class Emulator:
             if k0 > kprev:
                 P[row0:r1, k0:k0 + nb] -= P[row0:r1, kprev:k0] @ P[k0:k0 + nb, kprev:k0].T
             P[row0:r1, k0:k0 + nb] = sla.solve_triangular(L11, P[row0:r1, k0:k0 + nb].T, lower=True).T
+            if fuse_nb > 0:                  # fused look-ahead potrf of the next diagonal block
+                assert row0 == k0 + nb and r1 >= min(k0 + nb + fuse_nb, f)
+                self._k1(np.array([[front, k0 + nb, fuse_nb, kprev]]))
 
     def _k3(self, T):      # update
         TILE = 128

@@ -112,17 +112,19 @@ __device__ __forceinline__ double *front_dinv(const DevCtx &c, const FrontDesc &
     return c.dinv + fd.dinvoff + (i64)(k0 / NB_IN) * (NB_IN * NB_IN);
 }
 
-__global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {
+constexpr int POTRF_SCRATCH = NB_IN * (NB_IN + 1) + 5 * NB_IN;   // doubles of LDS scratch
+
+__device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb,
+                                            const i32 kprev, double *scratch) {
     // Register-resident: thread (r, cg) owns A[r][col] and W[r][col] for col = cg + 4q, q = 0..15.
     // Per step only the pivot column of A and the pivot row of W go through LDS (double-buffered
     // by step parity => one barrier per column and no dependent LDS read-modify-write chains).
-    __shared__ double colbuf[2][NB_IN];
-    __shared__ double rowbuf[2][NB_IN];
-    __shared__ double dg[NB_IN];
-    const PotrfTask t = tasks[blockIdx.x];
-    const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, nb = t.nb;
-    double *P = c.Lval + fd.loff + (i64)t.k0 + (i64)t.k0 * f;
+    double *Ds = scratch;                                   // NB_IN x (NB_IN + 1)
+    double (*colbuf)[NB_IN] = reinterpret_cast<double (*)[NB_IN]>(scratch + NB_IN * (NB_IN + 1));
+    double (*rowbuf)[NB_IN] = colbuf + 2;
+    double *dg = scratch + NB_IN * (NB_IN + 1) + 4 * NB_IN;
+    const i32 f = fd.f;
+    double *P = c.Lval + fd.loff + (i64)bk0 + (i64)bk0 * f;
     const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
     const bool rok = r < nb;
     double av[16], wv[16];
@@ -130,11 +132,10 @@ __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tas
     // already factored 64-wide steps of this block column.  Wave w computes the 16 x 64 row strip
     // w of the 64 x 64 product on the matrix cores (operands straight from L2), the result goes
     // through LDS into the per-thread layout.
-    __shared__ double Ds[NB_IN * (NB_IN + 1)];
-    const i32 Kp = t.k0 - t.kprev;
+    const i32 Kp = bk0 - kprev;
     if (Kp > 0) {
         const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-        const double *X = c.Lval + fd.loff + (i64)t.k0 + (i64)t.kprev * f;     // X[rr][k] = X[rr + k*f]
+        const double *X = c.Lval + fd.loff + (i64)bk0 + (i64)kprev * f;     // X[rr][k] = X[rr + k*f]
         v4f64 dacc[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) dacc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tas
         __syncthreads();
         double d = colbuf[pb][j];
         if (!(d > 0.0)) {
-            if (tid == 0) atomicMin(c.info, fd.col0 + t.k0 + j);
+            if (tid == 0) atomicMin(c.info, fd.col0 + bk0 + j);
             d = 1.0;
         }
         const double inv2 = 1.0 / d, sq = sqrt(d), isq = 1.0 / sq;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tas
         dg[r] = v;
     }
     __syncthreads();
-    double *W = front_dinv(c, fd, t.k0);          // column-major nb x nb, ld = nb, upper part zero
+    double *W = front_dinv(c, fd, bk0);          // column-major nb x nb, ld = nb, upper part zero
     if (rok) {
         const double idg = 1.0 / dg[r];
 #pragma unroll
@@ -222,6 +223,13 @@ __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tas
     }
 }
 
+__global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double scratch[POTRF_SCRATCH];
+    const PotrfTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    potrf_block(c, fd, t.k0, t.nb, t.kprev, scratch);
+}
+
 // ------------------------------------------------------------------------------------------
 // trsm on the matrix cores: X = B * L11^{-T} as the product with the inverted diagonal block,
 // computed transposed (D[c][r] = sum_k Linv[c][k] * B[r][k]) so that consecutive lanes write
@@ -232,6 +240,7 @@ __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tas
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
     constexpr int LDW = NB_IN + 16;                 // == 16 mod 32: conflict-free ds_read_b64
+    static_assert(NB_IN * LDW >= POTRF_SCRATCH, "trsm LDS doubles as the fused potrf scratch");
     __shared__ double Ws[NB_IN * LDW];              // staged operand: Ws[k*LDW + c]
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
@@ -304,34 +313,42 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
         Ws[k * LDW + cc] = (cc < nb && k < nb) ? W[(i64)cc + (i64)k * nb] : 0.0;
     }
     __syncthreads();
-    if (!active) return;
+    if (active) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+        for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            if (4 * ks > 16 * a + 15) continue;       // Linv[c][k] = 0 for k > c: whole block is zero
-            const double wv = Ws[(4 * ks + lk) * LDW + a * 16 + lr];
+            for (int a = 0; a < 4; ++a) {
+                if (4 * ks > 16 * a + 15) continue;       // Linv[c][k] = 0 for k > c: whole block is zero
+                const double wv = Ws[(4 * ks + lk) * LDW + a * 16 + lr];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, bf[b][ks], acc[a][b], 0, 0, 0);
-        }
-    }
-    // D[i][j] (reg q: i = lk + 4q -> column c = 16a + i ; j = lr -> row)
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const i32 row = rbase + b * 16 + lr;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const i32 cc = a * 16 + lk + 4 * q;
-                if (row < f && cc < nb) P[(i64)row + (i64)(t.k0 + cc) * f] = acc[a][b][q];
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, bf[b][ks], acc[a][b], 0, 0, 0);
             }
         }
+        // D[i][j] (reg q: i = lk + 4q -> column c = 16a + i ; j = lr -> row)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const i32 row = rbase + b * 16 + lr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const i32 cc = a * 16 + lk + 4 * q;
+                    if (row < f && cc < nb) P[(i64)row + (i64)(t.k0 + cc) * f] = acc[a][b][q];
+                }
+            }
+    }
+    // Fused look-ahead: the workgroup that owns the first 128 rows below the block also holds the
+    // next diagonal block of this block column; it factors it right away (its inputs are complete:
+    // earlier launches + this workgroup's own stores), so that potrf leaves the critical path.
+    if (t.fuse_nb > 0) {
+        __syncthreads();                                // own global stores visible, Ws free
+        potrf_block(c, fd, t.k0 + nb, t.fuse_nb, t.kprev, Ws);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -689,6 +689,9 @@ static void build_schedule(Symbolic &S) {
                 const i32 ii = r / 3, kind = r % 3;
                 const i32 ki = ko + ii * NB_IN;
                 const i64 f_potrf = (i64)S.potrf_tasks.size(), f_trsm = (i64)S.trsm_tasks.size(), f_upd = (i64)S.update_tasks.size();
+                // pass 0 emits the look-ahead (fused potrf) trsm workgroups of every front first so
+                // that they start with the launch; pass 1 emits the remaining row chunks
+                for (int pass = 0; pass < (kind == 1 ? 2 : 1); ++pass)
                 for (i32 t = t0; t < t1; ++t) {
                     const i32 s = S.level_fronts[t];
                     if (!S.front_local[s]) continue;
@@ -697,11 +700,19 @@ static void build_schedule(Symbolic &S) {
                     const i32 no = std::min(NB_OUT, w.ns - ko);
                     if (ki >= ko + no) continue;
                     const i32 ni = std::min(NB_IN, ko + no - ki);
-                    // the columns [ko, ki) of this block column are applied inside k_potrf (to the
-                    // diagonal block) and k_trsm (to the rows below): no separate inner update pass
-                    if (kind == 0) S.potrf_tasks.push_back(PotrfTask{s, ki, ni, ko});
+                    // The columns [ko, ki) of this block column are applied inside k_potrf (to the
+                    // diagonal block) and k_trsm (to the rows below): no separate inner update pass.
+                    // The next 64-wide step's potrf is fused into the first trsm workgroup of this
+                    // step (its 128 rows contain the next diagonal block): only the first step of a
+                    // block column has a stand-alone potrf launch.
+                    const i32 next_nb = std::min(NB_IN, ko + no - (ki + ni));      // <= 0: last step
+                    if (kind == 0) { if (ii == 0) S.potrf_tasks.push_back(PotrfTask{s, ki, ni, ko}); }
                     else if (kind == 1) {
-                        for (i32 r0 = ki + ni; r0 < w.f; r0 += TRSM_ROWS) S.trsm_tasks.push_back(TrsmTask{s, ki, ni, r0, ko, 0, 0, 0});
+                        for (i32 r0 = ki + ni; r0 < w.f; r0 += TRSM_ROWS) {
+                            const bool first = (r0 == ki + ni);
+                            if ((pass == 0) != first) continue;
+                            S.trsm_tasks.push_back(TrsmTask{s, ki, ni, r0, ko, (first && next_nb > 0) ? next_nb : 0, 0, 0});
+                        }
                     }
                 }
                 push_launch(S.factor_launches, LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
