@@ -32,7 +32,7 @@ class Emulator:
             LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 3),
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
             LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),
-            LK["UPDATE"]: g("update_tasks").reshape(-1, 6),
+            LK["UPDATE"]: g("update_tasks").reshape(-1, 7),
             LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 6),
             LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 6),
             LK["FWD_UPDATE"]: g("fwd_update_tasks").reshape(-1, 6),
@@ -116,10 +116,8 @@ class Emulator:
             f, ns = int(self.f[front]), int(self.ns[front])
             rs = f - ns
             if front not in self.U:
-                self.U[front] = np.full((rs, rs), np.nan)       # NaN = never zeroed: catches missing tasks
+                self.U[front] = np.full((rs, rs), np.nan)       # NaN = never written: catches missing tasks
             Up = self.U[front]
-            for col in range(max(j0, ns), j1):
-                Up[col - ns:, col - ns] = 0.0
             P = self.panel(front)
             for c in self.kids(front):
                 relc = self.relidx(c)
@@ -169,7 +167,7 @@ class Emulator:
 
     def _k3(self, T):      # update
         TILE = 128
-        for front, k0, kw, i0, j0, jlim in T:
+        for front, k0, kw, i0, j0, jlim, beta0 in T:
             P = self.panel(front)
             f, ns = int(self.f[front]), int(self.ns[front])
             i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)
@@ -185,7 +183,12 @@ class Emulator:
                 if c < ns:
                     P[rsel, c] -= G[rsel - i0, c - j0]
                 else:
-                    self.U[front][rsel - ns, c - ns] -= G[rsel - i0, c - j0]
+                    if front not in self.U:
+                        self.U[front] = np.full((f - ns, f - ns), np.nan)
+                    if beta0:
+                        self.U[front][rsel - ns, c - ns] = -G[rsel - i0, c - j0]
+                    else:
+                        self.U[front][rsel - ns, c - ns] -= G[rsel - i0, c - j0]
             del mask
 
     # ---- solve! ----

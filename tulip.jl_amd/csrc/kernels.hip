@@ -53,8 +53,9 @@ __global__ void k_assemble(i64 nent, const i64 *__restrict__ target, const i32 *
 }
 
 // ------------------------------------------------------------------------------------------
-// extend-add: one workgroup owns parent columns [j0, j1); it zeroes the U part of those columns
-// and then adds, child after child, the child update-matrix columns that land in its range.
+// extend-add: one workgroup owns parent columns [j0, j1) and adds, child after child, the child
+// update-matrix columns that land in its range (panel columns before the front is factorised, U
+// columns after its U has been written by k_update).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ tasks, DevCtx c) {
     // Parent column tc of the range is owned by wave (tc - j0) & 3 for the whole kernel: every
@@ -67,10 +68,6 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
     double *Up = front_u(c, fd);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // zero the lower part of the U columns this wave owns
-    for (i32 col = t.j0 + wave; col < t.j1; col += 4)
-        if (col >= ns)
-            for (i32 r = col + lane; r < f; r += 64) Up[(i64)(r - ns) + (i64)(col - ns) * rs] = 0.0;
     for (i32 ci = 0; ci < fd.nchild; ++ci) {
         const FrontDesc cd = c.fronts[c.children[fd.child_ptr + ci]];
         const i32 rsc = cd.f - cd.ns;
@@ -492,9 +489,11 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
             for (int q = 0; q < 4; ++q) {
                 const i32 col = jbase + a * 16 + lk + 4 * q;
                 if (FULL || (row < f && col < t.jlim && row >= col)) {
-                    double *dst = (col < ns) ? (Pw + (i64)row + (i64)col * f)
-                                             : (Uw + (i64)(row - ns) + (i64)(col - ns) * rs);
-                    *dst -= acc[a][b][q];
+                    if (col < ns) Pw[(i64)row + (i64)col * f] -= acc[a][b][q];
+                    else {
+                        double *dst = Uw + (i64)(row - ns) + (i64)(col - ns) * rs;
+                        *dst = t.beta0 ? -acc[a][b][q] : (*dst - acc[a][b][q]);
+                    }
                 }
             }
         }

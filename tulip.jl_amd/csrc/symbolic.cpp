@@ -637,20 +637,23 @@ static void build_schedule(Symbolic &S) {
     for (i32 d = S.nlevels - 1; d >= 0; --d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
         const bool root_level = (d == 0 && S.root_front >= 0);
-        // (a) extend-add: zero U, add children's update matrices
-        {
+        // (a) extend-add, panel part: the children's update-matrix columns that land in the pivot
+        // columns [0, ns) of their parent.  The U part [ns, f) is added AFTER the front's single
+        // U update has written U (beta = 0), so U is never zero-filled nor read back by k_update.
+        auto push_ea = [&](bool u_part) {
             const i64 first = (i64)S.ea_tasks.size();
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
                 if (!S.front_local[s]) continue;
                 const FrontDesc &w = S.fronts[s];
-                if (w.f == w.ns && w.nchild == 0) continue;
-                // columns with any work: all of [0,f) when children exist, else only U's columns
-                const i32 jbeg = (w.nchild > 0) ? 0 : w.ns;
-                for (i32 j = jbeg; j < w.f; j += EA_COLS) S.ea_tasks.push_back(EaTask{s, j, std::min(j + EA_COLS, w.f), 0});
+                if (w.nchild == 0) continue;
+                const i32 jbeg = u_part ? w.ns : 0, jend = u_part ? w.f : w.ns;
+                const i32 cols = (w.f >= 2048) ? EA_COLS : 4;     // small fronts: more, narrower workgroups
+                for (i32 j = jbeg; j < jend; j += cols) S.ea_tasks.push_back(EaTask{s, j, std::min(j + cols, jend), 0});
             }
             push_launch(S.factor_launches, LK_EXTEND_ADD, first, (i64)S.ea_tasks.size() - first);
-        }
+        };
+        push_ea(false);
         if (root_level) S.factor_launches.push_back(Launch{LK_ALLREDUCE_ROOT, 0, 0, 0});
         // (b) blocked partial factorisation.  Outer level LEFT-looking: before the 256-wide block
         // column `io` of a front is factorised, one MFMA update accumulates the contribution of
@@ -662,12 +665,12 @@ static void build_schedule(Symbolic &S) {
         i32 max_ns = 0;
         for (i32 t = t0; t < t1; ++t) if (S.front_local[S.level_fronts[t]]) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         const i32 nouter = (max_ns + NB_OUT - 1) / NB_OUT;
-        auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1) {
+        auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0) {
             if (kw <= 0 || c0 >= c1) return;
             for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * kw * (double)(w.f - cc);
             for (i32 j0 = c0; j0 < c1; j0 += TILE)
                 for (i32 i0 = j0; i0 < w.f; i0 += TILE)
-                    S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, 0, 0});
+                    S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0});
         };
         for (i32 io = 0; io <= nouter; ++io) {
             const i32 ko = io * NB_OUT;
@@ -679,8 +682,8 @@ static void build_schedule(Symbolic &S) {
                     if (!S.front_local[s]) continue;
                     const FrontDesc &w = S.fronts[s];
                     const i32 my_nouter = (w.ns + NB_OUT - 1) / NB_OUT;
-                    if (io < my_nouter) push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns));
-                    else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f);
+                    if (io < my_nouter) push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns), 0);
+                    else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f, 1);   // U = -L21 L21' (written)
                 }
                 push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
             }
@@ -720,6 +723,8 @@ static void build_schedule(Symbolic &S) {
                 push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
             }
         }
+        // (c) extend-add, U part (every U of this level has been written by now)
+        push_ea(true);
     }
     // ---------------- forward solve: deepest level first ----------------
     for (i32 d = S.nlevels - 1; d >= 0; --d) {

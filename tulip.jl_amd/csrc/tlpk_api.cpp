@@ -550,7 +550,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "root_front") tmp.assign(1, S.root_front);
     else if (w == "potrf_tasks") { for (auto &t : S.potrf_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.kprev); } }
     else if (w == "trsm_tasks") { for (auto &t : S.trsm_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.kprev); tmp.push_back(t.fuse_nb); } }
-    else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); } }
+    else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); } }
     else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); } }
     else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks" || w == "bwd_diag_tasks") {
         const std::vector<SolveTask> &v = (w == "fwd_gather_tasks") ? S.fwd_gather_tasks : (w == "fwd_diag_tasks") ? S.fwd_diag_tasks :
