@@ -253,6 +253,9 @@ class Emulator:
                     self.xw[c0 + r] -= acc[t]
                 else:
                     self.uc[front][r - ns] -= acc[t]
+            if _[1] > 0:                      # fused look-ahead: solve the next diagonal block
+                assert row0 == k0 + nb and r1 >= min(k0 + nb + _[1], ns)
+                self._k5(np.array([[front, k0 + nb, _[1], 0, 0, 0]]))
 
     def _k7(self, T):      # bwd update: partial sums per row chunk
         if not hasattr(self, "bpart"):

@@ -593,27 +593,28 @@ __device__ __forceinline__ double dot4(const double *M, i64 ldm, const double *v
 
 // forward diagonal block (nb <= SOLVE_NB = 2 sub-blocks of NB_IN): with the inverted sub-blocks
 // written by k_potrf,  y1 = Wa b1 ;  y2 = Wb (b2 - L21 y1).  Fixed summation order.
-__global__ __launch_bounds__(256) void k_fwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
-    __shared__ double bs[SOLVE_NB];
-    __shared__ double ys[SOLVE_NB];
-    __shared__ double ps[4][NB_IN];
-    const SolveTask t = tasks[blockIdx.x];
-    const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, nb = t.nb, na = min(nb, NB_IN), nb2 = nb - na;
-    const double *Wa = front_dinv(c, fd, t.k0);
+// LDS scratch: 2*SOLVE_NB + 4*NB_IN doubles.
+constexpr int FWD_DIAG_SCRATCH = 2 * SOLVE_NB + 4 * NB_IN;
+
+__device__ __forceinline__ void fwd_diag_block(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb,
+                                               double *scratch) {
+    double *bs = scratch, *ys = scratch + SOLVE_NB;
+    double (*ps)[NB_IN] = reinterpret_cast<double (*)[NB_IN]>(scratch + 2 * SOLVE_NB);
+    const i32 f = fd.f, na = min(nb, NB_IN), nb2 = nb - na;
+    const double *Wa = front_dinv(c, fd, bk0);
     const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
-    double *xs = c.xw + fd.col0 + t.k0;
+    double *xs = c.xw + fd.col0 + bk0;
     if (tid < nb) bs[tid] = xs[tid];
     __syncthreads();
     double y = dot4<0>(Wa, na, bs, i, part, na, na, ps);
     if (part == 0 && i < na) ys[i] = y;
     __syncthreads();
     if (nb2 > 0) {
-        const double *L21 = c.Lval + fd.loff + (i64)(t.k0 + NB_IN) + (i64)t.k0 * f;     // rows k0+64.., cols k0..
+        const double *L21 = c.Lval + fd.loff + (i64)(bk0 + NB_IN) + (i64)bk0 * f;     // rows bk0+64.., cols bk0..
         const double s = dot4<1>(L21, f, ys, i, part, nb2, NB_IN, ps);
         if (part == 0 && i < nb2) bs[NB_IN + i] -= s;
         __syncthreads();
-        const double *Wb = front_dinv(c, fd, t.k0 + NB_IN);
+        const double *Wb = front_dinv(c, fd, bk0 + NB_IN);
         y = dot4<0>(Wb, nb2, bs + NB_IN, i, part, nb2, nb2, ps);
         if (part == 0 && i < nb2) ys[NB_IN + i] = y;
         __syncthreads();
@@ -621,9 +622,20 @@ __global__ __launch_bounds__(256) void k_fwd_diag(const SolveTask *__restrict__ 
     if (tid < nb) xs[tid] = ys[tid];
 }
 
-// forward update: rows below a solved block: rhs[r] -= sum_j L[r, k0+j] * y[j].
+__global__ __launch_bounds__(256) void k_fwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double scratch[FWD_DIAG_SCRATCH];
+    const SolveTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    fwd_diag_block(c, fd, t.k0, t.nb, scratch);
+}
+
+// forward update: rows below a solved block: rhs[r] -= sum_j L[r, k0+j] * y[j].  The workgroup
+// that owns the first SOLVE_ROWS rows below the block also holds the NEXT block's rows: when
+// t.nslot (= width of the next block) is set it solves that diagonal block right away
+// (look-ahead), so the forward sweep needs one launch per block instead of two.
 __global__ __launch_bounds__(256) void k_fwd_update(const SolveTask *__restrict__ tasks, DevCtx c) {
     __shared__ double ys[SOLVE_NB];
+    __shared__ double scratch[FWD_DIAG_SCRATCH];
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, nb = t.nb;
@@ -631,11 +643,16 @@ __global__ __launch_bounds__(256) void k_fwd_update(const SolveTask *__restrict_
     if (threadIdx.x < nb) ys[threadIdx.x] = c.xw[fd.col0 + t.k0 + threadIdx.x];
     __syncthreads();
     const i32 r = t.row0 + threadIdx.x;
-    if (r >= f) return;
-    double acc = 0.0;
-    for (i32 j = 0; j < nb; ++j) acc += P[(i64)r + (i64)j * f] * ys[j];
-    if (r < ns) c.xw[fd.col0 + r] -= acc;
-    else c.uc[fd.ucoff + (r - ns)] -= acc;
+    if (r < f) {
+        double acc = 0.0;
+        for (i32 j = 0; j < nb; ++j) acc += P[(i64)r + (i64)j * f] * ys[j];
+        if (r < ns) c.xw[fd.col0 + r] -= acc;
+        else c.uc[fd.ucoff + (r - ns)] -= acc;
+    }
+    if (t.nslot > 0) {
+        __syncthreads();                      // this workgroup's own updates of the next block's rhs
+        fwd_diag_block(c, fd, t.k0 + nb, t.nslot, scratch);
+    }
 }
 
 // backward update: partial sums  part[slot][j] = sum_{r in chunk} L[r, k0+j] * x_front[r]  for one

@@ -746,14 +746,22 @@ static void build_schedule(Symbolic &S) {
         for (i32 t = t0; t < t1; ++t) if (S.front_local[S.level_fronts[t]]) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         for (i32 kb = 0; kb < max_ns; kb += SOLVE_NB) {
             const i64 f_diag = (i64)S.fwd_diag_tasks.size(), f_upd = (i64)S.fwd_update_tasks.size();
+            // pass 0: the look-ahead workgroups (first row chunk: they also solve the next diagonal
+            // block) of every front, so that they start with the launch; pass 1: the other chunks
+            for (int pass = 0; pass < 2; ++pass)
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
                 if (!S.front_local[s]) continue;
                 const FrontDesc &w = S.fronts[s];
                 if (kb >= w.ns) continue;
                 const i32 nb = std::min(SOLVE_NB, w.ns - kb);
-                S.fwd_diag_tasks.push_back(SolveTask{s, kb, nb, 0, 0, 0, 0, 0});
-                for (i32 r0 = kb + nb; r0 < w.f; r0 += SOLVE_ROWS) S.fwd_update_tasks.push_back(SolveTask{s, kb, nb, r0, 0, 0, 0, 0});
+                const i32 next_nb = std::min(SOLVE_NB, w.ns - (kb + nb));      // <= 0: last block
+                if (pass == 0 && kb == 0) S.fwd_diag_tasks.push_back(SolveTask{s, kb, nb, 0, 0, 0, 0, 0});
+                for (i32 r0 = kb + nb; r0 < w.f; r0 += SOLVE_ROWS) {
+                    const bool first = (r0 == kb + nb);
+                    if ((pass == 0) != first) continue;
+                    S.fwd_update_tasks.push_back(SolveTask{s, kb, nb, r0, 0, (first && next_nb > 0) ? next_nb : 0, 0, 0});
+                }
             }
             push_launch(S.fwd_launches, LK_FWD_DIAG, f_diag, (i64)S.fwd_diag_tasks.size() - f_diag);
             push_launch(S.fwd_launches, LK_FWD_UPDATE, f_upd, (i64)S.fwd_update_tasks.size() - f_upd);
