@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--m0", type=int, default=1000)
     ap.add_argument("--nnz-col", type=int, default=4)
     ap.add_argument("--regime", default="mid", choices=["mid", "late"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "headline"],
+                    help="c4: BASELINE configs[3] (default). headline: the north-star instance, 100 blocks x "
+                         "(2e4 inequality rows x 1e4 vars) + 1e3 linking rows = 1e6 vars / 2e6 constraints")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -58,7 +61,7 @@ def cpu_baseline(args):
     import tulip_jl_amd as tk
     from oracle_binding import OracleK1
     from workloads import block_angular_lp, kernel_inputs
-    A, _ = block_angular_lp(args.blocks, args.mk, args.nk, 0, args.nnz_col, 0.5, blocks=[0])
+    A, _ = block_angular_lp(args.blocks, args.mk, args.nk, 0, args.nnz_col, 0.5, blocks=[0], ineq=args.ineq)
     m, n = A.shape
     perm = tk.setup(A, tk.K1(), tk.Backend(device=-1)).perm()      # same fill-reducing ordering
     th, rp, rd, xp, xd = kernel_inputs(m, n, 7, args.regime)
@@ -76,6 +79,9 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    args.ineq = False
+    if args.workload == "headline":
+        args.blocks, args.mk, args.nk, args.m0, args.ineq = 100, 20000, 10000, 1000, True
     import torch
     import tulip_jl_amd as tk
     from workloads import block_angular_lp, kernel_inputs
@@ -96,7 +102,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    A, row_block = block_angular_lp(args.blocks, args.mk, args.nk, args.m0, args.nnz_col, 0.5)
+    A, row_block = block_angular_lp(args.blocks, args.mk, args.nk, args.m0, args.nnz_col, 0.5, ineq=args.ineq)
     m, n = A.shape
     kkt = tk.setup(A, tk.K1(), tk.Backend(device=local_rank, row_block=row_block, rank=rank, nranks=world))
     st = kkt.stats()
@@ -175,8 +181,10 @@ def main():
         "value": 1e3 / ms_per_step, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3]: block-angular LP, %d blocks x (%d x %d, %d nnz/col) + %d linking rows; "
-                               "m=%d n=%d nnz(A)=%d" % (args.blocks, args.mk, args.nk, args.nnz_col, args.m0, m, n, A.nnz),
+        "config": {"workload": "%s: block-angular LP, %d blocks x (%d %s rows x %d vars, %d nnz/col) + %d linking rows; "
+                               "m=%d n=%d nnz(A)=%d" % ("BASELINE configs[3]" if args.workload == "c4" else "north-star headline",
+                                                        args.blocks, args.mk, "inequality" if args.ineq else "equality",
+                                                        args.nk, args.nnz_col, args.m0, m, n, A.nnz),
                    "solves_per_step": args.solves, "regime": args.regime, "parallelism": "blocks/%d" % world,
                    "nnzS": st["nnzS"], "nnzL": st["nnzL"], "nnzL_stored": st["nnzL_stored"],
                    "flops_chol": st["flops_chol"], "n_supernodes": st["n_supernodes"], "n_levels": st["n_levels"],

@@ -19,11 +19,14 @@ def sparse_columns(m, n, nnz_per_col, rng):
 
 
 def block_angular_lp(nblocks=64, mk=5000, nk=10000, m0=1000, nnz_in=4, link_prob=0.5, seed=SEED,
-                     blocks=None):
+                     blocks=None, ineq=False):
     """Config C4: `nblocks` diagonal blocks A_k (mk x nk, nnz_in per column, equality rows) and
     m0 linking rows; each column touches one linking row w.p. link_prob (SURVEY.md 8d proposal,
     seed + k per block).  `blocks` restricts generation to a subset of block ids (same content
-    per block as in the full problem).  Returns (A csc, row_block) with linking rows last."""
+    per block as in the full problem).  ineq=True: the block rows are "<=" constraints, i.e. the
+    standard-form matrix gets one slack column per block row (A_k = [A0_k I], ipmdata.jl:90-96)
+    -- the north-star headline instance is 100 x (2e4 inequality rows x 1e4 vars) + 1e3 linking.
+    Returns (A csc, row_block) with linking rows last."""
     ids = list(range(nblocks)) if blocks is None else list(blocks)
     diag, link = [], []
     for k in ids:
@@ -33,6 +36,10 @@ def block_angular_lp(nblocks=64, mk=5000, nk=10000, m0=1000, nnz_in=4, link_prob
         rows = rng.integers(0, max(m0, 1), size=cols.size)
         vals = rng.standard_normal(cols.size)
         Bk = sp.csc_matrix((vals, (rows, cols)), shape=(m0, nk)) if m0 > 0 else None
+        if ineq:
+            Ak = sp.hstack([Ak, sp.identity(mk, format="csc")], format="csc")
+            if Bk is not None:
+                Bk = sp.hstack([Bk, sp.csc_matrix((m0, mk))], format="csc")
         diag.append(Ak); link.append(Bk)
     top = sp.block_diag(diag, format="csc")
     A = sp.vstack([top, sp.hstack(link, format="csc")], format="csc") if m0 > 0 else top
