@@ -178,7 +178,14 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
             if (tid == 0) atomicMin(c.info, fd.col0 + bk0 + j);
             d = 1.0;
         }
-        const double inv2 = 1.0 / d, sq = sqrt(d), isq = 1.0 / sq;
+        // pivot arithmetic off one reciprocal square root (hardware estimate + 2 Newton steps, then a
+        // final correction of the square root): isq = d^-1/2, sq = d^1/2, inv2 = 1/d = isq^2
+        double isq = __builtin_amdgcn_rsq(d);
+        isq = isq * (1.5 - 0.5 * d * isq * isq);
+        isq = isq * (1.5 - 0.5 * d * isq * isq);
+        double sq = d * isq;
+        sq = fma(0.5 * isq, fma(-sq, sq, d), sq);
+        const double inv2 = isq * isq;
         const double arj = (rok && r > j) ? colbuf[pb][r] * inv2 : 0.0;    // multiplier L~[r][j]
         // all LDS reads first (independent), then branch-free predicated updates
         double cv[16], rv[16];
