@@ -49,7 +49,7 @@ typedef struct tlpk_options {
     int32_t relax;             /* supernode amalgamation: 0 = fundamental only, 1 = relaxed */
     int32_t profile;           /* 1 = time every kernel class with HIP events (tlpk_kernel_times) */
     int32_t rank, nranks;      /* block-angular sharding over ranks (nranks = 1: everything local) */
-    int32_t reserved0;
+    int32_t streams;           /* concurrent stream groups for block-angular LPs: 0 = auto (4), 1 = single stream */
     const int64_t *user_perm;  /* TLPK_ORDER_USER: perm[new] = old, in index_base, length m */
     const int64_t *row_block;  /* block-angular hook (length m): block id >= 0, or -1 for a linking
                                   row; NULL = general sparse.  Blocks are ordered independently,
@@ -141,7 +141,9 @@ int tlpk_root_copy(tlpk_handle *h, int which, int dir, double *d_buf);
 /* Introspection */
 int tlpk_info(const tlpk_handle *h, tlpk_stats *out);
 int tlpk_kernel_timing(const tlpk_handle *h, tlpk_kernel_times *out);
-int tlpk_set_profile(tlpk_handle *h, int on);   /* toggle per-launch HIP-event timing at run time */
+int tlpk_set_profile(tlpk_handle *h, int on);   /* toggle per-launch HIP-event timing at run time; while on, the
+                                                   stream groups are serialised on the main stream so that the
+                                                   per-kernel durations are not inflated by overlap */
 int tlpk_get_perm(const tlpk_handle *h, int64_t *perm /*m, 0-based, perm[new] = old*/);
 /* Symbolic structures, for tests and tools.  `what` selects an array; returns its length and,
  * if buf != NULL, copies min(len, cap) int64 entries. */

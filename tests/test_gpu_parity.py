@@ -233,3 +233,47 @@ def test_sharded_split_phase_on_device(world, tmp_path):
         assert np.abs(z["dx"] - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max())
         assert np.abs(z["dy"] - dyo).max() <= 1e-9 * max(1, np.abs(dyo).max())
         assert np.abs(z["dy_link"] - dyo[row_block < 0]).max() <= 1e-9 * max(1, np.abs(dyo).max())
+
+
+def test_c4_full_scale_identities_and_stream_groups():
+    """BASELINE config C4 at FULL size (64 blocks x (5000 x 10000) + 1000 linking rows, m = 321 000):
+    the residual identities of src/KKT/Test/test.jl:39-43 (size-independent), and the concurrent
+    stream-group schedule must give bit-identical results to the single-stream schedule."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from workloads import block_angular_lp, kernel_inputs
+    A, row_block = block_angular_lp()
+    m, n = A.shape
+    th, rp, rd, xp, xd = kernel_inputs(m, n, 7, "mid")
+    outs = []
+    for streams in (1, 4):
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=row_block, streams=streams))
+        assert int(kkt.symbolic("ngroups")[0]) == streams
+        tk.update(kkt, th, rp, rd)
+        dx = np.zeros(n); dy = np.zeros(m)
+        tk.solve(dx, dy, kkt, xp, xd)
+        r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+        scale = 1 + max(np.abs(xp).max(), np.abs(xd).max())
+        assert r1 <= 1e-8 * scale * max(1.0, np.abs(dy).max()) and r2 <= 1e-8 * scale * max(1.0, np.abs(dx).max())
+        outs.append((dx, dy))
+        kkt.close()
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
+def test_mpc_starting_point_pattern():
+    """MPC's starting point calls update!(zeros(n), ones(n), 1e-6*ones(m)) and two solves with one
+    zero right-hand-side half each (/root/reference/src/IPM/MPC/MPC.jl:359-363): D = 1,
+    S = A A' + 1e-6 I."""
+    A = random_lp_matrix(300, 800, 3, 31)
+    kkt = gpu_setup(A)
+    m, n = A.shape
+    th, rp, rd = np.zeros(n), np.ones(n), np.full(m, 1e-6)
+    tk.update(kkt, th, rp, rd)
+    orc = OracleK1(A, kkt.perm()); orc.update(th, rp, rd)
+    rng = np.random.default_rng(0)
+    for xp, xd in ((rng.standard_normal(m), np.zeros(n)), (np.zeros(m), rng.standard_normal(n))):
+        dx = np.zeros(n); dy = np.zeros(m)
+        tk.solve(dx, dy, kkt, xp, xd)
+        dxo, dyo = orc.solve(xp, xd)
+        assert np.abs(dy - dyo).max() <= 1e-8 * max(1.0, np.abs(dyo).max())
+        assert np.abs(dx - dxo).max() <= 1e-8 * max(1.0, np.abs(dxo).max())

@@ -23,7 +23,7 @@ pd = C.POINTER(C.c_double)
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("ordering", C.c_int32),
                 ("relax", C.c_int32), ("profile", C.c_int32), ("rank", C.c_int32),
-                ("nranks", C.c_int32), ("reserved0", C.c_int32),
+                ("nranks", C.c_int32), ("streams", C.c_int32),
                 ("user_perm", p64), ("row_block", p64), ("mem_budget_bytes", C.c_int64)]
 
 

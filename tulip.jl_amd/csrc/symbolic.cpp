@@ -9,6 +9,7 @@
 #include "../../include/tlpk.h"
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -495,6 +496,18 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         }
     }
 
+    // stream groups: the diagonal blocks are independent subtrees below the root front; block b runs
+    // on stream b % ngroups so that one group's latency-bound steps (potrf/trsm chains, diagonal
+    // solves) overlap the other groups' MFMA updates.  General sparse LPs: one group.
+    S.ngroups = 1;
+    if (opt.row_block && nblocks >= 2) {
+        S.ngroups = std::min(4, nblocks);
+        if (opt.streams > 0) S.ngroups = std::min({opt.streams, MAX_GROUPS, nblocks});
+        else if (const char *e = std::getenv("TLPK_STREAMS")) S.ngroups = std::max(1, std::min({std::atoi(e), MAX_GROUPS, nblocks}));
+    }
+    S.front_group.assign(ns_total, 0);
+    for (i32 s = 0; s < ns_total; ++s) if (S.front_block[s] >= 0) S.front_group[s] = S.front_block[s] % S.ngroups;
+
     // a rank only ever walks its own children: drop the other ranks' block roots from the
     // (replicated) root front's child list
     if (opt.nranks > 1)
@@ -533,15 +546,31 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         w.dinvoff = S.dinv_len;
         S.dinv_len += (w.ns >= NB_IN) ? (i64)((w.ns + NB_IN - 1) / NB_IN) * NB_IN * NB_IN : (i64)w.ns * w.ns;
     }
-    for (i32 d = 0; d < S.nlevels; ++d) {
-        i64 off = 0;
-        for (i32 t = S.level_ptr[d]; t < S.level_ptr[d + 1]; ++t) {
-            FrontDesc &w = S.fronts[S.level_fronts[t]];
-            if (!S.front_local[S.level_fronts[t]]) continue;
-            const i64 rs = w.f - w.ns;
-            w.uoff = off; off += rs * rs;
+    {
+        // update-matrix buffers: ping-pong by depth parity inside each stream group (groups are not
+        // level-synchronised with each other, so every group gets its own region of both buffers)
+        std::vector<std::array<i64, 2>> gmax(S.ngroups, {0, 0});
+        std::vector<i64> off;
+        for (i32 d = 0; d < S.nlevels; ++d) {
+            off.assign(S.ngroups, 0);
+            for (i32 t = S.level_ptr[d]; t < S.level_ptr[d + 1]; ++t) {
+                const i32 s = S.level_fronts[t];
+                FrontDesc &w = S.fronts[s];
+                if (!S.front_local[s]) continue;
+                const i64 rs = w.f - w.ns;
+                const i32 g = S.front_group[s];
+                w.uoff = off[g]; off[g] += rs * rs;           // group-relative for now
+            }
+            for (i32 g = 0; g < S.ngroups; ++g) gmax[g][d & 1] = std::max(gmax[g][d & 1], off[g]);
         }
-        S.ubuf_len[d & 1] = std::max(S.ubuf_len[d & 1], off);
+        std::array<i64, 2> base = {0, 0};
+        std::vector<std::array<i64, 2>> gbase(S.ngroups);
+        for (i32 g = 0; g < S.ngroups; ++g) { gbase[g] = base; base[0] += gmax[g][0]; base[1] += gmax[g][1]; }
+        S.ubuf_len[0] = base[0]; S.ubuf_len[1] = base[1];
+        for (i32 s = 0; s < ns_total; ++s) {
+            FrontDesc &w = S.fronts[s];
+            if (S.front_local[s]) w.uoff += gbase[S.front_group[s]][S.depth[s] & 1];
+        }
     }
     S.flops_panel = 0;
     for (i32 s = 0; s < ns_total; ++s) {
@@ -630,11 +659,15 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
 // ---------------------------------------------------------------------------------------------
 static void build_schedule(Symbolic &S) {
     const i32 slots_per_outer = (NB_OUT / NB_IN) * 3;
-    auto push_launch = [](std::vector<Launch> &L, i32 kind, i64 first, i64 count) {
-        if (count > 0) L.push_back(Launch{kind, 0, first, count});
+    // Scope of the level body being generated: stream group `cur_g` (fronts at depth >= 1 of that
+    // group) or -1 = the depth-0 fronts, which run on the main stream after all groups joined.
+    int cur_g = -1;
+    auto in_scope = [&](i32 s) { return S.front_local[s] && (cur_g < 0 || S.front_group[s] == cur_g); };
+    auto push_launch = [&](std::vector<Launch> &L, i32 kind, i64 first, i64 count) {
+        if (count > 0) L.push_back(Launch{kind, cur_g, first, count});
     };
     // ---------------- factorisation ----------------
-    for (i32 d = S.nlevels - 1; d >= 0; --d) {
+    auto factor_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
         const bool root_level = (d == 0 && S.root_front >= 0);
         // (a) extend-add, panel part: the children's update-matrix columns that land in the pivot
@@ -644,7 +677,7 @@ static void build_schedule(Symbolic &S) {
             const i64 first = (i64)S.ea_tasks.size();
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
-                if (!S.front_local[s]) continue;
+                if (!in_scope(s)) continue;
                 const FrontDesc &w = S.fronts[s];
                 if (w.nchild == 0) continue;
                 const i32 jbeg = u_part ? w.ns : 0, jend = u_part ? w.f : w.ns;
@@ -654,7 +687,7 @@ static void build_schedule(Symbolic &S) {
             push_launch(S.factor_launches, LK_EXTEND_ADD, first, (i64)S.ea_tasks.size() - first);
         };
         push_ea(false);
-        if (root_level) S.factor_launches.push_back(Launch{LK_ALLREDUCE_ROOT, 0, 0, 0});
+        if (root_level) S.factor_launches.push_back(Launch{LK_ALLREDUCE_ROOT, -1, 0, 0});
         // (b) blocked partial factorisation.  Outer level LEFT-looking: before the 256-wide block
         // column `io` of a front is factorised, one MFMA update accumulates the contribution of
         // ALL previous columns [0, ko) in registers and writes each target entry once (the
@@ -663,7 +696,7 @@ static void build_schedule(Symbolic &S) {
         // K = [0, ns) after the last block column.  Inside a block column: 64-wide steps, each
         // potrf/trsm first applying the block column's previous 64-wide steps (left-looking too).
         i32 max_ns = 0;
-        for (i32 t = t0; t < t1; ++t) if (S.front_local[S.level_fronts[t]]) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
+        for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         const i32 nouter = (max_ns + NB_OUT - 1) / NB_OUT;
         auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0) {
             if (kw <= 0 || c0 >= c1) return;
@@ -679,7 +712,7 @@ static void build_schedule(Symbolic &S) {
                 const i64 f_upd = (i64)S.update_tasks.size();
                 for (i32 t = t0; t < t1; ++t) {
                     const i32 s = S.level_fronts[t];
-                    if (!S.front_local[s]) continue;
+                    if (!in_scope(s)) continue;
                     const FrontDesc &w = S.fronts[s];
                     const i32 my_nouter = (w.ns + NB_OUT - 1) / NB_OUT;
                     if (io < my_nouter) push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns), 0);
@@ -697,7 +730,7 @@ static void build_schedule(Symbolic &S) {
                 for (int pass = 0; pass < (kind == 1 ? 2 : 1); ++pass)
                 for (i32 t = t0; t < t1; ++t) {
                     const i32 s = S.level_fronts[t];
-                    if (!S.front_local[s]) continue;
+                    if (!in_scope(s)) continue;
                     const FrontDesc &w = S.fronts[s];
                     if (ko >= w.ns) continue;
                     const i32 no = std::min(NB_OUT, w.ns - ko);
@@ -725,25 +758,29 @@ static void build_schedule(Symbolic &S) {
         }
         // (c) extend-add, U part (every U of this level has been written by now)
         push_ea(true);
-    }
+    };
+    for (cur_g = 0; cur_g < S.ngroups; ++cur_g)
+        for (i32 d = S.nlevels - 1; d >= 1; --d) factor_level(d);
+    cur_g = -1;
+    if (S.nlevels > 0) factor_level(0);
     // ---------------- forward solve: deepest level first ----------------
-    for (i32 d = S.nlevels - 1; d >= 0; --d) {
+    auto fwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
         const bool root_level = (d == 0 && S.root_front >= 0);
         {
             const i64 first = (i64)S.fwd_gather_tasks.size();
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
-                if (!S.front_local[s]) continue;
+                if (!in_scope(s)) continue;
                 const FrontDesc &w = S.fronts[s];
                 if (w.nchild == 0 && w.f == w.ns) continue;
                 S.fwd_gather_tasks.push_back(SolveTask{s, 0, 0, 0, 0, 0, 0, 0});
             }
             push_launch(S.fwd_launches, LK_FWD_GATHER, first, (i64)S.fwd_gather_tasks.size() - first);
         }
-        if (root_level) S.fwd_launches.push_back(Launch{LK_ALLREDUCE_ROOT, 0, 0, 0});
+        if (root_level) S.fwd_launches.push_back(Launch{LK_ALLREDUCE_ROOT, -1, 0, 0});
         i32 max_ns = 0;
-        for (i32 t = t0; t < t1; ++t) if (S.front_local[S.level_fronts[t]]) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
+        for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         for (i32 kb = 0; kb < max_ns; kb += SOLVE_NB) {
             const i64 f_diag = (i64)S.fwd_diag_tasks.size(), f_upd = (i64)S.fwd_update_tasks.size();
             // pass 0: the look-ahead workgroups (first row chunk: they also solve the next diagonal
@@ -751,7 +788,7 @@ static void build_schedule(Symbolic &S) {
             for (int pass = 0; pass < 2; ++pass)
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
-                if (!S.front_local[s]) continue;
+                if (!in_scope(s)) continue;
                 const FrontDesc &w = S.fronts[s];
                 if (kb >= w.ns) continue;
                 const i32 nb = std::min(SOLVE_NB, w.ns - kb);
@@ -766,13 +803,17 @@ static void build_schedule(Symbolic &S) {
             push_launch(S.fwd_launches, LK_FWD_DIAG, f_diag, (i64)S.fwd_diag_tasks.size() - f_diag);
             push_launch(S.fwd_launches, LK_FWD_UPDATE, f_upd, (i64)S.fwd_update_tasks.size() - f_upd);
         }
-    }
+    };
+    for (cur_g = 0; cur_g < S.ngroups; ++cur_g)
+        for (i32 d = S.nlevels - 1; d >= 1; --d) fwd_level(d);
+    cur_g = -1;
+    if (S.nlevels > 0) fwd_level(0);
     // ---------------- backward solve: root level first ----------------
     i64 slot_cursor = 0;
-    for (i32 d = 0; d < S.nlevels; ++d) {
+    auto bwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
         i32 max_ns = 0;
-        for (i32 t = t0; t < t1; ++t) if (S.front_local[S.level_fronts[t]]) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
+        for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         const i32 nblk = (max_ns + SOLVE_NB - 1) / SOLVE_NB;
         // fronts are right-aligned: step b handles each front's block (its_nblk - 1 - b) so that
         // every front walks its own blocks from last to first
@@ -780,7 +821,7 @@ static void build_schedule(Symbolic &S) {
             const i64 f_upd = (i64)S.bwd_update_tasks.size(), f_diag = (i64)S.bwd_diag_tasks.size();
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
-                if (!S.front_local[s]) continue;
+                if (!in_scope(s)) continue;
                 const FrontDesc &w = S.fronts[s];
                 const i32 my_nblk = (w.ns + SOLVE_NB - 1) / SOLVE_NB;
                 if (b >= my_nblk) continue;
@@ -798,7 +839,11 @@ static void build_schedule(Symbolic &S) {
             push_launch(S.bwd_launches, LK_BWD_UPDATE, f_upd, (i64)S.bwd_update_tasks.size() - f_upd);
             push_launch(S.bwd_launches, LK_BWD_DIAG, f_diag, (i64)S.bwd_diag_tasks.size() - f_diag);
         }
-    }
+    };
+    cur_g = -1;
+    if (S.nlevels > 0) bwd_level(0);
+    for (cur_g = 0; cur_g < S.ngroups; ++cur_g)
+        for (i32 d = 1; d < S.nlevels; ++d) bwd_level(d);
     S.bpart_len = slot_cursor * SOLVE_NB;
 }
 

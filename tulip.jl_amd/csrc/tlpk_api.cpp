@@ -26,7 +26,10 @@ struct tlpk_handle {
     int device = -1;
     bool has_device = false;
     bool profile = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                 // main stream (= group 0)
+    hipStream_t gstream[MAX_GROUPS] = {};         // gstream[0] == stream; others: concurrent subtree groups
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
+    bool forked = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_class;            // class of each recorded pair in the current call
@@ -91,8 +94,8 @@ int kind_class(i32 kind) {
 
 // profile helpers: record an event pair around one launch
 struct ProfScope {
-    tlpk_handle *h; bool on; size_t idx;
-    ProfScope(tlpk_handle *h_, int cls) : h(h_), on(h_->profile), idx(0) {
+    tlpk_handle *h; bool on; size_t idx; hipStream_t st;
+    ProfScope(tlpk_handle *h_, int cls, hipStream_t st_ = nullptr) : h(h_), on(h_->profile), idx(0), st(st_ ? st_ : h_->stream) {
         if (!on) return;
         if (h->ev_used + 2 > h->ev_pool.size()) {
             const size_t old = h->ev_pool.size();
@@ -101,9 +104,9 @@ struct ProfScope {
         }
         idx = h->ev_used; h->ev_used += 2;
         h->ev_class.push_back(cls);
-        hipEventRecord(h->ev_pool[idx], h->stream);
+        hipEventRecord(h->ev_pool[idx], st);
     }
-    ~ProfScope() { if (on) hipEventRecord(h->ev_pool[idx + 1], h->stream); }
+    ~ProfScope() { if (on) hipEventRecord(h->ev_pool[idx + 1], st); }
 };
 void prof_begin(tlpk_handle *h, bool reset) {
     if (!h->profile) return;
@@ -122,12 +125,39 @@ void prof_collect(tlpk_handle *h) {          // stream must be synchronised
     h->ev_used = 0; h->ev_class.clear();
 }
 
+// Stream groups: launches tagged with group g >= 1 go to their own stream.  fork = the group
+// streams wait for everything enqueued on the main stream so far; join = the main stream waits for
+// the group streams.  A launch tagged -1 (depth-0 fronts) and the end of a range force a join.
+void fork_groups(tlpk_handle *h) {
+    if (h->forked || h->S.ngroups <= 1) return;
+    hipEventRecord(h->ev_fork, h->stream);
+    for (int g = 1; g < h->S.ngroups; ++g) hipStreamWaitEvent(h->gstream[g], h->ev_fork, 0);
+    h->forked = true;
+}
+void join_groups(tlpk_handle *h) {
+    if (!h->forked) return;
+    for (int g = 1; g < h->S.ngroups; ++g) {
+        hipEventRecord(h->ev_join[g], h->gstream[g]);
+        hipStreamWaitEvent(h->stream, h->ev_join[g], 0);
+    }
+    h->forked = false;
+}
+
 void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, size_t to) {
     for (size_t i = from; i < to; ++i) {
+        if (L[i].group < 0) join_groups(h);
         if (L[i].kind == LK_ALLREDUCE_ROOT) continue;
-        ProfScope ps(h, kind_class(L[i].kind));
-        launch_tasks(h->stream, h->d, L[i]);
+        hipStream_t st = h->stream;
+        // profiling serialises everything on the main stream: per-launch HIP-event durations are
+        // then the kernels' own durations, not time shared with other groups' kernels
+        if (!h->profile) {
+            if (L[i].group >= 1) { fork_groups(h); st = h->gstream[L[i].group]; }
+            else if (L[i].group == 0) fork_groups(h);      // group 0 runs on the main stream itself
+        }
+        ProfScope ps(h, kind_class(L[i].kind), st);
+        launch_tasks(st, h->d, L[i]);
     }
+    join_groups(h);
 }
 
 int upload_all(tlpk_handle *h) {
@@ -236,6 +266,7 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
     try {
         h->opt.ordering = def.ordering; h->opt.relax = def.relax;
         h->opt.rank = def.rank; h->opt.nranks = def.nranks < 1 ? 1 : def.nranks;
+        h->opt.streams = def.streams;
         if (def.row_block && m > 0) {
             h->row_block_copy.assign(def.row_block, def.row_block + m);
             h->opt.row_block = h->row_block_copy.data();
@@ -264,6 +295,10 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
                 h->device = def.device;
                 hipError_t e = hipSetDevice(h->device);
                 if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+                h->gstream[0] = h->stream;
+                for (int g = 1; g < MAX_GROUPS && e == hipSuccess; ++g) e = hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+                for (int g = 1; g < MAX_GROUPS && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming);
                 if (e == hipSuccess) e = hipEventCreate(&h->ev0);
                 if (e == hipSuccess) e = hipEventCreate(&h->ev1);
                 if (e != hipSuccess) rc = hip_fail(h, e, "device init");
@@ -307,6 +342,11 @@ void tlpk_destroy(tlpk_handle *h) {
         for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
+        if (h->ev_fork) hipEventDestroy(h->ev_fork);
+        for (int g = 1; g < MAX_GROUPS; ++g) {
+            if (h->ev_join[g]) hipEventDestroy(h->ev_join[g]);
+            if (h->gstream[g]) { hipStreamSynchronize(h->gstream[g]); hipStreamDestroy(h->gstream[g]); }
+        }
         if (h->stream) hipStreamDestroy(h->stream);
     }
     delete h;
@@ -535,6 +575,8 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "children") from32(S.children);
     else if (w == "depth") from32(S.depth);
     else if (w == "front_block") from32(S.front_block);
+    else if (w == "front_group") from32(S.front_group);
+    else if (w == "ngroups") tmp.assign(1, S.ngroups);
     else if (w == "front_local") tmp.assign(S.front_local.begin(), S.front_local.end());
     else if (w == "col_local") tmp.assign(S.col_local.begin(), S.col_local.end());
     else if (w == "row_local") tmp.assign(S.row_local.begin(), S.row_local.end());

@@ -19,6 +19,7 @@ constexpr int TILE = 128;     // update-kernel tile (TILE x TILE per workgroup)
 constexpr int TRSM_ROWS = 128; // rows per trsm workgroup (4 waves x 32 rows)
 constexpr int EA_COLS = 16;   // parent columns per extend-add workgroup
 constexpr int SOLVE_NB = 128; // block width of the triangular-solve kernels (two NB_IN sub-blocks)
+constexpr int MAX_GROUPS = 8;    // concurrent streams for independent diagonal blocks
 constexpr int SOLVE_ROWS = 256; // rows per forward-update workgroup
 constexpr int BWD_ROWS = 128;   // rows per backward-update workgroup (partial sums, reduced in fixed order)
 
@@ -50,10 +51,10 @@ enum LaunchKind : i32 {
     LK_FWD_GATHER, LK_FWD_DIAG, LK_FWD_UPDATE, LK_BWD_UPDATE, LK_BWD_DIAG,
     LK_ALLREDUCE_ROOT   // marker: everything after this belongs to the replicated root front
 };
-struct Launch { i32 kind; i32 pad; i64 first; i64 count; };   // tasks[first .. first+count) of that kind
+struct Launch { i32 kind; i32 group; i64 first; i64 count; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
 
 struct Options {
-    i32 ordering = 0, relax = 1, rank = 0, nranks = 1;
+    i32 ordering = 0, relax = 1, rank = 0, nranks = 1, streams = 0;
     const i64 *user_perm = nullptr;   // 0-based here
     const i64 *row_block = nullptr;
 };
@@ -87,6 +88,8 @@ struct Symbolic {
     std::vector<char> col_local;           // column of A handled by this rank
     std::vector<char> row_local;           // 0 = other rank's block row, 1 = local block row, 2 = linking row
     i32 root_front = -1;                   // the replicated linking front (or -1)
+    i32 ngroups = 1;                       // independent subtree groups run on concurrent streams
+    std::vector<i32> front_group;          // group of each front (fronts at depth 0 run after the join)
     i32 n_local_blocks = 0;
     // assembly of S = A*D*A' + Rd into the panels
     std::vector<i64> s_target;             // per S entry: position in Lval

@@ -31,7 +31,7 @@ Base.@kwdef mutable struct Options
     profile::Int32 = 0
     rank::Int32 = 0
     nranks::Int32 = 1
-    reserved0::Int32 = 0
+    streams::Int32 = 0
     user_perm::Ptr{Int64} = C_NULL
     row_block::Ptr{Int64} = C_NULL
     mem_budget_bytes::Int64 = 0

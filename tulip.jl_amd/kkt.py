@@ -45,7 +45,7 @@ class Backend:
     """
 
     def __init__(self, device=0, ordering="amd", relax=True, row_block=None, user_perm=None,
-                 profile=False, rank=0, nranks=1, mem_budget_bytes=0):
+                 profile=False, rank=0, nranks=1, mem_budget_bytes=0, streams=0):
         self.device = device
         self.ordering = {"amd": _lib.ORDER_AMD, "natural": _lib.ORDER_NATURAL, "user": _lib.ORDER_USER}[ordering]
         self.relax = bool(relax)
@@ -54,6 +54,7 @@ class Backend:
         self.profile = bool(profile)
         self.rank, self.nranks = int(rank), int(nranks)
         self.mem_budget_bytes = int(mem_budget_bytes)
+        self.streams = int(streams)            # 0 = auto (4 concurrent block groups), 1 = single stream
 
 
 def _raise_for(code, handle=None, what=""):
@@ -94,6 +95,7 @@ class HIPNormalEquations:
         opt.profile = int(backend_.profile)
         opt.rank, opt.nranks = backend_.rank, backend_.nranks
         opt.mem_budget_bytes = backend_.mem_budget_bytes
+        opt.streams = backend_.streams
         self._keep = []
         if backend_.row_block is not None:
             if backend_.row_block.shape != (self.m,):
