@@ -436,6 +436,57 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         }
     };
 
+    if constexpr (FULL) {
+        // Interior tiles, K a multiple of the slab depth: the staging work is spread INSIDE the MFMA
+        // block instead of in front of it (ablation: the 16 loads + address arithmetic issued before
+        // the first MFMA of a round cost ~19 % with L2-hot data, i.e. pure issue time).  Registers
+        // hold slab t+1 at the start of round t: its LDS stores go with the first MFMA group, the
+        // loads of slab t+2 with the second and third, so the prefetch distance is two rounds.
+        if ((t.kw % UPD_KT) == 0 && t.kw >= 2 * UPD_KT) {
+            const double *pa_ptr = Pa, *pb_ptr = Pb;
+            const i64 step = (i64)UPD_KT * f, two_f = 2 * (i64)f;
+            auto ld_a = [&]() {
+#pragma unroll
+                for (int it = 0; it < UPD_NLD; ++it) pa[it] = pa_ptr[it * two_f];
+            };
+            auto ld_b = [&]() {
+#pragma unroll
+                for (int it = 0; it < UPD_NLD; ++it) pb[it] = pb_ptr[it * two_f];
+            };
+            ld_a(); ld_b();
+            store_slab(0);
+            pa_ptr += step; pb_ptr += step;
+            ld_a(); ld_b();                                   // slab 1 in flight
+            __syncthreads();
+            int cur = 0;
+            const i32 nrounds = t.kw / UPD_KT;
+            for (i32 rd = 0; rd < nrounds; ++rd) {
+                const double *At = As[cur] + wr * 64 + lr + lk * UPD_LD;
+                const double *Bt = Bs[cur] + wc * 64 + lr + lk * UPD_LD;
+                const bool have_next = rd + 1 < nrounds, have_next2 = rd + 2 < nrounds;
+#pragma unroll
+                for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) av[a] = Bt[k4 * UPD_LD + a * 16];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bv[b] = At[k4 * UPD_LD + b * 16];
+                    if (k4 == 0 && have_next) { store_slab(cur ^ 1); pa_ptr += step; pb_ptr += step; }
+                    if (k4 == 4 && have_next2) ld_a();
+                    if (k4 == 8 && have_next2) ld_b();
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+            goto epilogue;
+        }
+    }
+    {
     load_slab(0, UPD_KT <= t.kw);
     store_slab(0);
     __syncthreads();
@@ -475,6 +526,8 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
 #endif
         cur ^= 1;
     }
+    }
+epilogue:
     if (!any) return;
 #if defined(UPD_VARIANT) && (UPD_VARIANT == 2 || UPD_VARIANT == 6)   /* ablation: no epilogue read-modify-write */
 #pragma unroll
