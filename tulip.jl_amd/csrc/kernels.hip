@@ -442,7 +442,7 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         // the first MFMA of a round cost ~19 % with L2-hot data, i.e. pure issue time).  Registers
         // hold slab t+1 at the start of round t: its LDS stores go with the first MFMA group, the
         // loads of slab t+2 with the second and third, so the prefetch distance is two rounds.
-        if ((t.kw % UPD_KT) == 0 && t.kw >= 2 * UPD_KT) {
+        if (t.kw >= 2 * UPD_KT) {
             const double *pa_ptr = Pa, *pb_ptr = Pb;
             const i64 step = (i64)UPD_KT * f, two_f = 2 * (i64)f;
             auto ld_a = [&]() {
@@ -482,6 +482,26 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
                 }
                 __syncthreads();
                 cur ^= 1;
+            }
+            if (t.kw % UPD_KT) {                              // K tail: one guarded, zero-filled slab
+                load_slab(nrounds * UPD_KT, false);
+                store_slab(cur);
+                __syncthreads();
+                const double *At = As[cur] + wr * 64 + lr + lk * UPD_LD;
+                const double *Bt = Bs[cur] + wc * 64 + lr + lk * UPD_LD;
+#pragma unroll
+                for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) av[a] = Bt[k4 * UPD_LD + a * 16];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bv[b] = At[k4 * UPD_LD + b * 16];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+                }
             }
             goto epilogue;
         }
