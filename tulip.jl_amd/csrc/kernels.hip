@@ -458,75 +458,88 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         }
     };
 
-    if constexpr (FULL) {
-        // Interior tiles, K a multiple of the slab depth: the staging work is spread INSIDE the MFMA
-        // block instead of in front of it (ablation: the 16 loads + address arithmetic issued before
-        // the first MFMA of a round cost ~19 % with L2-hot data, i.e. pure issue time).  Registers
+    if (t.kw >= 2 * UPD_KT) {
+        // Main path (every tile with K >= 2 slabs): the staging work is spread INSIDE the MFMA block
+        // instead of in front of it (ablation: the 16 loads + address arithmetic issued before the
+        // first MFMA of a round cost ~19 % even with L2-hot data, i.e. pure issue time).  Registers
         // hold slab t+1 at the start of round t: its LDS stores go with the first MFMA group, the
         // loads of slab t+2 with the second and third, so the prefetch distance is two rounds.
-        if (t.kw >= 2 * UPD_KT) {
-            const double *pa_ptr = Pa, *pb_ptr = Pb;
-            const i64 step = (i64)UPD_KT * f, two_f = 2 * (i64)f;
-            auto ld_a = [&]() {
+        // Edge and diagonal tiles run the same straight-line loop: their staging rows are clamped to
+        // the last row of the front (a clamped row only feeds outputs that the guarded epilogue
+        // never stores), all 16 MFMA blocks of an active wave are computed, the epilogue masks.
+        const i32 rac = min(t.i0 + sr, f - 1), rbc = min(t.j0 + sr, f - 1);
+        const double *pa_ptr = P + (i64)(t.k0 + sk0) * f + rac;
+        const double *pb_ptr = P + (i64)(t.k0 + sk0) * f + rbc;
+        const i64 step = (i64)UPD_KT * f, two_f = 2 * (i64)f;
+        auto ld_a = [&]() {
 #pragma unroll
-                for (int it = 0; it < UPD_NLD; ++it) pa[it] = pa_ptr[it * two_f];
-            };
-            auto ld_b = [&]() {
+            for (int it = 0; it < UPD_NLD; ++it) pa[it] = pa_ptr[it * two_f];
+        };
+        auto ld_b = [&]() {
 #pragma unroll
-                for (int it = 0; it < UPD_NLD; ++it) pb[it] = pb_ptr[it * two_f];
-            };
-            ld_a(); ld_b();
-            store_slab(0);
-            pa_ptr += step; pb_ptr += step;
-            ld_a(); ld_b();                                   // slab 1 in flight
+            for (int it = 0; it < UPD_NLD; ++it) pb[it] = pb_ptr[it * two_f];
+        };
+        auto st_ab = [&](int buf) {
+#pragma unroll
+            for (int it = 0; it < UPD_NLD; ++it) {
+                As[buf][(sk0 + 2 * it) * UPD_LD + sr] = pa[it];
+                Bs[buf][(sk0 + 2 * it) * UPD_LD + sr] = pb[it];
+            }
+        };
+        auto mfma_round = [&](int buf, auto &&hook) {
+            const double *At = As[buf] + wr * 64 + lr + lk * UPD_LD;
+            const double *Bt = Bs[buf] + wc * 64 + lr + lk * UPD_LD;
+#pragma unroll
+            for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
+                double av[4], bv[4];
+                if (any) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) av[a] = Bt[k4 * UPD_LD + a * 16];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bv[b] = At[k4 * UPD_LD + b * 16];
+                }
+                hook(k4);
+                if (any) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+                }
+            }
+        };
+        ld_a(); ld_b();
+        st_ab(0);
+        pa_ptr += step; pb_ptr += step;
+        ld_a(); ld_b();                                   // slab 1 in flight
+        __syncthreads();
+        int cur = 0;
+        const i32 nrounds = t.kw / UPD_KT;
+        for (i32 rd = 0; rd < nrounds; ++rd) {
+            const bool have_next = rd + 1 < nrounds, have_next2 = rd + 2 < nrounds;
+            mfma_round(cur, [&](int k4) {
+                if (k4 == 0 && have_next) { st_ab(cur ^ 1); pa_ptr += step; pb_ptr += step; }
+                if (k4 == 4 && have_next2) ld_a();
+                if (k4 == 8 && have_next2) ld_b();
+            });
             __syncthreads();
-            int cur = 0;
-            const i32 nrounds = t.kw / UPD_KT;
-            for (i32 rd = 0; rd < nrounds; ++rd) {
-                const double *At = As[cur] + wr * 64 + lr + lk * UPD_LD;
-                const double *Bt = Bs[cur] + wc * 64 + lr + lk * UPD_LD;
-                const bool have_next = rd + 1 < nrounds, have_next2 = rd + 2 < nrounds;
-#pragma unroll
-                for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) av[a] = Bt[k4 * UPD_LD + a * 16];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) bv[b] = At[k4 * UPD_LD + b * 16];
-                    if (k4 == 0 && have_next) { store_slab(cur ^ 1); pa_ptr += step; pb_ptr += step; }
-                    if (k4 == 4 && have_next2) ld_a();
-                    if (k4 == 8 && have_next2) ld_b();
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
-                }
-                __syncthreads();
-                cur ^= 1;
-            }
-            if (t.kw % UPD_KT) {                              // K tail: one guarded, zero-filled slab
-                load_slab(nrounds * UPD_KT, false);
-                store_slab(cur);
-                __syncthreads();
-                const double *At = As[cur] + wr * 64 + lr + lk * UPD_LD;
-                const double *Bt = Bs[cur] + wc * 64 + lr + lk * UPD_LD;
-#pragma unroll
-                for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) av[a] = Bt[k4 * UPD_LD + a * 16];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) bv[b] = At[k4 * UPD_LD + b * 16];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
-                }
-            }
-            goto epilogue;
+            cur ^= 1;
         }
+        if (t.kw % UPD_KT) {                              // K tail: one zero-filled slab
+            const i32 kk = nrounds * UPD_KT;
+            pa_ptr = P + (i64)(t.k0 + kk + sk0) * f + rac;
+            pb_ptr = P + (i64)(t.k0 + kk + sk0) * f + rbc;
+#pragma unroll
+            for (int it = 0; it < UPD_NLD; ++it) {
+                const bool kok = (kk + sk0 + 2 * it) < t.kw;
+                pa[it] = kok ? pa_ptr[it * two_f] : 0.0;
+                pb[it] = kok ? pb_ptr[it * two_f] : 0.0;
+            }
+            st_ab(cur);
+            __syncthreads();
+            mfma_round(cur, [](int) {});
+        }
+        goto epilogue;
     }
     {
     load_slab(0, UPD_KT <= t.kw);
