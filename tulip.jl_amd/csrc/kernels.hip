@@ -159,14 +159,27 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
 #pragma unroll
         for (int a = 0; a < 4; ++a) dacc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
         const i32 rrow = 16 * cg + lr;                                           // this wave's rows
-        for (i32 ks = 0; ks < Kp; ks += 4) {
-            const double bvv = (rrow < nb) ? X[(i64)rrow + (i64)(ks + lk) * f] : 0.0;
+        // rows are clamped instead of guarded (a clamped row only feeds entries that are never read),
+        // and 4 k-steps of operands (20 loads) are issued before their MFMAs: the loop used to wait
+        // for an L2 round trip per k-step, on the factorisation's critical path
+        const i32 rr_c = min(rrow, nb - 1);
+        i32 cr_c[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const i32 crow = 16 * a + lr;
-                const double avv = (crow < nb) ? X[(i64)crow + (i64)(ks + lk) * f] : 0.0;
-                dacc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(avv, bvv, dacc[a], 0, 0, 0);
+        for (int a = 0; a < 4; ++a) cr_c[a] = min(16 * a + lr, nb - 1);
+        for (i32 ks = 0; ks < Kp; ks += 16) {             // Kp is a multiple of NB_IN
+            double bq[4], aq[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const i64 coff = (i64)(ks + 4 * u + lk) * f;
+                bq[u] = X[(i64)rr_c + coff];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) aq[u][a] = X[(i64)cr_c[a] + coff];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    dacc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[u][a], bq[u], dacc[a], 0, 0, 0);
         }
         // D[i][j]: i = lk + 4q -> column 16a + i, j = lr -> row 16*cg + lr
 #pragma unroll
