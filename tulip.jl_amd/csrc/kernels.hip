@@ -291,16 +291,26 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     const int lr = lane & 15, lk = lane >> 4;
     const i32 rbase = t.row0 + wave * 32;
     const bool active = rbase < f;
-    // B fragments: bf[b][ks] = B[rbase + 16b + lr][k0 + 4ks + lk]
+    // B fragments: bf[b][ks] = B[rbase + 16b + lr][k0 + 4ks + lk].  Rows are clamped to the front
+    // instead of guarded (per-lane guards turn every load into its own exec-masked branch with its
+    // own wait; a clamped row only produces entries the guarded stores skip).
     double bf[2][16];
+    i32 rowc[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const i32 row = rbase + b * 16 + lr;
+    for (int b = 0; b < 2; ++b) rowc[b] = min(rbase + b * 16 + lr, f - 1);
+    if (nb == NB_IN) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const i32 k = 4 * ks + lk;
-            bf[b][ks] = (row < f && k < nb) ? P[(i64)row + (i64)(t.k0 + k) * f] : 0.0;
-        }
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) bf[b][ks] = P[(i64)rowc[b] + (i64)(t.k0 + 4 * ks + lk) * f];
+    } else {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const i32 k = 4 * ks + lk;
+                bf[b][ks] = (k < nb) ? P[(i64)rowc[b] + (i64)(t.k0 + k) * f] : 0.0;
+            }
     }
     v4f64 acc[4][2];
     // ---- left-looking inside the block column: B -= X_prev * L[k0.., kprev..k0)'  ----
@@ -317,12 +327,10 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
         if (active) {
             double xf[2][16];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const i32 row = rbase + b * 16 + lr;
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
-                    xf[b][ks] = (row < f) ? P[(i64)row + (i64)(t.kprev + c0 + 4 * ks + lk) * f] : 0.0;
-            }
+                    xf[b][ks] = P[(i64)rowc[b] + (i64)(t.kprev + c0 + 4 * ks + lk) * f];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
