@@ -37,7 +37,6 @@ class Emulator:
             LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 6),
             LK["FWD_UPDATE"]: g("fwd_update_tasks").reshape(-1, 6),
             LK["BWD_UPDATE"]: g("bwd_update_tasks").reshape(-1, 6),
-            LK["BWD_DIAG"]: g("bwd_diag_tasks").reshape(-1, 6),
         }
         self.factor_launches = g("factor_launches").reshape(-1, 3)
         self.fwd_launches = g("fwd_launches").reshape(-1, 3)
@@ -210,6 +209,7 @@ class Emulator:
 
     def solve_finish(self, xi_d, A):
         self._run(self.fwd_launches, False, start=self._resume_fwd)
+        self._bwd_seen = {}
         self._run(self.bwd_launches)
         dy = np.zeros(self.m)
         dy[self.perm] = self.xw
@@ -257,26 +257,27 @@ class Emulator:
                 assert row0 == k0 + nb and r1 >= min(k0 + nb + _[1], ns)
                 self._k5(np.array([[front, k0 + nb, _[1], 0, 0, 0]]))
 
-    def _k7(self, T):      # bwd update: partial sums per row chunk
-        if not hasattr(self, "bpart"):
-            self.bpart = {}
-        for front, k0, nb, row0, slot, _ in T:
+    def _k7(self, T):      # bwd step: remove solved source rows from one column block (+ solve it)
+        import scipy.linalg as sla
+        for front, k0, nb, row0, nrows, diag in T:
             P = self.panel(front); c0 = int(self.col0[front])
             f, ns = int(self.f[front]), int(self.ns[front])
             rows = self.rows(front)
-            xf = np.concatenate([self.xw[c0: c0 + ns], self.xw[rows[ns:]]])
-            r1 = min(row0 + 128, f)
-            self.bpart[int(slot)] = P[row0:r1, k0:k0 + nb].T @ xf[row0:r1]
-
-    def _k8(self, T):      # bwd diag
-        import scipy.linalg as sla
-        for front, k0, nb, _, slot, nslot in T:
-            P = self.panel(front); c0 = int(self.col0[front])
-            L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
-            x = self.xw[c0 + k0: c0 + k0 + nb].copy()
-            for sl in range(int(slot), int(slot) + int(nslot)):
-                x -= self.bpart.pop(sl)          # pop: every slot is consumed exactly once
-            self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11.T, x, lower=False)
+            assert row0 >= k0 + nb and row0 + nrows <= f
+            if nrows > 0:
+                xf = np.concatenate([self.xw[c0: c0 + ns], self.xw[rows[ns:]]])
+                self.xw[c0 + k0: c0 + k0 + nb] -= P[row0:row0 + nrows, k0:k0 + nb].T @ xf[row0:row0 + nrows]
+            self._bwd_seen.setdefault((int(front), int(k0)), []).append((int(row0), int(nrows)))
+            if diag:
+                # every row below the block must have been applied exactly once before it is solved
+                seen = sorted(self._bwd_seen[(int(front), int(k0))])
+                pos = k0 + nb
+                for r0, nr in seen:
+                    assert r0 == pos or nr == 0, (front, k0, seen)
+                    pos = max(pos, r0 + nr)
+                assert pos == f, (front, k0, seen)
+                L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
+                self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11.T, self.xw[c0 + k0: c0 + k0 + nb], lower=False)
 
     # dense L in permuted numbering, from the panels
     def dense_L(self):

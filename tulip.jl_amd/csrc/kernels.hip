@@ -791,74 +791,21 @@ __global__ __launch_bounds__(256) void k_fwd_update(const SolveTask *__restrict_
     }
 }
 
-// backward update: partial sums  part[slot][j] = sum_{r in chunk} L[r, k0+j] * x_front[r]  for one
-// chunk of BWD_ROWS rows below the block; wave w takes columns w, w+4, ...; shuffle-tree
-// reduction (fixed order).  The diagonal task adds the chunks' partials in slot order.
-__global__ __launch_bounds__(256) void k_bwd_update(const SolveTask *__restrict__ tasks, DevCtx c) {
-    __shared__ double xs[BWD_ROWS];
-    const SolveTask t = tasks[blockIdx.x];
-    const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, ns = fd.ns, nb = t.nb;
-    const i32 *rows = c.rowidx + fd.rowoff;
-    const i32 nr = min(BWD_ROWS, f - t.row0);
-    for (i32 i = threadIdx.x; i < nr; i += 256) {
-        const i32 r = t.row0 + i;
-        xs[i] = (r < ns) ? c.xw[fd.col0 + r] : c.xw[rows[r]];
-    }
-    __syncthreads();
-    const double *P = c.Lval + fd.loff + (i64)t.k0 * f + t.row0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *part = c.bpart + (i64)t.slot * SOLVE_NB;
-    // each lane keeps its (up to 4) x values in registers; a wave takes 4 columns at a time so
-    // that 16 independent loads are in flight before the shuffle reductions start
-    double xr[BWD_ROWS / 64];
-#pragma unroll
-    for (int u = 0; u < BWD_ROWS / 64; ++u) xr[u] = (lane + 64 * u < nr) ? xs[lane + 64 * u] : 0.0;
-    for (i32 j0 = wave * 4; j0 < nb; j0 += 16) {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const i32 j = j0 + jj;
-            if (j < nb) {
-                const double *col = P + (i64)j * f;
-#pragma unroll
-                for (int u = 0; u < BWD_ROWS / 64; ++u)
-                    if (lane + 64 * u < nr) acc[jj] += col[lane + 64 * u] * xr[u];
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[jj] += __shfl_down(acc[jj], off);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) if (j0 + jj < nb) part[j0 + jj] = acc[jj];
-        }
-    }
-}
-
-// backward diagonal block (nb <= SOLVE_NB): t = x - sum of the chunks' partial sums, then with the
-// inverted sub-blocks  x2 = Wb' t2 ;  x1 = Wa' (t1 - L21' x2).
-__global__ __launch_bounds__(256) void k_bwd_diag(const SolveTask *__restrict__ tasks, DevCtx c) {
-    __shared__ double ts[SOLVE_NB];
-    __shared__ double xo[SOLVE_NB];
-    __shared__ double ps[4][NB_IN];
-    const SolveTask t = tasks[blockIdx.x];
-    const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, nb = t.nb, na = min(nb, NB_IN), nb2 = nb - na;
+// backward diagonal block (nb <= SOLVE_NB): t = current rhs of the block (all later rows already
+// eliminated), then with the inverted sub-blocks  x2 = Wb' t2 ;  x1 = Wa' (t1 - L21' x2).
+// LDS scratch: 2*SOLVE_NB + 4*NB_IN doubles.
+__device__ __forceinline__ void bwd_diag_block(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb,
+                                               double *scratch) {
+    double *ts = scratch, *xo = scratch + SOLVE_NB;
+    double (*ps)[NB_IN] = reinterpret_cast<double (*)[NB_IN]>(scratch + 2 * SOLVE_NB);
+    const i32 f = fd.f, na = min(nb, NB_IN), nb2 = nb - na;
     const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
-    double *xs = c.xw + fd.col0 + t.k0;
-    if (tid < nb) {
-        double x = xs[tid];
-        const double *pp = c.bpart + (i64)t.slot * SOLVE_NB + tid;
-        for (i32 s = 0; s < t.nslot; ++s) x -= pp[(i64)s * SOLVE_NB];
-        ts[tid] = x;
-    }
+    double *xs = c.xw + fd.col0 + bk0;
+    if (tid < nb) ts[tid] = xs[tid];
     __syncthreads();
     if (nb2 > 0) {
-        const double *Wb = front_dinv(c, fd, t.k0 + NB_IN);
-        const double *L21 = c.Lval + fd.loff + (i64)(t.k0 + NB_IN) + (i64)t.k0 * f;
+        const double *Wb = front_dinv(c, fd, bk0 + NB_IN);
+        const double *L21 = c.Lval + fd.loff + (i64)(bk0 + NB_IN) + (i64)bk0 * f;
         const double x2 = dot4<2>(Wb, nb2, ts + NB_IN, i, part, nb2, nb2, ps);          // sum_k Wb[k][i] t2[k]
         if (part == 0 && i < nb2) xo[NB_IN + i] = x2;
         __syncthreads();
@@ -873,11 +820,74 @@ __global__ __launch_bounds__(256) void k_bwd_diag(const SolveTask *__restrict__ 
         if (part == 0 && i < na) ts[i] -= ((ps[0][i] + ps[1][i]) + ps[2][i]) + ps[3][i];
         __syncthreads();
     }
-    const double *Wa = front_dinv(c, fd, t.k0);
+    const double *Wa = front_dinv(c, fd, bk0);
     const double x1 = dot4<2>(Wa, na, ts, i, part, na, na, ps);
     if (part == 0 && i < na) xo[i] = x1;
     __syncthreads();
     if (tid < nb) xs[tid] = xo[tid];
+}
+
+// backward step (column-oriented, the mirror image of the forward sweep): the rows
+// [row0, row0 + nrows) of the front hold final solution values (the front's rows below the pivot
+// block come from the ancestors, a pivot block from an earlier launch); their contribution is
+// removed from the rhs of ONE earlier column block:  t[k0 + j] -= sum_r L[r, k0 + j] * x[r].
+// Every column block is owned by exactly one workgroup per launch (no partial-sum slots, no
+// atomics, fixed summation order).  The workgroup of the column block right above the source rows
+// (t.nslot != 0) has then seen every contribution to its block and solves the diagonal block at
+// once, so the backward sweep needs one launch per block.
+// A wave takes 8 columns at a time (16 independent 512-byte loads in flight), lanes run along the
+// contiguous rows; shuffle-tree reduction.
+__global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double scratch[FWD_DIAG_SCRATCH];
+    const SolveTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns, nb = t.nb, nrows = t.slot;
+    const i32 *rows = c.rowidx + fd.rowoff;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // running sums per column live in LDS (a column belongs to one wave: no synchronisation needed)
+    __shared__ double tacc[SOLVE_NB];
+    if (threadIdx.x < SOLVE_NB) tacc[threadIdx.x] = 0.0;
+    __syncthreads();
+    const double *P0 = c.Lval + fd.loff + (i64)t.k0 * f;
+    for (i32 rc = t.row0; rc < t.row0 + nrows; rc += BWD_ROWS) {
+        const i32 nr = min(BWD_ROWS, t.row0 + nrows - rc);
+        double xr[BWD_ROWS / 64];
+        i32 ro[BWD_ROWS / 64];
+#pragma unroll
+        for (int u = 0; u < BWD_ROWS / 64; ++u) {
+            const i32 r = rc + lane + 64 * u;
+            xr[u] = (lane + 64 * u < nr) ? ((r < ns) ? c.xw[fd.col0 + r] : c.xw[rows[r]]) : 0.0;
+            ro[u] = min(lane + 64 * u, nr - 1);           // clamped: the matching xr is zero
+        }
+        const double *P = P0 + rc;
+#pragma unroll 1
+        for (i32 j0 = wave * 8; j0 < nb; j0 += 32) {
+            double acc[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const double *col = P + (i64)min(j0 + jj, nb - 1) * f;      // clamped: extra columns are dropped below
+                double a = 0.0;
+#pragma unroll
+                for (int u = 0; u < BWD_ROWS / 64; ++u) a += col[ro[u]] * xr[u];
+                acc[jj] = a;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) acc[jj] += __shfl_down(acc[jj], off);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) if (j0 + jj < nb) tacc[j0 + jj] += acc[jj];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nb && nrows > 0) c.xw[fd.col0 + t.k0 + threadIdx.x] -= tacc[threadIdx.x];
+    if (t.nslot != 0) {
+        __syncthreads();                      // this workgroup's own updates of the block's rhs
+        bwd_diag_block(c, fd, t.k0, nb, scratch);
+    }
 }
 
 __global__ void k_unpermute(i64 m, const i32 *__restrict__ perm, const char *__restrict__ row_local,
@@ -926,7 +936,6 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(256), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
     case LK_FWD_UPDATE: hipLaunchKernelGGL(k_fwd_update, g, dim3(256), 0, st, a.fwd_update_tasks + L.first, a.ctx); break;
     case LK_BWD_UPDATE: hipLaunchKernelGGL(k_bwd_update, g, dim3(256), 0, st, a.bwd_update_tasks + L.first, a.ctx); break;
-    case LK_BWD_DIAG: hipLaunchKernelGGL(k_bwd_diag, g, dim3(256), 0, st, a.bwd_diag_tasks + L.first, a.ctx); break;
     default: break;
     }
 }

@@ -809,42 +809,43 @@ static void build_schedule(Symbolic &S) {
     cur_g = -1;
     if (S.nlevels > 0) fwd_level(0);
     // ---------------- backward solve: root level first ----------------
-    i64 slot_cursor = 0;
+    // Column-oriented: launch 0 of a level removes the rows below the pivot block (known from the
+    // ancestors) from every column block of every front and solves each front's last block; launch
+    // b >= 1 removes the block solved by launch b-1 from the column blocks before it and solves the
+    // next one.  SolveTask fields here: k0/nb = target column block, row0/slot = first source row
+    // and number of source rows, nslot != 0 = also solve the diagonal block k0.
     auto bwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
         i32 max_ns = 0;
         for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         const i32 nblk = (max_ns + SOLVE_NB - 1) / SOLVE_NB;
-        // fronts are right-aligned: step b handles each front's block (its_nblk - 1 - b) so that
-        // every front walks its own blocks from last to first
         for (i32 b = 0; b < nblk; ++b) {
-            const i64 f_upd = (i64)S.bwd_update_tasks.size(), f_diag = (i64)S.bwd_diag_tasks.size();
+            const i64 f_upd = (i64)S.bwd_update_tasks.size();
+            // pass 0: the workgroups that also solve a diagonal block (critical path) start first
+            for (int pass = 0; pass < 2; ++pass)
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
                 if (!in_scope(s)) continue;
                 const FrontDesc &w = S.fronts[s];
                 const i32 my_nblk = (w.ns + SOLVE_NB - 1) / SOLVE_NB;
                 if (b >= my_nblk) continue;
-                const i32 kb = (my_nblk - 1 - b) * SOLVE_NB;
-                const i32 nb = std::min(SOLVE_NB, w.ns - kb);
-                // rows below the block are cut into chunks; each chunk writes SOLVE_NB partial sums
-                // into its own slot, the diagonal task adds the slots in order (deterministic)
-                const i32 slot0 = (i32)slot_cursor;
-                i32 nsl = 0;
-                for (i32 r0 = kb + nb; r0 < w.f; r0 += BWD_ROWS, ++nsl)
-                    S.bwd_update_tasks.push_back(SolveTask{s, kb, nb, r0, slot0 + nsl, 0, 0, 0});
-                slot_cursor += nsl;
-                S.bwd_diag_tasks.push_back(SolveTask{s, kb, nb, 0, slot0, nsl, 0, 0});
+                const i32 ksrc = my_nblk - b;                       // source block (== my_nblk: rows below the pivot block)
+                const i32 row0 = (b == 0) ? w.ns : ksrc * SOLVE_NB;
+                const i32 nrows = (b == 0) ? (w.f - w.ns) : std::min(SOLVE_NB, w.ns - row0);
+                for (i32 J = ksrc - 1; J >= 0; --J) {
+                    const bool diag = (J == ksrc - 1);
+                    if ((pass == 0) != diag) continue;
+                    if (!diag && nrows == 0) continue;
+                    S.bwd_update_tasks.push_back(SolveTask{s, J * SOLVE_NB, std::min(SOLVE_NB, w.ns - J * SOLVE_NB), row0, nrows, diag ? 1 : 0, 0, 0});
+                }
             }
             push_launch(S.bwd_launches, LK_BWD_UPDATE, f_upd, (i64)S.bwd_update_tasks.size() - f_upd);
-            push_launch(S.bwd_launches, LK_BWD_DIAG, f_diag, (i64)S.bwd_diag_tasks.size() - f_diag);
         }
     };
     cur_g = -1;
     if (S.nlevels > 0) bwd_level(0);
     for (cur_g = 0; cur_g < S.ngroups; ++cur_g)
         for (i32 d = 1; d < S.nlevels; ++d) bwd_level(d);
-    S.bpart_len = slot_cursor * SOLVE_NB;
 }
 
 }  // namespace tlpk

@@ -16,7 +16,6 @@ struct DevCtx {
     double *U0, *U1;    // ping-pong update-matrix buffers (by tree depth parity)
     double *uc;         // solve contribution vectors
     double *xw;         // permuted right-hand side / solution
-    double *bpart;      // backward-solve partial sums (SOLVE_NB doubles per slot)
     double *dinv;       // inverses of the NB_IN x NB_IN diagonal blocks of L (written by k_potrf)
     int *info;          // info[0] = smallest failing pivot column (INT_MAX = none)
 };
@@ -37,7 +36,7 @@ struct DevArrays {
     EaTask *ea_tasks = nullptr; PotrfTask *potrf_tasks = nullptr; TrsmTask *trsm_tasks = nullptr;
     UpdateTask *update_tasks = nullptr;
     SolveTask *fwd_gather_tasks = nullptr, *fwd_diag_tasks = nullptr, *fwd_update_tasks = nullptr,
-              *bwd_update_tasks = nullptr, *bwd_diag_tasks = nullptr;
+              *bwd_update_tasks = nullptr;
 };
 
 void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D);

@@ -99,12 +99,12 @@ struct Symbolic {
     std::vector<i32> pair_j;               // j
     std::vector<char> s_local;             // entry assembled by this rank
     // sizes
-    i64 nnzS = 0, nnzL = 0, lval_len = 0, ubuf_len[2] = {0, 0}, uc_len = 0, max_front = 0, bpart_len = 0, dinv_len = 0;
+    i64 nnzS = 0, nnzL = 0, lval_len = 0, ubuf_len[2] = {0, 0}, uc_len = 0, max_front = 0, dinv_len = 0;
     double flops_chol = 0, flops_panel = 0, flops_update = 0;
     // schedules
     std::vector<PotrfTask> potrf_tasks; std::vector<TrsmTask> trsm_tasks;
     std::vector<UpdateTask> update_tasks; std::vector<EaTask> ea_tasks;
-    std::vector<SolveTask> fwd_gather_tasks, fwd_diag_tasks, fwd_update_tasks, bwd_update_tasks, bwd_diag_tasks;
+    std::vector<SolveTask> fwd_gather_tasks, fwd_diag_tasks, fwd_update_tasks, bwd_update_tasks;
     std::vector<Launch> factor_launches, fwd_launches, bwd_launches;
     std::string error;
 };
