@@ -24,6 +24,7 @@ class Emulator:
         self.root_front = int(g("root_front")[0])
         self.rank = kkt.backend_options.rank
         self.rowidx = g("rowidx"); self.rel = g("rel"); self.children = g("children")
+        self.ucoff = g("front_ucoff"); self.gth_ptr = g("gth_ptr"); self.gth_src = g("gth_src")
         self.s_target = g("s_target"); self.s_diag_row = g("s_diag_row")
         self.pair_ptr = g("pair_ptr"); self.pair_j = g("pair_j")
         from tulip_jl_amd import _lib
@@ -198,7 +199,7 @@ class Emulator:
         rl = self.row_local
         xi = np.where(rl == 0, 0.0, xi + np.where((rl == 2) & (self.rank != 0), 0.0, xi_p))
         self.xw = xi[self.perm].copy()
-        self.uc = {}
+        self.ucflat = np.full(max(int((self.ucoff + self.f - self.ns).max()), 1), np.nan)
         self._resume_fwd = self._run(self.fwd_launches, True)
 
     def root_rhs(self):
@@ -221,17 +222,20 @@ class Emulator:
         self.solve_local(xi_p, xi_d, A)
         return self.solve_finish(xi_d, A)
 
-    def _k4(self, T):      # fwd gather
-        for front, *_ in T:
-            ns = int(self.ns[front]); rs = int(self.f[front]) - ns
-            self.uc[front] = np.zeros(rs)
-            c0 = int(self.col0[front])
-            for c in self.kids(front):
-                relc = self.relidx(c)
-                src = self.uc[c]
-                pv = relc < ns
-                self.xw[c0 + relc[pv]] += src[pv]
-                self.uc[front][relc[~pv] - ns] += src[~pv]
+    def _k4(self, T):      # fwd gather: one row chunk of a front, sources from the gather lists
+        for front, _, _, row0, *_ in T:
+            f, ns = int(self.f[front]), int(self.ns[front])
+            c0 = int(self.col0[front]); ro = int(self.rowoff[front]); uo = int(self.ucoff[front])
+            for r in range(row0, min(row0 + 256, f)):
+                q0, q1 = self.gth_ptr[ro + r], self.gth_ptr[ro + r + 1]
+                v = self.xw[c0 + r] if r < ns else 0.0
+                for q in range(q0, q1):
+                    assert not np.isnan(self.ucflat[self.gth_src[q]])
+                    v += self.ucflat[self.gth_src[q]]
+                if r < ns:
+                    self.xw[c0 + r] = v
+                else:
+                    self.ucflat[uo + r - ns] = v
 
     def _k5(self, T):      # fwd diag
         import scipy.linalg as sla
@@ -246,13 +250,12 @@ class Emulator:
             f, ns = int(self.f[front]), int(self.ns[front])
             r1 = min(row0 + 256, f)
             acc = P[row0:r1, k0:k0 + nb] @ self.xw[c0 + k0: c0 + k0 + nb]
-            if front not in self.uc:
-                self.uc[front] = np.full(f - ns, np.nan)
+            uo = int(self.ucoff[front])
             for t, r in enumerate(range(row0, r1)):
                 if r < ns:
                     self.xw[c0 + r] -= acc[t]
                 else:
-                    self.uc[front][r - ns] -= acc[t]
+                    self.ucflat[uo + r - ns] -= acc[t]
             if _[1] > 0:                      # fused look-ahead: solve the next diagonal block
                 assert row0 == k0 + nb and r1 >= min(k0 + nb + _[1], ns)
                 self._k5(np.array([[front, k0 + nb, _[1], 0, 0, 0]]))

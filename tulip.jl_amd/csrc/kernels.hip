@@ -681,27 +681,20 @@ __global__ __launch_bounds__(256) void k_rhs(i64 m, const i32 *__restrict__ perm
     if (lane == 0) xw[ii] = (rl == 0) ? 0.0 : (((rl == 2 && rank != 0) ? 0.0 : xi_p[i]) + s);
 }
 
-// forward gather: uc_s = 0; then children's contribution vectors are added into the front's
-// right-hand side (pivot rows: xw, rows below: uc_s).  One workgroup per front, children in order.
+// forward gather: row t of the front receives the entries of its children's contribution vectors
+// listed in gth_src (child order = summation order): pivot rows add them to xw, rows below the
+// pivot block start the front's own contribution vector uc.  One thread per row, no conflicts.
 __global__ __launch_bounds__(256) void k_fwd_gather(const SolveTask *__restrict__ tasks, DevCtx c) {
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    const i32 ns = fd.ns, rs = fd.f - ns;
-    double *ucp = c.uc + fd.ucoff;
-    double *xs = c.xw + fd.col0;
-    for (i32 r = threadIdx.x; r < rs; r += 256) ucp[r] = 0.0;
-    __syncthreads();
-    for (i32 ci = 0; ci < fd.nchild; ++ci) {
-        const FrontDesc cd = c.fronts[c.children[fd.child_ptr + ci]];
-        const i32 rsc = cd.f - cd.ns;
-        const double *src = c.uc + cd.ucoff;
-        const i32 *relc = c.rel + cd.reloff;
-        for (i32 r = threadIdx.x; r < rsc; r += 256) {
-            const i32 tr = relc[r];
-            if (tr < ns) xs[tr] += src[r]; else ucp[tr - ns] += src[r];
-        }
-        __syncthreads();
-    }
+    const i32 r = t.row0 + threadIdx.x;
+    if (r >= fd.f) return;
+    const i64 q0 = c.gth_ptr[fd.rowoff + r], q1 = c.gth_ptr[fd.rowoff + r + 1];
+    double *dst = (r < fd.ns) ? (c.xw + fd.col0 + r) : (c.uc + fd.ucoff + (r - fd.ns));
+    if (r < fd.ns && q0 == q1) return;
+    double v = (r < fd.ns) ? *dst : 0.0;
+    for (i64 q = q0; q < q1; ++q) v += c.uc[c.gth_src[q]];
+    *dst = v;
 }
 
 // 64-long dot products split over the 4 waves (16 terms each), partials combined in fixed order.

@@ -596,6 +596,34 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         }
     }
 
+    // ---- 13b. forward-solve gather lists: for every row t of a front, the entries of its
+    // children's contribution vectors that land on it, in child order (the order the sums are
+    // taken in).  One thread per row then gathers without conflicts.
+    {
+        const i64 nrow_total = (i64)S.rowidx.size();
+        S.gth_ptr.assign(nrow_total + 1, 0);
+        for (i32 s = 0; s < ns_total; ++s) {
+            const FrontDesc &w = S.fronts[s];
+            if (!S.front_local[s]) continue;
+            for (i32 t = 0; t < w.nchild; ++t) {
+                const FrontDesc &cd = S.fronts[S.children[w.child_ptr + t]];
+                const i32 rsc = cd.f - cd.ns;
+                for (i32 r = 0; r < rsc; ++r) ++S.gth_ptr[w.rowoff + S.rel[cd.reloff + r] + 1];
+            }
+        }
+        for (i64 i = 0; i < nrow_total; ++i) S.gth_ptr[i + 1] += S.gth_ptr[i];
+        S.gth_src.assign(S.gth_ptr[nrow_total], 0);
+        std::vector<i64> cur(S.gth_ptr.begin(), S.gth_ptr.end() - 1);
+        for (i32 s = 0; s < ns_total; ++s) {
+            const FrontDesc &w = S.fronts[s];
+            if (!S.front_local[s]) continue;
+            for (i32 t = 0; t < w.nchild; ++t) {
+                const FrontDesc &cd = S.fronts[S.children[w.child_ptr + t]];
+                const i32 rsc = cd.f - cd.ns;
+                for (i32 r = 0; r < rsc; ++r) S.gth_src[cur[w.rowoff + S.rel[cd.reloff + r]]++] = cd.ucoff + r;
+            }
+        }
+    }
     // ---- 14. assembly lists: S[ii,kk] = sum_j A[i,j] D_j A[k,j] (+ regD on the diagonal) ----
     {
         S.s_target.assign((size_t)S.nnzS, -1);
@@ -774,7 +802,9 @@ static void build_schedule(Symbolic &S) {
                 if (!in_scope(s)) continue;
                 const FrontDesc &w = S.fronts[s];
                 if (w.nchild == 0 && w.f == w.ns) continue;
-                S.fwd_gather_tasks.push_back(SolveTask{s, 0, 0, 0, 0, 0, 0, 0});
+                // leaves only clear their contribution vector (rows >= ns)
+                for (i32 r0 = (w.nchild == 0) ? (w.ns / SOLVE_ROWS) * SOLVE_ROWS : 0; r0 < w.f; r0 += SOLVE_ROWS)
+                    S.fwd_gather_tasks.push_back(SolveTask{s, 0, 0, r0, 0, 0, 0, 0});
             }
             push_launch(S.fwd_launches, LK_FWD_GATHER, first, (i64)S.fwd_gather_tasks.size() - first);
         }

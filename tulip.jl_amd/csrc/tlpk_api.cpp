@@ -203,6 +203,8 @@ int upload_all(tlpk_handle *h) {
     { i32 *p; UP(p, S.rel); re = p; }
     { i32 *p; UP(p, S.children); ch = p; }
     d.ctx.fronts = fr; d.ctx.rowidx = ri; d.ctx.rel = re; d.ctx.children = ch;
+    { i64 *p; UP(p, S.gth_ptr); d.ctx.gth_ptr = p; }
+    { i64 *p; UP(p, S.gth_src); d.ctx.gth_src = p; }
     UP(d.ea_tasks, S.ea_tasks); UP(d.potrf_tasks, S.potrf_tasks); UP(d.trsm_tasks, S.trsm_tasks);
     UP(d.update_tasks, S.update_tasks);
     UP(d.fwd_gather_tasks, S.fwd_gather_tasks); UP(d.fwd_diag_tasks, S.fwd_diag_tasks);
@@ -601,6 +603,8 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "front_ucoff") field([](const FrontDesc &f) { return f.ucoff; });
     else if (w == "front_uoff") field([](const FrontDesc &f) { return f.uoff; });
     else if (w == "front_ubuf") field([](const FrontDesc &f) { return f.ubuf; });
+    else if (w == "gth_ptr") tmp.assign(S.gth_ptr.begin(), S.gth_ptr.end());
+    else if (w == "gth_src") tmp.assign(S.gth_src.begin(), S.gth_src.end());
     else if (w == "factor_launches") { for (auto &L : S.factor_launches) { tmp.push_back(L.kind); tmp.push_back(L.first); tmp.push_back(L.count); } }
     else if (w == "fwd_launches") { for (auto &L : S.fwd_launches) { tmp.push_back(L.kind); tmp.push_back(L.first); tmp.push_back(L.count); } }
     else if (w == "bwd_launches") { for (auto &L : S.bwd_launches) { tmp.push_back(L.kind); tmp.push_back(L.first); tmp.push_back(L.count); } }

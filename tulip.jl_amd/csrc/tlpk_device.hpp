@@ -12,6 +12,7 @@ struct DevCtx {
     const i32 *rowidx;
     const i32 *rel;
     const i32 *children;
+    const i64 *gth_ptr, *gth_src;   // forward gather lists (per front row: the children's uc entries)
     double *Lval;       // supernodal panels of L
     double *U0, *U1;    // ping-pong update-matrix buffers (by tree depth parity)
     double *uc;         // solve contribution vectors

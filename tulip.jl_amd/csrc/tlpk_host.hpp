@@ -77,6 +77,7 @@ struct Symbolic {
     std::vector<i32> sn_of_col;
     std::vector<i32> rowidx;               // concatenated front row lists (permuted indices)
     std::vector<i32> rel;                  // concatenated relative indices
+    std::vector<i64> gth_ptr, gth_src;     // forward gather lists: front row (rowoff + t) -> children's uc entries, in child order
     std::vector<i32> children;             // concatenated child lists
     std::vector<i32> depth;                // depth of each front (roots = 0)
     i32 nlevels = 0;
