@@ -7,7 +7,7 @@ the product."""
 import numpy as np
 
 LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
-          BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9)
+          BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12)
 
 
 class Emulator:
@@ -33,7 +33,7 @@ class Emulator:
             LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 3),
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
             LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),
-            LK["UPDATE"]: g("update_tasks").reshape(-1, 7),
+            LK["UPDATE"]: g("update_tasks").reshape(-1, 8),
             LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 6),
             LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 6),
             LK["FWD_UPDATE"]: g("fwd_update_tasks").reshape(-1, 6),
@@ -46,6 +46,7 @@ class Emulator:
         self.lval_len = st["nnzL_stored"]
         self.Lval = np.zeros(max(self.lval_len, 1))
         self.U = {}          # front -> rs x rs array (lower part meaningful)
+        self.cnt = {}        # front -> arrived diagonal-block tiles
         self.fail_col = None
 
     # views
@@ -106,6 +107,10 @@ class Emulator:
                 if stop_at_marker:
                     return li + 1
                 continue
+            if kind in (LK["SIDE_FORK"], LK["SIDE_JOIN"]):      # stream markers: no work
+                continue
+            if kind == LK["POTRF_WIDE"]:
+                kind = LK["POTRF"]
             T = self.tasks[kind][first: first + count]
             getattr(self, "_k%d" % kind)(T)
         return len(launches)
@@ -133,13 +138,15 @@ class Emulator:
                     else:
                         Up[tr - ns, tc - ns] += src
 
-    def _k1(self, T):      # potrf
-        for front, k0, nb, kprev in T:
+    def _k1(self, T):      # potrf of a block column's diagonal block (nb <= 256)
+        for front, k0, nb, need in T:
+            # the diagonal block's update tiles must all have signalled before (list order = the
+            # order the launches are enqueued in: the waiting kernel may never come first)
+            if need > 0:
+                assert self.cnt.get(int(front), 0) == need, (front, k0, need, self.cnt.get(int(front), 0))
+                self.cnt[int(front)] = 0
             P = self.panel(front)
             blk = np.tril(P[k0:k0 + nb, k0:k0 + nb])
-            if k0 > kprev:      # columns [kprev, k0) of this block column, applied inside the kernel
-                X = P[k0:k0 + nb, kprev:k0]
-                blk = blk - np.tril(X @ X.T)
             for j in range(nb):
                 d = blk[j, j]
                 if not d > 0:
@@ -151,23 +158,21 @@ class Emulator:
                 blk[j + 1:, j] /= blk[j, j]
             P[k0:k0 + nb, k0:k0 + nb] = blk
 
-    def _k2(self, T):      # trsm
+    def _k2(self, T):      # trsm: 64 rows below the diagonal block of a block column, whole width
         import scipy.linalg as sla
-        for front, k0, nb, row0, kprev, fuse_nb in T:
+        for front, k0, nb, row0, *_ in T:
             P = self.panel(front)
             f = int(self.f[front])
-            r1 = min(row0 + 128, f)
+            r1 = min(row0 + 64, f)
+            assert row0 >= k0 + nb
             L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
-            if k0 > kprev:
-                P[row0:r1, k0:k0 + nb] -= P[row0:r1, kprev:k0] @ P[k0:k0 + nb, kprev:k0].T
             P[row0:r1, k0:k0 + nb] = sla.solve_triangular(L11, P[row0:r1, k0:k0 + nb].T, lower=True).T
-            if fuse_nb > 0:                  # fused look-ahead potrf of the next diagonal block
-                assert row0 == k0 + nb and r1 >= min(k0 + nb + fuse_nb, f)
-                self._k1(np.array([[front, k0 + nb, fuse_nb, kprev]]))
 
     def _k3(self, T):      # update
         TILE = 128
-        for front, k0, kw, i0, j0, jlim, beta0 in T:
+        for front, k0, kw, i0, j0, jlim, beta0, signal in T:
+            if signal:
+                self.cnt[int(front)] = self.cnt.get(int(front), 0) + 1
             P = self.panel(front)
             f, ns = int(self.f[front]), int(self.ns[front])
             i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)

@@ -262,98 +262,84 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
     }
 }
 
-__global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {
-    __shared__ double scratch[POTRF_SCRATCH];
-    const PotrfTask t = tasks[blockIdx.x];
-    const FrontDesc fd = c.fronts[t.front];
-    potrf_block(c, fd, t.k0, t.nb, t.kprev, scratch);
-}
-
 // ------------------------------------------------------------------------------------------
 // trsm on the matrix cores: X = B * L11^{-T} as the product with the inverted diagonal block,
 // computed transposed (D[c][r] = sum_k Linv[c][k] * B[r][k]) so that consecutive lanes write
-// consecutive panel rows.  One workgroup = 128 rows, one wave = 32 rows x all nb columns: the
-// wave loads its own B fragments straight from HBM into registers (each element is needed by
-// exactly one lane), Linv is shared through LDS.  In place: a wave only overwrites its own rows,
-// after all of its loads.
+// consecutive panel rows.  The operand fragments of a 16-row strip stay in registers: each
+// element is needed by exactly one lane, and the accumulator layout of D coincides lane by lane
+// with the operand layout (element (a, q) <-> fragment 4a + q), so a solved 64-column step feeds
+// the following steps without leaving the registers.  The 64 x 64 blocks of L / Linv are shared
+// through LDS.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
-    constexpr int LDW = NB_IN + 16;                 // == 16 mod 32: conflict-free ds_read_b64
-    static_assert(NB_IN * LDW >= POTRF_SCRATCH, "trsm LDS doubles as the fused potrf scratch");
-    __shared__ double Ws[NB_IN * LDW];              // staged operand: Ws[k*LDW + c]
-    const TrsmTask t = tasks[blockIdx.x];
-    const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, nb = t.nb;
+constexpr int LDW = NB_IN + 16;                 // == 16 mod 32: conflict-free ds_read_b64
+static_assert(NB_IN * LDW >= POTRF_SCRATCH, "the trsm LDS block doubles as the potrf scratch");
+
+// Rows [row0, min(row0 + 64, rowlim)) of the 64-wide step k0 (width nb), inside the diagonal
+// block of a block column: B -= X_prev * L[k0.., kprev..k0)' first (left-looking), then the
+// solve.  One wave = 16 rows (keeps the kernel within 256 registers: its workgroup must fit
+// next to a k_update workgroup on the same CU).  In place: a wave only overwrites its own rows, after all of its loads.
+__device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, const i32 k0, const i32 nb,
+                                          const i32 row0, const i32 rowlim, const i32 kprev, double *Ws) {
+    const i32 f = fd.f;
     double *P = c.Lval + fd.loff;
-    const double *W = front_dinv(c, fd, t.k0);
+    const double *W = front_dinv(c, fd, k0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
-    const i32 rbase = t.row0 + wave * 32;
-    const bool active = rbase < f;
-    // B fragments: bf[b][ks] = B[rbase + 16b + lr][k0 + 4ks + lk].  Rows are clamped to the front
-    // instead of guarded (per-lane guards turn every load into its own exec-masked branch with its
-    // own wait; a clamped row only produces entries the guarded stores skip).
-    double bf[2][16];
-    i32 rowc[2];
+    constexpr int NBR = 1;                          // 16-row blocks per wave
+    const i32 rbase = row0 + wave * 16 * NBR;
+    const bool active = rbase < rowlim;
+    // rows are clamped instead of guarded (per-lane guards turn every load into its own
+    // exec-masked branch with its own wait; a clamped row only produces entries the stores skip)
+    double bf[NBR][16];
+    i32 rowc[NBR];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) rowc[b] = min(rbase + b * 16 + lr, f - 1);
-    if (nb == NB_IN) {
+    for (int b = 0; b < NBR; ++b) rowc[b] = min(rbase + b * 16 + lr, rowlim - 1);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NBR; ++b)
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) bf[b][ks] = P[(i64)rowc[b] + (i64)(t.k0 + 4 * ks + lk) * f];
-    } else {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const i32 k = 4 * ks + lk;
-                bf[b][ks] = (k < nb) ? P[(i64)rowc[b] + (i64)(t.k0 + k) * f] : 0.0;
-            }
-    }
-    v4f64 acc[4][2];
-    // ---- left-looking inside the block column: B -= X_prev * L[k0.., kprev..k0)'  ----
-    // (transposed: D[c][r] = sum_k L[k0+c][k] * X[r][k]); the accumulator layout of D coincides
-    // lane by lane with the operand layout of bf: element (a, q) <-> bf[.][4a + q].
-    const i32 Kp = t.k0 - t.kprev;
+        for (int ks = 0; ks < 16; ++ks) {
+            const i32 k = 4 * ks + lk;
+            bf[b][ks] = (k < nb) ? P[(i64)rowc[b] + (i64)(k0 + k) * f] : 0.0;
+        }
+    v4f64 acc[4][NBR];
+    const i32 Kp = k0 - kprev;
     for (i32 c0 = 0; c0 < Kp; c0 += NB_IN) {
         __syncthreads();
         for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
             const int cc = idx & (NB_IN - 1), k = idx >> 6;
-            Ws[k * LDW + cc] = (cc < nb) ? P[(i64)(t.k0 + cc) + (i64)(t.kprev + c0 + k) * f] : 0.0;
+            Ws[k * LDW + cc] = (cc < nb) ? P[(i64)(k0 + cc) + (i64)(kprev + c0 + k) * f] : 0.0;
         }
         __syncthreads();
         if (active) {
-            double xf[2][16];
+            double xf[NBR][16];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NBR; ++b)
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
-                    xf[b][ks] = P[(i64)rowc[b] + (i64)(t.kprev + c0 + 4 * ks + lk) * f];
+                    xf[b][ks] = P[(i64)rowc[b] + (i64)(kprev + c0 + 4 * ks + lk) * f];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+                for (int b = 0; b < NBR; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const double wv = Ws[(4 * ks + lk) * LDW + a * 16 + lr];
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < NBR; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, xf[b][ks], acc[a][b], 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < NBR; ++b)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bf[b][4 * a + q] -= acc[a][b][q];
         }
     }
-    // ---- X = B * L11^{-T} with the inverted diagonal block ----
     __syncthreads();
     for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
         const int cc = idx & (NB_IN - 1), k = idx >> 6;
@@ -364,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            for (int b = 0; b < NBR; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
@@ -372,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
                 if (4 * ks > 16 * a + 15) continue;       // Linv[c][k] = 0 for k > c: whole block is zero
                 const double wv = Ws[(4 * ks + lk) * LDW + a * 16 + lr];
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < NBR; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, bf[b][ks], acc[a][b], 0, 0, 0);
             }
         }
@@ -380,21 +366,174 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < NBR; ++b) {
                 const i32 row = rbase + b * 16 + lr;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const i32 cc = a * 16 + lk + 4 * q;
-                    if (row < f && cc < nb) P[(i64)row + (i64)(t.k0 + cc) * f] = acc[a][b][q];
+                    if (row < rowlim && cc < nb) P[(i64)row + (i64)(k0 + cc) * f] = acc[a][b][q];
                 }
             }
     }
-    // Fused look-ahead: the workgroup that owns the first 128 rows below the block also holds the
-    // next diagonal block of this block column; it factors it right away (its inputs are complete:
-    // earlier launches + this workgroup's own stores), so that potrf leaves the critical path.
-    if (t.fuse_nb > 0) {
-        __syncthreads();                                // own global stores visible, Ws free
-        potrf_block(c, fd, t.k0 + nb, t.fuse_nb, t.kprev, Ws);
+}
+
+// Diagonal block of one block column (t.nb <= NB_OUT columns from t.k0; the columns before k0 have
+// already been applied by the left-looking k_update): 64-wide steps, each a potrf of the step's
+// diagonal block followed by the trsm of the rows below it INSIDE the block -- one workgroup runs
+// the whole chain, so the factorisation's critical path costs one launch per block column.
+// Wait until `need` k_update tiles of the front's diagonal block have been stored (they run in a
+// launch that was enqueued BEFORE this kernel, on the group's other stream), then reset the counter.
+__device__ __forceinline__ void wait_tiles(const DevCtx &c, const i32 front, const i32 need) {
+    if (need <= 0) return;
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(c.cnt + front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(32);
+        __hip_atomic_store(c.cnt + front, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    __threadfence();                    // acquire: the tiles' stores are visible (L1 invalidated)
+}
+
+__global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {      // t.nb <= NB_IN
+    __shared__ double scratch[POTRF_SCRATCH];
+    const PotrfTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    wait_tiles(c, t.front, t.kprev);
+    potrf_block(c, fd, t.k0, t.nb, t.k0, scratch);
+}
+__global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double Ws[NB_IN * LDW];
+    const PotrfTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
+    wait_tiles(c, t.front, t.kprev);
+    potrf_block(c, fd, k0, min(w, NB_IN), k0, Ws);
+    for (i32 ks = k0; ks + NB_IN < kend; ks += NB_IN) {          // step ks is factored: rows below, next diagonal block
+        for (i32 r0 = ks + NB_IN; r0 < kend; r0 += NB_IN) {
+            __syncthreads();                                     // own global stores visible, Ws free
+            trsm_rows(c, fd, ks, NB_IN, r0, kend, k0, Ws);
+        }
+        __syncthreads();
+        potrf_block(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
+    }
+}
+
+// Rows below the diagonal block of a block column: X = B * L11^{-T} for the whole (<= 256 wide)
+// block column in ONE pass: a wave keeps its 16 rows x 256 columns in registers, and walks the
+// 64-wide steps: B_i -= sum_{j<i} X_j L_ij' ; X_i = B_i Linv_ii'.  The panel is read once and
+// written once (the stepwise variant re-read the solved steps of the block column from HBM for
+// every following step).
+__global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double Ws[NB_IN * LDW];              // staged operand: Ws[k*LDW + c]
+    const TrsmTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, k0 = t.k0, w = t.nb;
+    double *P = c.Lval + fd.loff;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const i32 rbase = t.row0 + wave * 16;
+    const bool active = rbase < f;
+    const i32 rowc = min(rbase + lr, f - 1);        // clamped, stores are guarded
+    double bf[4][16];                               // bf[i][ks] = B[row][k0 + 64 i + 4 ks + lk]
+    if (w == NB_OUT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) bf[i][ks] = P[(i64)rowc + (i64)(k0 + 64 * i + 4 * ks + lk) * f];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const i32 col = 64 * i + 4 * ks + lk;
+                bf[i][ks] = (col < w) ? P[(i64)rowc + (i64)(k0 + col) * f] : 0.0;
+            }
+    }
+    // The 64 x 64 operand blocks are staged in the order (i=0: Linv_0), (i=1: L_10, Linv_1),
+    // (i=2: L_20, L_21, Linv_2), ...; block n+1 is fetched into registers while the matrix cores
+    // work on block n (global latency off the workgroup's serial chain).
+    double pre[16];
+    auto fetch = [&](const int i, const int j) {        // j < i: L[k0+64i.., k0+64j..) ; j == i: Linv_i
+        const i32 nbi = min(NB_IN, w - 64 * i);
+        if (j < i) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = tid + 256 * u, cc = idx & (NB_IN - 1), k = idx >> 6;
+                pre[u] = (cc < nbi) ? P[(i64)(k0 + 64 * i + cc) + (i64)(k0 + 64 * j + k) * f] : 0.0;
+            }
+        } else {
+            const double *W = front_dinv(c, fd, k0 + 64 * i);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = tid + 256 * u, cc = idx & (NB_IN - 1), k = idx >> 6;
+                pre[u] = (cc < nbi && k < nbi) ? W[(i64)cc + (i64)k * nbi] : 0.0;
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = tid + 256 * u, cc = idx & (NB_IN - 1), k = idx >> 6;
+            Ws[k * LDW + cc] = pre[u];
+        }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (64 * i < w) {                            // wave-uniform
+            v4f64 acc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < i; ++j) {            // solved steps: acc += X_j * L[k0+64i.., k0+64j..]'
+                __syncthreads();
+                stage();
+                __syncthreads();
+                fetch(i, j + 1);
+                if (active) {
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+                            acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[(4 * ks + lk) * LDW + a * 16 + lr], bf[j][ks], acc[a], 0, 0, 0);
+                }
+            }
+            if (i > 0) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bf[i][4 * a + q] -= acc[a][q];
+            }
+            __syncthreads();
+            stage();
+            __syncthreads();
+            if (i < 3 && 64 * (i + 1) < w) fetch(i + 1, 0);
+            if (active) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (4 * ks > 16 * a + 15) continue;       // Linv[c][k] = 0 for k > c: whole block is zero
+                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[(4 * ks + lk) * LDW + a * 16 + lr], bf[i][ks], acc[a], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bf[i][4 * a + q] = acc[a][q];
+            }
+        }
+    }
+    if (active && rbase + lr < f) {
+        const i32 row = rbase + lr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const i32 col = 64 * i + 4 * ks + lk;
+                if (col < w) P[(i64)row + (i64)(k0 + col) * f] = bf[i][ks];
+            }
     }
 }
 
@@ -651,6 +790,13 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
     const bool full = (t.i0 + TILE <= fd.f) && (t.j0 + TILE <= t.jlim) && (t.i0 >= t.j0 + TILE);
     if (full) update_tile<true>(t, fd, c, As, Bs);
     else update_tile<false>(t, fd, c, As, Bs);
+    // tiles of a block column's diagonal block announce their completion: the k_potrf* workgroup of
+    // the front (other stream, same time) starts factoring as soon as the block is complete
+    if (t.pad1) {
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(c.cnt + t.front, 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -923,6 +1069,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     switch (L.kind) {
     case LK_EXTEND_ADD: hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, a.ea_tasks + L.first, a.ctx); break;
     case LK_POTRF: hipLaunchKernelGGL(k_potrf, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
+    case LK_POTRF_WIDE: hipLaunchKernelGGL(k_potrf_wide, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
     case LK_TRSM: hipLaunchKernelGGL(k_trsm, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
     case LK_UPDATE: hipLaunchKernelGGL(k_update, g, dim3(256), 0, st, a.update_tasks + L.first, a.ctx); break;
     case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;

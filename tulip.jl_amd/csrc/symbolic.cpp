@@ -501,7 +501,9 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     // solves) overlap the other groups' MFMA updates.  General sparse LPs: one group.
     S.ngroups = 1;
     if (opt.row_block && nblocks >= 2) {
-        S.ngroups = std::min(4, nblocks);
+        // 2 groups x (stream + side stream) = 4 streams = the runtime's default number of hardware
+        // queues; more streams share queues and serialise (measured: 2 -> 69.5, 3 -> 75.5, 4 -> 74.3 ms/step on C4)
+        S.ngroups = std::min(2, nblocks);
         if (opt.streams > 0) S.ngroups = std::min({opt.streams, MAX_GROUPS, nblocks});
         else if (const char *e = std::getenv("TLPK_STREAMS")) S.ngroups = std::max(1, std::min({std::atoi(e), MAX_GROUPS, nblocks}));
     }
@@ -686,13 +688,12 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
 // replays them once per update! (factor) and 2..6 times per Newton step (solves).
 // ---------------------------------------------------------------------------------------------
 static void build_schedule(Symbolic &S) {
-    const i32 slots_per_outer = (NB_OUT / NB_IN) * 3;
     // Scope of the level body being generated: stream group `cur_g` (fronts at depth >= 1 of that
     // group) or -1 = the depth-0 fronts, which run on the main stream after all groups joined.
-    int cur_g = -1;
+    int cur_g = -1, cur_side = 0;
     auto in_scope = [&](i32 s) { return S.front_local[s] && (cur_g < 0 || S.front_group[s] == cur_g); };
     auto push_launch = [&](std::vector<Launch> &L, i32 kind, i64 first, i64 count) {
-        if (count > 0) L.push_back(Launch{kind, cur_g, first, count});
+        if (count > 0) L.push_back(Launch{kind, cur_g, first, count, cur_side, 0});
     };
     // ---------------- factorisation ----------------
     auto factor_level = [&](i32 d) {
@@ -721,67 +722,80 @@ static void build_schedule(Symbolic &S) {
         // ALL previous columns [0, ko) in registers and writes each target entry once (the
         // right-looking variant re-wrote the whole trailing matrix every 256 columns and was
         // HBM-bound on that read-modify-write).  The update matrix U gets a single update with
-        // K = [0, ns) after the last block column.  Inside a block column: 64-wide steps, each
-        // potrf/trsm first applying the block column's previous 64-wide steps (left-looking too).
+        // K = [0, ns) after the last block column.
         i32 max_ns = 0;
         for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         const i32 nouter = (max_ns + NB_OUT - 1) / NB_OUT;
-        auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0) {
-            if (kw <= 0 || c0 >= c1) return;
-            for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * kw * (double)(w.f - cc);
+        // part: 0 = only the tiles of the block column's diagonal block (rows < c0 + NB_OUT; they
+        //       signal the front's arrival counter), 1 = only the tiles below it, 2 = all (no signal)
+        // returns the number of tiles pushed
+        auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0, int part) -> i32 {
+            if (kw <= 0 || c0 >= c1) return 0;
+            if (part != 1) for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * kw * (double)(w.f - cc);
+            i32 cnt = 0;
             for (i32 j0 = c0; j0 < c1; j0 += TILE)
-                for (i32 i0 = j0; i0 < w.f; i0 += TILE)
-                    S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0});
+                for (i32 i0 = j0; i0 < w.f; i0 += TILE) {
+                    const bool diag_blk = i0 < c0 + NB_OUT;
+                    if ((part == 0 && !diag_blk) || (part == 1 && diag_blk)) continue;
+                    S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, part == 0 ? 1 : 0});
+                    ++cnt;
+                }
+            return cnt;
         };
+        auto for_fronts = [&](auto &&fn) {
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (in_scope(s)) fn(s, S.fronts[s]);
+            }
+        };
+        std::vector<i32> ndiag_tiles(S.fronts.size(), 0);
         for (i32 io = 0; io <= nouter; ++io) {
             const i32 ko = io * NB_OUT;
-            // left-looking update of block column io (or of U when the front has no column left)
+            // Block column io: ONE left-looking update launch on the group's stream, the tiles of the
+            // diagonal blocks first; the k_potrf* launch goes to the group's side stream and each of
+            // its workgroups starts as soon as its front's diagonal tiles have arrived -- the
+            // factorisation of the diagonal block (a serial chain in one workgroup) is hidden
+            // behind the update of the rows below.  The potrf launch is enqueued AFTER the update
+            // launch, so it can never block it, whatever the stream -> hardware queue mapping.
+            const bool overlap = io > 0 && io < nouter;
+            if (overlap) S.factor_launches.push_back(Launch{LK_SIDE_FORK, cur_g, 0, 0, 0, 0});
             {
                 const i64 f_upd = (i64)S.update_tasks.size();
-                for (i32 t = t0; t < t1; ++t) {
-                    const i32 s = S.level_fronts[t];
-                    if (!in_scope(s)) continue;
-                    const FrontDesc &w = S.fronts[s];
+                if (overlap)
+                    for_fronts([&](i32 s, const FrontDesc &w) {
+                        ndiag_tiles[s] = (ko < w.ns) ? push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns), 0, 0) : 0;
+                    });
+                // rows below the diagonal block (or, past the last block column, U = -L21 L21', written)
+                for_fronts([&](i32 s, const FrontDesc &w) {
                     const i32 my_nouter = (w.ns + NB_OUT - 1) / NB_OUT;
-                    if (io < my_nouter) push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns), 0);
-                    else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f, 1);   // U = -L21 L21' (written)
-                }
+                    if (io < my_nouter) push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns), 0, overlap ? 1 : 2);
+                    else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f, 1, 2);
+                });
                 push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
             }
             if (io == nouter) break;
-            for (i32 r = 0; r < slots_per_outer; ++r) {
-                const i32 ii = r / 3, kind = r % 3;
-                const i32 ki = ko + ii * NB_IN;
-                const i64 f_potrf = (i64)S.potrf_tasks.size(), f_trsm = (i64)S.trsm_tasks.size(), f_upd = (i64)S.update_tasks.size();
-                // pass 0 emits the look-ahead (fused potrf) trsm workgroups of every front first so
-                // that they start with the launch; pass 1 emits the remaining row chunks
-                for (int pass = 0; pass < (kind == 1 ? 2 : 1); ++pass)
-                for (i32 t = t0; t < t1; ++t) {
-                    const i32 s = S.level_fronts[t];
-                    if (!in_scope(s)) continue;
-                    const FrontDesc &w = S.fronts[s];
-                    if (ko >= w.ns) continue;
+            cur_side = overlap ? 1 : 0;
+            // narrow blocks (one 64-wide step) and wide ones go to different kernels
+            for (int wide = 0; wide < 2; ++wide) {
+                const i64 f_potrf = (i64)S.potrf_tasks.size();
+                for_fronts([&](i32 s, const FrontDesc &w) {
+                    if (ko >= w.ns) return;
                     const i32 no = std::min(NB_OUT, w.ns - ko);
-                    if (ki >= ko + no) continue;
-                    const i32 ni = std::min(NB_IN, ko + no - ki);
-                    // The columns [ko, ki) of this block column are applied inside k_potrf (to the
-                    // diagonal block) and k_trsm (to the rows below): no separate inner update pass.
-                    // The next 64-wide step's potrf is fused into the first trsm workgroup of this
-                    // step (its 128 rows contain the next diagonal block): only the first step of a
-                    // block column has a stand-alone potrf launch.
-                    const i32 next_nb = std::min(NB_IN, ko + no - (ki + ni));      // <= 0: last step
-                    if (kind == 0) { if (ii == 0) S.potrf_tasks.push_back(PotrfTask{s, ki, ni, ko}); }
-                    else if (kind == 1) {
-                        for (i32 r0 = ki + ni; r0 < w.f; r0 += TRSM_ROWS) {
-                            const bool first = (r0 == ki + ni);
-                            if ((pass == 0) != first) continue;
-                            S.trsm_tasks.push_back(TrsmTask{s, ki, ni, r0, ko, (first && next_nb > 0) ? next_nb : 0, 0, 0});
-                        }
-                    }
-                }
-                push_launch(S.factor_launches, LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
+                    if ((no > NB_IN) == (wide == 1)) S.potrf_tasks.push_back(PotrfTask{s, ko, no, overlap ? ndiag_tiles[s] : 0});
+                });
+                push_launch(S.factor_launches, wide ? LK_POTRF_WIDE : LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
+            }
+            cur_side = 0;
+            if (overlap) S.factor_launches.push_back(Launch{LK_SIDE_JOIN, cur_g, 0, 0, 0, 0});
+            // k_trsm solves the rows below the diagonal block in one pass
+            {
+                const i64 f_trsm = (i64)S.trsm_tasks.size();
+                for_fronts([&](i32 s, const FrontDesc &w) {
+                    if (ko >= w.ns) return;
+                    const i32 no = std::min(NB_OUT, w.ns - ko);
+                    for (i32 r0 = ko + no; r0 < w.f; r0 += TRSM_WG_ROWS) S.trsm_tasks.push_back(TrsmTask{s, ko, no, r0, ko, 0, 0, 0});
+                });
                 push_launch(S.factor_launches, LK_TRSM, f_trsm, (i64)S.trsm_tasks.size() - f_trsm);
-                push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
             }
         }
         // (c) extend-add, U part (every U of this level has been written by now)

@@ -29,6 +29,8 @@ struct tlpk_handle {
     hipStream_t stream = nullptr;                 // main stream (= group 0)
     hipStream_t gstream[MAX_GROUPS] = {};         // gstream[0] == stream; others: concurrent subtree groups
     hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
+    hipStream_t sstream[MAX_GROUPS] = {};         // side stream of each group: diagonal-block chains overlap the bulk update
+    hipEvent_t ev_side[MAX_GROUPS] = {};
     bool forked = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_pool;
@@ -84,7 +86,7 @@ int dev_upload(tlpk_handle *h, T **out, const std::vector<T> &v) {
 int kind_class(i32 kind) {
     switch (kind) {
     case LK_EXTEND_ADD: return TLPK_KC_EXTEND_ADD;
-    case LK_POTRF: return TLPK_KC_POTRF;
+    case LK_POTRF: case LK_POTRF_WIDE: return TLPK_KC_POTRF;
     case LK_TRSM: return TLPK_KC_TRSM;
     case LK_UPDATE: return TLPK_KC_UPDATE;
     case LK_FWD_GATHER: case LK_FWD_DIAG: case LK_FWD_UPDATE: return TLPK_KC_SOLVE_FWD;
@@ -150,9 +152,24 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
         hipStream_t st = h->stream;
         // profiling serialises everything on the main stream: per-launch HIP-event durations are
         // then the kernels' own durations, not time shared with other groups' kernels
-        if (!h->profile) {
+        const bool marker = (L[i].kind == LK_SIDE_FORK || L[i].kind == LK_SIDE_JOIN);
+        if (h->profile) { if (marker) continue; }
+        else {
             if (L[i].group >= 1) { fork_groups(h); st = h->gstream[L[i].group]; }
             else if (L[i].group == 0) fork_groups(h);      // group 0 runs on the main stream itself
+            // side stream of the group (slot 0 also serves the depth-0 fronts, group -1)
+            const int sg = std::max(L[i].group, 0);
+            if (L[i].kind == LK_SIDE_FORK) {
+                hipEventRecord(h->ev_side[sg], st);
+                hipStreamWaitEvent(h->sstream[sg], h->ev_side[sg], 0);
+                continue;
+            }
+            if (L[i].kind == LK_SIDE_JOIN) {
+                hipEventRecord(h->ev_side[sg], h->sstream[sg]);
+                hipStreamWaitEvent(st, h->ev_side[sg], 0);
+                continue;
+            }
+            if (L[i].side) st = h->sstream[sg];
         }
         ProfScope ps(h, kind_class(L[i].kind), st);
         launch_tasks(st, h->d, L[i]);
@@ -212,7 +229,7 @@ int upload_all(tlpk_handle *h) {
 #undef UP
 #define AL(dst, cnt) if ((rc = dev_alloc(h, &(dst), (cnt))) != TLPK_OK) return rc
     AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
-    AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4); AL(d.ctx.dinv, S.dinv_len);
+    AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4); AL(d.ctx.cnt, (i64)S.fronts.size()); AL(d.ctx.dinv, S.dinv_len);
     AL(h->d_theta, S.n); AL(h->d_regP, S.n); AL(h->d_regD, S.m); AL(h->d_D, S.n);
     AL(h->d_xip, S.m); AL(h->d_xid, S.n); AL(h->d_dx, S.n); AL(h->d_dy, S.m);
 #undef AL
@@ -300,6 +317,8 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
                 for (int g = 1; g < MAX_GROUPS && e == hipSuccess; ++g) e = hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking);
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
                 for (int g = 1; g < MAX_GROUPS && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming);
+                for (int g = 0; g < MAX_GROUPS && e == hipSuccess; ++g) e = hipStreamCreateWithFlags(&h->sstream[g], hipStreamNonBlocking);
+                for (int g = 0; g < MAX_GROUPS && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_side[g], hipEventDisableTiming);
                 if (e == hipSuccess) e = hipEventCreate(&h->ev0);
                 if (e == hipSuccess) e = hipEventCreate(&h->ev1);
                 if (e != hipSuccess) rc = hip_fail(h, e, "device init");
@@ -344,6 +363,10 @@ void tlpk_destroy(tlpk_handle *h) {
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
         if (h->ev_fork) hipEventDestroy(h->ev_fork);
+        for (int g = 0; g < MAX_GROUPS; ++g) {
+            if (h->ev_side[g]) hipEventDestroy(h->ev_side[g]);
+            if (h->sstream[g]) { hipStreamSynchronize(h->sstream[g]); hipStreamDestroy(h->sstream[g]); }
+        }
         for (int g = 1; g < MAX_GROUPS; ++g) {
             if (h->ev_join[g]) hipEventDestroy(h->ev_join[g]);
             if (h->gstream[g]) { hipStreamSynchronize(h->gstream[g]); hipStreamDestroy(h->gstream[g]); }
@@ -372,6 +395,7 @@ int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_reg
     {
         ProfScope ps(h, TLPK_KC_ASSEMBLE);
         if (S.lval_len > 0) HIPCHK(h, hipMemsetAsync(h->d.ctx.Lval, 0, (size_t)S.lval_len * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d.ctx.cnt, 0, std::max<size_t>(S.fronts.size(), 1) * sizeof(int), h->stream));   // tile-arrival counters
         launch_assemble(h->stream, h->d, h->d_D, h->d_regD);
     }
     run_launches(h, S.factor_launches, 0, h->factor_marker);
@@ -593,7 +617,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "root_front") tmp.assign(1, S.root_front);
     else if (w == "potrf_tasks") { for (auto &t : S.potrf_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.kprev); } }
     else if (w == "trsm_tasks") { for (auto &t : S.trsm_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.kprev); tmp.push_back(t.fuse_nb); } }
-    else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); } }
+    else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); } }
     else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks") {
         const std::vector<SolveTask> &v = (w == "fwd_gather_tasks") ? S.fwd_gather_tasks : (w == "fwd_diag_tasks") ? S.fwd_diag_tasks :

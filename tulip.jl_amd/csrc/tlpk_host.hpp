@@ -16,7 +16,8 @@ using i64 = int64_t;
 constexpr int NB_IN = 64;     // diagonal-block / triangular-solve width (potrf + trsm kernels)
 constexpr int NB_OUT = 256;   // outer panel width: trailing updates run with K = NB_OUT
 constexpr int TILE = 128;     // update-kernel tile (TILE x TILE per workgroup)
-constexpr int TRSM_ROWS = 128; // rows per trsm workgroup (4 waves x 32 rows)
+constexpr int TRSM_ROWS = 64;  // rows per trsm_rows call inside the diagonal block (4 waves x 16 rows)
+constexpr int TRSM_WG_ROWS = 64;   // rows per k_trsm workgroup (4 waves x 16 rows x whole block column)
 constexpr int EA_COLS = 16;   // parent columns per extend-add workgroup
 constexpr int SOLVE_NB = 128; // block width of the triangular-solve kernels (two NB_IN sub-blocks)
 constexpr int MAX_GROUPS = 8;    // concurrent streams for independent diagonal blocks
@@ -40,18 +41,22 @@ struct FrontDesc {
 };
 static_assert(sizeof(FrontDesc) == 80, "FrontDesc layout");
 
-struct PotrfTask { i32 front, k0, nb, kprev; };              // kprev: first column of the block column
+struct PotrfTask { i32 front, k0, nb, kprev; };              // kprev: number of k_update tiles of the diagonal block to wait for (0 = none)
 struct TrsmTask  { i32 front, k0, nb, row0, kprev, fuse_nb, pad1, pad2; };   // fuse_nb: also factor the next diagonal block
-struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; };  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
+struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; };  // pad1 != 0: tile of the block column's diagonal block (signals cnt[front])
+//  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
 struct EaTask    { i32 front, j0, j1, pad; };                        // parent columns [j0, j1)
 struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };  // slot: partial-sum slots (backward)
 
 enum LaunchKind : i32 {
     LK_EXTEND_ADD = 0, LK_POTRF, LK_TRSM, LK_UPDATE,
     LK_FWD_GATHER, LK_FWD_DIAG, LK_FWD_UPDATE, LK_BWD_UPDATE, LK_BWD_DIAG,
-    LK_ALLREDUCE_ROOT   // marker: everything after this belongs to the replicated root front
+    LK_ALLREDUCE_ROOT,  // marker: everything after this belongs to the replicated root front
+    LK_POTRF_WIDE,      // diagonal block wider than NB_IN (several 64-wide steps in one workgroup)
+    LK_SIDE_FORK,       // marker: the group's side stream waits for the group's stream
+    LK_SIDE_JOIN        // marker: the group's stream waits for its side stream
 };
-struct Launch { i32 kind; i32 group; i64 first; i64 count; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
+struct Launch { i32 kind; i32 group; i64 first; i64 count; i32 side = 0; i32 pad = 0; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
 
 struct Options {
     i32 ordering = 0, relax = 1, rank = 0, nranks = 1, streams = 0;
