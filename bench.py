@@ -45,9 +45,12 @@ def parse():
     ap.add_argument("--m0", type=int, default=1000)
     ap.add_argument("--nnz-col", type=int, default=4)
     ap.add_argument("--regime", default="mid", choices=["mid", "late"])
-    ap.add_argument("--workload", default="c4", choices=["c4", "headline"],
+    ap.add_argument("--workload", default="c4", choices=["c4", "headline", "c3"],
                     help="c4: BASELINE configs[3] (default). headline: the north-star instance, 100 blocks x "
-                         "(2e4 inequality rows x 1e4 vars) + 1e3 linking rows = 1e6 vars / 2e6 constraints")
+                         "(2e4 inequality rows x 1e4 vars) + 1e3 linking rows = 1e6 vars / 2e6 constraints. "
+                         "c3: BASELINE configs[2] (general sparse, A = [A0 I], 25 nnz/col) at --c3-rows rows "
+                         "(the 5e5-row original has a ~0.86 TB factor); single GPU only")
+    ap.add_argument("--c3-rows", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -102,7 +105,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    A, row_block = block_angular_lp(args.blocks, args.mk, args.nk, args.m0, args.nnz_col, 0.5, ineq=args.ineq)
+    if args.workload == "c3":
+        if world > 1:
+            raise SystemExit("general sparse LPs run on one GPU (replicas only, SURVEY.md 8e)")
+        from workloads import general_sparse_lp
+        A, row_block = general_sparse_lp(args.c3_rows), None
+        args.no_cpu_baseline = True        # the oracle needs minutes at this size; see tests for its parity role
+    else:
+        A, row_block = block_angular_lp(args.blocks, args.mk, args.nk, args.m0, args.nnz_col, 0.5, ineq=args.ineq)
     m, n = A.shape
     kkt = tk.setup(A, tk.K1(), tk.Backend(device=local_rank, row_block=row_block, rank=rank, nranks=world))
     st = kkt.stats()
@@ -169,7 +179,7 @@ def main():
     if dist is not None:       # block rows / columns live on their owner; linking rows replicated
         t1, t2 = d_dx.clone(), d_dy.clone()
         dist.all_reduce(t1)
-        lk = torch.from_numpy((row_block < 0)).to(dev)
+        lk = torch.from_numpy((row_block < 0)).to(dev)   # world > 1 implies a block-angular workload
         t2 = torch.where(lk, t2 / world, t2)
         dist.all_reduce(t2)
         dx, dy = t1.cpu().numpy(), t2.cpu().numpy()
@@ -181,7 +191,9 @@ def main():
         "value": 1e3 / ms_per_step, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: block-angular LP, %d blocks x (%d %s rows x %d vars, %d nnz/col) + %d linking rows; "
+        "config": {"workload": ("BASELINE configs[2] at reduced scale: general sparse LP A=[A0 I], %d rows x %d structural "
+                                "columns, 25 nnz/col; m=%d n=%d nnz(A)=%d" % (m, n - m, m, n, A.nnz)) if args.workload == "c3" else
+                               "%s: block-angular LP, %d blocks x (%d %s rows x %d vars, %d nnz/col) + %d linking rows; "
                                "m=%d n=%d nnz(A)=%d" % ("BASELINE configs[3]" if args.workload == "c4" else "north-star headline",
                                                         args.blocks, args.mk, "inequality" if args.ineq else "equality",
                                                         args.nk, args.nnz_col, args.m0, m, n, A.nnz),
@@ -196,8 +208,8 @@ def main():
 
     if not args.no_roofline:
         # Per-kernel-class device time of one Newton step, HIP events around every launch on the
-        # stream it is launched on.  The timed region above runs the diagonal blocks on 4
-        # concurrent stream groups; under that overlap a kernel's [start, end] interval includes
+        # stream it is launched on.  The timed region above runs the diagonal blocks on concurrent
+        # stream groups (plus side streams); under that overlap a kernel's [start, end] interval includes
         # time it shares the chip with other groups' kernels, so the roofline leg replays the SAME
         # LP and the SAME kernels with a single-stream schedule (streams=1), where every launch
         # has the device to itself.  profiles/*kernel_stats.csv is taken the same way.

@@ -46,7 +46,6 @@ class Emulator:
         self.lval_len = st["nnzL_stored"]
         self.Lval = np.zeros(max(self.lval_len, 1))
         self.U = {}          # front -> rs x rs array (lower part meaningful)
-        self.cnt = {}        # front -> arrived diagonal-block tiles
         self.fail_col = None
 
     # views
@@ -139,12 +138,7 @@ class Emulator:
                         Up[tr - ns, tc - ns] += src
 
     def _k1(self, T):      # potrf of a block column's diagonal block (nb <= 256)
-        for front, k0, nb, need in T:
-            # the diagonal block's update tiles must all have signalled before (list order = the
-            # order the launches are enqueued in: the waiting kernel may never come first)
-            if need > 0:
-                assert self.cnt.get(int(front), 0) == need, (front, k0, need, self.cnt.get(int(front), 0))
-                self.cnt[int(front)] = 0
+        for front, k0, nb, _ in T:
             P = self.panel(front)
             blk = np.tril(P[k0:k0 + nb, k0:k0 + nb])
             for j in range(nb):
@@ -170,9 +164,7 @@ class Emulator:
 
     def _k3(self, T):      # update
         TILE = 128
-        for front, k0, kw, i0, j0, jlim, beta0, signal in T:
-            if signal:
-                self.cnt[int(front)] = self.cnt.get(int(front), 0) + 1
+        for front, k0, kw, i0, j0, jlim, beta0, _ in T:
             P = self.panel(front)
             f, ns = int(self.f[front]), int(self.ns[front])
             i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)

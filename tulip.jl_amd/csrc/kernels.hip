@@ -381,23 +381,10 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 // already been applied by the left-looking k_update): 64-wide steps, each a potrf of the step's
 // diagonal block followed by the trsm of the rows below it INSIDE the block -- one workgroup runs
 // the whole chain, so the factorisation's critical path costs one launch per block column.
-// Wait until `need` k_update tiles of the front's diagonal block have been stored (they run in a
-// launch that was enqueued BEFORE this kernel, on the group's other stream), then reset the counter.
-__device__ __forceinline__ void wait_tiles(const DevCtx &c, const i32 front, const i32 need) {
-    if (need <= 0) return;
-    if (threadIdx.x == 0) {
-        while (__hip_atomic_load(c.cnt + front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(32);
-        __hip_atomic_store(c.cnt + front, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    __threadfence();                    // acquire: the tiles' stores are visible (L1 invalidated)
-}
-
 __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {      // t.nb <= NB_IN
     __shared__ double scratch[POTRF_SCRATCH];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    wait_tiles(c, t.front, t.kprev);
     potrf_block(c, fd, t.k0, t.nb, t.k0, scratch);
 }
 __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restrict__ tasks, DevCtx c) {
@@ -405,7 +392,6 @@ __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restri
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
-    wait_tiles(c, t.front, t.kprev);
     potrf_block(c, fd, k0, min(w, NB_IN), k0, Ws);
     for (i32 ks = k0; ks + NB_IN < kend; ks += NB_IN) {          // step ks is factored: rows below, next diagonal block
         for (i32 r0 = ks + NB_IN; r0 < kend; r0 += NB_IN) {
@@ -790,13 +776,6 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
     const bool full = (t.i0 + TILE <= fd.f) && (t.j0 + TILE <= t.jlim) && (t.i0 >= t.j0 + TILE);
     if (full) update_tile<true>(t, fd, c, As, Bs);
     else update_tile<false>(t, fd, c, As, Bs);
-    // tiles of a block column's diagonal block announce their completion: the k_potrf* workgroup of
-    // the front (other stream, same time) starts factoring as soon as the block is complete
-    if (t.pad1) {
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(c.cnt + t.front, 1);
-    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -726,21 +726,17 @@ static void build_schedule(Symbolic &S) {
         i32 max_ns = 0;
         for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         const i32 nouter = (max_ns + NB_OUT - 1) / NB_OUT;
-        // part: 0 = only the tiles of the block column's diagonal block (rows < c0 + NB_OUT; they
-        //       signal the front's arrival counter), 1 = only the tiles below it, 2 = all (no signal)
-        // returns the number of tiles pushed
-        auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0, int part) -> i32 {
-            if (kw <= 0 || c0 >= c1) return 0;
+        // part: 0 = only the tiles of the block column's diagonal block (rows < c0 + NB_OUT),
+        //       1 = only the tiles below it, 2 = all
+        auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0, int part) {
+            if (kw <= 0 || c0 >= c1) return;
             if (part != 1) for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * kw * (double)(w.f - cc);
-            i32 cnt = 0;
             for (i32 j0 = c0; j0 < c1; j0 += TILE)
                 for (i32 i0 = j0; i0 < w.f; i0 += TILE) {
                     const bool diag_blk = i0 < c0 + NB_OUT;
                     if ((part == 0 && !diag_blk) || (part == 1 && diag_blk)) continue;
-                    S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, part == 0 ? 1 : 0});
-                    ++cnt;
+                    S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0});
                 }
-            return cnt;
         };
         auto for_fronts = [&](auto &&fn) {
             for (i32 t = t0; t < t1; ++t) {
@@ -748,24 +744,39 @@ static void build_schedule(Symbolic &S) {
                 if (in_scope(s)) fn(s, S.fronts[s]);
             }
         };
-        std::vector<i32> ndiag_tiles(S.fronts.size(), 0);
         for (i32 io = 0; io <= nouter; ++io) {
             const i32 ko = io * NB_OUT;
-            // Block column io: ONE left-looking update launch on the group's stream, the tiles of the
-            // diagonal blocks first; the k_potrf* launch goes to the group's side stream and each of
-            // its workgroups starts as soon as its front's diagonal tiles have arrived -- the
-            // factorisation of the diagonal block (a serial chain in one workgroup) is hidden
-            // behind the update of the rows below.  The potrf launch is enqueued AFTER the update
-            // launch, so it can never block it, whatever the stream -> hardware queue mapping.
+            // Block column io.  The left-looking update of its DIAGONAL block and the factorisation
+            // of that block (k_potrf*: a serial chain inside one workgroup per front) go to the
+            // group's side stream; the update of the rows below runs concurrently on the group's
+            // stream and hides them.  Only stream order and events: correct under any scheduling
+            // (a profiler that serialises dispatches included).
             const bool overlap = io > 0 && io < nouter;
             if (overlap) S.factor_launches.push_back(Launch{LK_SIDE_FORK, cur_g, 0, 0, 0, 0});
-            {
+            cur_side = overlap ? 1 : 0;
+            if (overlap) {
                 const i64 f_upd = (i64)S.update_tasks.size();
-                if (overlap)
+                for_fronts([&](i32 s, const FrontDesc &w) {
+                    if (ko < w.ns) push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns), 0, 0);
+                });
+                push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
+            }
+            if (io < nouter) {
+                // narrow blocks (one 64-wide step) and wide ones go to different kernels
+                for (int wide = 0; wide < 2; ++wide) {
+                    const i64 f_potrf = (i64)S.potrf_tasks.size();
                     for_fronts([&](i32 s, const FrontDesc &w) {
-                        ndiag_tiles[s] = (ko < w.ns) ? push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns), 0, 0) : 0;
+                        if (ko >= w.ns) return;
+                        const i32 no = std::min(NB_OUT, w.ns - ko);
+                        if ((no > NB_IN) == (wide == 1)) S.potrf_tasks.push_back(PotrfTask{s, ko, no, ko});
                     });
+                    push_launch(S.factor_launches, wide ? LK_POTRF_WIDE : LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
+                }
+            }
+            cur_side = 0;
+            {
                 // rows below the diagonal block (or, past the last block column, U = -L21 L21', written)
+                const i64 f_upd = (i64)S.update_tasks.size();
                 for_fronts([&](i32 s, const FrontDesc &w) {
                     const i32 my_nouter = (w.ns + NB_OUT - 1) / NB_OUT;
                     if (io < my_nouter) push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns), 0, overlap ? 1 : 2);
@@ -773,20 +784,8 @@ static void build_schedule(Symbolic &S) {
                 });
                 push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
             }
-            if (io == nouter) break;
-            cur_side = overlap ? 1 : 0;
-            // narrow blocks (one 64-wide step) and wide ones go to different kernels
-            for (int wide = 0; wide < 2; ++wide) {
-                const i64 f_potrf = (i64)S.potrf_tasks.size();
-                for_fronts([&](i32 s, const FrontDesc &w) {
-                    if (ko >= w.ns) return;
-                    const i32 no = std::min(NB_OUT, w.ns - ko);
-                    if ((no > NB_IN) == (wide == 1)) S.potrf_tasks.push_back(PotrfTask{s, ko, no, overlap ? ndiag_tiles[s] : 0});
-                });
-                push_launch(S.factor_launches, wide ? LK_POTRF_WIDE : LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
-            }
-            cur_side = 0;
             if (overlap) S.factor_launches.push_back(Launch{LK_SIDE_JOIN, cur_g, 0, 0, 0, 0});
+            if (io == nouter) break;
             // k_trsm solves the rows below the diagonal block in one pass
             {
                 const i64 f_trsm = (i64)S.trsm_tasks.size();

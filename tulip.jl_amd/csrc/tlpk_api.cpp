@@ -229,7 +229,7 @@ int upload_all(tlpk_handle *h) {
 #undef UP
 #define AL(dst, cnt) if ((rc = dev_alloc(h, &(dst), (cnt))) != TLPK_OK) return rc
     AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
-    AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4); AL(d.ctx.cnt, (i64)S.fronts.size()); AL(d.ctx.dinv, S.dinv_len);
+    AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4); AL(d.ctx.dinv, S.dinv_len);
     AL(h->d_theta, S.n); AL(h->d_regP, S.n); AL(h->d_regD, S.m); AL(h->d_D, S.n);
     AL(h->d_xip, S.m); AL(h->d_xid, S.n); AL(h->d_dx, S.n); AL(h->d_dy, S.m);
 #undef AL
@@ -395,7 +395,6 @@ int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_reg
     {
         ProfScope ps(h, TLPK_KC_ASSEMBLE);
         if (S.lval_len > 0) HIPCHK(h, hipMemsetAsync(h->d.ctx.Lval, 0, (size_t)S.lval_len * 8, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d.ctx.cnt, 0, std::max<size_t>(S.fronts.size(), 1) * sizeof(int), h->stream));   // tile-arrival counters
         launch_assemble(h->stream, h->d, h->d_D, h->d_regD);
     }
     run_launches(h, S.factor_launches, 0, h->factor_marker);

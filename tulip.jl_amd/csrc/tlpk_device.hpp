@@ -19,7 +19,6 @@ struct DevCtx {
     double *xw;         // permuted right-hand side / solution
     double *dinv;       // inverses of the NB_IN x NB_IN diagonal blocks of L (written by k_potrf)
     int *info;          // info[0] = smallest failing pivot column (INT_MAX = none)
-    int *cnt;           // per front: finished k_update tiles of the current diagonal block (k_potrf* wait on it)
 };
 
 struct DevArrays {

@@ -41,10 +41,9 @@ struct FrontDesc {
 };
 static_assert(sizeof(FrontDesc) == 80, "FrontDesc layout");
 
-struct PotrfTask { i32 front, k0, nb, kprev; };              // kprev: number of k_update tiles of the diagonal block to wait for (0 = none)
+struct PotrfTask { i32 front, k0, nb, kprev; };              // diagonal block of a block column: columns [k0, k0 + nb), nb <= NB_OUT; kprev = k0
 struct TrsmTask  { i32 front, k0, nb, row0, kprev, fuse_nb, pad1, pad2; };   // fuse_nb: also factor the next diagonal block
-struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; };  // pad1 != 0: tile of the block column's diagonal block (signals cnt[front])
-//  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
+struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; }; //  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
 struct EaTask    { i32 front, j0, j1, pad; };                        // parent columns [j0, j1)
 struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };  // slot: partial-sum slots (backward)
 

@@ -48,6 +48,19 @@ def block_angular_lp(nblocks=64, mk=5000, nk=10000, m0=1000, nnz_in=4, link_prob
     return A, row_block
 
 
+def general_sparse_lp(m=50000, n0=None, nnz_col=25, seed=SEED):
+    """Config C3 at a feasible scale: A0 in R^{m x n0} (n0 = 0.4 m as in the 5e5 x
+    2e5 original), ~nnz_col N(0,1) entries per column at uniform rows, rows are "<=" constraints
+    => A = [A0 I].  No block structure: one supernodal tree, ends in a large dense front.  As
+    specified (m = 5e5) the factor would be ~0.86 TB; the caller picks m so that it fits."""
+    n0 = int(0.4 * m) if n0 is None else n0
+    rng = np.random.default_rng(seed)
+    A0 = sparse_columns(m, n0, nnz_col, rng)
+    A = sp.hstack([A0, sp.identity(m, format="csc")], format="csc")
+    A.sort_indices()
+    return A
+
+
 def kernel_inputs(m, n, seed=7, regime="mid"):
     """Kernel-level benchmark inputs: theta_inv = 10^U(-3,3), regP = regD = 1e-4
     ('mid-IPM'), or 10^U(-8,8) with 5 % exact zeros and regs = sqrt(eps) ('late')."""
