@@ -26,6 +26,7 @@ struct tlpk_handle {
     int device = -1;
     bool has_device = false;
     bool profile = false;
+    bool serial = false;          // TLPK_SERIAL=1: every launch on the main stream (what profile mode does), for external profilers
     hipStream_t stream = nullptr;                 // main stream (= group 0)
     hipStream_t gstream[MAX_GROUPS] = {};         // gstream[0] == stream; others: concurrent subtree groups
     hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
@@ -153,7 +154,7 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
         // profiling serialises everything on the main stream: per-launch HIP-event durations are
         // then the kernels' own durations, not time shared with other groups' kernels
         const bool marker = (L[i].kind == LK_SIDE_FORK || L[i].kind == LK_SIDE_JOIN);
-        if (h->profile) { if (marker) continue; }
+        if (h->profile || h->serial) { if (marker) continue; }
         else {
             if (L[i].group >= 1) { fork_groups(h); st = h->gstream[L[i].group]; }
             else if (L[i].group == 0) fork_groups(h);      // group 0 runs on the main stream itself
@@ -295,6 +296,7 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
             h->opt.user_perm = h->user_perm_copy.data();
         }
         h->profile = def.profile != 0;
+        if (const char *e = std::getenv("TLPK_SERIAL")) h->serial = std::atoi(e) != 0;
         const auto t0 = std::chrono::steady_clock::now();
         rc = analyse(h->S, m, n, colptr, rowval, nzval, index_base, h->opt);
         h->ms_analyse = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
