@@ -49,7 +49,7 @@ typedef struct tlpk_options {
     int32_t relax;             /* supernode amalgamation: 0 = fundamental only, 1 = relaxed */
     int32_t profile;           /* 1 = time every kernel class with HIP events (tlpk_kernel_times) */
     int32_t rank, nranks;      /* block-angular sharding over ranks (nranks = 1: everything local) */
-    int32_t streams;           /* concurrent stream groups for block-angular LPs: 0 = auto (4), 1 = single stream */
+    int32_t streams;           /* concurrent stream groups for block-angular LPs: 0 = auto (2), 1 = single group; each group also owns a side stream */
     const int64_t *user_perm;  /* TLPK_ORDER_USER: perm[new] = old, in index_base, length m */
     const int64_t *row_block;  /* block-angular hook (length m): block id >= 0, or -1 for a linking
                                   row; NULL = general sparse.  Blocks are ordered independently,

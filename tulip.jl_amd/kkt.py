@@ -54,7 +54,7 @@ class Backend:
         self.profile = bool(profile)
         self.rank, self.nranks = int(rank), int(nranks)
         self.mem_budget_bytes = int(mem_budget_bytes)
-        self.streams = int(streams)            # 0 = auto (4 concurrent block groups), 1 = single stream
+        self.streams = int(streams)            # 0 = auto (2 concurrent block groups), 1 = single group
 
 
 def _raise_for(code, handle=None, what=""):
