@@ -744,8 +744,37 @@ static void build_schedule(Symbolic &S) {
                 if (in_scope(s)) fn(s, S.fronts[s]);
             }
         };
+        // Macro columns: G consecutive block columns share ONE left-looking update with
+        // K = [0, kM) (kM = first column of the macro column); inside the macro column a block
+        // column only adds the short update K = [kM, ko).  G is chosen at the start of every macro
+        // column so that the long-K launch has >= ~2000 tiles (4 waves of the chip): G = 1 (every
+        // block column pulls all previous columns itself) while a block-column launch is that big
+        // anyway; a level with a single huge front (general sparse LPs), and the last block columns
+        // of any level, get wider macro columns -- a tile with K = 40 000 runs for 10 ms whatever
+        // the number of tiles beside it.  G depends on ALL fronts of the level (not only this stream
+        // group's or this rank's): the blocking, hence the rounding, must not depend on how the
+        // work is distributed.
+        constexpr i32 G_MAX = 16;
+        i64 TILES_WANTED = 2048;
+        if (const char *e = std::getenv("TLPK_MACRO_TILES")) TILES_WANTED = std::atoll(e);    // tuning knob; 0 = no macro columns
+        auto macro_width = [&](i32 ko) {
+            i64 tiles_bc = 0;
+            for (i32 t = t0; t < t1; ++t) {
+                const FrontDesc &w = S.fronts[S.level_fronts[t]];
+                if (w.ns > ko + NB_OUT) tiles_bc += 2 * (i64)((w.f - ko + TILE - 1) / TILE);
+            }
+            // launches of >= ~1000 tiles are left alone (measured on C4: macro columns there cost 0.3 ms,
+            // two stream groups already fill each other's tails)
+            if (tiles_bc <= 0 || 2 * tiles_bc >= TILES_WANTED) return (i32)1;
+            return (i32)std::min<i64>(G_MAX, (TILES_WANTED + tiles_bc - 1) / tiles_bc);
+        };
+        i32 G = 1, io_macro = 0;                           // current macro column: block columns [io_macro, io_macro + G)
         for (i32 io = 0; io <= nouter; ++io) {
             const i32 ko = io * NB_OUT;
+            if (io >= io_macro + G) { io_macro = io; G = macro_width(ko); }
+            else if (io == 0) G = macro_width(0);
+            const i32 gi = io - io_macro, kM = io_macro * NB_OUT;
+            const i32 ka = (gi == 0) ? 0 : kM;             // this block column still needs K = [ka, ko)
             // Block column io.  The left-looking update of its DIAGONAL block and the factorisation
             // of that block (k_potrf*: a serial chain inside one workgroup per front) go to the
             // group's side stream; the update of the rows below runs concurrently on the group's
@@ -757,7 +786,7 @@ static void build_schedule(Symbolic &S) {
             if (overlap) {
                 const i64 f_upd = (i64)S.update_tasks.size();
                 for_fronts([&](i32 s, const FrontDesc &w) {
-                    if (ko < w.ns) push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns), 0, 0);
+                    if (ko < w.ns) push_update_region(s, w, ka, ko - ka, ko, std::min(ko + NB_OUT, w.ns), 0, 0);
                 });
                 push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
             }
@@ -775,12 +804,17 @@ static void build_schedule(Symbolic &S) {
             }
             cur_side = 0;
             {
-                // rows below the diagonal block (or, past the last block column, U = -L21 L21', written)
+                // rows below the diagonal block; at the start of a macro column also the other block
+                // columns of the macro column (K = [0, kM)); past the last block column of a front,
+                // U = -L21 L21' (written)
                 const i64 f_upd = (i64)S.update_tasks.size();
                 for_fronts([&](i32 s, const FrontDesc &w) {
                     const i32 my_nouter = (w.ns + NB_OUT - 1) / NB_OUT;
-                    if (io < my_nouter) push_update_region(s, w, 0, ko, ko, std::min(ko + NB_OUT, w.ns), 0, overlap ? 1 : 2);
-                    else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f, 1, 2);
+                    if (io < my_nouter) {
+                        push_update_region(s, w, ka, ko - ka, ko, std::min(ko + NB_OUT, w.ns), 0, overlap ? 1 : 2);
+                        if (gi == 0 && G > 1)
+                            push_update_region(s, w, 0, kM, ko + NB_OUT, std::min(kM + G * NB_OUT, w.ns), 0, 2);
+                    } else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f, 1, 2);
                 });
                 push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
             }
