@@ -10,7 +10,7 @@ TLPK_STREAMS=1 TLPK_SERIAL=1 timeout 600 rocprofv3 --kernel-trace --stats --outp
     python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/prof_final.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
     d=gpurun_out/pmc_$(echo $c | tr A-Z a-z | sed 's/_size//')
-    TLPK_STREAMS=1 timeout 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- \
+    TLPK_STREAMS=1 TLPK_SERIAL=1 timeout 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- \
         python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $d.log 2>&1
 done
 ls -R gpurun_out/prof_final gpurun_out/pmc_fetch gpurun_out/pmc_write | head -30

@@ -147,6 +147,7 @@ void join_groups(tlpk_handle *h) {
 }
 
 void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, size_t to) {
+    size_t skip_update = (size_t)-1;
     for (size_t i = from; i < to; ++i) {
         if (L[i].group < 0) join_groups(h);
         if (L[i].kind == LK_ALLREDUCE_ROOT) continue;
@@ -172,8 +173,21 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
             }
             if (L[i].side) st = h->sstream[sg];
         }
-        ProfScope ps(h, kind_class(L[i].kind), st);
-        launch_tasks(st, h->d, L[i]);
+        Launch cur = L[i];
+        if ((h->profile || h->serial) && cur.kind == LK_UPDATE) {
+            // single-stream modes: the side-stream update of a block column's diagonal tiles and the
+            // main-stream update of the rows below are adjacent task ranges; run them as ONE launch
+            // (before the potrf), so that a serialised launch still has the whole device to fill
+            if (skip_update == i) continue;
+            if (cur.side) {
+                for (size_t j = i + 1; j < to && L[j].kind != LK_SIDE_JOIN; ++j)
+                    if (L[j].kind == LK_UPDATE && !L[j].side && L[j].first == cur.first + cur.count) {
+                        cur.count += L[j].count; skip_update = j; break;
+                    }
+            }
+        }
+        ProfScope ps(h, kind_class(cur.kind), st);
+        launch_tasks(st, h->d, cur);
     }
     join_groups(h);
 }
