@@ -8,6 +8,9 @@ Test infrastructure only.  It restates, as a driver of the three-function KKT in
   * the homogeneous self-dual loop of /root/reference/src/IPM/HSD/HSD.jl:203-350 and
     /root/reference/src/IPM/HSD/step.jl:10-401 (Mehrotra predictor-corrector + Gondzio's multiple
     centrality corrections, regularisation schedule and the PosDefException retry loop),
+  * Mehrotra's predictor-corrector loop of /root/reference/src/IPM/MPC/MPC.jl:101-410 and
+    /root/reference/src/IPM/MPC/step.jl:10-358 (starting point from two half-zero solves, clamped
+    regularisations, separate primal/dual step lengths, extra centrality corrections),
 with Tulip's defaults (/root/reference/src/IPM/options.jl:1-25).  No presolve and no scaling
 (Presolve_Level = 0 semantics; src/Presolve is out of scope).
 
@@ -481,9 +484,238 @@ class HSD:
                 "primal_status": self.primal_status, "dual_status": self.dual_status, "rho": self.rho}
 
 
-def solve_lp(lp, backend_factory, options=None):
-    """load -> standard form -> KKT.setup -> HSD -> solution (optimize! without presolve)."""
+# ------------------------------------------------------------------------------------------------
+# MPC (Mehrotra predictor-corrector): MPC/MPC.jl:218-410, MPC/step.jl
+# ------------------------------------------------------------------------------------------------
+def _max_step_pd(pt, d):                       # MPC/step.jl:206-217: separate primal / dual step lengths
+    ap = min(1.0, _max_step_vec(pt.xl, d.xl), _max_step_vec(pt.xu, d.xu))
+    ad = min(1.0, _max_step_vec(pt.zl, d.zl), _max_step_vec(pt.zu, d.zu))
+    return ap, ad
+
+
+class MPC:
+    """Restated caller of the KKT ABI for the non-homogeneous algorithm.  Its call pattern differs
+    from HSD's: the starting point costs one update! with theta_inv = 0, regP = 1, regD = 1e-6 and
+    two solve! calls with a zero half of the right-hand side (MPC.jl:359-363); every iteration
+    is one update! (regularisations /10, clamped to [sqrt(eps), 1], x100 on PosDefException)
+    and 2 + ncor solve! calls."""
+
+    def __init__(self, dat, backend, options=None):
+        self.dat, self.kkt, self.opt = dat, backend, options or Options()
+        m, n = dat.nrow, dat.ncol
+        self.p = int(dat.lflag.sum() + dat.uflag.sum())
+        self.pt = Point(m, n, self.p)
+        self.regP = np.ones(n); self.regD = np.ones(m)          # MPC.jl:73-74
+        self.niter = 0
+        self.status = "Trm_Unknown"
+        self.primal_status = self.dual_status = "Sln_Unknown"
+        self.timers = {"Factorization": 0.0, "KKT": 0.0, "n_update": 0, "n_solve": 0, "n_bump": 0}
+        self.log = []
+        self.alpha_p = self.alpha_d = 0.0
+
+    def _update_mu(self):                       # point.jl:45-48 with hflag = false
+        pt = self.pt
+        pt.mu = (pt.xl @ pt.zl + pt.xu @ pt.zu) / pt.p
+
+    def _kkt_update(self, th, rp, rd):
+        t0 = time.perf_counter()
+        self.kkt.update(th, rp, rd)
+        self.timers["Factorization"] += time.perf_counter() - t0
+        self.timers["n_update"] += 1
+
+    def _kkt_solve(self, dx, dy, xp, xd):
+        t0 = time.perf_counter()
+        self.kkt.solve(dx, dy, np.ascontiguousarray(xp), np.ascontiguousarray(xd))
+        self.timers["KKT"] += time.perf_counter() - t0
+        self.timers["n_solve"] += 1
+
+    # MPC.jl:353-410
+    def compute_starting_point(self):
+        pt, d = self.pt, self.dat
+        m, n = pt.m, pt.n
+        self._kkt_update(np.zeros(n), np.ones(n), np.full(m, 1e-6))
+        self._kkt_solve(np.zeros(n), pt.y, np.zeros(m), d.c)     # y: unused half is a fresh temporary
+        self._kkt_solve(pt.x, np.zeros(m), d.b, np.zeros(n))     # x
+        dl = np.where(d.lflag, pt.x - d.lz, 0.0)
+        du = np.where(d.uflag, d.uz - pt.x, 0.0)
+        dxs = 1.0 + max(0.0, -1.5 * dl.min(initial=0.0), -1.5 * du.min(initial=0.0))
+        pt.xl = np.where(d.lflag, dl + dxs, 0.0)
+        pt.xu = np.where(d.uflag, du + dxs, 0.0)
+        z = d.c - d.A.T @ pt.y
+        nb = d.lflag.astype(float) + d.uflag.astype(float)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pt.zl = np.where(d.lflag, z / nb, 0.0)
+            pt.zu = np.where(d.uflag, -z / nb, 0.0)
+        dzs = 1.0 + max(0.0, -1.5 * pt.zl.min(initial=0.0), -1.5 * pt.zu.min(initial=0.0))
+        pt.zl[d.lflag] += dzs
+        pt.zu[d.uflag] += dzs
+        pt.tau, pt.kappa = 1.0, 0.0
+        mu = pt.xl @ pt.zl + pt.xu @ pt.zu
+        ddx = mu / (2 * (pt.zl.sum() + pt.zu.sum()))
+        ddz = mu / (2 * (pt.xl.sum() + pt.xu.sum()))
+        pt.xl[d.lflag] += ddx; pt.xu[d.uflag] += ddx
+        pt.zl[d.lflag] += ddz; pt.zu[d.uflag] += ddz
+        self._update_mu()
+
+    # MPC.jl:101-141
+    def compute_residuals(self):
+        pt, d = self.pt, self.dat
+        self.rp = d.b - d.A @ pt.x
+        self.rl = ((d.lz + pt.xl) - pt.x) * d.lflag
+        self.ru = (d.uz - (pt.x + pt.xu)) * d.uflag
+        self.rd = d.c - d.A.T @ pt.y + pt.zu * d.uflag - pt.zl * d.lflag
+        nrm = lambda v: float(np.abs(v).max(initial=0.0))    # noqa: E731
+        self.rp_nrm, self.rl_nrm, self.ru_nrm, self.rd_nrm = nrm(self.rp), nrm(self.rl), nrm(self.ru), nrm(self.rd)
+        self.primal_objective = d.c @ pt.x + d.c0
+        self.dual_objective = d.b @ pt.y + d.lz @ pt.zl - d.uz @ pt.zu + d.c0
+
+    # MPC.jl:149-214
+    def update_solver_status(self):
+        o, pt, d = self.opt, self.pt, self.dat
+        nrm = lambda v: float(np.abs(v).max(initial=0.0))    # noqa: E731
+        self.status = "Trm_Unknown"
+        rho_p = max(self.rp_nrm / (1 + nrm(d.b)), self.rl_nrm / (1 + nrm(d.lz)), self.ru_nrm / (1 + nrm(d.uz)))
+        rho_d = self.rd_nrm / (1 + nrm(d.c))
+        rho_g = abs(self.primal_objective - self.dual_objective) / (1 + abs(self.primal_objective))
+        self.rho = (rho_p, rho_d, rho_g)
+        self.primal_status = "Sln_FeasiblePoint" if rho_p <= o.TolerancePFeas else "Sln_Unknown"
+        self.dual_status = "Sln_FeasiblePoint" if rho_d <= o.ToleranceDFeas else "Sln_Unknown"
+        if rho_p <= o.TolerancePFeas and rho_d <= o.ToleranceDFeas and rho_g <= o.ToleranceRGap:
+            self.primal_status = self.dual_status = "Sln_Optimal"
+            self.status = "Trm_Optimal"
+            return
+        if max(nrm(d.A @ pt.x), nrm((pt.x - pt.xl) * d.lflag), nrm((pt.x + pt.xu) * d.uflag)) * \
+                (nrm(d.c) / max(1.0, nrm(d.b))) < -o.ToleranceIFeas * (d.c @ pt.x):
+            self.primal_status = "Sln_InfeasibilityCertificate"
+            self.status = "Trm_DualInfeasible"
+            return
+        delta = d.A.T @ pt.y + pt.zl * d.lflag - pt.zu * d.uflag
+        if nrm(delta) * max(nrm(d.lz), nrm(d.uz), nrm(d.b)) / max(1.0, nrm(d.c)) < \
+                (d.b @ pt.y + d.lz @ pt.zl - d.uz @ pt.zu) * o.ToleranceIFeas:
+            self.dual_status = "Sln_InfeasibilityCertificate"
+            self.status = "Trm_PrimalInfeasible"
+
+    # MPC/step.jl:165-203
+    def solve_newton_system(self, D, xi_p, xi_l, xi_u, xi_d, xi_xzl, xi_xzu):
+        pt, d = self.pt, self.dat
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tl = np.where(d.lflag, (xi_xzl + pt.zl * xi_l) / pt.xl, 0.0)
+            tu = np.where(d.uflag, (xi_xzu - pt.zu * xi_u) / pt.xu, 0.0)
+        self._kkt_solve(D.x, D.y, xi_p, xi_d - tl + tu)
+        D.xl = (-xi_l + D.x) * d.lflag
+        D.xu = (xi_u - D.x) * d.uflag
+        with np.errstate(divide="ignore", invalid="ignore"):
+            D.zl = np.where(d.lflag, (xi_xzl - pt.zl * D.xl) / pt.xl, 0.0)
+            D.zu = np.where(d.uflag, (xi_xzu - pt.zu * D.xu) / pt.xu, 0.0)
+        D.tau = D.kappa = 0.0
+
+    # MPC/step.jl:10-123
+    def compute_step(self):
+        o, pt, d = self.opt, self.pt, self.dat
+        with np.errstate(divide="ignore", invalid="ignore"):
+            th_l = np.where(d.lflag, pt.zl / pt.xl, 0.0)
+            th_u = np.where(d.uflag, pt.zu / pt.xu, 0.0)
+        theta_inv = th_l + th_u
+        self.regP = np.clip(self.regP / 10, SQRT_EPS, 1.0)       # step.jl:29-32
+        self.regD = np.clip(self.regD / 10, SQRT_EPS, 1.0)
+        nbump = 0
+        while nbump <= 3:
+            try:
+                self._kkt_update(theta_inv, self.regP, self.regD)
+                break
+            except PosDef:
+                self.regD *= 100; self.regP *= 100
+                nbump += 1
+                self.timers["n_bump"] += 1
+        if not nbump < 3:                              # step.jl:51
+            raise PosDef("factorization could not be saved")
+        D, Dc = Point(pt.m, pt.n, pt.p), Point(pt.m, pt.n, pt.p)
+        lf, uf = d.lflag, d.uflag
+        # predictor (affine scaling), step.jl:225-241
+        xi_p, xi_l, xi_u, xi_d = self.rp.copy(), self.rl.copy(), self.ru.copy(), self.rd.copy()
+        self.solve_newton_system(D, xi_p, xi_l, xi_u, xi_d, -(pt.xl * pt.zl) * lf, -(pt.xu * pt.zu) * uf)
+        ap, ad = _max_step_pd(pt, D)
+        # corrector, step.jl:246-274
+        mu_a = (((pt.xl + ap * D.xl) * lf) @ (pt.zl + ad * D.zl) + ((pt.xu + ap * D.xu) * uf) @ (pt.zu + ad * D.zu)) / pt.p
+        sigma = min(max((mu_a / pt.mu) ** 3, SQRT_EPS), 1.0 - SQRT_EPS)
+        self.solve_newton_system(Dc, xi_p, xi_l, xi_u, xi_d,
+                                 (sigma * pt.mu - D.xl * D.zl - pt.xl * pt.zl) * lf,
+                                 (sigma * pt.mu - D.xu * D.zu - pt.xu * pt.zu) * uf)
+        ap, ad = _max_step_pd(pt, Dc)
+        D, Dc = Dc, Point(pt.m, pt.n, pt.p)
+        # extra centrality corrections, step.jl:71-109, 279-322
+        z_m, z_n = np.zeros(pt.m), np.zeros(pt.n)
+        ncor = 0
+        while ncor < o.CorrectionLimit:
+            ap_, ad_ = min(ap + 0.3, 1.0), min(ad + 0.3, 1.0)
+            g = pt.xl @ pt.zl + pt.xu @ pt.zu
+            ga = ((pt.xl + ap * D.xl) * lf) @ (pt.zl + ad * D.zl) + ((pt.xu + ap * D.xu) * uf) @ (pt.zu + ad * D.zu)
+            mu = (ga / g) * (ga / g) * (ga / pt.p)
+
+            def target(x, dx, z, dz):                  # compute_target!, step.jl:329-358 (gamma = 0.1)
+                v = (x + ap_ * dx) * (z + ad_ * dz)
+                tmin, tmax = mu * 0.1, mu / 0.1
+                return np.where(v < tmin, tmin - v, np.where(v > tmax, tmax - v, 0.0))
+            self.solve_newton_system(Dc, z_m, z_n, z_n, z_n, target(pt.xl, D.xl, pt.zl, D.zl), target(pt.xu, D.xu, pt.zu, D.zu))
+            for k in ("x", "xl", "xu", "y", "zl", "zu"):
+                setattr(Dc, k, getattr(Dc, k) + getattr(D, k))
+            apc, adc = _max_step_pd(pt, Dc)
+            if apc >= 1.01 * ap and adc >= 1.01 * ad:
+                ap, ad = apc, adc
+                D, Dc = Dc, Point(pt.m, pt.n, pt.p)
+                ncor += 1
+            else:
+                break
+        ap *= o.StepDampFactor; ad *= o.StepDampFactor
+        self.alpha_p, self.alpha_d = ap, ad
+        pt.x += ap * D.x; pt.xl += ap * D.xl; pt.xu += ap * D.xu
+        pt.y += ad * D.y; pt.zl += ad * D.zl; pt.zu += ad * D.zu
+        self._update_mu()
+
+    # MPC.jl:218-351
+    def optimize(self):
+        o, pt, d = self.opt, self.pt, self.dat
+        tstart = time.perf_counter()
+        self.niter = 0
+        self.compute_starting_point()
+        while True:
+            self.compute_residuals()
+            self._update_mu()
+            eps_ = 1.0 if d.objsense else -1.0
+            self.log.append((self.niter, eps_ * self.primal_objective, eps_ * self.dual_objective,
+                             max(self.rp_nrm, self.rl_nrm, self.ru_nrm), self.rd_nrm, float("nan"), pt.mu))
+            if o.OutputLevel > 0:
+                print("%4d  %+14.7e  %+14.7e  %8.2e %8.2e %8.2e  %7.1e" % self.log[-1])
+            self.update_solver_status()
+            if self.status in ("Trm_Optimal", "Trm_PrimalInfeasible", "Trm_DualInfeasible"):
+                break
+            if self.niter >= o.IterationsLimit:
+                self.status = "Trm_IterationLimit"; break
+            if time.perf_counter() - tstart >= o.TimeLimit:
+                self.status = "Trm_TimeLimit"; break
+            try:
+                self.compute_step()
+            except PosDef:
+                self.status = "Trm_NumericalProblem"; break
+            except MemoryError:
+                self.status = "Trm_MemoryLimit"; break
+            self.niter += 1
+        return self
+
+    def solution(self):                         # tau = 1 throughout: no rescaling
+        pt, d = self.pt, self.dat
+        n = d.nvar
+        sgn = 1.0 if d.objsense else -1.0
+        return {"status": self.status, "niter": self.niter, "x": pt.x[:n].copy(), "y": pt.y.copy(),
+                "s": (pt.zl[:n] - pt.zu[:n]).copy(),
+                "z_primal": sgn * self.primal_objective, "z_dual": sgn * self.dual_objective,
+                "primal_status": self.primal_status, "dual_status": self.dual_status, "rho": self.rho}
+
+
+def solve_lp(lp, backend_factory, options=None, algorithm="hsd"):
+    """load -> standard form -> KKT.setup -> HSD (default, model.jl) or MPC -> solution
+    (optimize! without presolve)."""
     dat = standard_form(lp)
     be = backend_factory(dat.A)
-    hsd = HSD(dat, be, options).optimize()
-    return hsd, hsd.solution()
+    ipm = (HSD if algorithm == "hsd" else MPC)(dat, be, options).optimize()
+    return ipm, ipm.solution()

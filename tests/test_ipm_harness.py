@@ -1,4 +1,4 @@
-"""End-to-end IPM checks through the restated HSD driver (tests/ipm_harness.py).
+"""End-to-end IPM checks through the restated HSD and MPC drivers (tests/ipm_harness.py).
 
 CPU (always): the four example LPs of the reference with the answers its own test-suite asserts
 (/root/reference/examples/*.jl, run by test/examples.jl) -- on the oracle backend: this is
@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from ipm_harness import (HSD, LP, HipBackend, Options, OracleBackend, read_free_mps, solve_lp,
+from ipm_harness import (HSD, LP, MPC, HipBackend, Options, OracleBackend, read_free_mps, solve_lp,
                          standard_form, _max_step_vec)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -93,6 +93,60 @@ def test_examples_on_cpu_backend_config_c1():
     assert hsd.timers["n_update"] == hsd.niter and hsd.timers["n_solve"] >= 3 * hsd.niter   # 1 factorise + 3..6 solves
 
 
+def _mpc_unit_problem():
+    """test/IPM/MPC.jl:45-63: min x1 - x2  s.t. x1 + x2 = 1, x1 - x2 = 0, 0 <= x <= 2."""
+    A = sp.csc_matrix(np.array([[1.0, 1.0], [1.0, -1.0]]))
+    lp = LP(A, np.array([1.0, -1.0]), 0.0, np.array([1.0, 0.0]), np.array([1.0, 0.0]), np.zeros(2), np.full(2, 2.0))
+    dat = standard_form(lp)
+    return lp, MPC(dat, OracleBackend(dat.A))
+
+
+def test_reference_mpc_unit_facts():
+    """test/IPM/MPC.jl:65-90 (convergence at the known optimum) and :104-147 (residual identities)."""
+    lp, ipm = _mpc_unit_problem()
+    pt, d = ipm.pt, ipm.dat
+    pt.x[:] = [0.5, 0.5]; pt.xl[:] = [0.5, 0.5]; pt.xu[:] = [1.5, 1.5]
+    pt.y[:] = [0.0, 1.0]; pt.zl[:] = 0.0; pt.zu[:] = 0.0
+    pt.tau, pt.kappa, pt.mu = 1.0, 0.0, 0.0
+    ipm.compute_residuals()
+    ipm.update_solver_status()
+    assert ipm.status == "Trm_Optimal"
+    x = pt.x[:] = [3.0, 5.0]; xl = pt.xl[:] = [1.0, 8.0]; xu = pt.xu[:] = [2.0, 1.0]
+    y = pt.y[:] = [10.0, -2.0]; zl = pt.zl[:] = [2.0, 1.0]; zu = pt.zu[:] = [5.0, 7.0]
+    x, xl, xu, y, zl, zu = (np.array(v) for v in (x, xl, xu, y, zl, zu))
+    ipm.compute_residuals()
+    A = d.A.toarray()
+    np.testing.assert_allclose(ipm.rp, d.b - A @ x)
+    np.testing.assert_allclose(ipm.rl, d.l - (x - xl))
+    np.testing.assert_allclose(ipm.ru, d.u - (x + xu))
+    np.testing.assert_allclose(ipm.rd, d.c - A.T @ y - zl + zu)
+    assert ipm.rp_nrm == np.abs(ipm.rp).max() and ipm.rd_nrm == np.abs(ipm.rd).max()
+
+
+def test_mpc_examples_on_cpu_backend():
+    """test/examples.jl:8,17 run ex_optimal and ex_freevars with IPM_Factory = MPC; the other two
+    example LPs exercise the certificate tests of MPC.jl:178-203.  The call pattern seen by the KKT
+    backend: 1 update! + 2 solve! for the starting point, then 1 update! + >= 2 solve! per iteration."""
+    lp = read_free_mps(os.path.join(GOLDEN, "lpex_opt.mps"))
+    ipm, sol = solve_lp(lp, lambda A: OracleBackend(A), algorithm="mpc"); check_optimal(sol)
+    assert ipm.timers["n_update"] == ipm.niter + 1 and ipm.timers["n_solve"] >= 2 + 2 * ipm.niter
+    lp = read_free_mps(os.path.join(GOLDEN, "lpex_freevars.mps"))
+    check_freevars(solve_lp(lp, lambda A: OracleBackend(A), algorithm="mpc")[1])
+    lp = read_free_mps(os.path.join(GOLDEN, "lpex_inf.mps"))
+    assert solve_lp(lp, lambda A: OracleBackend(A), algorithm="mpc")[1]["status"] == "Trm_PrimalInfeasible"
+    lp = read_free_mps(os.path.join(GOLDEN, "lpex_ubd.mps"))
+    assert solve_lp(lp, lambda A: OracleBackend(A), algorithm="mpc")[1]["status"] == "Trm_DualInfeasible"
+
+
+def test_mpc_random_lp_matches_highs():
+    from scipy.optimize import linprog
+    lp = random_feasible_lp(30, 60, 2)
+    ipm, sol = solve_lp(lp, lambda A: OracleBackend(A), algorithm="mpc")
+    assert sol["status"] == "Trm_Optimal"
+    ref = linprog(lp.obj, A_eq=lp.A, b_eq=lp.lcon, bounds=[(0, None)] * 60, method="highs")
+    assert abs(sol["z_primal"] - ref.fun) <= 1e-6 * (1 + abs(ref.fun))
+
+
 def random_feasible_lp(m, n, seed, ineq=False):
     rng = np.random.default_rng(seed)
     A = sp.random(m, n, density=min(1.0, 4.0 / n), random_state=seed, format="csc",
@@ -170,3 +224,27 @@ def test_block_angular_lp_end_to_end_on_hip():
     assert sg["status"] == sc["status"] == "Trm_Optimal"
     assert abs(hg.niter - hc.niter) <= 1
     assert abs(sg["z_primal"] - sc["z_primal"]) <= 1e-8 * (1 + abs(sc["z_primal"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ineq", [False, True])
+def test_mpc_random_lp_hip_vs_cpu(ineq):
+    """The MPC caller (starting-point update with theta_inv = 0 and regD = 1e-6, half-zero right-hand
+    sides, separate primal/dual steps) on the HIP backend vs the CPU oracle backend."""
+    lp = random_feasible_lp(300, 700, 11, ineq=ineq)
+    hg, sg = solve_lp(lp, lambda A: HipBackend(A, device=0), algorithm="mpc")
+    perm = hg.kkt.kkt.perm()
+    hc, sc = solve_lp(lp, lambda A: OracleBackend(A, perm), algorithm="mpc")
+    assert sg["status"] == sc["status"] == "Trm_Optimal"
+    assert abs(hg.niter - hc.niter) <= 1
+    assert abs(sg["z_primal"] - sc["z_primal"]) <= 1e-8 * (1 + abs(sc["z_primal"]))
+    assert abs(sg["z_dual"] - sc["z_dual"]) <= 1e-8 * (1 + abs(sc["z_dual"]))
+    assert max(sg["rho"]) <= float(np.sqrt(np.finfo(float).eps))
+
+
+@pytest.mark.gpu
+def test_mpc_examples_on_hip_backend():
+    lp = read_free_mps(os.path.join(GOLDEN, "lpex_opt.mps"))
+    check_optimal(solve_lp(lp, lambda A: HipBackend(A, device=0), algorithm="mpc")[1])
+    lp = read_free_mps(os.path.join(GOLDEN, "lpex_freevars.mps"))
+    check_freevars(solve_lp(lp, lambda A: HipBackend(A, device=0), algorithm="mpc")[1])
