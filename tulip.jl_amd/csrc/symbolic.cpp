@@ -751,15 +751,17 @@ static void build_schedule(Symbolic &S) {
         // block column pulls all previous columns itself) while a block-column launch is that big
         // anyway; a level with a single huge front (general sparse LPs), and the last block columns
         // of any level, get wider macro columns -- a tile with K = 40 000 runs for 10 ms whatever
-        // the number of tiles beside it.  G depends on ALL fronts of the level (not only this stream
-        // group's or this rank's): the blocking, hence the rounding, must not depend on how the
-        // work is distributed.
+        // the number of tiles beside it.  G depends on all of this rank's fronts of the level, not only
+        // on the current stream group's: the rounding must not depend on the number of streams
+        // (across rank counts the all-reduce order differs anyway; a rank with few blocks needs the
+        // wider macro columns to fill its GPU).
         constexpr i32 G_MAX = 16;
         i64 TILES_WANTED = 2048;
         if (const char *e = std::getenv("TLPK_MACRO_TILES")) TILES_WANTED = std::atoll(e);    // tuning knob; 0 = no macro columns
         auto macro_width = [&](i32 ko) {
             i64 tiles_bc = 0;
             for (i32 t = t0; t < t1; ++t) {
+                if (!S.front_local[S.level_fronts[t]]) continue;
                 const FrontDesc &w = S.fronts[S.level_fronts[t]];
                 if (w.ns > ko + NB_OUT) tiles_bc += 2 * (i64)((w.f - ko + TILE - 1) / TILE);
             }
