@@ -81,6 +81,20 @@ def test_large_fronts_blocked_path():
     compare_with_oracle(A, kkt, 2, ltol=1e-10, xtol=1e-8)
 
 
+def test_general_sparse_c3_shape_macro_columns():
+    """BASELINE configs[2] shape at test scale: A = [A0 I], 25 nnz per structural column => one dense
+    front of ~2400 columns.  A single front has few tiles per block column, so the schedule groups
+    block columns into macro columns (one long-K update + short in-macro updates); the factor is
+    compared entry by entry with the oracle's."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from workloads import general_sparse_lp
+    A = general_sparse_lp(2500)
+    kkt = gpu_setup(A)
+    assert kkt.symbolic("front_ns").max() > 2000
+    compare_with_oracle(A, kkt, 6, ltol=1e-10, xtol=1e-8)
+
+
 def test_inequality_rows_with_slacks():
     A = random_lp_matrix(700, 500, 4, 5, slack=True)
     compare_with_oracle(A, gpu_setup(A), 1)

@@ -81,6 +81,28 @@ def test_large_front_exercises_blocking():
     check_against_oracle(A, kkt, 2, tol=1e-8)
 
 
+def test_macro_columns_on_a_single_dense_front(monkeypatch):
+    """A general sparse LP of BASELINE configs[2]'s shape (A = [A0 I], 25 nnz/col) ends in ONE dense
+    front: few tiles per block column, so block columns are grouped into macro columns (one long-K
+    update with K = [0, kM) for the whole group + short updates K = [kM, ko) inside it).  The
+    schedule must contain both kinds and still reproduce the oracle's factor."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from workloads import general_sparse_lp
+    # the tile target is scaled down with the problem (tuning knob of the analyse phase) so that this
+    # 1400-row instance gets macro columns of 3 block columns, as a 50 000-row one does by default
+    monkeypatch.setenv("TLPK_MACRO_TILES", "50")
+    A = general_sparse_lp(1400)
+    kkt = analyse_only(A)
+    assert kkt.symbolic("front_ns").max() > 1200
+    ut = kkt.symbolic("update_tasks").reshape(-1, 8)
+    panel_updates = ut[ut[:, 6] == 0]                          # beta0 == 0: targets inside a panel
+    assert (panel_updates[:, 1] > 0).any(), "no in-macro update (K starting at kM > 0)"
+    # a macro update covers more than one 256-wide block column: its column limit is > j0 + 256
+    assert ((panel_updates[:, 1] == 0) & (panel_updates[:, 5] - panel_updates[:, 4] > 256)).any()
+    check_against_oracle(A, kkt, 3, tol=1e-8)
+
+
 def test_late_ipm_regime():
     A = random_lp_matrix(70, 200, 3, 21)
     kkt = analyse_only(A)

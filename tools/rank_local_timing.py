@@ -18,7 +18,7 @@ ORDER = os.environ.get("ORDER", "handle_first")
 if ORDER != "handle_first":
     d = [torch.from_numpy(v).to(dev) for v in (th, rp, rd, xp, xd)]
     d_dx = torch.empty(n, dtype=torch.float64, device=dev); d_dy = torch.empty(m, dtype=torch.float64, device=dev)
-for N in (1, 2, 4, 8):
+for N in [int(v) for v in os.environ.get("NLIST", "1,2,4,8").split(",")]:
     kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=row_block, rank=0, nranks=N, streams=int(os.environ.get('NG', '0'))))
     if ORDER == "handle_first":
         d = [torch.from_numpy(v).to(dev) for v in (th, rp, rd, xp, xd)]
