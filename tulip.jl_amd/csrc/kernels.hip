@@ -788,22 +788,23 @@ __global__ __launch_bounds__(256) void k_rhs(i64 m, const i32 *__restrict__ perm
                       const double *__restrict__ D, const double *__restrict__ xi_p,
                       const double *__restrict__ xi_d, const char *__restrict__ row_local,
                       const char *__restrict__ col_local, int rank, double *__restrict__ xw) {
-    // one wave per row (linking rows are long); fixed shuffle-tree reduction
-    const i64 ii = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (ii >= m) return;
-    const i32 i = perm[ii];
-    const char rl = row_local[i];
+    // 8 lanes per row (LP rows are short: a wave per row left 7/8 of the lanes idle; a long linking
+    // row just takes more trips); fixed shuffle-tree reduction inside the 8-lane group
+    const i64 ii = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int lane = threadIdx.x & 7;
+    const bool live = ii < m;
+    const i32 i = live ? perm[ii] : 0;
+    const char rl = live ? row_local[i] : 0;
     double s = 0.0;
     if (rl != 0) {
-        for (i64 q = Tp[i] + lane; q < Tp[i + 1]; q += 64) {
+        for (i64 q = Tp[i] + lane; q < Tp[i + 1]; q += 8) {
             const i32 j = Tj[q];
             if (col_local[j]) s += Tx[q] * (D[j] * xi_d[j]);
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if (lane == 0) xw[ii] = (rl == 0) ? 0.0 : (((rl == 2 && rank != 0) ? 0.0 : xi_p[i]) + s);
+    for (int off = 4; off > 0; off >>= 1) s += __shfl_down(s, off, 8);
+    if (live && lane == 0) xw[ii] = (rl == 0) ? 0.0 : (((rl == 2 && rank != 0) ? 0.0 : xi_p[i]) + s);
 }
 
 // forward gather: row t of the front receives the entries of its children's contribution vectors
@@ -1060,7 +1061,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
 }
 void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank) {
     if (a.m > 0)
-        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 64, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, D, xi_p, xi_d,
+        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, D, xi_p, xi_d,
                            a.row_local, a.col_local, rank, a.ctx.xw);
 }
 void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy) {
