@@ -192,8 +192,12 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const i32 col = cg + 4 * q;
-        av[q] = (rok && col < nb && r >= col) ? P[(i64)r + (i64)col * f] : 0.0;
-        if (Kp > 0 && rok && col < nb && r >= col) av[q] -= Ds[col * (NB_IN + 1) + r];
+        // clamped address + select instead of a guarded load: a branch around each load makes it wait
+        // for the previous one (16 dependent L2 round trips on the factorisation's serial chain)
+        const bool mine = rok && col < nb && r >= col;
+        const double pv = P[(i64)min(r, nb - 1) + (i64)min(col, nb - 1) * f];
+        const double dv = (Kp > 0) ? Ds[col * (NB_IN + 1) + r] : 0.0;
+        av[q] = mine ? (pv - dv) : 0.0;
         wv[q] = (r == col) ? 1.0 : 0.0;
     }
     for (i32 j = 0; j < nb; ++j) {
@@ -301,7 +305,8 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const i32 k = 4 * ks + lk;
-            bf[b][ks] = (k < nb) ? P[(i64)rowc[b] + (i64)(k0 + k) * f] : 0.0;
+            const double v = P[(i64)rowc[b] + (i64)(k0 + min(k, nb - 1)) * f];      // clamped, not guarded
+            bf[b][ks] = (k < nb) ? v : 0.0;
         }
     v4f64 acc[4][NBR];
     const i32 Kp = k0 - kprev;
@@ -309,7 +314,8 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
         __syncthreads();
         for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
             const int cc = idx & (NB_IN - 1), k = idx >> 6;
-            Ws[k * LDW + cc] = (cc < nb) ? P[(i64)(k0 + cc) + (i64)(kprev + c0 + k) * f] : 0.0;
+            const double v = P[(i64)(k0 + min(cc, nb - 1)) + (i64)(kprev + c0 + k) * f];
+            Ws[k * LDW + cc] = (cc < nb) ? v : 0.0;
         }
         __syncthreads();
         if (active) {
@@ -344,7 +350,8 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
     __syncthreads();
     for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
         const int cc = idx & (NB_IN - 1), k = idx >> 6;
-        Ws[k * LDW + cc] = (cc < nb && k < nb) ? W[(i64)cc + (i64)k * nb] : 0.0;
+        const double v = W[(i64)min(cc, nb - 1) + (i64)min(k, nb - 1) * nb];
+        Ws[k * LDW + cc] = (cc < nb && k < nb) ? v : 0.0;
     }
     __syncthreads();
     if (active) {
@@ -433,7 +440,8 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const i32 col = 64 * i + 4 * ks + lk;
-                bf[i][ks] = (col < w) ? P[(i64)rowc + (i64)(k0 + col) * f] : 0.0;
+                const double v = P[(i64)rowc + (i64)(k0 + min(col, w - 1)) * f];
+                bf[i][ks] = (col < w) ? v : 0.0;
             }
     }
     // The 64 x 64 operand blocks are staged in the order (i=0: Linv_0), (i=1: L_10, Linv_1),
