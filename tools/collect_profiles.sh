@@ -14,3 +14,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
         python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $d.log 2>&1
 done
 ls -R gpurun_out/prof_final gpurun_out/pmc_fetch gpurun_out/pmc_write | head -30
+timeout 900 python bench.py --workload headline --steps 3 --warmup 1 > gpurun_out/headline_bench.json 2> gpurun_out/headline_bench.err
+timeout 900 python bench.py --workload c3 --c3-rows 50000 --steps 2 --warmup 1 > gpurun_out/bench_c3_50k.json 2> gpurun_out/c3.err
+NLIST=1,2,4,8 timeout 600 python tools/rank_local_timing.py > gpurun_out/rank_local_timing.txt 2>&1
