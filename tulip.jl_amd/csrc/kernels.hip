@@ -47,7 +47,19 @@ __global__ void k_assemble(i64 nent, const i64 *__restrict__ target, const i32 *
     if (e >= nent) return;
     const i64 p0 = pptr[e], p1 = pptr[e + 1];
     double s = 0.0;
-    for (i64 p = p0; p < p1; ++p) s += pw[p] * D[pj[p]];
+    // four products per trip, indices clamped and weights zeroed past the end: the index -> D[j]
+    // chains of a trip are independent loads (one product per trip waited for each chain in turn);
+    // same summation order
+    for (i64 p = p0; p < p1; p += 4) {
+        double w[4]; i32 j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const i64 q = min(p + u, p1 - 1); w[u] = pw[q]; j[u] = pj[q]; }
+        double d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = D[j[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += ((p + u < p1) ? w[u] : 0.0) * d[u];
+    }
     const i32 dr = diag_row[e];
     if (dr >= 0) s += regD[dr];
     Lval[target[e]] = s;
@@ -994,7 +1006,15 @@ __global__ __launch_bounds__(256) void k_fwd_update(const SolveTask *__restrict_
     double acc = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc += pv[j] * ys[j];             // ys is zero beyond nb
-    for (i32 j = 16; j < nb; ++j) acc += P[(i64)rc + (i64)j * f] * ys[j];
+    // 16 columns per trip, all 16 loads in flight (the compiler unrolled the plain loop by 4: 28
+    // dependent round trips per block step on the sweep's serial chain); columns clamped, ys zero
+    // beyond nb
+    for (i32 jb = 16; jb < nb; jb += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) pv[j] = P[(i64)rc + (i64)min(jb + j, nb - 1) * f];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += pv[j] * ys[jb + j];
+    }
     double v = 0.0;
     if (r < f) {
         double *dst = (r < ns) ? (c.xw + fd.col0 + r) : (c.uc + fd.ucoff + (r - ns));
