@@ -1056,11 +1056,18 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
         const i32 nr = min(BWD_ROWS, t.row0 + nrows - rc);
         double xr[BWD_ROWS / 64];
         i32 ro[BWD_ROWS / 64];
+        i32 xi[BWD_ROWS / 64];
+#pragma unroll
+        for (int u = 0; u < BWD_ROWS / 64; ++u) {           // unconditional loads, clamped rows, selects
+            ro[u] = min(lane + 64 * u, nr - 1);           // clamped: the matching xr is zeroed
+            const i32 r = rc + ro[u];
+            const i32 gr = rows[r];
+            xi[u] = (r < ns) ? (fd.col0 + r) : gr;
+        }
 #pragma unroll
         for (int u = 0; u < BWD_ROWS / 64; ++u) {
-            const i32 r = rc + lane + 64 * u;
-            xr[u] = (lane + 64 * u < nr) ? ((r < ns) ? c.xw[fd.col0 + r] : c.xw[rows[r]]) : 0.0;
-            ro[u] = min(lane + 64 * u, nr - 1);           // clamped: the matching xr is zero
+            const double xv = c.xw[xi[u]];
+            xr[u] = (lane + 64 * u < nr) ? xv : 0.0;
         }
         const double *P = P0 + rc;
         // a wave owns 32 of the 128 columns: batches of 8, the next batch is requested while the current
@@ -1079,7 +1086,8 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
         fetch(cur, wave * CB);
 #pragma unroll 1
         for (i32 j0 = wave * CB; j0 < nb; j0 += 4 * CB) {
-            if (j0 + 4 * CB < nb) fetch(nxt, j0 + 4 * CB);
+            fetch(nxt, j0 + 4 * CB);                 // unconditional (columns are clamped): a guarded fetch
+                                                     // forces a full wait at the join and hides nothing
             double acc[CB];
 #pragma unroll
             for (int jj = 0; jj < CB; ++jj) {
