@@ -7,7 +7,8 @@ the product."""
 import numpy as np
 
 LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
-          BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12)
+          BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12,
+          UPDATE_REDUCE=13)
 
 
 class Emulator:
@@ -34,6 +35,7 @@ class Emulator:
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
             LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),
             LK["UPDATE"]: g("update_tasks").reshape(-1, 8),
+            LK["UPDATE_REDUCE"]: g("reduce_tasks").reshape(-1, 8),
             LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 6),
             LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 6),
             LK["FWD_UPDATE"]: g("fwd_update_tasks").reshape(-1, 6),
@@ -46,6 +48,7 @@ class Emulator:
         self.lval_len = st["nnzL_stored"]
         self.Lval = np.zeros(max(self.lval_len, 1))
         self.U = {}          # front -> rs x rs array (lower part meaningful)
+        self.spart = {}      # split-K scratch slot -> partial tile
         self.fail_col = None
 
     # views
@@ -164,13 +167,17 @@ class Emulator:
 
     def _k3(self, T):      # update
         TILE = 128
-        for front, k0, kw, i0, j0, jlim, beta0, _ in T:
+        for front, k0, kw, i0, j0, jlim, beta0, slot1 in T:
             P = self.panel(front)
             f, ns = int(self.f[front]), int(self.ns[front])
             i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)
             if i1 <= i0 or j1 <= j0:
                 continue
             G = P[i0:i1, k0:k0 + kw] @ P[j0:j1, k0:k0 + kw].T
+            if slot1:            # split-K part: raw tile to its scratch slot (each slot written exactly once)
+                assert int(slot1) - 1 not in self.spart
+                self.spart[int(slot1) - 1] = G
+                continue
             rr = np.arange(i0, i1)[:, None]; cc = np.arange(j0, j1)[None, :]
             mask = rr >= cc
             for c in range(j0, j1):
@@ -187,6 +194,29 @@ class Emulator:
                     else:
                         self.U[front][rsel - ns, c - ns] -= G[rsel - i0, c - j0]
             del mask
+
+    def _k13(self, T):     # split-K reduce: parts of a tile summed in slot order, then applied like _k3
+        TILE = 128
+        for front, slot0, parts, i0, j0, jlim, beta0, _ in T:
+            f, ns = int(self.f[front]), int(self.ns[front])
+            i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)
+            G = self.spart.pop(int(slot0))          # pop: a slot may be reused by a later launch of the stream
+            for sp in range(1, int(parts)):
+                G = G + self.spart.pop(int(slot0) + sp)
+            P = self.panel(front)
+            for c in range(j0, j1):
+                rsel = np.arange(max(i0, c), i1)
+                if rsel.size == 0:
+                    continue
+                if c < ns:
+                    P[rsel, c] -= G[rsel - i0, c - j0]
+                else:
+                    if front not in self.U:
+                        self.U[front] = np.full((f - ns, f - ns), np.nan)
+                    if beta0:
+                        self.U[front][rsel - ns, c - ns] = -G[rsel - i0, c - j0]
+                    else:
+                        self.U[front][rsel - ns, c - ns] -= G[rsel - i0, c - j0]
 
     # ---- solve! ----
     def solve_local(self, xi_p, xi_d, A):

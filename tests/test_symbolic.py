@@ -100,6 +100,10 @@ def test_macro_columns_on_a_single_dense_front(monkeypatch):
     assert (panel_updates[:, 1] > 0).any(), "no in-macro update (K starting at kM > 0)"
     # a macro update covers more than one 256-wide block column: its column limit is > j0 + 256
     assert ((panel_updates[:, 1] == 0) & (panel_updates[:, 5] - panel_updates[:, 4] > 256)).any()
+    # ... and, with so few tiles per launch, split-K: partial tiles to scratch + ordered reduce launches
+    red = kkt.symbolic("reduce_tasks").reshape(-1, 8)
+    assert len(red) > 0 and red[:, 2].max() >= 2 and (ut[:, 7] > 0).any()
+    assert kkt.symbolic("factor_launches").reshape(-1, 3)[:, 0].tolist().count(13) > 0
     check_against_oracle(A, kkt, 3, tol=1e-8)
 
 

@@ -751,6 +751,20 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
     }
 epilogue:
     if (!any) return;
+    if (t.pad1) {
+        // split-K part: the raw tile goes to its scratch slot, k_update_reduce applies the parts in order
+        double *Sp = c.spart + (i64)(t.pad1 - 1) * (TILE * TILE);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if constexpr (!FULL) { if (!valid[a][b]) continue; }
+                const i32 lrow = wr * 64 + b * 16 + lr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Sp[lrow + (wc * 64 + a * 16 + lk + 4 * q) * TILE] = acc[a][b][q];
+            }
+        return;
+    }
 #if defined(UPD_VARIANT) && (UPD_VARIANT == 2 || UPD_VARIANT == 6)   /* ablation: no epilogue read-modify-write */
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -797,6 +811,30 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
     const bool full = (t.i0 + TILE <= fd.f) && (t.j0 + TILE <= t.jlim) && (t.i0 >= t.j0 + TILE);
     if (full) update_tile<true>(t, fd, c, As, Bs);
     else update_tile<false>(t, fd, c, As, Bs);
+}
+
+// Split-K: when an update launch has too few tiles to fill the chip, the K range of every tile is
+// cut into parts computed by different workgroups (k_update with pad1 != 0 writes the raw
+// 128 x 128 partial products to scratch); this kernel adds the parts of one tile in fixed order
+// and applies the sum to the tile's targets with the masks of the ordinary epilogue.
+__global__ __launch_bounds__(256) void k_update_reduce(const UpdateTask *__restrict__ tasks, DevCtx c) {
+    const UpdateTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns, rs = f - ns;
+    const double *Sp = c.spart + (i64)t.k0 * (TILE * TILE);
+    double *Pw = c.Lval + fd.loff;
+    double *Uw = front_u(c, fd);
+    for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+        const i32 row = t.i0 + (e & (TILE - 1)), col = t.j0 + (e >> 7);
+        if (row >= f || col >= t.jlim || row < col) continue;
+        double sum = Sp[e];
+        for (i32 sp = 1; sp < t.kw; ++sp) sum += Sp[(i64)sp * (TILE * TILE) + e];
+        if (col < ns) Pw[(i64)row + (i64)col * f] -= sum;
+        else {
+            double *dst = Uw + (i64)(row - ns) + (i64)(col - ns) * rs;
+            *dst = t.beta0 ? -sum : (*dst - sum);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1171,6 +1209,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     case LK_POTRF_WIDE: hipLaunchKernelGGL(k_potrf_wide, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
     case LK_TRSM: hipLaunchKernelGGL(k_trsm, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
     case LK_UPDATE: hipLaunchKernelGGL(k_update, g, dim3(256), 0, st, a.update_tasks + L.first, a.ctx); break;
+    case LK_UPDATE_REDUCE: hipLaunchKernelGGL(k_update_reduce, g, dim3(256), 0, st, a.reduce_tasks + L.first, a.ctx); break;
     case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;
     case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(256), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
     case LK_FWD_UPDATE: hipLaunchKernelGGL(k_fwd_update, g, dim3(256), 0, st, a.fwd_update_tasks + L.first, a.ctx); break;

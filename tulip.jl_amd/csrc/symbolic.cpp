@@ -691,6 +691,7 @@ static void build_schedule(Symbolic &S) {
     // Scope of the level body being generated: stream group `cur_g` (fronts at depth >= 1 of that
     // group) or -1 = the depth-0 fronts, which run on the main stream after all groups joined.
     int cur_g = -1, cur_side = 0;
+    std::vector<i64> region_slots;          // split-K scratch slots needed per (stream group, side) region
     auto in_scope = [&](i32 s) { return S.front_local[s] && (cur_g < 0 || S.front_group[s] == cur_g); };
     auto push_launch = [&](std::vector<Launch> &L, i32 kind, i64 first, i64 count) {
         if (count > 0) L.push_back(Launch{kind, cur_g, first, count, cur_side, 0});
@@ -728,21 +729,65 @@ static void build_schedule(Symbolic &S) {
         const i32 nouter = (max_ns + NB_OUT - 1) / NB_OUT;
         // part: 0 = only the tiles of the block column's diagonal block (rows < c0 + NB_OUT),
         //       1 = only the tiles below it, 2 = all
+        // dry != nullptr: only count the tiles (into *dry), for every front the caller passes
+        i64 *dry = nullptr;
         auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0, int part) {
             if (kw <= 0 || c0 >= c1) return;
-            if (part != 1) for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * kw * (double)(w.f - cc);
+            if (!dry && part != 1) for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * kw * (double)(w.f - cc);
             for (i32 j0 = c0; j0 < c1; j0 += TILE)
                 for (i32 i0 = j0; i0 < w.f; i0 += TILE) {
                     const bool diag_blk = i0 < c0 + NB_OUT;
                     if ((part == 0 && !diag_blk) || (part == 1 && diag_blk)) continue;
-                    S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0});
+                    if (dry) ++*dry; else S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0});
                 }
         };
-        auto for_fronts = [&](auto &&fn) {
+        auto for_fronts = [&](auto &&fn) {              // dry runs see all of the rank's fronts of the level
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
-                if (in_scope(s)) fn(s, S.fronts[s]);
+                if (dry ? (bool)S.front_local[s] : in_scope(s)) fn(s, S.fronts[s]);
             }
+        };
+        // One update launch: `gen` pushes its tiles.  Split-K: when the launch would leave most of the
+        // chip idle (fewer than ~128 tiles over ALL of the rank's fronts of the level -- the decision
+        // must not depend on the stream groups), the K range of every tile is cut into up to 8 parts of
+        // >= 256 columns, computed by different workgroups into scratch and applied in order by a
+        // k_update_reduce launch.  A tile with K = 3300 runs for ~0.9 ms whatever runs beside it: with
+        // 8 blocks per rank (8-GPU sharding), for the root front, and for the diagonal-block tiles on
+        // the side stream this is the critical path.
+        auto emit_update_launch = [&](auto &&gen) {
+            i64 t_level = 0;
+            dry = &t_level; gen(); dry = nullptr;
+            const i64 f_upd = (i64)S.update_tasks.size();
+            gen();
+            const i64 cnt = (i64)S.update_tasks.size() - f_upd;
+            if (cnt == 0) return;
+            i64 want = 256;
+            if (const char *e = std::getenv("TLPK_SPLITK_TILES")) want = std::atoll(e);       // tuning knob; 0 = off
+            const i32 nsplit = (t_level > 0) ? (i32)std::min<i64>(8, want / t_level) : 1;
+            if (nsplit < 2) { push_launch(S.factor_launches, LK_UPDATE, f_upd, cnt); return; }
+            std::vector<UpdateTask> orig(S.update_tasks.begin() + f_upd, S.update_tasks.end());
+            S.update_tasks.resize(f_upd);
+            const i64 f_red = (i64)S.reduce_tasks.size();
+            i32 slot = 0;
+            for (const UpdateTask &t : orig) {
+                const i32 parts = std::min(nsplit, t.kw / 256);
+                if (parts < 2) { S.update_tasks.push_back(t); continue; }
+                const i32 base = (t.kw / parts) / 16 * 16;              // multiples of the kernel's K slab
+                i32 k = 0;
+                for (i32 sp = 0; sp < parts; ++sp) {
+                    const i32 kw_s = (sp == parts - 1) ? t.kw - k : base;
+                    S.update_tasks.push_back(UpdateTask{t.front, t.k0 + k, kw_s, t.i0, t.j0, t.jlim, t.beta0, slot + sp + 1});
+                    k += kw_s;
+                }
+                S.reduce_tasks.push_back(UpdateTask{t.front, slot, parts, t.i0, t.j0, t.jlim, t.beta0, 0});
+                slot += parts;
+            }
+            // slots are relative to the scratch region of this launch's stream for now (see below)
+            const int region = (cur_g + 1) * 2 + cur_side;
+            if ((int)region_slots.size() <= region) region_slots.resize(region + 1, 0);
+            region_slots[region] = std::max<i64>(region_slots[region], slot);
+            push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
+            push_launch(S.factor_launches, LK_UPDATE_REDUCE, f_red, (i64)S.reduce_tasks.size() - f_red);
         };
         // Macro columns: G consecutive block columns share ONE left-looking update with
         // K = [0, kM) (kM = first column of the macro column); inside the macro column a block
@@ -785,13 +830,12 @@ static void build_schedule(Symbolic &S) {
             const bool overlap = io > 0 && io < nouter;
             if (overlap) S.factor_launches.push_back(Launch{LK_SIDE_FORK, cur_g, 0, 0, 0, 0});
             cur_side = overlap ? 1 : 0;
-            if (overlap) {
-                const i64 f_upd = (i64)S.update_tasks.size();
-                for_fronts([&](i32 s, const FrontDesc &w) {
-                    if (ko < w.ns) push_update_region(s, w, ka, ko - ka, ko, std::min(ko + NB_OUT, w.ns), 0, 0);
+            if (overlap)
+                emit_update_launch([&]() {
+                    for_fronts([&](i32 s, const FrontDesc &w) {
+                        if (ko < w.ns) push_update_region(s, w, ka, ko - ka, ko, std::min(ko + NB_OUT, w.ns), 0, 0);
+                    });
                 });
-                push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
-            }
             if (io < nouter) {
                 // narrow blocks (one 64-wide step) and wide ones go to different kernels
                 for (int wide = 0; wide < 2; ++wide) {
@@ -809,16 +853,16 @@ static void build_schedule(Symbolic &S) {
                 // rows below the diagonal block; at the start of a macro column also the other block
                 // columns of the macro column (K = [0, kM)); past the last block column of a front,
                 // U = -L21 L21' (written)
-                const i64 f_upd = (i64)S.update_tasks.size();
-                for_fronts([&](i32 s, const FrontDesc &w) {
-                    const i32 my_nouter = (w.ns + NB_OUT - 1) / NB_OUT;
-                    if (io < my_nouter) {
-                        push_update_region(s, w, ka, ko - ka, ko, std::min(ko + NB_OUT, w.ns), 0, overlap ? 1 : 2);
-                        if (gi == 0 && G > 1)
-                            push_update_region(s, w, 0, kM, ko + NB_OUT, std::min(kM + G * NB_OUT, w.ns), 0, 2);
-                    } else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f, 1, 2);
+                emit_update_launch([&]() {
+                    for_fronts([&](i32 s, const FrontDesc &w) {
+                        const i32 my_nouter = (w.ns + NB_OUT - 1) / NB_OUT;
+                        if (io < my_nouter) {
+                            push_update_region(s, w, ka, ko - ka, ko, std::min(ko + NB_OUT, w.ns), 0, overlap ? 1 : 2);
+                            if (gi == 0 && G > 1)
+                                push_update_region(s, w, 0, kM, ko + NB_OUT, std::min(kM + G * NB_OUT, w.ns), 0, 2);
+                        } else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f, 1, 2);
+                    });
                 });
-                push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
             }
             if (overlap) S.factor_launches.push_back(Launch{LK_SIDE_JOIN, cur_g, 0, 0, 0, 0});
             if (io == nouter) break;
@@ -840,6 +884,22 @@ static void build_schedule(Symbolic &S) {
         for (i32 d = S.nlevels - 1; d >= 1; --d) factor_level(d);
     cur_g = -1;
     if (S.nlevels > 0) factor_level(0);
+    // split-K scratch: every stream (group x side) gets its own region, launches of one stream reuse it;
+    // make the slot numbers absolute
+    {
+        std::vector<i64> base(region_slots.size() + 1, 0);
+        for (size_t r = 0; r < region_slots.size(); ++r) base[r + 1] = base[r] + region_slots[r];
+        S.spart_len = base.back() * (i64)TILE * TILE;
+        for (const Launch &L : S.factor_launches) {
+            if (L.kind != LK_UPDATE && L.kind != LK_UPDATE_REDUCE) continue;
+            const size_t region = (size_t)((L.group + 1) * 2 + L.side);
+            if (region >= region_slots.size() || base[region] == 0) continue;
+            for (i64 q = L.first; q < L.first + L.count; ++q) {
+                if (L.kind == LK_UPDATE) { if (S.update_tasks[q].pad1) S.update_tasks[q].pad1 += (i32)base[region]; }
+                else S.reduce_tasks[q].k0 += (i32)base[region];
+            }
+        }
+    }
     // ---------------- forward solve: deepest level first ----------------
     auto fwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];

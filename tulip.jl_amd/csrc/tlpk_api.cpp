@@ -94,7 +94,7 @@ int kind_class(i32 kind) {
     case LK_EXTEND_ADD: return TLPK_KC_EXTEND_ADD;
     case LK_POTRF: case LK_POTRF_WIDE: return TLPK_KC_POTRF;
     case LK_TRSM: return TLPK_KC_TRSM;
-    case LK_UPDATE: return TLPK_KC_UPDATE;
+    case LK_UPDATE: case LK_UPDATE_REDUCE: return TLPK_KC_UPDATE;
     case LK_FWD_GATHER: case LK_FWD_DIAG: case LK_FWD_UPDATE: return TLPK_KC_SOLVE_FWD;
     default: return TLPK_KC_SOLVE_BWD;
     }
@@ -243,13 +243,13 @@ int upload_all(tlpk_handle *h) {
     { i64 *p; UP(p, S.gth_ptr); d.ctx.gth_ptr = p; }
     { i64 *p; UP(p, S.gth_src); d.ctx.gth_src = p; }
     UP(d.ea_tasks, S.ea_tasks); UP(d.potrf_tasks, S.potrf_tasks); UP(d.trsm_tasks, S.trsm_tasks);
-    UP(d.update_tasks, S.update_tasks);
+    UP(d.update_tasks, S.update_tasks); UP(d.reduce_tasks, S.reduce_tasks);
     UP(d.fwd_gather_tasks, S.fwd_gather_tasks); UP(d.fwd_diag_tasks, S.fwd_diag_tasks);
     UP(d.fwd_update_tasks, S.fwd_update_tasks); UP(d.bwd_update_tasks, S.bwd_update_tasks);
 #undef UP
 #define AL(dst, cnt) if ((rc = dev_alloc(h, &(dst), (cnt))) != TLPK_OK) return rc
     AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
-    AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4); AL(d.ctx.dinv, S.dinv_len);
+    AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4); AL(d.ctx.dinv, S.dinv_len); AL(d.ctx.spart, S.spart_len);
     AL(h->d_theta, S.n); AL(h->d_regP, S.n); AL(h->d_regD, S.m); AL(h->d_D, S.n);
     AL(h->d_xip, S.m); AL(h->d_xid, S.n); AL(h->d_dx, S.n); AL(h->d_dy, S.m);
 #undef AL
@@ -643,6 +643,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "potrf_tasks") { for (auto &t : S.potrf_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.kprev); } }
     else if (w == "trsm_tasks") { for (auto &t : S.trsm_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.kprev); tmp.push_back(t.fuse_nb); } }
     else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
+    else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); } }
     else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks") {
         const std::vector<SolveTask> &v = (w == "fwd_gather_tasks") ? S.fwd_gather_tasks : (w == "fwd_diag_tasks") ? S.fwd_diag_tasks :

@@ -18,6 +18,7 @@ struct DevCtx {
     double *uc;         // solve contribution vectors
     double *xw;         // permuted right-hand side / solution
     double *dinv;       // inverses of the NB_IN x NB_IN diagonal blocks of L (written by k_potrf)
+    double *spart;      // split-K scratch: one TILE x TILE partial product per slot
     int *info;          // info[0] = smallest failing pivot column (INT_MAX = none)
 };
 
@@ -35,7 +36,7 @@ struct DevArrays {
     double *pair_w = nullptr; i32 *pair_j = nullptr;
     // task arrays
     EaTask *ea_tasks = nullptr; PotrfTask *potrf_tasks = nullptr; TrsmTask *trsm_tasks = nullptr;
-    UpdateTask *update_tasks = nullptr;
+    UpdateTask *update_tasks = nullptr, *reduce_tasks = nullptr;
     SolveTask *fwd_gather_tasks = nullptr, *fwd_diag_tasks = nullptr, *fwd_update_tasks = nullptr,
               *bwd_update_tasks = nullptr;
 };

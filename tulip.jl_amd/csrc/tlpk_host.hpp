@@ -43,7 +43,9 @@ static_assert(sizeof(FrontDesc) == 80, "FrontDesc layout");
 
 struct PotrfTask { i32 front, k0, nb, kprev; };              // diagonal block of a block column: columns [k0, k0 + nb), nb <= NB_OUT; kprev = k0
 struct TrsmTask  { i32 front, k0, nb, row0, kprev, fuse_nb, pad1, pad2; };   // fuse_nb: also factor the next diagonal block
-struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; }; //  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
+struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; }; // pad1 = slot + 1: split-K part, the raw tile goes to scratch slot `slot`;
+// in reduce_tasks: k0 = first slot, kw = number of parts
+//  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
 struct EaTask    { i32 front, j0, j1, pad; };                        // parent columns [j0, j1)
 struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };  // slot: partial-sum slots (backward)
 
@@ -53,7 +55,8 @@ enum LaunchKind : i32 {
     LK_ALLREDUCE_ROOT,  // marker: everything after this belongs to the replicated root front
     LK_POTRF_WIDE,      // diagonal block wider than NB_IN (several 64-wide steps in one workgroup)
     LK_SIDE_FORK,       // marker: the group's side stream waits for the group's stream
-    LK_SIDE_JOIN        // marker: the group's stream waits for its side stream
+    LK_SIDE_JOIN,       // marker: the group's stream waits for its side stream
+    LK_UPDATE_REDUCE    // applies the split-K partial tiles of the preceding LK_UPDATE launch to their targets
 };
 struct Launch { i32 kind; i32 group; i64 first; i64 count; i32 side = 0; i32 pad = 0; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
 
@@ -108,7 +111,8 @@ struct Symbolic {
     double flops_chol = 0, flops_panel = 0, flops_update = 0;
     // schedules
     std::vector<PotrfTask> potrf_tasks; std::vector<TrsmTask> trsm_tasks;
-    std::vector<UpdateTask> update_tasks; std::vector<EaTask> ea_tasks;
+    std::vector<UpdateTask> update_tasks, reduce_tasks; std::vector<EaTask> ea_tasks;
+    i64 spart_len = 0;                     // split-K scratch: TILE x TILE doubles per partial tile
     std::vector<SolveTask> fwd_gather_tasks, fwd_diag_tasks, fwd_update_tasks, bwd_update_tasks;
     std::vector<Launch> factor_launches, fwd_launches, bwd_launches;
     std::string error;
