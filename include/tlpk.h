@@ -89,7 +89,8 @@ typedef struct tlpk_stats {
 #define TLPK_KC_SOLVE_FWD 5
 #define TLPK_KC_SOLVE_BWD 6
 #define TLPK_KC_SPMV 7
-#define TLPK_KC_COUNT 8
+#define TLPK_KC_UPDATE_REDUCE 8   /* split-K: ordered sum of partial tiles + application to the targets */
+#define TLPK_KC_COUNT 9
 typedef struct tlpk_kernel_times {
     double  ms[TLPK_KC_COUNT];       /* summed duration of the class in the last update+solve */
     int64_t launches[TLPK_KC_COUNT];

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libtlpk.so")
 
 OK, NOT_POSDEF, BADARG, OOM, HIPERR, NO_DEVICE, TOO_LARGE, NOT_FACTORED, INTERNAL = range(9)
 ORDER_AMD, ORDER_NATURAL, ORDER_USER = 0, 1, 2
-KC_NAMES = ["assemble", "extend_add", "potrf", "trsm", "update", "solve_fwd", "solve_bwd", "spmv"]
+KC_NAMES = ["assemble", "extend_add", "potrf", "trsm", "update", "solve_fwd", "solve_bwd", "spmv", "update_reduce"]
 
 p64 = C.POINTER(C.c_int64)
 pd = C.POINTER(C.c_double)
@@ -42,10 +42,10 @@ class Stats(C.Structure):
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_int64 * 8)]
+    _fields_ = [("ms", C.c_double * len(KC_NAMES)), ("launches", C.c_int64 * len(KC_NAMES))]
 
     def as_dict(self):
-        return {KC_NAMES[i]: {"ms": self.ms[i], "launches": self.launches[i]} for i in range(8)}
+        return {KC_NAMES[i]: {"ms": self.ms[i], "launches": self.launches[i]} for i in range(len(KC_NAMES))}
 
 
 _lib = None
