@@ -21,6 +21,7 @@ class Emulator:
         self.parent = g("front_parent"); self.loff = g("front_loff"); self.rowoff = g("front_rowoff")
         self.reloff = g("front_reloff"); self.child_ptr = g("front_child_ptr"); self.nchild = g("front_nchild")
         self.local = g("front_local")
+        self.single = g("front_single")
         self.row_local = g("row_local"); self.col_local = g("col_local")
         self.root_front = int(g("root_front")[0])
         self.rank = kkt.backend_options.rank
@@ -88,6 +89,13 @@ class Emulator:
             self.Lval[self.s_target[e]] = v
         self.U = {}
         self.fail_col = None
+        for s_ in np.nonzero(self.single & (self.local != 0))[0]:      # k_single_factor
+            d = self.Lval[self.loff[s_]]
+            if not d > 0:
+                col = int(self.col0[s_])
+                self.fail_col = col if self.fail_col is None else min(self.fail_col, col)
+                d = 1.0
+            self.Lval[self.loff[s_]] = np.sqrt(d)
         self._resume = self._run(self.factor_launches, True)
         if not stop_at_marker:
             self.update_finish()
@@ -226,6 +234,9 @@ class Emulator:
         rl = self.row_local
         xi = np.where(rl == 0, 0.0, xi + np.where((rl == 2) & (self.rank != 0), 0.0, xi_p))
         self.xw = xi[self.perm].copy()
+        for s_ in np.nonzero(self.single & (self.local != 0))[0]:          # k_single_solve
+            l = self.Lval[self.loff[s_]]
+            self.xw[self.col0[s_]] = self.xw[self.col0[s_]] / l / l
         self.ucflat = np.full(max(int((self.ucoff + self.f - self.ns).max()), 1), np.nan)
         self._resume_fwd = self._run(self.fwd_launches, True)
 

@@ -95,6 +95,28 @@ def test_general_sparse_c3_shape_macro_columns():
     compare_with_oracle(A, kkt, 6, ltol=1e-10, xtol=1e-8)
 
 
+def test_isolated_singleton_fronts_on_device():
+    """Rows that only hold their slack are isolated 1 x 1 fronts: one thread each (k_single_factor /
+    k_single_solve); a non-positive one must still raise PosDefException with its column."""
+    from test_symbolic import singleton_rows_matrix
+    A = singleton_rows_matrix()
+    kkt = gpu_setup(A)
+    assert kkt.symbolic("front_single").sum() > 50
+    compare_with_oracle(A, kkt, 8)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 8)
+    empty = np.nonzero(np.diff(A[:, : n - m].tocsr().indptr) == 0)[0]
+    th2 = th.copy(); th2[n - m + empty[0]] = -2.0 * rp[0] - 1.0          # slack of an isolated row: D < 0 there
+    rd2 = np.zeros(m)
+    with pytest.raises(tk.PosDefException):
+        tk.update(kkt, th2, rp, rd2)
+    tk.update(kkt, th, rp, rd)                                             # the handle stays usable
+    dx = np.zeros(n); dy = np.zeros(m)
+    tk.solve(dx, dy, kkt, xp, xd)
+    r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+    assert r1 <= 1e-8 * (1 + np.abs(xp).max()) * max(1.0, np.abs(dy).max())
+
+
 def test_inequality_rows_with_slacks():
     A = random_lp_matrix(700, 500, 4, 5, slack=True)
     compare_with_oracle(A, gpu_setup(A), 1)

@@ -107,6 +107,34 @@ def test_macro_columns_on_a_single_dense_front(monkeypatch):
     check_against_oracle(A, kkt, 3, tol=1e-8)
 
 
+def singleton_rows_matrix(m=300, n0=200, seed=4):
+    """A = [A0 I] where a third of the rows of A0 are empty: those rows only hold their slack, i.e. they
+    are isolated 1 x 1 fronts of the normal equations (13 % of the rows of the headline instance)."""
+    rng = np.random.default_rng(seed)
+    live = np.sort(rng.choice(m, size=2 * m // 3, replace=False))
+    rows = live[rng.integers(0, live.size, size=(n0, 3))].ravel()
+    cols = np.repeat(np.arange(n0), 3)
+    A0 = sp.csc_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(m, n0))
+    A0.sum_duplicates()
+    A = sp.hstack([A0, sp.identity(m, format="csc")], format="csc")
+    A.sort_indices()
+    return A
+
+
+def test_isolated_singleton_fronts():
+    A = singleton_rows_matrix()
+    kkt = analyse_only(A)
+    single = kkt.symbolic("front_single")
+    assert single.sum() >= A.shape[0] // 4
+    f, ns = kkt.symbolic("front_f"), kkt.symbolic("front_ns")
+    assert (f[single != 0] == 1).all() and (ns[single != 0] == 1).all()
+    # no schedule touches them: they are factored and solved by the one-thread-per-front kernels
+    for name, width in (("potrf_tasks", 4), ("fwd_diag_tasks", 6), ("bwd_update_tasks", 6), ("fwd_gather_tasks", 6)):
+        fronts = kkt.symbolic(name).reshape(-1, width)[:, 0]
+        assert not single[fronts].any(), name
+    check_against_oracle(A, kkt, 5)
+
+
 def test_late_ipm_regime():
     A = random_lp_matrix(70, 200, 3, 21)
     kkt = analyse_only(A)

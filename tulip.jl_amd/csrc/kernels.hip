@@ -65,6 +65,26 @@ __global__ void k_assemble(i64 nent, const i64 *__restrict__ target, const i32 *
     Lval[target[e]] = s;
 }
 
+// Isolated 1 x 1 fronts, one thread each: L = sqrt(s), and the whole solve x = b / s in one step
+// (nothing else reads or writes their entries).
+__global__ void k_single_factor(i64 n, const i64 *__restrict__ loff, const i64 *__restrict__ dinvoff,
+                                const i32 *__restrict__ col, double *__restrict__ Lval, double *__restrict__ dinv, int *info) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double d = Lval[loff[i]];
+    if (!(d > 0.0)) { atomicMin(info, col[i]); d = 1.0; }      // same convention as potrf_block
+    const double l = sqrt(d);
+    Lval[loff[i]] = l;
+    dinv[dinvoff[i]] = 1.0 / l;
+}
+__global__ void k_single_solve(i64 n, const i64 *__restrict__ dinvoff, const i32 *__restrict__ col,
+                               const double *__restrict__ dinv, double *__restrict__ xw) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double w = dinv[dinvoff[i]];
+    xw[col[i]] = (xw[col[i]] * w) * w;                            // forward (x L^-1) then backward (x L^-1)
+}
+
 // ------------------------------------------------------------------------------------------
 // extend-add: one workgroup owns parent columns [j0, j1) and adds, child after child, the child
 // update-matrix columns that land in its range (panel columns before the front is factorised, U
@@ -1199,6 +1219,16 @@ void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const 
     if (a.n_asm > 0)
         hipLaunchKernelGGL(k_assemble, dim3(nblk(a.n_asm, 256)), dim3(256), 0, st, a.n_asm, a.asm_target, a.asm_diag,
                            a.asm_ptr, a.pair_w, a.pair_j, D, regD, a.ctx.Lval);
+}
+void launch_single_factor(hipStream_t st, const DevArrays &a) {
+    if (a.n_single > 0)
+        hipLaunchKernelGGL(k_single_factor, dim3(nblk(a.n_single, 256)), dim3(256), 0, st, a.n_single, a.single_loff, a.single_dinvoff,
+                           a.single_col, a.ctx.Lval, a.ctx.dinv, a.ctx.info);
+}
+void launch_single_solve(hipStream_t st, const DevArrays &a) {
+    if (a.n_single > 0)
+        hipLaunchKernelGGL(k_single_solve, dim3(nblk(a.n_single, 256)), dim3(256), 0, st, a.n_single, a.single_dinvoff, a.single_col,
+                           a.ctx.dinv, a.ctx.xw);
 }
 void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     if (L.count <= 0) return;

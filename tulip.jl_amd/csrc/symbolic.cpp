@@ -692,7 +692,19 @@ static void build_schedule(Symbolic &S) {
     // group) or -1 = the depth-0 fronts, which run on the main stream after all groups joined.
     int cur_g = -1, cur_side = 0;
     std::vector<i64> region_slots;          // split-K scratch slots needed per (stream group, side) region
-    auto in_scope = [&](i32 s) { return S.front_local[s] && (cur_g < 0 || S.front_group[s] == cur_g); };
+    // Isolated 1 x 1 fronts (an LP row that shares no column with any other row -- e.g. an inequality
+    // row whose only entry is its slack: 13 % of the rows of the headline instance): one thread each in
+    // k_single_factor / k_single_solve instead of a 256-thread workgroup in six different launches.
+    S.front_single.assign(S.fronts.size(), 0);
+    S.single_loff.clear(); S.single_dinvoff.clear(); S.single_col.clear();
+    for (size_t s = 0; s < S.fronts.size(); ++s) {
+        const FrontDesc &w = S.fronts[s];
+        if (w.f == 1 && w.ns == 1 && w.nchild == 0 && w.parent < 0 && (i32)s != S.root_front) {
+            S.front_single[s] = 1;
+            if (S.front_local[s]) { S.single_loff.push_back(w.loff); S.single_dinvoff.push_back(w.dinvoff); S.single_col.push_back(w.col0); }
+        }
+    }
+    auto in_scope = [&](i32 s) { return S.front_local[s] && !S.front_single[s] && (cur_g < 0 || S.front_group[s] == cur_g); };
     auto push_launch = [&](std::vector<Launch> &L, i32 kind, i64 first, i64 count) {
         if (count > 0) L.push_back(Launch{kind, cur_g, first, count, cur_side, 0});
     };

@@ -245,6 +245,8 @@ int upload_all(tlpk_handle *h) {
     { i64 *p; UP(p, S.gth_src); d.ctx.gth_src = p; }
     UP(d.ea_tasks, S.ea_tasks); UP(d.potrf_tasks, S.potrf_tasks); UP(d.trsm_tasks, S.trsm_tasks);
     UP(d.update_tasks, S.update_tasks); UP(d.reduce_tasks, S.reduce_tasks);
+    d.n_single = (i64)S.single_col.size();
+    UP(d.single_loff, S.single_loff); UP(d.single_dinvoff, S.single_dinvoff); UP(d.single_col, S.single_col);
     UP(d.fwd_gather_tasks, S.fwd_gather_tasks); UP(d.fwd_diag_tasks, S.fwd_diag_tasks);
     UP(d.fwd_update_tasks, S.fwd_update_tasks); UP(d.bwd_update_tasks, S.bwd_update_tasks);
 #undef UP
@@ -423,6 +425,7 @@ int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_reg
         ProfScope ps(h, TLPK_KC_ASSEMBLE);
         if (S.lval_len > 0) HIPCHK(h, hipMemsetAsync(h->d.ctx.Lval, 0, (size_t)S.lval_len * 8, h->stream));
         launch_assemble(h->stream, h->d, h->d_D, h->d_regD);
+        launch_single_factor(h->stream, h->d);
     }
     run_launches(h, S.factor_launches, 0, h->factor_marker);
     HIPCHK(h, hipGetLastError());
@@ -496,7 +499,7 @@ int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
     prof_begin(h, false);
     h->solve_timed = false;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    { ProfScope ps(h, TLPK_KC_SPMV); launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank); }
+    { ProfScope ps(h, TLPK_KC_SPMV); launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank); launch_single_solve(h->stream, h->d); }
     run_launches(h, h->S.fwd_launches, 0, h->fwd_marker);
     HIPCHK(h, hipGetLastError());
     return TLPK_OK;
@@ -644,6 +647,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "potrf_tasks") { for (auto &t : S.potrf_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.kprev); } }
     else if (w == "trsm_tasks") { for (auto &t : S.trsm_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.kprev); tmp.push_back(t.fuse_nb); } }
     else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
+    else if (w == "front_single") tmp.assign(S.front_single.begin(), S.front_single.end());
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); } }
     else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks") {

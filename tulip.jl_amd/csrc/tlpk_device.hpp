@@ -37,6 +37,7 @@ struct DevArrays {
     // task arrays
     EaTask *ea_tasks = nullptr; PotrfTask *potrf_tasks = nullptr; TrsmTask *trsm_tasks = nullptr;
     UpdateTask *update_tasks = nullptr, *reduce_tasks = nullptr;
+    i64 n_single = 0; i64 *single_loff = nullptr, *single_dinvoff = nullptr; i32 *single_col = nullptr;   // isolated 1 x 1 fronts
     SolveTask *fwd_gather_tasks = nullptr, *fwd_diag_tasks = nullptr, *fwd_update_tasks = nullptr,
               *bwd_update_tasks = nullptr;
 };
@@ -44,6 +45,8 @@ struct DevArrays {
 void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D);
 void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD);
 void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L);
+void launch_single_factor(hipStream_t st, const DevArrays &a);
+void launch_single_solve(hipStream_t st, const DevArrays &a);
 void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank);
 void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy);
 void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx);
