@@ -8,7 +8,7 @@ import numpy as np
 
 LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
           BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12,
-          UPDATE_REDUCE=13)
+          UPDATE_REDUCE=13, TRSM_THIN=14)
 
 
 class Emulator:
@@ -121,6 +121,9 @@ class Emulator:
                 continue
             if kind == LK["POTRF_WIDE"]:
                 kind = LK["POTRF"]
+            if kind == LK["TRSM_THIN"]:                          # same tasks, 256 rows per task
+                self._k2(self.tasks[LK["TRSM"]][first: first + count], rows_per_task=256)
+                continue
             T = self.tasks[kind][first: first + count]
             getattr(self, "_k%d" % kind)(T)
         return len(launches)
@@ -163,12 +166,12 @@ class Emulator:
                 blk[j + 1:, j] /= blk[j, j]
             P[k0:k0 + nb, k0:k0 + nb] = blk
 
-    def _k2(self, T):      # trsm: 64 rows below the diagonal block of a block column, whole width
+    def _k2(self, T, rows_per_task=64):      # trsm: rows below the diagonal block of a block column, whole width
         import scipy.linalg as sla
         for front, k0, nb, row0, *_ in T:
             P = self.panel(front)
             f = int(self.f[front])
-            r1 = min(row0 + 64, f)
+            r1 = min(row0 + rows_per_task, f)
             assert row0 >= k0 + nb
             L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
             P[row0:r1, k0:k0 + nb] = sla.solve_triangular(L11, P[row0:r1, k0:k0 + nb].T, lower=True).T

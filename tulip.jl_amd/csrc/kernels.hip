@@ -564,6 +564,34 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     }
 }
 
+// Thin block columns (w <= TRSM_THIN_W: the small fronts of the leaf levels): X = B * L11^{-T} with
+// one thread per row -- the row's w entries in registers, the inverted block broadcast from LDS;
+// consecutive threads touch consecutive rows of each column (coalesced).
+__global__ __launch_bounds__(256) void k_trsm_thin(const TrsmTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double Wl[TRSM_THIN_W * TRSM_THIN_W];
+    const TrsmTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, w = t.nb;
+    const double *W = front_dinv(c, fd, t.k0);          // w x w, column-major, ld = w, upper part zero
+    for (int idx = threadIdx.x; idx < w * w; idx += 256) Wl[idx] = W[idx];
+    __syncthreads();
+    const i32 r = t.row0 + threadIdx.x;
+    if (r >= f) return;
+    double *P = c.Lval + fd.loff + (i64)r + (i64)t.k0 * f;
+    double b[TRSM_THIN_W];
+#pragma unroll
+    for (int k = 0; k < TRSM_THIN_W; ++k) b[k] = P[(i64)min(k, w - 1) * f];          // clamped, used only for k < w
+#pragma unroll
+    for (int cc = 0; cc < TRSM_THIN_W; ++cc) {
+        if (cc < w) {                                    // workgroup-uniform
+            double x = 0.0;
+#pragma unroll
+            for (int k = 0; k <= cc; ++k) x += Wl[cc + k * w] * b[k];
+            P[(i64)cc * f] = x;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // update: T[I,J] -= P[I,K] * P[J,K]'  on the lower triangle, one TILE x TILE tile per workgroup,
 // on the fp64 matrix cores.  v_mfma_f64_16x16x4_f64: A operand lane l = A[l&15][l>>4], B operand
@@ -1238,6 +1266,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     case LK_POTRF: hipLaunchKernelGGL(k_potrf, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
     case LK_POTRF_WIDE: hipLaunchKernelGGL(k_potrf_wide, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
     case LK_TRSM: hipLaunchKernelGGL(k_trsm, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
+    case LK_TRSM_THIN: hipLaunchKernelGGL(k_trsm_thin, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
     case LK_UPDATE: hipLaunchKernelGGL(k_update, g, dim3(256), 0, st, a.update_tasks + L.first, a.ctx); break;
     case LK_UPDATE_REDUCE: hipLaunchKernelGGL(k_update_reduce, g, dim3(256), 0, st, a.reduce_tasks + L.first, a.ctx); break;
     case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;

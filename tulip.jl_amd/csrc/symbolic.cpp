@@ -879,14 +879,18 @@ static void build_schedule(Symbolic &S) {
             if (overlap) S.factor_launches.push_back(Launch{LK_SIDE_JOIN, cur_g, 0, 0, 0, 0});
             if (io == nouter) break;
             // k_trsm solves the rows below the diagonal block in one pass
-            {
+            // (thin block columns -- the small fronts of the leaf levels -- take one thread per row instead
+            // of 16-row MFMA strips that would be 90 % padding)
+            for (int thin = 0; thin < 2; ++thin) {
                 const i64 f_trsm = (i64)S.trsm_tasks.size();
                 for_fronts([&](i32 s, const FrontDesc &w) {
                     if (ko >= w.ns) return;
                     const i32 no = std::min(NB_OUT, w.ns - ko);
-                    for (i32 r0 = ko + no; r0 < w.f; r0 += TRSM_WG_ROWS) S.trsm_tasks.push_back(TrsmTask{s, ko, no, r0, ko, 0, 0, 0});
+                    if ((no <= TRSM_THIN_W) != (thin == 1)) return;
+                    const i32 step = thin ? 256 : TRSM_WG_ROWS;
+                    for (i32 r0 = ko + no; r0 < w.f; r0 += step) S.trsm_tasks.push_back(TrsmTask{s, ko, no, r0, ko, 0, 0, 0});
                 });
-                push_launch(S.factor_launches, LK_TRSM, f_trsm, (i64)S.trsm_tasks.size() - f_trsm);
+                push_launch(S.factor_launches, thin ? LK_TRSM_THIN : LK_TRSM, f_trsm, (i64)S.trsm_tasks.size() - f_trsm);
             }
         }
         // (c) extend-add, U part (every U of this level has been written by now)

@@ -93,7 +93,7 @@ int kind_class(i32 kind) {
     switch (kind) {
     case LK_EXTEND_ADD: return TLPK_KC_EXTEND_ADD;
     case LK_POTRF: case LK_POTRF_WIDE: return TLPK_KC_POTRF;
-    case LK_TRSM: return TLPK_KC_TRSM;
+    case LK_TRSM: case LK_TRSM_THIN: return TLPK_KC_TRSM;
     case LK_UPDATE: return TLPK_KC_UPDATE;
     case LK_UPDATE_REDUCE: return TLPK_KC_UPDATE_REDUCE;
     case LK_FWD_GATHER: case LK_FWD_DIAG: case LK_FWD_UPDATE: return TLPK_KC_SOLVE_FWD;

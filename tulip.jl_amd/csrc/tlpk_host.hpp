@@ -17,6 +17,7 @@ constexpr int NB_IN = 64;     // diagonal-block / triangular-solve width (potrf 
 constexpr int NB_OUT = 256;   // outer panel width: trailing updates run with K = NB_OUT
 constexpr int TILE = 128;     // update-kernel tile (TILE x TILE per workgroup)
 constexpr int TRSM_ROWS = 64;  // rows per trsm_rows call inside the diagonal block (4 waves x 16 rows)
+constexpr int TRSM_THIN_W = 32;    // widest block column handled by k_trsm_thin (one thread per row, 256 rows per workgroup)
 constexpr int TRSM_WG_ROWS = 64;   // rows per k_trsm workgroup (4 waves x 16 rows x whole block column)
 constexpr int EA_COLS = 16;   // parent columns per extend-add workgroup
 constexpr int SOLVE_NB = 128; // block width of the triangular-solve kernels (two NB_IN sub-blocks)
@@ -56,7 +57,8 @@ enum LaunchKind : i32 {
     LK_POTRF_WIDE,      // diagonal block wider than NB_IN (several 64-wide steps in one workgroup)
     LK_SIDE_FORK,       // marker: the group's side stream waits for the group's stream
     LK_SIDE_JOIN,       // marker: the group's stream waits for its side stream
-    LK_UPDATE_REDUCE    // applies the split-K partial tiles of the preceding LK_UPDATE launch to their targets
+    LK_UPDATE_REDUCE,   // applies the split-K partial tiles of the preceding LK_UPDATE launch to their targets
+    LK_TRSM_THIN        // block columns of <= TRSM_THIN_W columns: one thread per row (no MFMA strips)
 };
 struct Launch { i32 kind; i32 group; i64 first; i64 count; i32 side = 0; i32 pad = 0; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
 
