@@ -135,6 +135,44 @@ def test_isolated_singleton_fronts():
     check_against_oracle(A, kkt, 5)
 
 
+def test_sharded_schedule_with_split_k_and_wide_root():
+    """Two ranks emulated in one process (the all-reduces are plain sums here): a block-angular LP
+    whose root front is wider than two block columns, so that its few update tiles are split along K
+    (partial tiles + ordered reduce launches) on every rank, and the block fronts exercise the wide
+    potrf / single-pass trsm / side-stream launch kinds."""
+    A, row_block = block_angular(nblocks=4, mk=260, nk=520, m0=600, nnz_in=3, link_prob=0.9, seed=21)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 4)
+    ems = []
+    for rank in range(2):
+        kkt = analyse_only(A, row_block=row_block, rank=rank, nranks=2)
+        kinds = kkt.symbolic("factor_launches").reshape(-1, 3)[:, 0].tolist()
+        assert 13 in kinds, "no split-K reduce launch on the 600-column root front"
+        ems.append(Emulator(kkt))
+    for em in ems:
+        em.update(th, rp, rd, stop_at_marker=True)
+    total = sum(em.root_panel().copy() for em in ems)
+    for em in ems:
+        em.root_panel()[:] = total
+        em.update_finish()
+        assert em.fail_col is None
+    for em in ems:
+        em.solve_local(xp, xd, A)
+    rhs = sum(em.root_rhs().copy() for em in ems)
+    sols = []
+    for em in ems:
+        em.root_rhs()[:] = rhs
+        sols.append(em.solve_finish(xd, A))
+    orc = OracleK1(A); orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    link = row_block < 0
+    dx = sols[0][0] + sols[1][0]
+    dy = sols[0][1] + sols[1][1]
+    dy[link] /= 2                                   # linking rows are replicated
+    assert np.abs(dx - dxo).max() <= 1e-9 * max(1.0, np.abs(dxo).max())
+    assert np.abs(dy - dyo).max() <= 1e-9 * max(1.0, np.abs(dyo).max())
+
+
 def test_late_ipm_regime():
     A = random_lp_matrix(70, 200, 3, 21)
     kkt = analyse_only(A)
