@@ -8,7 +8,7 @@ import numpy as np
 
 LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
           BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12,
-          UPDATE_REDUCE=13, TRSM_THIN=14)
+          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16)
 
 
 class Emulator:
@@ -41,6 +41,8 @@ class Emulator:
             LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 6),
             LK["FWD_UPDATE"]: g("fwd_update_tasks").reshape(-1, 6),
             LK["BWD_UPDATE"]: g("bwd_update_tasks").reshape(-1, 6),
+            LK["FWD_SMALL"]: g("fwd_small_tasks").reshape(-1, 6),
+            LK["BWD_SMALL"]: g("bwd_small_tasks").reshape(-1, 6),
         }
         self.factor_launches = g("factor_launches").reshape(-1, 3)
         self.fwd_launches = g("fwd_launches").reshape(-1, 3)
@@ -121,6 +123,21 @@ class Emulator:
                 continue
             if kind == LK["POTRF_WIDE"]:
                 kind = LK["POTRF"]
+            if kind in (LK["FWD_SMALL"], LK["BWD_SMALL"]):      # count = workgroups of 4 fronts (list padded with -1)
+                T = self.tasks[kind][first: first + 4 * count]
+                assert len(T) == 4 * count
+                for front, _, nb, *_r in T:
+                    if front < 0:
+                        continue
+                    f, ns = int(self.f[front]), int(self.ns[front])
+                    assert nb == ns and ns <= 16
+                    if kind == LK["FWD_SMALL"]:
+                        self._k5(np.array([[front, 0, ns, 0, 0, 0]]))
+                        for r0 in range(ns, f, 256):
+                            self._k6(np.array([[front, 0, ns, r0, 0, 0]]))
+                    else:
+                        self._k7(np.array([[front, 0, ns, ns, f - ns, 1]]))
+                continue
             if kind == LK["TRSM_THIN"]:                          # same tasks, 256 rows per task
                 self._k2(self.tasks[LK["TRSM"]][first: first + count], rows_per_task=256)
                 continue

@@ -1214,6 +1214,109 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small fronts (ns <= SMALL_NS pivot columns, any number of rows below): one WAVE per front does a
+// whole sweep step of the front -- the leaf levels hold most of the fronts, and a 256-thread
+// workgroup per front in two or three kernels per level is nearly all fixed latency.  Four fronts per
+// workgroup; the task list of a launch is padded with front = -1.  No shared memory, no barriers.
+//   forward : y = L11^{-1} b (inverted block W, lane i = row i), then rows below: uc[r] -= L[r,:] y
+//   backward: t = b - L21' x_below (lanes along rows, shuffle reduction), then x = W' t
+// ------------------------------------------------------------------------------------------
+constexpr int SMALL_RPL = SMALL_ROWS / 64;       // rows below per lane
+__global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
+    if (t.front < 0) return;
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns, rs = f - ns;
+    const double *__restrict__ W = front_dinv(c, fd, 0);          // ns x ns, column-major, ld = ns, upper part zero
+    const double *__restrict__ P = c.Lval + fd.loff;
+    double *xs = c.xw + fd.col0;
+    double *__restrict__ uc = c.uc + fd.ucoff;
+    // every load of the step is requested up front (clamped addresses, selects afterwards): the wave is
+    // alone with its front, so each dependent round trip would be paid in full
+    const i32 ic = min(lane, ns - 1);
+    double wv[SMALL_NS], bv[SMALL_NS], lv[SMALL_RPL][SMALL_NS], uv[SMALL_RPL];
+#pragma unroll
+    for (int k = 0; k < SMALL_NS; ++k) {
+        const i32 kc = min(k, ns - 1);
+        wv[k] = W[(i64)ic + (i64)kc * ns];
+        bv[k] = xs[kc];
+    }
+#pragma unroll
+    for (int u = 0; u < SMALL_RPL; ++u) {
+        const i32 rr = min(lane + 64 * u, max(rs - 1, 0));         // row below, clamped (rs may be 0: stays inside the panel)
+        uv[u] = (rs > 0) ? uc[rr] : 0.0;
+#pragma unroll
+        for (int k = 0; k < SMALL_NS; ++k) lv[u][k] = P[(i64)min(ns + rr, f - 1) + (i64)min(k, ns - 1) * f];
+    }
+    double y = 0.0;
+#pragma unroll
+    for (int k = 0; k < SMALL_NS; ++k) y += (k < ns && k <= lane) ? wv[k] * bv[k] : 0.0;
+    if (lane < ns) xs[lane] = y;
+    double yv[SMALL_NS];
+#pragma unroll
+    for (int k = 0; k < SMALL_NS; ++k) yv[k] = __shfl(y, k);        // only k < ns is used
+#pragma unroll
+    for (int u = 0; u < SMALL_RPL; ++u) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < SMALL_NS; ++k) acc += (k < ns) ? lv[u][k] * yv[k] : 0.0;
+        if (lane + 64 * u < rs) uc[lane + 64 * u] = uv[u] - acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
+    if (t.front < 0) return;
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns, rs = f - ns;
+    const double *__restrict__ P = c.Lval + fd.loff;
+    const double *__restrict__ W = front_dinv(c, fd, 0);
+    const i32 *__restrict__ rows = c.rowidx + fd.rowoff;
+    double *xs = c.xw + fd.col0;
+    const i32 ic = min(lane, ns - 1);
+    double wv[SMALL_NS], bv[SMALL_NS], lv[SMALL_RPL][SMALL_NS], xr[SMALL_RPL];
+    i32 gi[SMALL_RPL];
+#pragma unroll
+    for (int u = 0; u < SMALL_RPL; ++u) gi[u] = rows[min(ns + lane + 64 * u, f - 1)];   // rows below: values of the ancestors
+#pragma unroll
+    for (int k = 0; k < SMALL_NS; ++k) {
+        const i32 kc = min(k, ns - 1);
+        wv[k] = W[(i64)kc + (i64)ic * ns];                           // column `lane` of W
+        bv[k] = xs[kc];
+    }
+#pragma unroll
+    for (int u = 0; u < SMALL_RPL; ++u) {
+        const i32 r = min(ns + lane + 64 * u, f - 1);
+#pragma unroll
+        for (int k = 0; k < SMALL_NS; ++k) lv[u][k] = P[(i64)r + (i64)min(k, ns - 1) * f];
+        const double xv = c.xw[gi[u]];
+        xr[u] = (lane + 64 * u < rs) ? xv : 0.0;
+    }
+    double acc[SMALL_NS];
+#pragma unroll
+    for (int k = 0; k < SMALL_NS; ++k) {
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < SMALL_RPL; ++u) a += lv[u][k] * xr[u];
+        acc[k] = (k < ns) ? a : 0.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < SMALL_NS; ++k) acc[k] += __shfl_down(acc[k], off);
+    }
+    double x = 0.0;                                                  // x[i] = sum_{k >= i} W[k][i] (b[k] - sum[k])
+#pragma unroll
+    for (int k = 0; k < SMALL_NS; ++k) {
+        const double tk = bv[k] - __shfl(acc[k], 0);
+        x += (k < ns && k >= lane) ? wv[k] * tk : 0.0;
+    }
+    if (lane < ns) xs[lane] = x;
+}
+
 __global__ void k_unpermute(i64 m, const i32 *__restrict__ perm, const char *__restrict__ row_local,
                             const double *__restrict__ xw, double *__restrict__ dy) {
     const i64 ii = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1273,6 +1376,8 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(256), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
     case LK_FWD_UPDATE: hipLaunchKernelGGL(k_fwd_update, g, dim3(256), 0, st, a.fwd_update_tasks + L.first, a.ctx); break;
     case LK_BWD_UPDATE: hipLaunchKernelGGL(k_bwd_update, g, dim3(256), 0, st, a.bwd_update_tasks + L.first, a.ctx); break;
+    case LK_FWD_SMALL: hipLaunchKernelGGL(k_fwd_small, g, dim3(256), 0, st, a.fwd_small_tasks + L.first, a.ctx); break;
+    case LK_BWD_SMALL: hipLaunchKernelGGL(k_bwd_small, g, dim3(256), 0, st, a.bwd_small_tasks + L.first, a.ctx); break;
     default: break;
     }
 }

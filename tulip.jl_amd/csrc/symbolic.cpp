@@ -925,6 +925,8 @@ static void build_schedule(Symbolic &S) {
         }
     }
     // ---------------- forward solve: deepest level first ----------------
+    // (thin but TALL fronts keep the workgroup-per-row-chunk kernels: one wave walking 1000 rows is slower)
+    auto is_small = [&](i32 s) { return S.fronts[s].ns <= SMALL_NS && S.fronts[s].f - S.fronts[s].ns <= SMALL_ROWS && s != S.root_front; };
     auto fwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
         const bool root_level = (d == 0 && S.root_front >= 0);
@@ -942,8 +944,20 @@ static void build_schedule(Symbolic &S) {
             push_launch(S.fwd_launches, LK_FWD_GATHER, first, (i64)S.fwd_gather_tasks.size() - first);
         }
         if (root_level) S.fwd_launches.push_back(Launch{LK_ALLREDUCE_ROOT, -1, 0, 0});
+        // small fronts (<= SMALL_NS pivot columns: most fronts of the leaf levels): diagonal solve and
+        // update of the rows below by ONE wave per front, four fronts per workgroup (a 256-thread
+        // workgroup per front and kernel is mostly fixed latency); padded to a multiple of 4
+        {
+            const i64 first = (i64)S.fwd_small_tasks.size();
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (in_scope(s) && is_small(s)) S.fwd_small_tasks.push_back(SolveTask{s, 0, S.fronts[s].ns, 0, 0, 0, 0, 0});
+            }
+            while (((i64)S.fwd_small_tasks.size() - first) % 4) S.fwd_small_tasks.push_back(SolveTask{-1, 0, 0, 0, 0, 0, 0, 0});
+            push_launch(S.fwd_launches, LK_FWD_SMALL, first, ((i64)S.fwd_small_tasks.size() - first) / 4);
+        }
         i32 max_ns = 0;
-        for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
+        for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t]) && !is_small(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         for (i32 kb = 0; kb < max_ns; kb += SOLVE_NB) {
             const i64 f_diag = (i64)S.fwd_diag_tasks.size(), f_upd = (i64)S.fwd_update_tasks.size();
             // pass 0: the look-ahead workgroups (first row chunk: they also solve the next diagonal
@@ -951,7 +965,7 @@ static void build_schedule(Symbolic &S) {
             for (int pass = 0; pass < 2; ++pass)
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
-                if (!in_scope(s)) continue;
+                if (!in_scope(s) || is_small(s)) continue;
                 const FrontDesc &w = S.fronts[s];
                 if (kb >= w.ns) continue;
                 const i32 nb = std::min(SOLVE_NB, w.ns - kb);
@@ -979,8 +993,17 @@ static void build_schedule(Symbolic &S) {
     // and number of source rows, nslot != 0 = also solve the diagonal block k0.
     auto bwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
+        {
+            const i64 first = (i64)S.bwd_small_tasks.size();
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (in_scope(s) && is_small(s)) S.bwd_small_tasks.push_back(SolveTask{s, 0, S.fronts[s].ns, 0, 0, 0, 0, 0});
+            }
+            while (((i64)S.bwd_small_tasks.size() - first) % 4) S.bwd_small_tasks.push_back(SolveTask{-1, 0, 0, 0, 0, 0, 0, 0});
+            push_launch(S.bwd_launches, LK_BWD_SMALL, first, ((i64)S.bwd_small_tasks.size() - first) / 4);
+        }
         i32 max_ns = 0;
-        for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
+        for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t]) && !is_small(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
         const i32 nblk = (max_ns + SOLVE_NB - 1) / SOLVE_NB;
         for (i32 b = 0; b < nblk; ++b) {
             const i64 f_upd = (i64)S.bwd_update_tasks.size();
@@ -988,7 +1011,7 @@ static void build_schedule(Symbolic &S) {
             for (int pass = 0; pass < 2; ++pass)
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
-                if (!in_scope(s)) continue;
+                if (!in_scope(s) || is_small(s)) continue;
                 const FrontDesc &w = S.fronts[s];
                 const i32 my_nblk = (w.ns + SOLVE_NB - 1) / SOLVE_NB;
                 if (b >= my_nblk) continue;

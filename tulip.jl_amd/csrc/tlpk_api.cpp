@@ -96,7 +96,7 @@ int kind_class(i32 kind) {
     case LK_TRSM: case LK_TRSM_THIN: return TLPK_KC_TRSM;
     case LK_UPDATE: return TLPK_KC_UPDATE;
     case LK_UPDATE_REDUCE: return TLPK_KC_UPDATE_REDUCE;
-    case LK_FWD_GATHER: case LK_FWD_DIAG: case LK_FWD_UPDATE: return TLPK_KC_SOLVE_FWD;
+    case LK_FWD_GATHER: case LK_FWD_DIAG: case LK_FWD_UPDATE: case LK_FWD_SMALL: return TLPK_KC_SOLVE_FWD;
     default: return TLPK_KC_SOLVE_BWD;
     }
 }
@@ -249,6 +249,7 @@ int upload_all(tlpk_handle *h) {
     UP(d.single_loff, S.single_loff); UP(d.single_dinvoff, S.single_dinvoff); UP(d.single_col, S.single_col);
     UP(d.fwd_gather_tasks, S.fwd_gather_tasks); UP(d.fwd_diag_tasks, S.fwd_diag_tasks);
     UP(d.fwd_update_tasks, S.fwd_update_tasks); UP(d.bwd_update_tasks, S.bwd_update_tasks);
+    UP(d.fwd_small_tasks, S.fwd_small_tasks); UP(d.bwd_small_tasks, S.bwd_small_tasks);
 #undef UP
 #define AL(dst, cnt) if ((rc = dev_alloc(h, &(dst), (cnt))) != TLPK_OK) return rc
     AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
@@ -650,9 +651,10 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "front_single") tmp.assign(S.front_single.begin(), S.front_single.end());
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); } }
-    else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks") {
+    else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks" || w == "fwd_small_tasks" || w == "bwd_small_tasks") {
         const std::vector<SolveTask> &v = (w == "fwd_gather_tasks") ? S.fwd_gather_tasks : (w == "fwd_diag_tasks") ? S.fwd_diag_tasks :
-                                          (w == "fwd_update_tasks") ? S.fwd_update_tasks : S.bwd_update_tasks;
+                                          (w == "fwd_update_tasks") ? S.fwd_update_tasks : (w == "bwd_update_tasks") ? S.bwd_update_tasks :
+                                          (w == "fwd_small_tasks") ? S.fwd_small_tasks : S.bwd_small_tasks;
         for (auto &t : v) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.slot); tmp.push_back(t.nslot); }
     }
     else if (w == "front_ucoff") field([](const FrontDesc &f) { return f.ucoff; });

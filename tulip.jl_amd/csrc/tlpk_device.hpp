@@ -39,7 +39,7 @@ struct DevArrays {
     UpdateTask *update_tasks = nullptr, *reduce_tasks = nullptr;
     i64 n_single = 0; i64 *single_loff = nullptr, *single_dinvoff = nullptr; i32 *single_col = nullptr;   // isolated 1 x 1 fronts
     SolveTask *fwd_gather_tasks = nullptr, *fwd_diag_tasks = nullptr, *fwd_update_tasks = nullptr,
-              *bwd_update_tasks = nullptr;
+              *bwd_update_tasks = nullptr, *fwd_small_tasks = nullptr, *bwd_small_tasks = nullptr;
 };
 
 void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D);

@@ -17,6 +17,8 @@ constexpr int NB_IN = 64;     // diagonal-block / triangular-solve width (potrf 
 constexpr int NB_OUT = 256;   // outer panel width: trailing updates run with K = NB_OUT
 constexpr int TILE = 128;     // update-kernel tile (TILE x TILE per workgroup)
 constexpr int TRSM_ROWS = 64;  // rows per trsm_rows call inside the diagonal block (4 waves x 16 rows)
+constexpr int SMALL_NS = 16;       // fronts with at most this many pivot columns and ...
+constexpr int SMALL_ROWS = 256;    // ... at most this many rows below them take the wave-per-front solve kernels
 constexpr int TRSM_THIN_W = 32;    // widest block column handled by k_trsm_thin (one thread per row, 256 rows per workgroup)
 constexpr int TRSM_WG_ROWS = 64;   // rows per k_trsm workgroup (4 waves x 16 rows x whole block column)
 constexpr int EA_COLS = 16;   // parent columns per extend-add workgroup
@@ -58,7 +60,8 @@ enum LaunchKind : i32 {
     LK_SIDE_FORK,       // marker: the group's side stream waits for the group's stream
     LK_SIDE_JOIN,       // marker: the group's stream waits for its side stream
     LK_UPDATE_REDUCE,   // applies the split-K partial tiles of the preceding LK_UPDATE launch to their targets
-    LK_TRSM_THIN        // block columns of <= TRSM_THIN_W columns: one thread per row (no MFMA strips)
+    LK_TRSM_THIN,       // block columns of <= TRSM_THIN_W columns: one thread per row (no MFMA strips)
+    LK_FWD_SMALL, LK_BWD_SMALL   // whole fronts of <= SMALL_NS pivot columns: one wave per front and sweep
 };
 struct Launch { i32 kind; i32 group; i64 first; i64 count; i32 side = 0; i32 pad = 0; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
 
@@ -117,7 +120,7 @@ struct Symbolic {
     std::vector<PotrfTask> potrf_tasks; std::vector<TrsmTask> trsm_tasks;
     std::vector<UpdateTask> update_tasks, reduce_tasks; std::vector<EaTask> ea_tasks;
     i64 spart_len = 0;                     // split-K scratch: TILE x TILE doubles per partial tile
-    std::vector<SolveTask> fwd_gather_tasks, fwd_diag_tasks, fwd_update_tasks, bwd_update_tasks;
+    std::vector<SolveTask> fwd_gather_tasks, fwd_diag_tasks, fwd_update_tasks, bwd_update_tasks, fwd_small_tasks, bwd_small_tasks;
     std::vector<Launch> factor_launches, fwd_launches, bwd_launches;
     std::string error;
 };
