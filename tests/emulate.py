@@ -8,7 +8,7 @@ import numpy as np
 
 LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
           BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12,
-          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16)
+          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17)
 
 
 class Emulator:
@@ -123,6 +123,11 @@ class Emulator:
                 continue
             if kind == LK["POTRF_WIDE"]:
                 kind = LK["POTRF"]
+            if kind == LK["POTRF_SMALL"]:                        # count = workgroups of 4 fronts (list padded with -1)
+                T = self.tasks[LK["POTRF"]][first: first + 4 * count]
+                assert len(T) == 4 * count and all(int(self.ns[t[0]]) <= 16 and t[1] == 0 for t in T if t[0] >= 0)
+                self._k1(T[T[:, 0] >= 0])
+                continue
             if kind in (LK["FWD_SMALL"], LK["BWD_SMALL"]):      # count = workgroups of 4 fronts (list padded with -1)
                 T = self.tasks[kind][first: first + 4 * count]
                 assert len(T) == 4 * count

@@ -311,6 +311,70 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
 constexpr int LDW = NB_IN + 16;                 // == 16 mod 32: conflict-free ds_read_b64
 static_assert(NB_IN * LDW >= POTRF_SCRATCH, "the trsm LDS block doubles as the potrf scratch");
 
+// Pivot block of a small front (ns <= SMALL_NS), one WAVE per front, four fronts per workgroup: lane i
+// holds row i of the lower triangle and row i of an identity block in registers, pivots and pivot
+// columns travel by shuffles.  Same algorithm as potrf_block: unit-lower eliminations applied to
+// [A | I], columns scaled by 1/sqrt(d), inverse rows scaled by 1/L_ii; a non-positive pivot records
+// its column and is replaced by 1.
+__global__ __launch_bounds__(256) void k_potrf_small(const PotrfTask *__restrict__ tasks, DevCtx c) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const PotrfTask t = tasks[(i64)blockIdx.x * 4 + wave];
+    if (t.front < 0) return;
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns;
+    double *P = c.Lval + fd.loff;
+    const i32 ic = min(lane, ns - 1);
+    double a[SMALL_NS], w[SMALL_NS];
+#pragma unroll
+    for (int j = 0; j < SMALL_NS; ++j) {
+        const double v = P[(i64)ic + (i64)min(j, ns - 1) * f];           // clamped, unconditional
+        a[j] = (lane < ns && j < ns && j <= lane) ? v : 0.0;
+        w[j] = (j == lane) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < SMALL_NS; ++k) {
+        if (k < ns) {                                                   // wave-uniform
+            double d = __shfl(a[k], k);
+            if (!(d > 0.0)) {
+                if (lane == 0) atomicMin(c.info, fd.col0 + k);
+                d = 1.0;
+            }
+            double isq = __builtin_amdgcn_rsq(d);
+            isq = isq * (1.5 - 0.5 * d * isq * isq);
+            isq = isq * (1.5 - 0.5 * d * isq * isq);
+            double sq = d * isq;
+            sq = fma(0.5 * isq, fma(-sq, sq, d), sq);
+            const double m = (lane > k) ? a[k] * (isq * isq) : 0.0;      // multiplier a_ik / d
+#pragma unroll
+            for (int j = k + 1; j < SMALL_NS; ++j) {
+                const double ajk = __shfl(a[k], j);                     // a_jk from lane j
+                a[j] -= (j <= lane) ? m * ajk : 0.0;
+            }
+#pragma unroll
+            for (int cc = 0; cc <= k; ++cc) {
+                const double wkc = __shfl(w[cc], k);                    // row k of the identity block
+                w[cc] -= m * wkc;
+            }
+            a[k] = (lane == k) ? sq : ((lane > k) ? a[k] * isq : a[k]);
+        }
+    }
+    // lane i: a[i] = L_ii.  Dynamic index -> select chain.
+    double lii = 1.0;
+#pragma unroll
+    for (int j = 0; j < SMALL_NS; ++j) lii = (j == lane) ? a[j] : lii;
+    const double ili = 1.0 / lii;
+    double *W = front_dinv(c, fd, 0);                                    // ns x ns, column-major, ld = ns
+    if (lane < ns) {
+#pragma unroll
+        for (int j = 0; j < SMALL_NS; ++j) {
+            if (j < ns) {
+                if (j <= lane) P[(i64)lane + (i64)j * f] = a[j];
+                W[(i64)lane + (i64)j * ns] = (j <= lane) ? w[j] * ili : 0.0;
+            }
+        }
+    }
+}
+
 // Rows [row0, min(row0 + 64, rowlim)) of the 64-wide step k0 (width nb), inside the diagonal
 // block of a block column: B -= X_prev * L[k0.., kprev..k0)' first (left-looking), then the
 // solve.  One wave = 16 rows (keeps the kernel within 256 registers: its workgroup must fit
@@ -1368,6 +1432,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     case LK_EXTEND_ADD: hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, a.ea_tasks + L.first, a.ctx); break;
     case LK_POTRF: hipLaunchKernelGGL(k_potrf, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
     case LK_POTRF_WIDE: hipLaunchKernelGGL(k_potrf_wide, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
+    case LK_POTRF_SMALL: hipLaunchKernelGGL(k_potrf_small, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
     case LK_TRSM: hipLaunchKernelGGL(k_trsm, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
     case LK_TRSM_THIN: hipLaunchKernelGGL(k_trsm_thin, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
     case LK_UPDATE: hipLaunchKernelGGL(k_update, g, dim3(256), 0, st, a.update_tasks + L.first, a.ctx); break;

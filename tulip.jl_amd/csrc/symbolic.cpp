@@ -858,14 +858,21 @@ static void build_schedule(Symbolic &S) {
                 });
             if (io < nouter) {
                 // narrow blocks (one 64-wide step) and wide ones go to different kernels
-                for (int wide = 0; wide < 2; ++wide) {
+                // (and the fronts with <= SMALL_NS pivot columns -- most fronts of the leaf levels -- take one
+                // wave per front, four fronts per workgroup, list padded with front = -1)
+                for (int cls = 0; cls < 3; ++cls) {              // 0 small, 1 narrow, 2 wide
                     const i64 f_potrf = (i64)S.potrf_tasks.size();
                     for_fronts([&](i32 s, const FrontDesc &w) {
                         if (ko >= w.ns) return;
                         const i32 no = std::min(NB_OUT, w.ns - ko);
-                        if ((no > NB_IN) == (wide == 1)) S.potrf_tasks.push_back(PotrfTask{s, ko, no, ko});
+                        const int c = (w.ns <= SMALL_NS) ? 0 : (no > NB_IN ? 2 : 1);
+                        if (c == cls) S.potrf_tasks.push_back(PotrfTask{s, ko, no, ko});
                     });
-                    push_launch(S.factor_launches, wide ? LK_POTRF_WIDE : LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
+                    if (cls == 0) {
+                        while (((i64)S.potrf_tasks.size() - f_potrf) % 4) S.potrf_tasks.push_back(PotrfTask{-1, 0, 0, 0});
+                        push_launch(S.factor_launches, LK_POTRF_SMALL, f_potrf, ((i64)S.potrf_tasks.size() - f_potrf) / 4);
+                    } else
+                        push_launch(S.factor_launches, cls == 2 ? LK_POTRF_WIDE : LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
                 }
             }
             cur_side = 0;

@@ -92,7 +92,7 @@ int dev_upload(tlpk_handle *h, T **out, const std::vector<T> &v) {
 int kind_class(i32 kind) {
     switch (kind) {
     case LK_EXTEND_ADD: return TLPK_KC_EXTEND_ADD;
-    case LK_POTRF: case LK_POTRF_WIDE: return TLPK_KC_POTRF;
+    case LK_POTRF: case LK_POTRF_WIDE: case LK_POTRF_SMALL: return TLPK_KC_POTRF;
     case LK_TRSM: case LK_TRSM_THIN: return TLPK_KC_TRSM;
     case LK_UPDATE: return TLPK_KC_UPDATE;
     case LK_UPDATE_REDUCE: return TLPK_KC_UPDATE_REDUCE;

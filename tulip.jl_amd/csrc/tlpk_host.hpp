@@ -61,7 +61,8 @@ enum LaunchKind : i32 {
     LK_SIDE_JOIN,       // marker: the group's stream waits for its side stream
     LK_UPDATE_REDUCE,   // applies the split-K partial tiles of the preceding LK_UPDATE launch to their targets
     LK_TRSM_THIN,       // block columns of <= TRSM_THIN_W columns: one thread per row (no MFMA strips)
-    LK_FWD_SMALL, LK_BWD_SMALL   // whole fronts of <= SMALL_NS pivot columns: one wave per front and sweep
+    LK_FWD_SMALL, LK_BWD_SMALL,  // whole fronts of <= SMALL_NS pivot columns: one wave per front and sweep
+    LK_POTRF_SMALL      // pivot blocks of fronts with <= SMALL_NS pivot columns: one wave per front
 };
 struct Launch { i32 kind; i32 group; i64 first; i64 count; i32 side = 0; i32 pad = 0; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
 
