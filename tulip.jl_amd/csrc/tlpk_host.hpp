@@ -45,16 +45,17 @@ struct FrontDesc {
 static_assert(sizeof(FrontDesc) == 80, "FrontDesc layout");
 
 struct PotrfTask { i32 front, k0, nb, kprev; };              // diagonal block of a block column: columns [k0, k0 + nb), nb <= NB_OUT; kprev = k0
-struct TrsmTask  { i32 front, k0, nb, row0, kprev, fuse_nb, pad1, pad2; };   // fuse_nb: also factor the next diagonal block
+struct TrsmTask  { i32 front, k0, nb, row0, kprev, fuse_nb, pad1, pad2; };   // rows [row0, ..) below the diagonal block [k0, k0 + nb) of a block column; kprev = k0, fuse_nb = 0 (unused)
 struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; }; // pad1 = slot + 1: split-K part, the raw tile goes to scratch slot `slot`;
 // in reduce_tasks: k0 = first slot, kw = number of parts
 //  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
 struct EaTask    { i32 front, j0, j1, pad; };                        // parent columns [j0, j1)
-struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };  // slot: partial-sum slots (backward)
+struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };  // forward: nslot = width of the next diagonal block solved by this workgroup (0 = none);
+// backward: k0/nb = target column block, row0/slot = first source row / number of source rows, nslot != 0 = also solve the diagonal block
 
 enum LaunchKind : i32 {
     LK_EXTEND_ADD = 0, LK_POTRF, LK_TRSM, LK_UPDATE,
-    LK_FWD_GATHER, LK_FWD_DIAG, LK_FWD_UPDATE, LK_BWD_UPDATE, LK_BWD_DIAG,
+    LK_FWD_GATHER, LK_FWD_DIAG, LK_FWD_UPDATE, LK_BWD_UPDATE, LK_BWD_DIAG /* unused: the diagonal solve is fused into LK_BWD_UPDATE */,
     LK_ALLREDUCE_ROOT,  // marker: everything after this belongs to the replicated root front
     LK_POTRF_WIDE,      // diagonal block wider than NB_IN (several 64-wide steps in one workgroup)
     LK_SIDE_FORK,       // marker: the group's side stream waits for the group's stream
