@@ -357,8 +357,11 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
                     size_t free_b = 0, total_b = 0;
                     hipMemGetInfo(&free_b, &total_b);
                     const double budget = def.mem_budget_bytes > 0 ? (double)def.mem_budget_bytes : 0.9 * (double)free_b;
-                    const double need = 8.0 * ((double)h->S.lval_len + (double)h->S.ubuf_len[0] + (double)h->S.ubuf_len[1]) +
-                                        12.0 * (double)h->S.pair_w.size() + 20.0 * (double)h->S.nnzS + 40.0 * (double)h->S.nnzA;
+                    const double need = 8.0 * ((double)h->S.lval_len + (double)h->S.ubuf_len[0] + (double)h->S.ubuf_len[1] +
+                                               (double)h->S.spart_len + (double)h->S.dinv_len + (double)h->S.uc_len +
+                                               (double)h->S.gth_ptr.size() + (double)h->S.gth_src.size()) +
+                                        12.0 * (double)h->S.pair_w.size() + 20.0 * (double)h->S.nnzS + 40.0 * (double)h->S.nnzA +
+                                        8.0 * (double)h->S.rowidx.size();
                     if (need > budget) {
                         h->last_error = "factor needs " + std::to_string(need / 1e9) + " GB, budget " + std::to_string(budget / 1e9) + " GB";
                         rc = TLPK_TOO_LARGE;
