@@ -9,6 +9,10 @@
 #include "../../include/tlpk.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <chrono>
+#include <cstdio>
 #include <array>
 #include <cstdio>
 #include <cstdlib>
@@ -73,8 +77,21 @@ static int fail(Symbolic &S, int code, const std::string &msg) { S.error = msg; 
 
 static void build_schedule(Symbolic &S);
 
+// TLPK_TIMING=1: wall time of the analyse phases on stderr
+struct PhaseTimer {
+    bool on; std::chrono::steady_clock::time_point t0; const char *name = nullptr;
+    PhaseTimer() : on(std::getenv("TLPK_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *next) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        if (name) std::fprintf(stderr, "[tlpk analyse] %-28s %8.1f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        name = next; t0 = t1;
+    }
+};
+
 int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval, const double *nzval,
             int base, const Options &opt) {
+    PhaseTimer pt;
     if (m64 < 0 || n64 < 0 || (base != 0 && base != 1) || !colptr) return fail(S, TLPK_BADARG, "bad dimensions or index base");
     if (m64 >= (i64)1 << 31 || n64 >= (i64)1 << 31) return fail(S, TLPK_TOO_LARGE, "m or n exceeds int32");
     const i64 nnz = colptr[n64] - base;
@@ -85,6 +102,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     if (opt.nranks < 1 || opt.rank < 0 || opt.rank >= opt.nranks) return fail(S, TLPK_BADARG, "bad rank/nranks");
     if (opt.nranks > 1 && !opt.row_block) return fail(S, TLPK_BADARG, "sharding needs row_block (general sparse LPs are single-GPU)");
 
+    pt.mark("copy A / CSR");
     // ---- 1. copy A (CSC) and build CSR ----
     S.Ap.resize((size_t)n + 1); S.Ai.resize((size_t)nnz); S.Ax.resize((size_t)nnz); S.Acol.resize((size_t)nnz);
     for (i32 j = 0; j <= n; ++j) {
@@ -110,6 +128,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
             }
     }
 
+    pt.mark("block structure");
     // ---- 2. block-angular structure (optional) ----
     std::vector<i32> row_block, col_block;
     i32 nblocks = 0, nlink = 0;
@@ -132,6 +151,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     }
     S.nblocks = nblocks;
 
+    pt.mark("graph of AA'");
     // ---- 3. adjacency graph of A*A' (original labels, no diagonal, both directions) ----
     std::vector<i64> xadj((size_t)m + 1, 0);
     std::vector<i32> adj;
@@ -153,6 +173,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         }
     }
 
+    pt.mark("ordering (AMD)");
     // ---- 4. fill-reducing ordering ----
     std::vector<i32> order0;
     order0.reserve(m);
@@ -174,11 +195,14 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         std::vector<std::vector<i32>> members(nblocks);
         for (i32 i = 0; i < m; ++i) if (row_block[i] >= 0) members[row_block[i]].push_back(i);
         std::vector<i32> local(m, -1);
-        for (i32 b = 0; b < nblocks; ++b) {
+        for (i32 b = 0; b < nblocks; ++b) for (size_t t = 0; t < members[b].size(); ++t) local[members[b][t]] = (i32)t;
+        // the blocks are independent graphs: ordered concurrently on the host's cores (the result does
+        // not depend on the number of threads: every block is ordered by itself)
+        std::vector<std::vector<i32>> border(nblocks);
+        auto order_block = [&](i32 b) {
             const auto &mb = members[b];
             const i32 nb = (i32)mb.size();
-            if (opt.ordering == TLPK_ORDER_NATURAL) { order0.insert(order0.end(), mb.begin(), mb.end()); continue; }
-            for (i32 t = 0; t < nb; ++t) local[mb[t]] = t;
+            if (opt.ordering == TLPK_ORDER_NATURAL) { border[b].resize(nb); std::iota(border[b].begin(), border[b].end(), 0); return; }
             std::vector<i64> bx((size_t)nb + 1, 0);
             std::vector<i32> ba;
             for (i32 t = 0; t < nb; ++t) {
@@ -189,14 +213,25 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
                 }
                 bx[t + 1] = (i64)ba.size();
             }
-            std::vector<i32> bo;
-            amd_order(nb, bx, ba, bo);
-            for (i32 t : bo) order0.push_back(mb[t]);
+            amd_order(nb, bx, ba, border[b]);
+        };
+        {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const i32 nthreads = (i32)std::min<unsigned>({hw, 16u, (unsigned)nblocks});
+            if (std::getenv("TLPK_TIMING")) std::fprintf(stderr, "[tlpk analyse] ordering %d blocks on %d threads\n", (int)nblocks, (int)nthreads);
+            std::atomic<i32> next{0};
+            auto worker = [&]() { for (i32 b; (b = next.fetch_add(1)) < nblocks;) order_block(b); };
+            std::vector<std::thread> pool;
+            for (i32 t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+            worker();
+            for (auto &th : pool) th.join();
         }
+        for (i32 b = 0; b < nblocks; ++b) for (i32 t : border[b]) order0.push_back(members[b][t]);
         for (i32 i = 0; i < m; ++i) if (row_block[i] < 0) { order0.push_back(i); is_link[i] = 1; }
     }
     if ((i32)order0.size() != m) return fail(S, TLPK_INTERNAL, "ordering did not return a permutation");
 
+    pt.mark("etree");
     // ---- 5. elimination tree, postorder ----
     std::vector<i32> iperm0(m);
     for (i32 i = 0; i < m; ++i) iperm0[order0[i]] = i;
@@ -218,6 +253,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     for (i32 k = 0; k < m; ++k) if (S.parent[k] != -1 && S.parent[k] <= k) return fail(S, TLPK_INTERNAL, "etree not topological");
     const i32 first_link = m - nlink;
 
+    pt.mark("pattern of S");
     // ---- 6. permuted lower pattern of S (rebuilt if the amalgamation re-orders columns) ----
     auto build_pattern = [&]() {
         S.Sp.assign((size_t)m + 1, 0);
@@ -239,6 +275,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     };
     build_pattern();
 
+    pt.mark("column counts");
     // ---- 7. column counts (Gilbert, Ng & Peyton 1994: row-subtree leaves + LCA by union-find) ----
     {
         std::vector<i32> tpost;
@@ -283,6 +320,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         S.nnzL += S.colcount[j]; S.flops_chol += (double)S.colcount[j] * (double)S.colcount[j];
     }
 
+    pt.mark("fundamental supernodes");
     // ---- 8. fundamental supernodes ----
     // start[s] = first column.  j joins j-1 when parent[j-1] == j and the structures nest exactly
     // (count[j-1] == count[j] + 1).  Linking columns form one forced root front.
@@ -300,6 +338,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     i32 ns_total = 0;
     std::vector<i32> sparent;
 
+    pt.mark("fronts");
     // ---- 9. supernodal tree and front row structures (for a given column partition) ----
     auto build_fronts = [&]() -> int {
         ns_total = (i32)sn_start.size() - 1;
@@ -362,6 +401,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     };
     { const int rc = build_fronts(); if (rc != TLPK_OK) return rc; }
 
+    pt.mark("amalgamation");
     // ---- 9b. relaxed amalgamation (any child, not only the adjacent one) ----
     // A child front c is merged into its parent p when either the explicit zeros stay small
     // (CHOLMOD-style width classes) or -- the multifrontal criterion -- padding c's ns_c columns
@@ -455,6 +495,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     }
     { std::vector<i32>().swap(adj); std::vector<i64>().swap(xadj); }
 
+    pt.mark("levels");
     // ---- 10. depths, levels ----
     S.depth.assign(ns_total, 0);
     for (i32 s = ns_total - 1; s >= 0; --s) S.depth[s] = (sparent[s] == -1) ? 0 : S.depth[sparent[s]] + 1;
@@ -469,6 +510,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         for (i32 s = 0; s < ns_total; ++s) S.level_fronts[cur[S.depth[s]]++] = s;
     }
 
+    pt.mark("ownership");
     // ---- 11. ownership (block-angular sharding) ----
     S.front_block.assign(ns_total, -1);
     S.front_local.assign(ns_total, 1);
@@ -545,6 +587,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         for (i32 i = 0; i < m; ++i) if (row_block[i] < 0) S.row_local[i] = 2;
     }
 
+    pt.mark("offsets");
     // ---- 12. storage offsets (local fronts only) ----
     S.lval_len = 0; S.uc_len = 0; S.ubuf_len[0] = S.ubuf_len[1] = 0; S.dinv_len = 0;
     for (i32 s = 0; s < ns_total; ++s) {
@@ -589,6 +632,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         S.flops_panel += k * k * k / 3.0 + (f - k) * k * k + (f - k) * (f - k) * k;
     }
 
+    pt.mark("relative indices");
     // ---- 13. relative indices (below-rows of each front -> position in the parent front) ----
     S.rel.clear();
     for (i32 s = 0; s < ns_total; ++s) {
@@ -606,6 +650,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         }
     }
 
+    pt.mark("gather lists");
     // ---- 13b. forward-solve gather lists: for every row t of a front, the entries of its
     // children's contribution vectors that land on it, in child order (the order the sums are
     // taken in).  One thread per row then gathers without conflicts.
@@ -634,6 +679,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
             }
         }
     }
+    pt.mark("assembly lists");
     // ---- 14. assembly lists: S[ii,kk] = sum_j A[i,j] D_j A[k,j] (+ regD on the diagonal) ----
     {
         S.s_target.assign((size_t)S.nnzS, -1);
@@ -687,7 +733,9 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
             }
         }
     }
+    pt.mark("schedule");
     build_schedule(S);
+    pt.mark(nullptr);
     return TLPK_OK;
 }
 
