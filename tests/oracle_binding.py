@@ -136,3 +136,92 @@ class OracleK1:
                 self._h = None
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------------------------------------
+# K2 (augmented system) oracle: oracle/k2_oracle.c -- pins the next row of the contract
+# ------------------------------------------------------------------------------------------------
+_LIB2 = None
+
+
+def _lib2():
+    global _LIB2
+    if _LIB2 is None:
+        path = os.path.join(_ORACLE_DIR, "libk2oracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        lib = C.CDLL(path)
+        p64, pd, vp = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p
+        lib.k2o_setup.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, p64, p64, pd, C.c_int, p64]
+        lib.k2o_setup.restype = C.c_int
+        lib.k2o_update.argtypes = [vp, pd, pd, pd]
+        lib.k2o_update.restype = C.c_int
+        lib.k2o_solve.argtypes = [vp, pd, pd, pd, pd]
+        lib.k2o_solve.restype = C.c_int
+        lib.k2o_free.argtypes = [vp]
+        lib.k2o_free.restype = None
+        for name in ("k2o_nnzK", "k2o_nnzL", "k2o_fail_col"):
+            getattr(lib, name).argtypes = [vp]
+            getattr(lib, name).restype = C.c_int64
+        lib.k2o_get_D.argtypes = [vp, pd]
+        _LIB2 = lib
+    return _LIB2
+
+
+class OracleZeroPivotError(ArithmeticError):
+    pass
+
+
+class OracleK2:
+    """CPU oracle for the K2 path: LDL' of [-(theta+regP) A'; A regD].  perm: optional permutation of the
+    n + m nodes (variables 0..n-1, constraints n..n+m-1), perm[new] = old."""
+
+    def __init__(self, A, perm=None):
+        lib = _lib2()
+        self.m, self.n = A.shape
+        self._colptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        self._rowval = np.ascontiguousarray(A.indices, dtype=np.int64)
+        self._nzval = np.ascontiguousarray(A.data, dtype=np.float64)
+        self._h = C.c_void_p()
+        pp = None
+        if perm is not None:
+            self._perm = np.ascontiguousarray(perm, dtype=np.int64)
+            pp = _p64(self._perm)
+        rc = lib.k2o_setup(C.byref(self._h), self.m, self.n, _p64(self._colptr), _p64(self._rowval),
+                           _pd(self._nzval), 0, pp)
+        if rc != OK:
+            raise RuntimeError(f"k2o_setup failed rc={rc}")
+
+    def update(self, theta, regP, regD):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        regP = np.ascontiguousarray(regP, dtype=np.float64)
+        regD = np.ascontiguousarray(regD, dtype=np.float64)
+        assert theta.shape == (self.n,) and regP.shape == (self.n,) and regD.shape == (self.m,)
+        rc = _lib2().k2o_update(self._h, _pd(theta), _pd(regP), _pd(regD))
+        if rc == 1:
+            raise OracleZeroPivotError(int(_lib2().k2o_fail_col(self._h)))
+        if rc != OK:
+            raise RuntimeError(f"k2o_update rc={rc}")
+
+    def solve(self, xi_p, xi_d):
+        xi_p = np.ascontiguousarray(xi_p, dtype=np.float64)
+        xi_d = np.ascontiguousarray(xi_d, dtype=np.float64)
+        dx = np.empty(self.n); dy = np.empty(self.m)
+        rc = _lib2().k2o_solve(self._h, _pd(dx), _pd(dy), _pd(xi_p), _pd(xi_d))
+        if rc != OK:
+            raise RuntimeError(f"k2o_solve rc={rc}")
+        return dx, dy
+
+    @property
+    def nnzL(self):
+        return int(_lib2().k2o_nnzL(self._h))
+
+    def D(self):
+        d = np.empty(self.n + self.m)
+        _lib2().k2o_get_D(self._h, _pd(d))
+        return d
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib2().k2o_free(self._h)
+            self._h = None

@@ -53,9 +53,10 @@ def test_product_does_not_reference_the_oracle():
         for fn in files:
             if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".jl")):
                 src = open(os.path.join(dirpath, fn), errors="ignore").read()
-                assert "k1o_" not in src and "libk1oracle" not in src and "oracle_binding" not in src, fn
+                assert "k1o_" not in src and "k2o_" not in src and "libk1oracle" not in src and "libk2oracle" not in src \
+                    and "oracle_binding" not in src, fn
     out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
-    assert "k1oracle" not in out
+    assert "k1oracle" not in out and "k2oracle" not in out
     assert "amdhip64" in out
 
 

@@ -108,3 +108,76 @@ def test_empty_and_degenerate_shapes():
     dx, dy = o.solve(np.ones(3), np.ones(0))
     np.testing.assert_allclose(dy, 0.5)
     assert dx.shape == (0,)
+
+
+# ------------------------------------------------------------------------------------------------
+# K2 (augmented system) oracle, oracle/k2_oracle.c: pinned ahead of the device path it will check
+# (SURVEY.md section 8(f)1).  K1 and K2 solve the SAME augmented system (KKT.jl:70-75), so the golden
+# dx, dy apply to both, and the two oracles must agree with each other.
+# ------------------------------------------------------------------------------------------------
+def test_k2_reference_fixture_run_ls_tests():
+    """/root/reference/test/KKT/Cholmod/cholmod.jl:3-16: run_ls_tests on the K2 solver, same 2 x 4 fixture."""
+    from oracle_binding import OracleK2
+    A = sp.csc_matrix(np.array([[1.0, 0, 1, 0], [0, 1, 0, 1]]))
+    o = OracleK2(A)
+    th = np.ones(4); rp = np.ones(4); rd = np.ones(2)
+    o.update(th, rp, rd)
+    dx, dy = o.solve(np.ones(2), np.ones(4))
+    rp_, rd_ = kkt_residuals(A, th, rp, rd, np.ones(2), np.ones(4), dx, dy)
+    assert rp_ <= SQRT_EPS and rd_ <= SQRT_EPS
+    np.testing.assert_allclose(dy, [1.0, 1.0], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(dx, np.zeros(4), rtol=0, atol=1e-15)
+    d = o.D()
+    assert (d[:4] < 0).all() and (d[4:] > 0).all()       # quasi-definite: n negative, m positive pivots
+
+
+@pytest.mark.parametrize("g", load_golden(), ids=lambda g: g["name"])
+def test_k2_golden_vectors(g):
+    from oracle_binding import OracleK2
+    o = OracleK2(g["A_csc"])
+    o.update(g["theta_inv"], g["regP"], g["regD"])
+    dx, dy = o.solve(g["xi_p"], g["xi_d"])
+    scale = max(np.abs(g["dx"]).max(), np.abs(g["dy"]).max(), 1.0)
+    tol = max(1e-13, 10 * np.finfo(float).eps * g["cond_S"])
+    assert np.abs(dx - g["dx"]).max() <= tol * scale
+    assert np.abs(dy - g["dy"]).max() <= tol * scale
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_k2_agrees_with_k1_and_dense(seed):
+    from oracle_binding import OracleK2
+    m, n = 60 + 25 * seed, 150 + 40 * seed
+    A = random_lp_matrix(m, n, 3, 70 + seed)
+    th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(m + n)                         # any symmetric permutation works for SQD matrices
+    for pp in (None, perm):
+        o2 = OracleK2(A, pp)
+        o2.update(th, rp, rd)
+        dx2, dy2 = o2.solve(xp, xd)
+        K = np.block([[-np.diag(th + rp), A.toarray().T], [A.toarray(), np.diag(rd)]])
+        ref = np.linalg.solve(K, np.concatenate([xd, xp]))
+        sc = max(1.0, np.abs(ref).max())
+        assert np.abs(dx2 - ref[:n]).max() <= 1e-9 * sc and np.abs(dy2 - ref[n:]).max() <= 1e-9 * sc
+        d = o2.D()
+        neg = np.array([(pp[k] if pp is not None else k) < n for k in range(m + n)])
+        assert (d[neg] < 0).all() and (d[~neg] > 0).all()
+    o1 = OracleK1(A); o1.update(th, rp, rd)
+    dx1, dy1 = o1.solve(xp, xd)
+    assert np.abs(dx1 - dx2).max() <= 1e-8 * max(1.0, np.abs(dx1).max())
+    assert np.abs(dy1 - dy2).max() <= 1e-8 * max(1.0, np.abs(dy1).max())
+
+
+def test_k2_zero_pivot_and_reuse():
+    """A failed factorisation reports the pivot and leaves the object reusable (HSD/step.jl:35-49)."""
+    from oracle_binding import OracleK2, OracleZeroPivotError
+    A = random_lp_matrix(20, 45, 3, 5)
+    th, rp, rd, xp, xd = ipm_like_data(20, 45, 1)
+    o = OracleK2(A)
+    bad = th.copy(); bad[3] = -rp[3]                       # -(theta + regP) = 0 on variable 3
+    with pytest.raises(OracleZeroPivotError):
+        o.update(bad, rp, rd)
+    o.update(th, rp, rd)
+    dx, dy = o.solve(xp, xd)
+    r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+    assert r1 <= 1e-9 * (1 + np.abs(xp).max()) * max(1, np.abs(dy).max()) and r2 <= 1e-9 * (1 + np.abs(xd).max()) * max(1, np.abs(dx).max())
