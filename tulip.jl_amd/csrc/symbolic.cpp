@@ -220,11 +220,16 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
             const i32 nthreads = (i32)std::min<unsigned>({hw, 16u, (unsigned)nblocks});
             if (std::getenv("TLPK_TIMING")) std::fprintf(stderr, "[tlpk analyse] ordering %d blocks on %d threads\n", (int)nblocks, (int)nthreads);
             std::atomic<i32> next{0};
-            auto worker = [&]() { for (i32 b; (b = next.fetch_add(1)) < nblocks;) order_block(b); };
+            std::atomic<int> failed{0};           // an exception must not escape a thread (std::terminate)
+            auto worker = [&]() {
+                try { for (i32 b; (b = next.fetch_add(1)) < nblocks;) order_block(b); }
+                catch (...) { failed = 1; }
+            };
             std::vector<std::thread> pool;
             for (i32 t = 1; t < nthreads; ++t) pool.emplace_back(worker);
             worker();
             for (auto &th : pool) th.join();
+            if (failed) return fail(S, TLPK_OOM, "out of memory while ordering the diagonal blocks");
         }
         for (i32 b = 0; b < nblocks; ++b) for (i32 t : border[b]) order0.push_back(members[b][t]);
         for (i32 i = 0; i < m; ++i) if (row_block[i] < 0) { order0.push_back(i); is_link[i] = 1; }
