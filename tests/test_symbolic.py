@@ -263,3 +263,54 @@ def test_numeric_calls_fail_loudly_without_device():
         tk.update(kkt, np.ones(20), np.ones(20), np.ones(10))
     with pytest.raises(tk.DimensionMismatch):
         tk.update(kkt, np.ones(19), np.ones(20), np.ones(10))
+
+
+# ------------------------------------------------------------------------------------------------
+# property test: ANY small LP matrix, with or without a block-angular structure, relaxed or
+# fundamental supernodes, AMD or natural ordering -- the exported schedule, executed in numpy, must
+# reproduce the oracle's factor and solution (hypothesis, derandomised: the same 150 cases every run)
+# ------------------------------------------------------------------------------------------------
+from hypothesis import given, settings, strategies as st, HealthCheck  # noqa: E402
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(m=st.integers(1, 28), n=st.integers(1, 45), density=st.floats(0.05, 0.6), seed=st.integers(0, 10_000),
+       relax=st.booleans(), ordering=st.sampled_from(["amd", "natural"]), nblocks=st.integers(0, 3), slack=st.booleans())
+def test_property_schedule_matches_oracle(m, n, density, seed, relax, ordering, nblocks, slack):
+    rng = np.random.default_rng(seed)
+    A = sp.random(m, n, density=density, random_state=seed, format="csc", data_rvs=rng.standard_normal)
+    if slack:                                               # every row gets a slack: S is non-singular whatever A is
+        A = sp.hstack([A, sp.identity(m, format="csc")], format="csc")
+    A.sort_indices()
+    kw = dict(relax=relax, ordering=ordering)
+    if nblocks >= 2 and m >= 2 * nblocks:
+        # rows dealt to blocks; a column may only touch rows of ONE block or linking rows: drop the others
+        rb = rng.integers(-1, nblocks, size=m)
+        A = A.tolil()
+        for j in range(A.shape[1]):
+            rows = A.rows[j] if False else A[:, j].nonzero()[0]
+            blocks = {int(rb[r]) for r in rows if rb[r] >= 0}
+            if len(blocks) > 1:
+                keep = min(blocks)
+                for r in rows:
+                    if rb[r] >= 0 and rb[r] != keep:
+                        A[r, j] = 0.0
+        A = A.tocsc(); A.eliminate_zeros(); A.sort_indices()
+        kw["row_block"] = rb.astype(np.int64)
+    mm, nn = A.shape
+    kkt = analyse_only(A, **kw)
+    th, rp, rd, xp, xd = ipm_like_data(mm, nn, seed % 7)
+    rd = np.maximum(rd, 1e-3)                               # empty rows of A rely on regD alone
+    perm = kkt.perm()
+    assert sorted(perm.tolist()) == list(range(mm))
+    orc = OracleK1(A, perm)
+    orc.update(th, rp, rd)
+    em = Emulator(kkt)
+    em.update(th, rp, rd)
+    assert em.fail_col is None and kkt.stats()["nnzL"] == orc.nnzL
+    Lo = orc.get_L().toarray()
+    assert np.abs(em.dense_L() - Lo).max() <= 1e-9 * max(1.0, np.abs(Lo).max())
+    dx, dy = em.solve(xp, xd, A)
+    dxo, dyo = orc.solve(xp, xd)
+    assert np.abs(dy - dyo).max() <= 1e-8 * max(1.0, np.abs(dyo).max())
+    assert np.abs(dx - dxo).max() <= 1e-8 * max(1.0, np.abs(dxo).max())
