@@ -189,7 +189,7 @@ def main():
     out = {
         "metric": "IPM Newton-step rate: KKT.update! (A*D*A'+Rd, supernodal Cholesky) + %d KKT.solve!" % args.solves,
         "value": 1e3 / ms_per_step, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[2] at reduced scale: general sparse LP A=[A0 I], %d rows x %d structural "
                                 "columns, 25 nnz/col; m=%d n=%d nnz(A)=%d" % (m, n - m, m, n, A.nnz)) if args.workload == "c3" else
