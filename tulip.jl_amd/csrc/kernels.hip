@@ -4,13 +4,23 @@
 //   update!  (/root/reference/src/KKT/Cholmod/spd.jl:22-50)
 //     k_compute_d     D = 1/(theta_inv + regP)                                  spd.jl:42
 //     k_assemble      S = A*D*A' + diag(regD) gathered straight into the supernodal panels  spd.jl:43
+//     k_single_factor isolated 1 x 1 fronts, one thread each
 //     k_extend_add    multifrontal assembly of the children's update matrices
-//     k_potrf / k_trsm / k_update   blocked dense partial Cholesky of every front; the rank-k
-//                     panel updates run on v_mfma_f64_16x16x4_f64                 spd.jl:46
+//     k_potrf / k_potrf_wide / k_potrf_small, k_trsm / k_trsm_thin, k_update (+ k_update_reduce)
+//                     blocked dense partial Cholesky of every front, per 256-wide block column:
+//                     left-looking rank-K update on v_mfma_f64_16x16x4_f64, diagonal block in one
+//                     workgroup (64-wide register-resident steps + inverses), rows below in one
+//                     register-resident MFMA pass                                spd.jl:46
 //   solve!   (spd.jl:52-70)
 //     k_rhs           xi = xi_p + A*(D.*xi_d), permuted                          spd.jl:56-57
-//     k_fwd_* / k_bwd_*  supernodal forward / backward substitution             spd.jl:61
+//     k_single_solve, k_fwd_gather / k_fwd_diag / k_fwd_update / k_fwd_small, k_bwd_update / k_bwd_small
+//                     supernodal forward / backward substitution                 spd.jl:61
 //     k_unpermute, k_dx  dy = P' x ;  dx = D.*(A'dy - xi_d)                      spd.jl:64-66
+//
+// Two rules learnt by measurement run through this file: (1) never guard a load that feeds the next
+// instruction (`c ? M[i] : 0`): clamp the address and select afterwards, or every load waits for the
+// previous one; (2) workgroups of one launch never talk to each other (the L2s of the 8 dies are not
+// coherent for ordinary stores inside a kernel): whatever crosses workgroups crosses a launch.
 //
 // Every kernel is deterministic (no floating-point atomics): sums that cross workgroups are
 // ordered by the static schedule built on the host (symbolic.cpp: build_schedule).
