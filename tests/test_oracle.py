@@ -181,3 +181,43 @@ def test_k2_zero_pivot_and_reuse():
     dx, dy = o.solve(xp, xd)
     r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
     assert r1 <= 1e-9 * (1 + np.abs(xp).max()) * max(1, np.abs(dy).max()) and r2 <= 1e-9 * (1 + np.abs(xd).max()) * max(1, np.abs(dx).max())
+
+
+def test_k2_signed_cholesky_design():
+    """Executable design note for the device K2 path: a symmetric quasi-definite
+    matrix K factors as L*S*L' with S = diag(+-1) known from the node type, and the unit-lower
+    elimination steps of the Cholesky kernels (a_rc -= a_rj*a_cj/d) are sign-agnostic: only the column
+    scaling uses |d| and sign(d).  The blocked form used on the device follows: trailing updates are
+    T -= X*S_K*X', panel solves X = B*L11^-T*S11, and the solve is x = L^-T S L^-1 b."""
+    rng = np.random.default_rng(3)
+    m, n = 7, 11
+    A = rng.standard_normal((m, n)) * (rng.random((m, n)) < 0.5)
+    K = np.block([[-np.diag(rng.uniform(0.5, 2.0, n)), A.T], [A, np.diag(rng.uniform(0.1, 1.0, m))]])
+    N = n + m
+    perm = rng.permutation(N)
+    Kp = K[np.ix_(perm, perm)]
+    s_expected = np.where(perm < n, -1.0, 1.0)
+    # column-by-column, exactly the arithmetic of potrf_block with signed pivots
+    a = np.tril(Kp).copy()
+    L = np.zeros((N, N)); s = np.zeros(N)
+    for j in range(N):
+        d = a[j, j]
+        s[j] = np.sign(d)
+        assert s[j] == s_expected[j]                       # quasi-definite: the sign is known a priori
+        mult = a[j + 1:, j] / d                            # unit-lower multipliers, sign-agnostic
+        a[j + 1:, j + 1:] -= np.tril(np.outer(mult, a[j + 1:, j]))
+        L[j, j] = np.sqrt(abs(d))
+        L[j + 1:, j] = a[j + 1:, j] * s[j] / L[j, j]
+    np.testing.assert_allclose(L @ np.diag(s) @ L.T, Kp, atol=1e-12)
+    # blocked (supernodal) form: two block columns
+    k = 8
+    L11 = L[:k, :k]; S1 = np.diag(s[:k])
+    X = Kp[k:, :k] @ np.linalg.inv(L11).T @ S1              # X = B * L11^-T * S11   (S^-1 = S)
+    np.testing.assert_allclose(X, L[k:, :k], atol=1e-12)
+    T = Kp[k:, k:] - X @ S1 @ X.T                           # trailing update with the signs of the K columns
+    np.testing.assert_allclose(np.tril(T), np.tril(L[k:, k:] @ np.diag(s[k:]) @ L[k:, k:].T), atol=1e-12)
+    # solve
+    b = rng.standard_normal(N)
+    y = np.linalg.solve(L, b)
+    x = np.linalg.solve(L.T, s * y)
+    np.testing.assert_allclose(Kp @ x, b, atol=1e-10)
