@@ -77,6 +77,28 @@ static int fail(Symbolic &S, int code, const std::string &msg) { S.error = msg; 
 
 static void build_schedule(Symbolic &S);
 
+// Host threads for the embarrassingly parallel parts of the analyse phase.  fn(thread, i) is called once
+// for every i in [0, n), items handed out dynamically; the result never depends on the number of
+// threads (every item writes its own outputs).  Returns false if a worker threw (out of memory).
+static unsigned host_threads(i64 n) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (unsigned)std::max<i64>(1, std::min<i64>({(i64)hw, 16, n}));
+}
+template <class F>
+static bool parallel_for(i64 n, unsigned nthreads, F &&fn) {
+    std::atomic<i64> next{0};
+    std::atomic<int> failed{0};
+    auto worker = [&](unsigned tid) {
+        try { for (i64 i; (i = next.fetch_add(1)) < n;) fn(tid, i); }
+        catch (...) { failed = 1; }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto &th : pool) th.join();
+    return !failed;
+}
+
 // TLPK_TIMING=1: wall time of the analyse phases on stderr
 struct PhaseTimer {
     bool on; std::chrono::steady_clock::time_point t0; const char *name = nullptr;
@@ -216,20 +238,10 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
             amd_order(nb, bx, ba, border[b]);
         };
         {
-            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            const i32 nthreads = (i32)std::min<unsigned>({hw, 16u, (unsigned)nblocks});
-            if (std::getenv("TLPK_TIMING")) std::fprintf(stderr, "[tlpk analyse] ordering %d blocks on %d threads\n", (int)nblocks, (int)nthreads);
-            std::atomic<i32> next{0};
-            std::atomic<int> failed{0};           // an exception must not escape a thread (std::terminate)
-            auto worker = [&]() {
-                try { for (i32 b; (b = next.fetch_add(1)) < nblocks;) order_block(b); }
-                catch (...) { failed = 1; }
-            };
-            std::vector<std::thread> pool;
-            for (i32 t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-            worker();
-            for (auto &th : pool) th.join();
-            if (failed) return fail(S, TLPK_OOM, "out of memory while ordering the diagonal blocks");
+            const unsigned nthreads = host_threads(nblocks);
+            if (std::getenv("TLPK_TIMING")) std::fprintf(stderr, "[tlpk analyse] ordering %d blocks on %u threads\n", (int)nblocks, nthreads);
+            if (!parallel_for(nblocks, nthreads, [&](unsigned, i64 b) { order_block((i32)b); }))
+                return fail(S, TLPK_OOM, "out of memory while ordering the diagonal blocks");
         }
         for (i32 b = 0; b < nblocks; ++b) for (i32 t : border[b]) order0.push_back(members[b][t]);
         for (i32 i = 0; i < m; ++i) if (row_block[i] < 0) { order0.push_back(i); is_link[i] = 1; }
@@ -691,23 +703,30 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         S.s_diag_row.assign((size_t)S.nnzS, -1);
         S.s_local.assign((size_t)S.nnzS, 0);
         S.pair_ptr.assign((size_t)S.nnzS + 1, 0);
-        std::vector<i32> pos_in_front(m, -1);
-        std::vector<i64> epos(m, -1);
         auto col_is_mine = [&](i32 j) -> bool {
             if (opt.nranks == 1 || !opt.row_block) return true;
             const i32 b = col_block[j];
             return (b < 0) ? (opt.rank == 0) : (block_owner[b] == opt.rank);
         };
-        // pass 1: targets + counts, pass 2: fill
+        // pass 1: targets + counts, pass 2: fill.  Fronts are independent (every stored entry of S belongs
+        // to exactly one pivot column of exactly one front): handed out to the host threads, each with
+        // its own scratch maps.
+        const unsigned nthreads = host_threads(ns_total);
+        std::vector<std::vector<i32>> t_pos(nthreads);
+        std::vector<std::vector<i64>> t_epos(nthreads);
+        std::vector<i64> cursor;
         for (int pass = 0; pass < 2; ++pass) {
-            std::vector<i64> cursor;
             if (pass) {
                 for (i64 e = 0; e < S.nnzS; ++e) S.pair_ptr[e + 1] += S.pair_ptr[e];
                 S.pair_w.resize((size_t)S.pair_ptr[S.nnzS]); S.pair_j.resize((size_t)S.pair_ptr[S.nnzS]);
                 cursor.assign(S.pair_ptr.begin(), S.pair_ptr.end() - 1);
             }
-            for (i32 s = 0; s < ns_total; ++s) {
-                if (!S.front_local[s]) continue;
+            const bool ok = parallel_for(ns_total, nthreads, [&](unsigned tid, i64 s64) {
+                const i32 s = (i32)s64;
+                if (!S.front_local[s]) return;
+                std::vector<i32> &pos_in_front = t_pos[tid];
+                std::vector<i64> &epos = t_epos[tid];
+                if (pos_in_front.empty()) { pos_in_front.assign(m, -1); epos.assign(m, -1); }
                 const FrontDesc &w = S.fronts[s];
                 const bool is_root = (s == S.root_front);
                 if (!pass) for (i32 t = 0; t < w.f; ++t) pos_in_front[S.rowidx[w.rowoff + t]] = t;
@@ -735,7 +754,8 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
                         }
                     }
                 }
-            }
+            });
+            if (!ok) return fail(S, TLPK_OOM, "out of memory while building the assembly lists");
         }
     }
     pt.mark("schedule");
