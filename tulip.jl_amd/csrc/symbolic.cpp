@@ -381,26 +381,45 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         }
         // rows(s) = cols(s) ++ sorted union of the below-diagonal structure of every column of s
         // and of the children's rows; merged (relaxed) supernodes carry explicit zeros.
-        std::vector<i32> mark(m, -1), tmp;
+        // A front needs the below-rows of its children: level by level, deepest first, the fronts of a
+        // level on the host threads (each with its own marker array), then one sequential pass lays the
+        // lists out in front order.
+        std::vector<std::vector<i32>> below(ns_total);
+        {
+            std::vector<i32> sdepth(ns_total, 0);
+            i32 maxd = 0;
+            for (i32 s = ns_total - 1; s >= 0; --s) { sdepth[s] = (sparent[s] == -1) ? 0 : sdepth[sparent[s]] + 1; maxd = std::max(maxd, sdepth[s]); }
+            std::vector<std::vector<i32>> bylevel(maxd + 1);
+            for (i32 s = 0; s < ns_total; ++s) bylevel[sdepth[s]].push_back(s);
+            const unsigned nthreads = host_threads(ns_total);
+            std::vector<std::vector<i32>> t_mark(nthreads);
+            for (i32 d = maxd; d >= 0; --d) {
+                const std::vector<i32> &lv = bylevel[d];
+                const bool ok = parallel_for((i64)lv.size(), std::min<unsigned>(nthreads, (unsigned)std::max<size_t>(1, lv.size())), [&](unsigned tid, i64 q) {
+                    const i32 s = lv[q];
+                    std::vector<i32> &mark = t_mark[tid];
+                    if (mark.empty()) mark.assign(m, -1);
+                    const i32 j0 = sn_start[s], j1 = sn_start[s + 1] - 1;
+                    std::vector<i32> &tmp = below[s];
+                    for (i32 j = j0; j <= j1; ++j)
+                        for (i64 p = S.Sp[j] + 1; p < S.Sp[j + 1]; ++p) {
+                            const i32 i = S.Si[p];
+                            if (i > j1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
+                        }
+                    const FrontDesc &fd = S.fronts[s];
+                    for (i32 t = 0; t < fd.nchild; ++t)
+                        for (const i32 i : below[S.children[fd.child_ptr + t]])
+                            if (i > j1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
+                    std::sort(tmp.begin(), tmp.end());
+                });
+                if (!ok) return fail(S, TLPK_OOM, "out of memory while building the front structures");
+            }
+        }
         S.rowidx.clear();
         S.max_front = 0;
         for (i32 s = 0; s < ns_total; ++s) {
             const i32 j0 = sn_start[s], j1 = sn_start[s + 1] - 1;
-            tmp.clear();
-            for (i32 j = j0; j <= j1; ++j)
-                for (i64 p = S.Sp[j] + 1; p < S.Sp[j + 1]; ++p) {
-                    const i32 i = S.Si[p];
-                    if (i > j1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
-                }
-            const FrontDesc &fd = S.fronts[s];
-            for (i32 t = 0; t < fd.nchild; ++t) {
-                const FrontDesc &cd = S.fronts[S.children[fd.child_ptr + t]];
-                for (i64 q = cd.rowoff + cd.ns; q < cd.rowoff + cd.f; ++q) {
-                    const i32 i = S.rowidx[q];
-                    if (i > j1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
-                }
-            }
-            std::sort(tmp.begin(), tmp.end());
+            const std::vector<i32> &tmp = below[s];
             FrontDesc &w = S.fronts[s];
             w.rowoff = (i64)S.rowidx.size();
             w.ns = j1 - j0 + 1;
