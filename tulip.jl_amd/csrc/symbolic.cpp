@@ -178,21 +178,35 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     std::vector<i64> xadj((size_t)m + 1, 0);
     std::vector<i32> adj;
     {
-        std::vector<i32> mark(m, -1);
-        i64 est = 0;
-        for (i32 j = 0; j < n; ++j) { const i64 c = S.Ap[j + 1] - S.Ap[j]; est += c * (c - 1); }
-        adj.reserve((size_t)std::min<i64>(est, (i64)1 << 33));
-        for (i32 k = 0; k < m; ++k) {
-            mark[k] = k;
-            for (i64 q = S.Tp[k]; q < S.Tp[k + 1]; ++q) {
-                const i32 j = S.Tj[q];
-                for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
-                    const i32 i = S.Ai[p];
-                    if (mark[i] != k) { mark[i] = k; adj.push_back(i); }
+        // rows are independent: chunks of rows on the host threads, count then fill (the marker array of a
+        // thread is stamped with 2k / 2k+1, so the two passes and the rows of a chunk never collide)
+        constexpr i64 CH = 4096;
+        const i64 nch = ((i64)m + CH - 1) / CH;
+        const unsigned nthreads = host_threads(nch);
+        std::vector<std::vector<i64>> t_mark(nthreads);
+        auto sweep = [&](bool fill) {
+            return parallel_for(nch, nthreads, [&](unsigned tid, i64 ch) {
+                std::vector<i64> &mark = t_mark[tid];
+                if (mark.empty()) mark.assign(m, -1);
+                for (i32 k = (i32)(ch * CH); k < (i32)std::min<i64>(m, (ch + 1) * CH); ++k) {
+                    const i64 stamp = 2 * (i64)k + (fill ? 1 : 0);
+                    mark[k] = stamp;
+                    i64 c = fill ? xadj[k] : 0;
+                    for (i64 q = S.Tp[k]; q < S.Tp[k + 1]; ++q) {
+                        const i32 j = S.Tj[q];
+                        for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
+                            const i32 i = S.Ai[p];
+                            if (mark[i] != stamp) { mark[i] = stamp; if (fill) adj[c] = i; ++c; }
+                        }
+                    }
+                    if (!fill) xadj[k + 1] = c;
                 }
-            }
-            xadj[k + 1] = (i64)adj.size();
-        }
+            });
+        };
+        if (!sweep(false)) return fail(S, TLPK_OOM, "out of memory while building the graph of A*A'");
+        for (i32 k = 0; k < m; ++k) xadj[k + 1] += xadj[k];
+        adj.resize((size_t)xadj[m]);
+        if (!sweep(true)) return fail(S, TLPK_OOM, "out of memory while building the graph of A*A'");
     }
 
     pt.mark("ordering (AMD)");
@@ -273,22 +287,31 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     pt.mark("pattern of S");
     // ---- 6. permuted lower pattern of S (rebuilt if the amalgamation re-orders columns) ----
     auto build_pattern = [&]() {
+        // columns are independent: chunks of columns on the host threads
+        constexpr i64 CH = 2048;
+        const i64 nch = ((i64)m + CH - 1) / CH;
+        const unsigned nthreads = host_threads(nch);
         S.Sp.assign((size_t)m + 1, 0);
-        for (i32 kk = 0; kk < m; ++kk) {
-            const i32 k = S.perm[kk];
-            i64 c = 1;
-            for (i64 p = xadj[k]; p < xadj[k + 1]; ++p) if (S.iperm[adj[p]] > kk) ++c;
-            S.Sp[kk + 1] = S.Sp[kk] + c;
-        }
+        parallel_for(nch, nthreads, [&](unsigned, i64 ch) {
+            for (i32 kk = (i32)(ch * CH); kk < (i32)std::min<i64>(m, (ch + 1) * CH); ++kk) {
+                const i32 k = S.perm[kk];
+                i64 c = 1;
+                for (i64 p = xadj[k]; p < xadj[k + 1]; ++p) if (S.iperm[adj[p]] > kk) ++c;
+                S.Sp[kk + 1] = c;
+            }
+        });
+        for (i32 kk = 0; kk < m; ++kk) S.Sp[kk + 1] += S.Sp[kk];
         S.nnzS = S.Sp[m];
         S.Si.resize((size_t)S.nnzS);
-        for (i32 kk = 0; kk < m; ++kk) {
-            const i32 k = S.perm[kk];
-            i64 q = S.Sp[kk];
-            S.Si[q++] = kk;
-            for (i64 p = xadj[k]; p < xadj[k + 1]; ++p) { const i32 ii = S.iperm[adj[p]]; if (ii > kk) S.Si[q++] = ii; }
-            std::sort(S.Si.begin() + S.Sp[kk] + 1, S.Si.begin() + q);
-        }
+        parallel_for(nch, nthreads, [&](unsigned, i64 ch) {
+            for (i32 kk = (i32)(ch * CH); kk < (i32)std::min<i64>(m, (ch + 1) * CH); ++kk) {
+                const i32 k = S.perm[kk];
+                i64 q = S.Sp[kk];
+                S.Si[q++] = kk;
+                for (i64 p = xadj[k]; p < xadj[k + 1]; ++p) { const i32 ii = S.iperm[adj[p]]; if (ii > kk) S.Si[q++] = ii; }
+                std::sort(S.Si.begin() + S.Sp[kk] + 1, S.Si.begin() + q);
+            }
+        });
     };
     build_pattern();
 
