@@ -693,20 +693,26 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
 
     pt.mark("relative indices");
     // ---- 13. relative indices (below-rows of each front -> position in the parent front) ----
-    S.rel.clear();
-    for (i32 s = 0; s < ns_total; ++s) {
-        FrontDesc &w = S.fronts[s];
-        w.reloff = (i64)S.rel.size();
-        if (w.parent == -1) continue;
-        const FrontDesc &p = S.fronts[w.parent];
-        i64 qp = p.rowoff;
-        const i64 qend = p.rowoff + p.f;
-        for (i64 q = w.rowoff + w.ns; q < w.rowoff + w.f; ++q) {
-            const i32 r = S.rowidx[q];
-            while (qp < qend && S.rowidx[qp] < r) ++qp;
-            if (qp == qend || S.rowidx[qp] != r) return fail(S, TLPK_INTERNAL, "child row missing from parent front");
-            S.rel.push_back((i32)(qp - p.rowoff));
-        }
+    {
+        // offsets first (prefix sum), then every front searches its parent on the host threads
+        i64 acc = 0;
+        for (i32 s = 0; s < ns_total; ++s) { FrontDesc &w = S.fronts[s]; w.reloff = acc; if (w.parent != -1) acc += w.f - w.ns; }
+        S.rel.assign((size_t)acc, 0);
+        std::atomic<int> bad{0};
+        parallel_for(ns_total, host_threads(ns_total), [&](unsigned, i64 s) {
+            const FrontDesc &w = S.fronts[s];
+            if (w.parent == -1) return;
+            const FrontDesc &p = S.fronts[w.parent];
+            i64 qp = p.rowoff, out = w.reloff;
+            const i64 qend = p.rowoff + p.f;
+            for (i64 q = w.rowoff + w.ns; q < w.rowoff + w.f; ++q) {
+                const i32 r = S.rowidx[q];
+                while (qp < qend && S.rowidx[qp] < r) ++qp;
+                if (qp == qend || S.rowidx[qp] != r) { bad = 1; return; }
+                S.rel[out++] = (i32)(qp - p.rowoff);
+            }
+        });
+        if (bad) return fail(S, TLPK_INTERNAL, "child row missing from parent front");
     }
 
     pt.mark("gather lists");
@@ -716,27 +722,29 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     {
         const i64 nrow_total = (i64)S.rowidx.size();
         S.gth_ptr.assign(nrow_total + 1, 0);
-        for (i32 s = 0; s < ns_total; ++s) {
+        const unsigned nthreads = host_threads(ns_total);
+        // the rows [rowoff, rowoff + f) of a front belong to that front alone: fronts on the host threads
+        parallel_for(ns_total, nthreads, [&](unsigned, i64 s) {
             const FrontDesc &w = S.fronts[s];
-            if (!S.front_local[s]) continue;
+            if (!S.front_local[s]) return;
             for (i32 t = 0; t < w.nchild; ++t) {
                 const FrontDesc &cd = S.fronts[S.children[w.child_ptr + t]];
                 const i32 rsc = cd.f - cd.ns;
                 for (i32 r = 0; r < rsc; ++r) ++S.gth_ptr[w.rowoff + S.rel[cd.reloff + r] + 1];
             }
-        }
+        });
         for (i64 i = 0; i < nrow_total; ++i) S.gth_ptr[i + 1] += S.gth_ptr[i];
         S.gth_src.assign(S.gth_ptr[nrow_total], 0);
         std::vector<i64> cur(S.gth_ptr.begin(), S.gth_ptr.end() - 1);
-        for (i32 s = 0; s < ns_total; ++s) {
+        parallel_for(ns_total, nthreads, [&](unsigned, i64 s) {
             const FrontDesc &w = S.fronts[s];
-            if (!S.front_local[s]) continue;
+            if (!S.front_local[s]) return;
             for (i32 t = 0; t < w.nchild; ++t) {
                 const FrontDesc &cd = S.fronts[S.children[w.child_ptr + t]];
                 const i32 rsc = cd.f - cd.ns;
                 for (i32 r = 0; r < rsc; ++r) S.gth_src[cur[w.rowoff + S.rel[cd.reloff + r]]++] = cd.ucoff + r;
             }
-        }
+        });
     }
     pt.mark("assembly lists");
     // ---- 14. assembly lists: S[ii,kk] = sum_j A[i,j] D_j A[k,j] (+ regD on the diagonal) ----
