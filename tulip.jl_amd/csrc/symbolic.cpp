@@ -25,11 +25,12 @@ namespace {
 
 // Liu's elimination-tree algorithm with path compression on a graph given in ORIGINAL labels
 // plus a labelling iperm (old -> new); returns parent in NEW labels.
-void etree_of(i32 m, const std::vector<i64> &xadj, const std::vector<i32> &adj, const std::vector<i32> &perm,
-              const std::vector<i32> &iperm, std::vector<i32> &parent) {
-    parent.assign(m, -1);
-    std::vector<i32> anc(m, -1);
-    for (i32 i = 0; i < m; ++i) {
+// Liu's algorithm with path compression for the nodes [i0, i1) of the ordering.  `parent` and `anc`
+// (both initialised to -1 by the caller) are only touched at positions < i1 that are connected to
+// the range, so disjoint ranges of mutually non-adjacent node sets can run concurrently.
+static void etree_range(i32 i0, i32 i1, const std::vector<i64> &xadj, const std::vector<i32> &adj, const std::vector<i32> &perm,
+                        const std::vector<i32> &iperm, std::vector<i32> &parent, std::vector<i32> &anc) {
+    for (i32 i = i0; i < i1; ++i) {
         const i32 old = perm[i];
         for (i64 p = xadj[old]; p < xadj[old + 1]; ++p) {
             i32 k = iperm[adj[p]];
@@ -41,6 +42,12 @@ void etree_of(i32 m, const std::vector<i64> &xadj, const std::vector<i32> &adj, 
             }
         }
     }
+}
+void etree_of(i32 m, const std::vector<i64> &xadj, const std::vector<i32> &adj, const std::vector<i32> &perm,
+              const std::vector<i32> &iperm, std::vector<i32> &parent) {
+    parent.assign(m, -1);
+    std::vector<i32> anc(m, -1);
+    etree_range(0, m, xadj, adj, perm, iperm, parent, anc);
 }
 
 // Postorder of a forest (children visited in increasing label order).  `skip[v]` nodes are cut
@@ -267,7 +274,22 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     std::vector<i32> iperm0(m);
     for (i32 i = 0; i < m; ++i) iperm0[order0[i]] = i;
     std::vector<i32> parent0;
-    etree_of(m, xadj, adj, order0, iperm0, parent0);
+    if (opt.row_block && nblocks >= 2 && opt.ordering != TLPK_ORDER_USER) {
+        // block-angular: the ordering lists block after block, then the linking rows.  The nodes of a block
+        // are adjacent only to their own block and to linking rows (which come later and are skipped by
+        // the k < i test), so the blocks' ranges are independent; the linking rows follow sequentially.
+        std::vector<i32> bstart;
+        for (i32 i = 0; i < m; ++i)
+            if (!is_link[order0[i]] && (i == 0 || row_block[order0[i]] != row_block[order0[i - 1]])) bstart.push_back(i);
+        const i32 first_link0 = m - nlink;
+        bstart.push_back(first_link0);
+        parent0.assign(m, -1);
+        std::vector<i32> anc(m, -1);
+        const i64 nb = (i64)bstart.size() - 1;
+        parallel_for(nb, host_threads(nb), [&](unsigned, i64 b) { etree_range(bstart[b], bstart[b + 1], xadj, adj, order0, iperm0, parent0, anc); });
+        etree_range(first_link0, m, xadj, adj, order0, iperm0, parent0, anc);
+    } else
+        etree_of(m, xadj, adj, order0, iperm0, parent0);
     // final order: postorder of the forest without the linking nodes, then the linking nodes
     std::vector<char> skip(m, 0);
     for (i32 i = 0; i < m; ++i) skip[i] = is_link[order0[i]];
