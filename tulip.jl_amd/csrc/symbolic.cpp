@@ -461,6 +461,11 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
             }
         }
         S.rowidx.clear();
+        {
+            size_t total = (size_t)m;
+            for (i32 s = 0; s < ns_total; ++s) total += below[s].size();
+            S.rowidx.reserve(total);
+        }
         S.max_front = 0;
         for (i32 s = 0; s < ns_total; ++s) {
             const i32 j0 = sn_start[s], j1 = sn_start[s + 1] - 1;
