@@ -402,7 +402,10 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
 
     pt.mark("fronts");
     // ---- 9. supernodal tree and front row structures (for a given column partition) ----
-    auto build_fronts = [&]() -> int {
+    // rows == false: only the supernodal tree and the front sizes (exact for fundamental supernodes:
+    // f = column count of the first column) -- all the amalgamation looks at; the row structures are
+    // then built once, for the final partition
+    auto build_fronts = [&](bool rows) -> int {
         ns_total = (i32)sn_start.size() - 1;
         S.nsuper = ns_total;
         S.sn_of_col.resize(m);
@@ -426,6 +429,14 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         }
         // rows(s) = cols(s) ++ sorted union of the below-diagonal structure of every column of s
         // and of the children's rows; merged (relaxed) supernodes carry explicit zeros.
+        if (!rows) {
+            for (i32 s = 0; s < ns_total; ++s) {
+                FrontDesc &w = S.fronts[s];
+                const i32 j0 = sn_start[s];
+                w.ns = sn_start[s + 1] - j0; w.f = (i32)S.colcount[j0]; w.col0 = j0; w.parent = sparent[s];
+            }
+            return TLPK_OK;
+        }
         // A front needs the below-rows of its children: level by level, deepest first, the fronts of a
         // level on the host threads (each with its own marker array), then one sequential pass lays the
         // lists out in front order.
@@ -485,7 +496,8 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         }
         return TLPK_OK;
     };
-    { const int rc = build_fronts(); if (rc != TLPK_OK) return rc; }
+    const bool will_relax = opt.relax && (i32)sn_start.size() - 1 > 1;
+    { const int rc = build_fronts(!will_relax); if (rc != TLPK_OK) return rc; }
 
     pt.mark("amalgamation");
     // ---- 9b. relaxed amalgamation (any child, not only the adjacent one) ----
@@ -575,9 +587,9 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
             if (nlink) for (i32 k = first_link; k < m; ++k) if (!is_link[S.perm[k]]) return fail(S, TLPK_INTERNAL, "linking rows moved");
             sn_start.swap(new_start);
             build_pattern();
-            const int rc = build_fronts();
-            if (rc != TLPK_OK) return rc;
         }
+        const int rc = build_fronts(true);
+        if (rc != TLPK_OK) return rc;
     }
     { std::vector<i32>().swap(adj); std::vector<i64>().swap(xadj); }
 
