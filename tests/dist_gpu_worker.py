@@ -49,10 +49,31 @@ def main():
             kkt.root_copy(which, "in", P(buf))
             kkt.sync()
 
+        # the composed entry points would skip the all-reduce of the root panel / rhs on a sharded
+        # handle and return a silently wrong factor: they must refuse (TLPK_BADARG -> DimensionMismatch)
+        for call in (lambda: tk.update(kkt, th, rp, rd), lambda: kkt.update_device(P(d[0]), P(d[1]), P(d[2]))):
+            try:
+                call()
+            except tk.DimensionMismatch as e:
+                assert "split-phase" in str(e)
+            else:
+                raise AssertionError("composed update on a sharded handle did not fail")
+        try:
+            kkt.solve_finish(P(d_dx), P(d_dy), P(d[4]))          # before any update / solve_local
+        except (RuntimeError, tk.DimensionMismatch):
+            pass
+        else:
+            raise AssertionError("solve_finish without solve_local did not fail")
         kkt.update_local(P(d[0]), P(d[1]), P(d[2]))
         kkt.sync()
         allreduce_device("panel", kkt.root_panel()[1])
         kkt.update_finish()
+        try:
+            kkt.solve_finish(P(d_dx), P(d_dy), P(d[4]))          # factored, but no solve_local yet
+        except tk.DimensionMismatch as e:
+            assert "tlpk_solve_local" in str(e)
+        else:
+            raise AssertionError("solve_finish without solve_local did not fail")
         kkt.solve_local(P(d[3]), P(d[4]))
         kkt.sync()
         allreduce_device("rhs", kkt.root_rhs()[1])

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ import tulip_jl_amd as tk
 from tulip_jl_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def header_functions():
@@ -90,3 +92,32 @@ def test_one_based_indices_like_julia():
     L.tlpk_get_perm(h, _lib.as_p64(p))
     assert (p == k0.perm()).all()
     L.tlpk_destroy(h)
+
+
+def _build_abi_smoke(tmp_path):
+    import shutil
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "no C compiler"
+    subprocess.check_call([cc, "-O1", "-Wall", "-Wextra", "-std=c99", "-o", exe, os.path.join(HERE, "abi_smoke.c"), "-ldl", "-lm"])
+    return exe
+
+
+def test_plain_c_caller_one_based_int64_csc_analyse_only(tmp_path):
+    """tests/abi_smoke.c = what the Julia `ccall`s do (1-based Int64 CSC, plain pointers): on a machine
+    without a GPU every numeric call must return TLPK_NO_DEVICE (no CPU fallback)."""
+    import subprocess
+    exe = _build_abi_smoke(tmp_path)
+    out = subprocess.run([exe, _lib.LIB_PATH, "cpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_smoke cpu ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_drives_setup_update_solve_on_device(tmp_path):
+    import subprocess
+    exe = _build_abi_smoke(tmp_path)
+    out = subprocess.run([exe, _lib.LIB_PATH, "gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_smoke gpu ok" in out.stdout

@@ -122,21 +122,50 @@ def test_inequality_rows_with_slacks():
     compare_with_oracle(A, gpu_setup(A), 1)
 
 
-def test_late_ipm_regime_residuals():
-    """theta_inv in 10^[-8,8] with exact zeros (free variables), regs = sqrt(eps)."""
-    A = random_lp_matrix(400, 1200, 3, 9)
-    kkt = gpu_setup(A)
+def late_regime_check(A, kkt, seed, label):
+    """Late-IPM data (theta_inv in 10^[-8,8] with exact zeros = free variables, regs = sqrt(eps):
+    cond(S) ~ 1e16).  In this regime no fp64 factorisation reproduces dy to many digits, so the
+    bar is the ORACLE'S OWN residuals on the same data: both residual norms of test.jl:39-43 for the
+    HIP solution must stay within 10x of the oracle's (floor: 100 ulps of the terms that cancel in
+    each identity).  This is where the explicit 64 x 64 inverses of the diagonal blocks and the
+    rsq + Newton square root would lose digits if they did."""
     m, n = A.shape
-    th, rp, rd, xp, xd = ipm_like_data(m, n, 4, "late")
+    th, rp, rd, xp, xd = ipm_like_data(m, n, seed, "late")
     tk.update(kkt, th, rp, rd)
     dx = np.zeros(n); dy = np.zeros(m)
     tk.solve(dx, dy, kkt, xp, xd)
     orc = OracleK1(A, kkt.perm()); orc.update(th, rp, rd)
     dxo, dyo = orc.solve(xp, xd)
-    assert np.abs(dy - dyo).max() <= 1e-6 * max(1.0, np.abs(dyo).max())
-    # the dual residual identity holds to rounding by construction of dx (spd.jl:64-66)
     r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
-    assert r2 <= 1e-7 * max(1.0, np.abs(xd).max(), np.abs((A.T @ dy)).max())
+    o1, o2 = kkt_residuals(A, th, rp, rd, xp, xd, dxo, dyo)
+    eps = np.finfo(float).eps
+    absA = abs(A)
+    f1 = 100 * eps * max(float((absA @ np.abs(dx)).max()), float(np.abs(xp).max()))          # |A||dx| + |xp|
+    f2 = 100 * eps * max(float(((th + rp) * np.abs(dx)).max()), float((absA.T @ np.abs(dy)).max()))
+    print(f"late[{label}] m={m}: r1 hip={r1:.3e} oracle={o1:.3e} floor={f1:.3e} | r2 hip={r2:.3e} oracle={o2:.3e} floor={f2:.3e} | "
+          f"|dy-dyo|/|dyo|={np.abs(dy - dyo).max() / max(1.0, np.abs(dyo).max()):.3e}")
+    assert r1 <= 10 * max(o1, f1)
+    assert r2 <= 10 * max(o2, f2)
+    return dy, dyo
+
+
+def test_late_ipm_regime_residuals():
+    """theta_inv in 10^[-8,8] with exact zeros (free variables), regs = sqrt(eps)."""
+    A = random_lp_matrix(400, 1200, 3, 9)
+    dy, dyo = late_regime_check(A, gpu_setup(A), 4, "400x1200")
+    assert np.abs(dy - dyo).max() <= 1e-6 * max(1.0, np.abs(dyo).max())
+
+
+def test_late_ipm_regime_at_c4_block_scale():
+    """The same at the size of one BASELINE configs[3] diagonal block (5000 x 10000, 4 nnz/col: a
+    ~3300-column dense front, 26 blocked 128-wide solve steps, 13 block columns of 256)."""
+    A = random_lp_matrix(5000, 10000, 4, 20260927)
+    late_regime_check(A, gpu_setup(A), 7, "5000x10000")
+
+
+def test_late_ipm_regime_block_angular_with_root_front():
+    A, row_block = block_angular(nblocks=6, mk=700, nk=1400, m0=120, nnz_in=4, link_prob=0.5, seed=21)
+    late_regime_check(A, gpu_setup(A, row_block=row_block), 5, "block-angular")
 
 
 def test_block_angular_single_gpu():

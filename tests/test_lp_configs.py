@@ -1,0 +1,159 @@
+"""BASELINE.json configs[1] ("Netlib 25fv47") and configs[4] ("pds-20 or equivalent") through the
+whole interior-point loop.  The Netlib / Mittelmann .mps files are not in the image (no network), so
+seeded generators of the same class stand in (tests/lp_generators.py; the 25fv47-class instance is
+committed as tests/golden/stair25.mps) and both backends read the SAME .mps input.
+
+Protocol (SURVEY.md 8d "Parity protocol" (ii), (iii)): HIP backend vs CPU-oracle backend (same
+ordering) -- same termination status, |delta niter| <= 1, primal / dual objectives to 1e-8 relative,
+final rho_p, rho_d, rho_g <= sqrt(eps) on both -- and the optimal value of HiGHS
+(scipy.optimize.linprog) as the independent third party, to 1e-6 relative.  At pds-20 scale
+(m = 3.4e4, nnz(L) = 4e7) the simplicial oracle needs minutes per factorisation, so the full-size
+run is checked against HiGHS and the residual norms only; the oracle comparison runs on the same
+generator at 1/10 of the nodes.  The PosDefException retry loop of HSD/step.jl:35-51 is driven by an
+LP engineered to fail numerically (lp_generators.bump_lp)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from ipm_harness import HipBackend, OracleBackend, read_free_mps, solve_lp
+from lp_generators import bump_lp, multicommodity_lp, staircase_lp, write_free_mps
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SQRT_EPS = float(np.sqrt(np.finfo(float).eps))
+# optimal values from HiGHS 1.x (scipy 1.15.3) at generation time; re-checked live by highs() below
+STAIR25_OPT = -17964.586599632254
+BUMP_OPT = 918.8095051124827
+
+
+def highs(lp):
+    from scipy.optimize import linprog
+    A = lp.A.tocsr()
+    eq = lp.lcon == lp.ucon
+    ru = np.nonzero(~eq & np.isfinite(lp.ucon))[0]; rl = np.nonzero(~eq & np.isfinite(lp.lcon))[0]
+    Aub = sp.vstack([A[ru], -A[rl]]) if ru.size + rl.size else None
+    bub = np.concatenate([lp.ucon[ru], -lp.lcon[rl]]) if Aub is not None else None
+    bounds = [(None if np.isinf(l) else l, None if np.isinf(u) else u) for l, u in zip(lp.lvar, lp.uvar)]
+    r = linprog(lp.obj if lp.objsense_min else -lp.obj, A_ub=Aub, b_ub=bub, A_eq=A[eq] if eq.any() else None,
+                b_eq=lp.lcon[eq] if eq.any() else None, bounds=bounds, method="highs")
+    assert r.status == 0, r.message
+    return (r.fun if lp.objsense_min else -r.fun) + lp.obj0
+
+
+def through_mps(lp, tmp_path):
+    p = str(tmp_path / f"{lp.name}.mps")
+    write_free_mps(lp, p)
+    return read_free_mps(p)
+
+
+def assert_backends_agree(hg, sg, hc, sc, niter_slack=1, obj_tol=1e-8):
+    assert sg["status"] == sc["status"] == "Trm_Optimal"
+    assert abs(hg.niter - hc.niter) <= niter_slack
+    assert abs(sg["z_primal"] - sc["z_primal"]) <= obj_tol * (1 + abs(sc["z_primal"]))
+    assert abs(sg["z_dual"] - sc["z_dual"]) <= obj_tol * (1 + abs(sc["z_dual"]))
+    assert max(sg["rho"]) <= SQRT_EPS and max(sc["rho"]) <= SQRT_EPS     # rho_p, rho_d, rho_g (HSD.jl:142-148)
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU: generators, fixtures, oracle backend
+# ---------------------------------------------------------------------------------------------
+def test_stair25_fixture_is_the_generator_output_and_roundtrips():
+    lp = read_free_mps(os.path.join(GOLDEN, "stair25.mps"))
+    g = staircase_lp()
+    assert lp.A.shape == g.A.shape == (821, 1572) and (lp.A != g.A).nnz == 0
+    assert np.array_equal(lp.obj, g.obj) and np.array_equal(lp.lvar, g.lvar) and np.array_equal(lp.uvar, g.uvar)
+    fin = np.isfinite(g.lcon)
+    assert np.array_equal(np.isfinite(lp.lcon), fin) and np.allclose(lp.lcon[fin], g.lcon[fin], rtol=1e-14, atol=1e-12)
+    assert np.array_equal(lp.ucon, g.ucon)
+    # every row / bound type of ipmdata.jl:64-173 is present
+    eq = g.lcon == g.ucon
+    assert eq.sum() > 300 and (np.isinf(g.lcon) & np.isfinite(g.ucon)).sum() > 100
+    assert (np.isfinite(g.lcon) & np.isinf(g.ucon)).sum() > 60 and (~eq & np.isfinite(g.lcon) & np.isfinite(g.ucon)).sum() > 20
+    assert (np.isinf(g.lvar) & np.isinf(g.uvar)).sum() > 30 and np.isfinite(g.uvar).sum() > 150
+
+
+@pytest.mark.parametrize("alg", ["hsd", "mpc"])
+def test_c2_equivalent_on_oracle_backend(alg):
+    lp = read_free_mps(os.path.join(GOLDEN, "stair25.mps"))
+    ipm, sol = solve_lp(lp, lambda A: OracleBackend(A), algorithm=alg)
+    assert sol["status"] == "Trm_Optimal" and max(sol["rho"]) <= SQRT_EPS
+    assert abs(sol["z_primal"] - STAIR25_OPT) <= 1e-6 * (1 + abs(STAIR25_OPT))
+    assert abs(highs(lp) - STAIR25_OPT) <= 1e-7 * (1 + abs(STAIR25_OPT))
+
+
+@pytest.mark.parametrize("alg", ["hsd", "mpc"])
+def test_retry_loop_fires_on_oracle_backend(alg):
+    """HSD/step.jl:35-51, MPC/step.jl:40-56: the factorisation fails numerically, regularisations are
+    multiplied by 100 and the step is retried; the run still ends optimal."""
+    lp = read_free_mps(os.path.join(GOLDEN, "bump.mps"))
+    ipm, sol = solve_lp(lp, lambda A: OracleBackend(A), algorithm=alg)
+    assert ipm.timers["n_bump"] > 0
+    assert sol["status"] == "Trm_Optimal"
+    assert abs(sol["z_primal"] - BUMP_OPT) <= 1e-6 * (1 + abs(BUMP_OPT))
+    assert abs(highs(lp) - BUMP_OPT) <= 1e-7 * (1 + abs(BUMP_OPT))
+
+
+def test_c5_equivalent_reduced_on_oracle_backend(tmp_path):
+    lp = through_mps(multicommodity_lp(nodes=300), tmp_path)
+    assert lp.A.shape == (3312, 9000)
+    ipm, sol = solve_lp(lp, lambda A: OracleBackend(A))
+    ref = highs(lp)
+    assert sol["status"] == "Trm_Optimal" and max(sol["rho"]) <= SQRT_EPS
+    assert abs(sol["z_primal"] - ref) <= 1e-6 * (1 + abs(ref))
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU: the HIP backend through the same loops
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["hsd", "mpc"])
+def test_c2_equivalent_hip_vs_oracle_and_highs(alg):
+    lp = read_free_mps(os.path.join(GOLDEN, "stair25.mps"))
+    hg, sg = solve_lp(lp, lambda A: HipBackend(A, device=0), algorithm=alg)
+    perm = hg.kkt.kkt.perm()
+    hc, sc = solve_lp(lp, lambda A: OracleBackend(A, perm), algorithm=alg)
+    assert_backends_agree(hg, sg, hc, sc)
+    assert hg.timers["n_bump"] == hc.timers["n_bump"] == 0
+    assert abs(sg["z_primal"] - STAIR25_OPT) <= 1e-6 * (1 + abs(STAIR25_OPT))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["hsd", "mpc"])
+def test_retry_loop_fires_on_hip_backend(alg):
+    """n_bump > 0 inside an IPM run on the device: TLPK_NOT_POSDEF -> PosDefException -> regs x100 ->
+    retry on the SAME handle.  Which pivot fails is decided by rounding, so the two backends may bump
+    at different iterations: iteration counts are compared loosely, the optimum against HiGHS."""
+    lp = read_free_mps(os.path.join(GOLDEN, "bump.mps"))
+    hg, sg = solve_lp(lp, lambda A: HipBackend(A, device=0), algorithm=alg)
+    hc, sc = solve_lp(lp, lambda A: OracleBackend(A, hg.kkt.kkt.perm()), algorithm=alg)
+    assert hg.timers["n_bump"] > 0 and hc.timers["n_bump"] > 0
+    assert sg["status"] == sc["status"] == "Trm_Optimal"
+    assert abs(hg.niter - hc.niter) <= 5
+    assert abs(sg["z_primal"] - BUMP_OPT) <= 1e-6 * (1 + abs(BUMP_OPT))
+    assert max(sg["rho"]) <= SQRT_EPS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["hsd", "mpc"])
+def test_c5_equivalent_reduced_hip_vs_oracle(alg, tmp_path):
+    lp = through_mps(multicommodity_lp(nodes=300), tmp_path)
+    hg, sg = solve_lp(lp, lambda A: HipBackend(A, device=0), algorithm=alg)
+    hc, sc = solve_lp(lp, lambda A: OracleBackend(A, hg.kkt.kkt.perm()), algorithm=alg)
+    assert_backends_agree(hg, sg, hc, sc)
+    ref = highs(lp)
+    assert abs(sg["z_primal"] - ref) <= 1e-6 * (1 + abs(ref))
+
+
+@pytest.mark.gpu
+def test_c5_equivalent_full_scale_hip_vs_highs(tmp_path):
+    """pds-20 scale: 33 805 rows x 92 400 columns (+ 3 005 slacks), nnz(L) = 4.1e7, one 7 900-column
+    front.  HIP backend through HSD; optimum vs HiGHS, residual norms of HSD.jl:142-148."""
+    lp = through_mps(multicommodity_lp(), tmp_path)
+    assert lp.A.shape[0] > 33000 and lp.A.shape[1] > 90000
+    hg, sg = solve_lp(lp, lambda A: HipBackend(A, device=0))
+    assert sg["status"] == "Trm_Optimal" and hg.niter <= 60
+    assert max(sg["rho"]) <= SQRT_EPS
+    ref = highs(lp)
+    assert abs(sg["z_primal"] - ref) <= 1e-6 * (1 + abs(ref))
+    assert abs(sg["z_dual"] - ref) <= 1e-6 * (1 + abs(ref))

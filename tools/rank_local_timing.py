@@ -29,9 +29,9 @@ for N in [int(v) for v in os.environ.get("NLIST", "1,2,4,8").split(",")]:
             kkt.solve_local(P(d[3]), P(d[4])); kkt.solve_finish(P(d_dx), P(d_dy), P(d[4]))
         kkt.sync()
     def fused():
-        kkt.update_device(P(d[0]), P(d[1]), P(d[2]))
+        kkt.update_local(P(d[0]), P(d[1]), P(d[2])); kkt.update_finish()    # rank-local work only: no all-reduce
         for _ in range(4):
-            kkt.solve_device(P(d_dx), P(d_dy), P(d[3]), P(d[4]), sync=False)
+            kkt.solve_local(P(d[3]), P(d[4])); kkt.solve_finish(P(d_dx), P(d_dy), P(d[4]))
         kkt.sync()
     for fn in ((fused, step) if N == 1 else (step,)):
         for _ in range(2): fn()

@@ -103,11 +103,24 @@ static bool parallel_for(i64 n, unsigned nthreads, F &&fn, i64 chunk = 1) {
                 for (i64 i = i0; i < std::min(n, i0 + chunk); ++i) fn(tid, i);
         } catch (...) { failed = 1; }
     };
+    // A thread that cannot be created (thread / pid limits of a container) is not an error: the
+    // threads that did start and the calling thread drain the work.  Nothing may escape while a
+    // started thread is still joinable (the vector's destructor would call std::terminate).
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);
+    try {
+        pool.reserve(nthreads);
+        for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);
+    } catch (...) { /* std::system_error / bad_alloc: go on with the threads we have */ }
     worker(0);
     for (auto &th : pool) th.join();
     return !failed;
+}
+
+// Same, for call sites without an error path of their own: a failed worker (out of memory) becomes a
+// std::bad_alloc AFTER every thread has been joined; tlpk_create maps it to TLPK_OOM.
+template <class F>
+static void parallel_for_throw(i64 n, unsigned nthreads, F &&fn, i64 chunk = 1) {
+    if (!parallel_for(n, nthreads, std::forward<F>(fn), chunk)) throw std::bad_alloc();
 }
 
 // TLPK_TIMING=1: wall time of the analyse phases on stderr
@@ -290,7 +303,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         parent0.assign(m, -1);
         std::vector<i32> anc(m, -1);
         const i64 nb = (i64)bstart.size() - 1;
-        parallel_for(nb, host_threads(nb), [&](unsigned, i64 b) { etree_range(bstart[b], bstart[b + 1], xadj, adj, order0, iperm0, parent0, anc); });
+        parallel_for_throw(nb, host_threads(nb), [&](unsigned, i64 b) { etree_range(bstart[b], bstart[b + 1], xadj, adj, order0, iperm0, parent0, anc); });
         etree_range(first_link0, m, xadj, adj, order0, iperm0, parent0, anc);
     } else
         etree_of(m, xadj, adj, order0, iperm0, parent0);
@@ -318,7 +331,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         const i64 nch = ((i64)m + CH - 1) / CH;
         const unsigned nthreads = host_threads(nch);
         S.Sp.assign((size_t)m + 1, 0);
-        parallel_for(nch, nthreads, [&](unsigned, i64 ch) {
+        parallel_for_throw(nch, nthreads, [&](unsigned, i64 ch) {
             for (i32 kk = (i32)(ch * CH); kk < (i32)std::min<i64>(m, (ch + 1) * CH); ++kk) {
                 const i32 k = S.perm[kk];
                 i64 c = 1;
@@ -329,7 +342,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         for (i32 kk = 0; kk < m; ++kk) S.Sp[kk + 1] += S.Sp[kk];
         S.nnzS = S.Sp[m];
         S.Si.resize((size_t)S.nnzS);
-        parallel_for(nch, nthreads, [&](unsigned, i64 ch) {
+        parallel_for_throw(nch, nthreads, [&](unsigned, i64 ch) {
             for (i32 kk = (i32)(ch * CH); kk < (i32)std::min<i64>(m, (ch + 1) * CH); ++kk) {
                 const i32 k = S.perm[kk];
                 i64 q = S.Sp[kk];
@@ -742,7 +755,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         for (i32 s = 0; s < ns_total; ++s) { FrontDesc &w = S.fronts[s]; w.reloff = acc; if (w.parent != -1) acc += w.f - w.ns; }
         S.rel.assign((size_t)acc, 0);
         std::atomic<int> bad{0};
-        parallel_for(ns_total, host_threads(ns_total), [&](unsigned, i64 s) {
+        parallel_for_throw(ns_total, host_threads(ns_total), [&](unsigned, i64 s) {
             const FrontDesc &w = S.fronts[s];
             if (w.parent == -1) return;
             const FrontDesc &p = S.fronts[w.parent];
@@ -767,7 +780,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         S.gth_ptr.assign(nrow_total + 1, 0);
         const unsigned nthreads = host_threads(ns_total);
         // the rows [rowoff, rowoff + f) of a front belong to that front alone: fronts on the host threads
-        parallel_for(ns_total, nthreads, [&](unsigned, i64 s) {
+        parallel_for_throw(ns_total, nthreads, [&](unsigned, i64 s) {
             const FrontDesc &w = S.fronts[s];
             if (!S.front_local[s]) return;
             for (i32 t = 0; t < w.nchild; ++t) {
@@ -779,7 +792,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         for (i64 i = 0; i < nrow_total; ++i) S.gth_ptr[i + 1] += S.gth_ptr[i];
         S.gth_src.assign(S.gth_ptr[nrow_total], 0);
         std::vector<i64> cur(S.gth_ptr.begin(), S.gth_ptr.end() - 1);
-        parallel_for(ns_total, nthreads, [&](unsigned, i64 s) {
+        parallel_for_throw(ns_total, nthreads, [&](unsigned, i64 s) {
             const FrontDesc &w = S.fronts[s];
             if (!S.front_local[s]) return;
             for (i32 t = 0; t < w.nchild; ++t) {

@@ -44,7 +44,7 @@ struct tlpk_handle {
     double *d_theta = nullptr, *d_regP = nullptr, *d_regD = nullptr, *d_D = nullptr;
     double *d_xip = nullptr, *d_xid = nullptr, *d_dx = nullptr, *d_dy = nullptr;
     int *h_info = nullptr;
-    bool factored = false, local_done = false, solve_timed = false;
+    bool factored = false, local_done = false, solve_local_done = false, solve_timed = false;
     i64 fail_col = -1;
     double ms_analyse = 0, ms_update = 0, ms_solve = 0;
     tlpk_kernel_times kt{};
@@ -55,9 +55,9 @@ struct tlpk_handle {
 
 namespace {
 
-// See tulip.jl_amd/__init__.py: more hardware queues than the runtime's default 4, unless the user
-// chose a value; only effective when this library is loaded before the HIP runtime initialises.
-struct HwQueueDefault { HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } hw_queue_default;
+// GPU_MAX_HW_QUEUES (more hardware queues than the runtime's default 4) is a tuning knob of the HOST
+// process: the Python and Julia glue set it before the HIP runtime initialises (tulip.jl_amd/__init__.py,
+// julia/libtlpk.jl).  The library itself never touches the environment.
 
 int hip_fail(tlpk_handle *h, hipError_t e, const char *what) {
     h->last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -415,7 +415,7 @@ int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_reg
     if (!h->has_device) return TLPK_NO_DEVICE;
     HIPCHK(h, hipSetDevice(h->device));
     const Symbolic &S = h->S;
-    h->factored = false; h->local_done = false; h->fail_col = -1; h->solve_timed = false;
+    h->factored = false; h->local_done = false; h->solve_local_done = false; h->fail_col = -1; h->solve_timed = false;
     prof_begin(h, true);
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     // stored copies (spd.jl:36-38): the caller may mutate its vectors right after the call
@@ -477,7 +477,19 @@ int tlpk_update_finish(tlpk_handle *h) {
     return TLPK_OK;
 }
 
+// The composed entry points run both halves back to back WITHOUT the all-reduce of the root panel /
+// root rhs: on a sharded handle that would factorise this rank's partial sum and return TLPK_OK.
+static int sharded_needs_split(tlpk_handle *h, const char *what) {
+    if (h && h->opt.nranks > 1 && h->S.root_front >= 0) {
+        h->last_error = std::string(what) + ": handle is sharded over " + std::to_string(h->opt.nranks) +
+                        " ranks with a replicated root front; use the split-phase calls (tlpk_*_local, all-reduce, tlpk_*_finish)";
+        return TLPK_BADARG;
+    }
+    return TLPK_OK;
+}
+
 int tlpk_update_device(tlpk_handle *h, const double *d_theta, const double *d_regP, const double *d_regD) {
+    if (int g = sharded_needs_split(h, "tlpk_update_device")) return g;
     int rc = tlpk_update_local(h, d_theta, d_regP, d_regD);
     if (rc != TLPK_OK) return rc;
     return tlpk_update_finish(h);
@@ -486,6 +498,7 @@ int tlpk_update_device(tlpk_handle *h, const double *d_theta, const double *d_re
 int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
     if (!h || !theta || !regP || !regD) return TLPK_BADARG;
     if (!h->has_device) return TLPK_NO_DEVICE;
+    if (int g = sharded_needs_split(h, "tlpk_update")) return g;
     HIPCHK(h, hipSetDevice(h->device));
     const Symbolic &S = h->S;
     HIPCHK(h, hipMemcpyAsync(h->d_theta, theta, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
@@ -506,6 +519,7 @@ int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
     { ProfScope ps(h, TLPK_KC_SPMV); launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank); launch_single_solve(h->stream, h->d); }
     run_launches(h, h->S.fwd_launches, 0, h->fwd_marker);
     HIPCHK(h, hipGetLastError());
+    h->solve_local_done = true;
     return TLPK_OK;
 }
 
@@ -521,6 +535,8 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     if (!h || !d_dx || !d_dy || !d_xid) return TLPK_BADARG;
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->factored) return TLPK_NOT_FACTORED;
+    if (!h->solve_local_done) { h->last_error = "tlpk_solve_finish without a preceding tlpk_solve_local"; return TLPK_BADARG; }
+    h->solve_local_done = false;
     HIPCHK(h, hipSetDevice(h->device));
     run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size());
     run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size());
@@ -533,6 +549,7 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
 }
 
 int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xip, const double *d_xid) {
+    if (int g = sharded_needs_split(h, "tlpk_solve_device")) return g;
     int rc = tlpk_solve_local(h, d_xip, d_xid);
     if (rc != TLPK_OK) return rc;
     return tlpk_solve_finish(h, d_dx, d_dy, d_xid);
@@ -559,6 +576,7 @@ int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const
     if (!h || !dx || !dy || !xi_p || !xi_d) return TLPK_BADARG;
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->factored) return TLPK_NOT_FACTORED;
+    if (int g = sharded_needs_split(h, "tlpk_solve")) return g;
     HIPCHK(h, hipSetDevice(h->device));
     const Symbolic &S = h->S;
     HIPCHK(h, hipMemcpyAsync(h->d_xip, xi_p, (size_t)S.m * 8, hipMemcpyHostToDevice, h->stream));

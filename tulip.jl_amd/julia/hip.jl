@@ -17,7 +17,9 @@ using ..KKT: AbstractKKTBackend, AbstractKKTSolver
 using ..KKT: AbstractKKTSystem, K1
 import ..KKT: setup, update!, solve!, backend, linear_system
 
-using ...LibTLPK    # src/LinearAlgebra/libtlpk.jl
+# libtlpk.jl is included from src/LinearAlgebra/LinearAlgebra.jl, i.e. INSIDE `module TLPLinearAlgebra`
+# (/root/reference/src/Tulip.jl:21 includes that file; `...` is `Tulip` seen from `Tulip.KKT.TlpHIP`)
+using ...TLPLinearAlgebra.LibTLPK
 
 """
     Backend(; device=0, row_block=nothing)
