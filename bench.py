@@ -9,13 +9,23 @@ xi_p, xi_d already resident in HBM and results left in HBM (device-pointer C ABI
 Workload at N=1: BASELINE.json configs[3] -- synthetic block-angular LP, 64 blocks x
 (5000 rows x 10000 vars, 4 nnz/col) + 1000 linking rows (SURVEY.md 8d's recorded choices),
 the configuration the multi-GPU metric is quoted on and the largest one that fits one GPU
-(configs[1]/[4] need Netlib .mps files that are not in the image; configs[2] has a ~0.86 TB
-factor).  At N>1 the same LP is sharded by diagonal blocks over N ranks ("strong" scaling);
-the linking-block Schur complement is all-reduced with RCCL (torch.distributed, backend nccl).
+(configs[1]/[4] need Netlib .mps files that are not in the image -- generated equivalents run
+end-to-end in tests/test_lp_configs.py; configs[2] has a ~0.86 TB factor).  At N>1 the same LP is
+sharded by diagonal blocks over N ranks ("strong" scaling); the linking-block Schur complement is
+all-reduced with RCCL (torch.distributed, backend nccl).
 
-Prints ONE JSON line on rank 0, including `roofline` (dominant kernel: the fp64-MFMA panel
-update, timed live with HIP events on the library's stream) and `cpu_baseline` (the C oracle on
-a bounded sample, timed on this host).
+Prints ONE JSON line on rank 0, with
+  roofline      dominant kernel (fp64-MFMA panel update k_update): ALGORITHMIC flops (the share of
+                sum_j l_j^2 that falls to that kernel, tlpk_stats.flops_update_alg) / its summed launch
+                durations, timed live with HIP events on the library's stream; `frac_executed` is the
+                same with the flops the kernel actually executes on the zero-padded supernodes;
+                `frac_step` = flops_chol / whole Newton-step time / peak.
+  solve_roofline  HBM: algorithmic bytes of one solve / its duration.
+  host_abi      the same Newton step through the HOST-pointer entry points Tulip's ccall glue uses
+                (tlpk_update / tlpk_solve: PCIe both ways, pinned staging) -- never `value`.
+  headline      the north-star instance (1e6 vars / 2e6 constraints block-angular) on the same GPU.
+  cpu_baseline  CHOLMOD-class CPU path (oracle/k1_supernodal.c: supernodal multifrontal on OpenBLAS,
+                OpenMP over the elimination tree, ALL host cores) on the same LP, same ordering.
 """
 import argparse
 import json
@@ -53,41 +63,100 @@ def parse():
     ap.add_argument("--c3-rows", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-headline", action="store_true", help="skip the extra north-star headline run (N=1, workload c4 only)")
+    ap.add_argument("--no-host-abi", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """Oracle (`port`, 1 thread) on ONE diagonal block of the workload: update + `solves` solves.
-    The block-angular LP is 64 such blocks plus the linking Schur complement; the reported value
-    extrapolates blocks x t_block (linking work excluded, which favours the CPU)."""
+def host_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return os.cpu_count() or 1, model
+
+
+def cpu_baseline(args, A, row_block, nblocks_total):
+    """CHOLMOD-class CPU path on the host cores of this box: supernodal multifrontal Cholesky on
+    OpenBLAS, OpenMP over the elimination tree (oracle/k1_supernodal.c, all cores), same ordering and
+    supernodes as the GPU run => same nnz(L), same flops.  One untimed update (first touch of the
+    factor storage) and then one Newton step.  If the whole LP would exceed the time budget on this host
+    the leading diagonal blocks are taken as the sample and the rate is scaled by flops."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import tulip_jl_amd as tk
-    from oracle_binding import OracleK1
-    from workloads import block_angular_lp, kernel_inputs
-    A, _ = block_angular_lp(args.blocks, args.mk, args.nk, 0, args.nnz_col, 0.5, blocks=[0], ineq=args.ineq)
+    from oracle_binding import SupernodalK1
+    from workloads import kernel_inputs
+    cores, model = host_info()
+    full = tk.setup(A, tk.K1(), tk.Backend(device=-1, row_block=row_block))
+    flops_full = full.stats()["flops_chol"]
+    # ~15 GFLOP/s per core is what OpenBLAS dpotrf/dsyrk sustain on server cores with one thread per front
+    est = 2.0 * flops_full / (15e9 * cores)
+    frac = 1.0
+    if row_block is not None and est > args.cpu_seconds and nblocks_total > 1:
+        nb = max(1, min(nblocks_total, int(nblocks_total * args.cpu_seconds / est)))
+        keep = np.nonzero((row_block < nb))[0]                     # leading blocks + linking rows
+        Ak = A.tocsr()[keep].tocsc()
+        used = np.nonzero(np.diff(Ak.indptr) > 0)[0]
+        Ak = Ak[:, used].tocsc(); Ak.sort_indices()
+        A, row_block = Ak, row_block[keep]
+        sub = tk.setup(A, tk.K1(), tk.Backend(device=-1, row_block=row_block))
+        frac = sub.stats()["flops_chol"] / flops_full
+        full = sub
     m, n = A.shape
-    perm = tk.setup(A, tk.K1(), tk.Backend(device=-1)).perm()      # same fill-reducing ordering
     th, rp, rd, xp, xd = kernel_inputs(m, n, 7, args.regime)
-    orc = OracleK1(A, perm)
+    sn = SupernodalK1(A, full, threads=0)
+    sn.update(th, rp, rd)                                          # untimed: page-faults the factor storage
     t0 = time.perf_counter()
-    orc.update(th, rp, rd)
+    sn.update(th, rp, rd)
+    t_upd = time.perf_counter() - t0
+    t0 = time.perf_counter()
     for _ in range(args.solves):
-        orc.solve(xp, xd)
-    t = time.perf_counter() - t0
-    return {"value": 1.0 / (t * args.blocks), "unit": "iter/s", "cores": 1, "kind": "port",
-            "sample": f"1 of {args.blocks} diagonal blocks ({m}x{n}, nnzL={orc.nnzL}): 1 update + {args.solves} "
-                      f"solves took {t:.2f} s on 1 core; value = 1/({args.blocks} x that), linking rows excluded",
-            "seconds_sample": t}
+        dx, dy = sn.solve(xp, xd)
+    t_sol = time.perf_counter() - t0
+    r_p = float(np.abs(A @ dx + rd * dy - xp).max()); r_d = float(np.abs(-dx * (th + rp) + A.T @ dy - xd).max())
+    t = (t_upd + t_sol) / frac
+    st = full.stats()
+    return {"value": 1.0 / t, "unit": "iter/s", "cores": sn.threads, "kind": "port",
+            "sample": ("whole LP" if frac == 1.0 else f"leading diagonal blocks + linking rows = {frac:.3f} of the LP's factor flops, time scaled by 1/{frac:.3f}")
+                      + f": 1 update {t_upd:.2f} s + {args.solves} solves {t_sol:.2f} s on {sn.threads} threads "
+                        f"(nnzL={st['nnzL']}, flops={st['flops_chol']:.3e}, {st['flops_chol'] / t_upd / 1e9:.0f} GFLOP/s); "
+                        "supernodal multifrontal Cholesky on SciPy's OpenBLAS + OpenMP tree parallelism, same ordering as the GPU run; "
+                        "the reference's Julia + CHOLMOD path cannot run in this image",
+            "ms_per_step": 1e3 * t, "seconds_update": t_upd, "seconds_solves": t_sol, "host_cores": cores, "host_cpu": model,
+            "residual_inf": [r_p, r_d]}
+
+
+def build_workload(args, workload):
+    from workloads import block_angular_lp, general_sparse_lp
+    if workload == "c3":
+        A, row_block = general_sparse_lp(args.c3_rows), None
+        desc = None
+    elif workload == "headline":
+        A, row_block = block_angular_lp(100, 20000, 10000, 1000, args.nnz_col, 0.5, ineq=True)
+        desc = ("north-star headline", 100, 20000, "inequality", 10000, 1000)
+    else:
+        A, row_block = block_angular_lp(args.blocks, args.mk, args.nk, args.m0, args.nnz_col, 0.5)
+        desc = ("BASELINE configs[3]", args.blocks, args.mk, "equality", args.nk, args.m0)
+    m, n = A.shape
+    if desc is None:
+        text = ("BASELINE configs[2] at reduced scale: general sparse LP A=[A0 I], %d rows x %d structural "
+                "columns, 25 nnz/col; m=%d n=%d nnz(A)=%d" % (m, n - m, m, n, A.nnz))
+    else:
+        text = ("%s: block-angular LP, %d blocks x (%d %s rows x %d vars, %d nnz/col) + %d linking rows; "
+                "m=%d n=%d nnz(A)=%d" % (desc[0], desc[1], desc[2], desc[3], desc[4], args.nnz_col, desc[5], m, n, A.nnz))
+    return A, row_block, text
 
 
 def main():
     args = parse()
-    args.ineq = False
-    if args.workload == "headline":
-        args.blocks, args.mk, args.nk, args.m0, args.ineq = 100, 20000, 10000, 1000, True
     import torch
     import tulip_jl_amd as tk
-    from workloads import block_angular_lp, kernel_inputs
+    from workloads import kernel_inputs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,157 +167,209 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-
-    if args.workload == "c3":
-        if world > 1:
+        if args.workload == "c3":
             raise SystemExit("general sparse LPs run on one GPU (replicas only, SURVEY.md 8e)")
-        from workloads import general_sparse_lp
-        A, row_block = general_sparse_lp(args.c3_rows), None
-        args.no_cpu_baseline = True        # the oracle needs minutes at this size; see tests for its parity role
-    else:
-        A, row_block = block_angular_lp(args.blocks, args.mk, args.nk, args.m0, args.nnz_col, 0.5, ineq=args.ineq)
-    m, n = A.shape
-    kkt = tk.setup(A, tk.K1(), tk.Backend(device=local_rank, row_block=row_block, rank=rank, nranks=world))
-    st = kkt.stats()
-    th, rp, rd, xp, xd = kernel_inputs(m, n, 7, args.regime)
-    dev = torch.device("cuda", local_rank)
-    d_th, d_rp, d_rd, d_xp, d_xd = (torch.from_numpy(v).to(dev) for v in (th, rp, rd, xp, xd))
-    d_dx = torch.empty(n, dtype=torch.float64, device=dev)
-    d_dy = torch.empty(m, dtype=torch.float64, device=dev)
     P = lambda t: t.data_ptr()   # noqa: E731
-
-    root_t = rhs_t = None
-    if world > 1:                         # torch-owned buffers for the two collectives
-        _, c = kkt.root_panel()
-        root_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
-        _, c = kkt.root_rhs()
-        rhs_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
-
-    def reduce_root(which, buf):
-        if buf is None:
-            return
-        kkt.root_copy(which, "out", P(buf))
-        kkt.sync()
-        dist.all_reduce(buf)
-        torch.cuda.current_stream().synchronize()
-        kkt.root_copy(which, "in", P(buf))
-
-    def newton_step():
-        if world == 1:
-            kkt.update_device(P(d_th), P(d_rp), P(d_rd))
-            for _ in range(args.solves):
-                kkt.solve_device(P(d_dx), P(d_dy), P(d_xp), P(d_xd), sync=False)
-            kkt.sync()
-        else:
-            kkt.update_local(P(d_th), P(d_rp), P(d_rd))
-            reduce_root("panel", root_t)
-            kkt.update_finish()
-            for _ in range(args.solves):
-                kkt.solve_local(P(d_xp), P(d_xd))
-                reduce_root("rhs", rhs_t)
-                kkt.solve_finish(P(d_dx), P(d_dy), P(d_xd))
-            kkt.sync()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        newton_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        newton_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_per_step = 1e3 * elapsed / args.steps
+    def run(workload, steps, warmup, roofline):
+        """Times `steps` Newton steps of `workload`; returns (result dict, A, row_block)."""
+        A, row_block, text = build_workload(args, workload)
+        m, n = A.shape
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=local_rank, row_block=row_block, rank=rank, nranks=world))
+        st = kkt.stats()
+        th, rp, rd, xp, xd = kernel_inputs(m, n, 7, args.regime)
+        d_th, d_rp, d_rd, d_xp, d_xd = (torch.from_numpy(v).to(dev) for v in (th, rp, rd, xp, xd))
+        d_dx = torch.empty(n, dtype=torch.float64, device=dev)
+        d_dy = torch.empty(m, dtype=torch.float64, device=dev)
+        root_t = rhs_t = None
+        if world > 1:                         # torch-owned buffers for the two collectives
+            _, c = kkt.root_panel()
+            root_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
+            _, c = kkt.root_rhs()
+            rhs_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
+        lib_stream = torch.cuda.ExternalStream(kkt.stream_ptr(), device=dev) if world > 1 else None
 
-    # sanity: the residual identities of the reference's conformance test on the last step
-    dx, dy = d_dx.cpu().numpy(), d_dy.cpu().numpy()
-    if dist is not None:       # block rows / columns live on their owner; linking rows replicated
-        t1, t2 = d_dx.clone(), d_dy.clone()
-        dist.all_reduce(t1)
-        lk = torch.from_numpy((row_block < 0)).to(dev)   # world > 1 implies a block-angular workload
-        t2 = torch.where(lk, t2 / world, t2)
-        dist.all_reduce(t2)
-        dx, dy = t1.cpu().numpy(), t2.cpu().numpy()
-    r_p = float(np.abs(A @ dx + rd * dy - xp).max())
-    r_d = float(np.abs(-dx * (th + rp) + A.T @ dy - xd).max())
+        def reduce_root(k, which, buf):
+            # library stream -> (event) -> torch's current stream runs the RCCL all-reduce -> (event) ->
+            # library stream: no host synchronisation between the two halves of update / solve
+            if buf is None:
+                return
+            k.root_copy(which, "out", P(buf))
+            ev = torch.cuda.Event(); ev.record(lib_stream)
+            torch.cuda.current_stream().wait_event(ev)
+            dist.all_reduce(buf)
+            ev2 = torch.cuda.Event(); ev2.record(torch.cuda.current_stream())
+            lib_stream.wait_event(ev2)
+            k.root_copy(which, "in", P(buf))
 
+        def newton_step(k):
+            if world == 1:
+                k.update_device(P(d_th), P(d_rp), P(d_rd))
+                for _ in range(args.solves):
+                    k.solve_device(P(d_dx), P(d_dy), P(d_xp), P(d_xd), sync=False)
+                k.sync()
+            else:
+                k.update_local(P(d_th), P(d_rp), P(d_rd))
+                reduce_root(k, "panel", root_t)
+                k.update_finish()
+                for _ in range(args.solves):
+                    k.solve_local(P(d_xp), P(d_xd))
+                    reduce_root(k, "rhs", rhs_t)
+                    k.solve_finish(P(d_dx), P(d_dy), P(d_xd))
+                k.sync()
+
+        for _ in range(warmup):
+            newton_step(kkt)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            newton_step(kkt)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        ms_per_step = 1e3 * elapsed / steps
+
+        # sanity: the residual identities of the reference's conformance test on the last step
+        dx, dy = d_dx.cpu().numpy(), d_dy.cpu().numpy()
+        if dist is not None:       # block rows / columns live on their owner; linking rows replicated
+            t1, t2 = d_dx.clone(), d_dy.clone()
+            dist.all_reduce(t1)
+            lk = torch.from_numpy((row_block < 0)).to(dev)   # world > 1 implies a block-angular workload
+            t2 = torch.where(lk, t2 / world, t2)
+            dist.all_reduce(t2)
+            dx, dy = t1.cpu().numpy(), t2.cpu().numpy()
+        r_p = float(np.abs(A @ dx + rd * dy - xp).max())
+        r_d = float(np.abs(-dx * (th + rp) + A.T @ dy - xd).max())
+
+        out = {"ms_per_step": ms_per_step, "value": 1e3 / ms_per_step,
+               "config": {"workload": text, "solves_per_step": args.solves, "regime": args.regime,
+                          "parallelism": "blocks/%d" % world, "stream_groups": int(kkt.symbolic("ngroups")[0]),
+                          "nnzS": st["nnzS"], "nnzL": st["nnzL"], "nnzL_stored": st["nnzL_stored"],
+                          "flops_chol": st["flops_chol"], "n_supernodes": st["n_supernodes"], "n_levels": st["n_levels"],
+                          "max_front": st["max_front"], "launches_update": st["launches_update"],
+                          "launches_solve": st["launches_solve"], "ms_analyse": st["ms_analyse"],
+                          "residual_inf": [r_p, r_d]},
+               "frac_step": st["flops_chol"] / (ms_per_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+
+        if roofline:
+            # Per-kernel-class device time of one Newton step, HIP events around every launch on the
+            # stream it is launched on.  The timed region above runs the diagonal blocks on concurrent
+            # stream groups (plus side streams); under that overlap a kernel's [start, end] interval includes
+            # time it shares the chip with other groups' kernels, so the roofline leg replays the SAME
+            # LP and the SAME kernels serialised on one stream (profile mode does that), where every launch
+            # has the device to itself.  profiles/*kernel_stats.csv is taken the same way.
+            # (block-angular LPs: a second handle with ONE stream group, so that a launch holds the tiles of all
+            # diagonal blocks, as it does when the groups run concurrently)
+            kkt1 = kkt if st["n_blocks"] < 2 else tk.setup(
+                A, tk.K1(), tk.Backend(device=local_rank, row_block=row_block, rank=rank, nranks=world, streams=1))
+            newton_step(kkt1)
+            kkt1.set_profile(True)
+            newton_step(kkt1)
+            kt = kkt1.kernel_times()
+            kkt1.set_profile(False)
+            if kkt1 is not kkt:
+                kkt1.close()
+            upd = kt["update"]
+            fl_alg, fl_exec = st["flops_update_alg"], st["flops_update"]
+            sec = upd["ms"] * 1e-3
+            ach = fl_alg / sec / 1e12 if sec > 0 else 0.0
+            traffic, traffic_src = None, None
+            try:        # HBM bytes per launch from the committed PMC pass of this command (cannot be collected in-process)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_update.json")))
+                if pm.get("workload") == workload and world == 1:
+                    traffic = pm["traffic_bytes_per_launch"]
+                    traffic_src = pm.get("source", "profiles/pmc_k_update.json (rocprofv3 --pmc passes of this command, not collected in this run)")
+            except Exception:
+                pass
+            nl = max(upd["launches"], 1)
+            out["roofline"] = {"bound": "mfma", "kernel": "k_update (v_mfma_f64_16x16x4_f64)", "achieved": ach,
+                               "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                               "traffic": traffic, "traffic_source": traffic_src, "launches": upd["launches"],
+                               "avg_launch_ms": upd["ms"] / nl,
+                               "flops_per_step": fl_alg, "flops_per_launch": fl_alg / nl,
+                               "flops": "algorithmic: share of sum_j l_j^2 whose targets lie outside column j's own 256-wide block column (tlpk_stats.flops_update_alg)",
+                               "frac_executed": (fl_exec / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS) if sec > 0 else 0.0,
+                               "flops_executed_per_step": fl_exec,
+                               "frac_if_all_of_flops_chol_were_credited": (st["flops_chol"] / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS) if sec > 0 else 0.0,
+                               "frac_step": out["frac_step"], "peak_measured": 77.9, "measured_with_streams": 1}
+            solve_bytes = 2 * 8 * st["nnzL"] + 2 * 12 * A.nnz + 8 * (4 * n + 3 * m)
+            sol_ms = (kt["solve_fwd"]["ms"] + kt["solve_bwd"]["ms"] + kt["spmv"]["ms"]) / max(args.solves, 1)
+            out["kernel_ms"] = {k: round(v["ms"], 4) for k, v in kt.items()}
+            out["kernel_launches"] = {k: v["launches"] for k, v in kt.items()}
+            out["solve_roofline"] = {"bound": "hbm", "achieved": solve_bytes / (sol_ms * 1e-3) / 1e9 if sol_ms > 0 else 0.0,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_solve": solve_bytes,
+                                     "ms_per_solve": sol_ms}
+            out["solve_roofline"]["frac"] = out["solve_roofline"]["achieved"] / HBM_PEAK_GBS
+
+        if world == 1 and not args.no_host_abi:
+            # The drop-in path: what the Julia glue calls (host pointers in, host pointers out, blocking).
+            dxh, dyh = np.empty(n), np.empty(m)
+            def host_step():
+                tk.update(kkt, th, rp, rd)
+                for _ in range(args.solves):
+                    tk.solve(dxh, dyh, kkt, xp, xd)
+            host_step()
+            hs = max(2, min(steps, 5))
+            t0 = time.perf_counter()
+            for _ in range(hs):
+                host_step()
+            t_host = (time.perf_counter() - t0) / hs
+            out["host_abi"] = {"ms_per_step": 1e3 * t_host, "value": 1.0 / t_host, "unit": "iter/s", "steps": hs,
+                               "pcie_bytes_per_step": 8 * (2 * n + m) + args.solves * 16 * (m + n),
+                               "note": "tlpk_update + %d x tlpk_solve with pageable host vectors through pinned staging; "
+                                       "PCIe-inclusive, never reported as `value`" % args.solves}
+        kkt.close()
+        del d_th, d_rp, d_rd, d_xp, d_xd, d_dx, d_dy
+        torch.cuda.empty_cache()
+        return out, A, row_block
+
+    res, A, row_block = run(args.workload, args.steps, args.warmup, not args.no_roofline)
     out = {
         "metric": "IPM Newton-step rate: KKT.update! (A*D*A'+Rd, supernodal Cholesky) + %d KKT.solve!" % args.solves,
-        "value": 1e3 / ms_per_step, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[2] at reduced scale: general sparse LP A=[A0 I], %d rows x %d structural "
-                                "columns, 25 nnz/col; m=%d n=%d nnz(A)=%d" % (m, n - m, m, n, A.nnz)) if args.workload == "c3" else
-                               "%s: block-angular LP, %d blocks x (%d %s rows x %d vars, %d nnz/col) + %d linking rows; "
-                               "m=%d n=%d nnz(A)=%d" % ("BASELINE configs[3]" if args.workload == "c4" else "north-star headline",
-                                                        args.blocks, args.mk, "inequality" if args.ineq else "equality",
-                                                        args.nk, args.nnz_col, args.m0, m, n, A.nnz),
-                   "solves_per_step": args.solves, "regime": args.regime, "parallelism": "blocks/%d" % world,
-                   "stream_groups": int(kkt.symbolic("ngroups")[0]),
-                   "nnzS": st["nnzS"], "nnzL": st["nnzL"], "nnzL_stored": st["nnzL_stored"],
-                   "flops_chol": st["flops_chol"], "n_supernodes": st["n_supernodes"], "n_levels": st["n_levels"],
-                   "max_front": st["max_front"], "launches_update": st["launches_update"],
-                   "launches_solve": st["launches_solve"], "ms_analyse": st["ms_analyse"],
-                   "residual_inf": [r_p, r_d]},
+        "value": res["value"], "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": res["config"],
     }
-
-    if not args.no_roofline:
-        # Per-kernel-class device time of one Newton step, HIP events around every launch on the
-        # stream it is launched on.  The timed region above runs the diagonal blocks on concurrent
-        # stream groups (plus side streams); under that overlap a kernel's [start, end] interval includes
-        # time it shares the chip with other groups' kernels, so the roofline leg replays the SAME
-        # LP and the SAME kernels with a single-stream schedule (streams=1), where every launch
-        # has the device to itself.  profiles/*kernel_stats.csv is taken the same way.
-        del d_dx  # free a little before the second handle
-        d_dx = torch.empty(n, dtype=torch.float64, device=dev)
-        kkt1 = kkt if st["n_blocks"] < 2 else tk.setup(
-            A, tk.K1(), tk.Backend(device=local_rank, row_block=row_block, rank=rank, nranks=world, streams=1))
-        main_kkt, kkt = kkt, kkt1
-        newton_step()                                   # warm-up of the second handle
-        kkt.set_profile(True)
-        newton_step()
-        kt = kkt.kernel_times()
-        kkt.set_profile(False)
-        upd = kt["update"]
-        fl = kkt.stats()["flops_update"]
-        kkt = main_kkt
-        ach = fl / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] > 0 else 0.0
-        traffic = None
-        try:        # HBM bytes per launch from the committed PMC pass of this command (cannot be collected in-process)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_update.json")))
-            if pm.get("workload") == args.workload and world == 1:
-                traffic = pm["traffic_bytes_per_launch"]
-        except Exception:
-            pass
-        out["roofline"] = {"bound": "mfma", "kernel": "k_update (v_mfma_f64_16x16x4_f64)", "achieved": ach,
-                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                           "traffic": traffic, "launches": upd["launches"],
-                           "avg_launch_ms": upd["ms"] / max(upd["launches"], 1), "flops_per_step": fl,
-                           "flops_per_launch": fl / max(upd["launches"], 1),
-                           "peak_measured": 77.9, "frac_measured": ach / 77.9, "measured_with_streams": 1}
-        solve_bytes = 2 * 8 * st["nnzL"] + 2 * 12 * A.nnz + 8 * (4 * n + 3 * m)
-        sol_ms = (kt["solve_fwd"]["ms"] + kt["solve_bwd"]["ms"] + kt["spmv"]["ms"]) / max(args.solves, 1)
-        out["kernel_ms"] = {k: round(v["ms"], 4) for k, v in kt.items()}
-        out["solve_roofline"] = {"bound": "hbm", "achieved": solve_bytes / (sol_ms * 1e-3) / 1e9 if sol_ms > 0 else 0.0,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_solve": solve_bytes,
-                                 "ms_per_solve": sol_ms}
-        out["solve_roofline"]["frac"] = out["solve_roofline"]["achieved"] / HBM_PEAK_GBS
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
+    out["config"]["configs_untested_by_name"] = ("Netlib 25fv47 / pds-20 .mps are not in the image; generated equivalents of both classes "
+                                                 "run end-to-end (HSD + MPC, HIP vs oracle vs HiGHS) in tests/test_lp_configs.py")
+    for k in ("roofline", "kernel_ms", "kernel_launches", "solve_roofline", "host_abi"):
+        if k in res:
+            out[k] = res[k]
+    if "roofline" not in out:
+        out["frac_step"] = res["frac_step"]
+    if rank == 0 and world == 1 and args.workload == "c4" and not args.no_headline:
+        try:
+            hres, _, _ = run("headline", max(2, min(args.steps, 5)), 1, not args.no_roofline)
+            out["headline"] = {"ms_per_step": hres["ms_per_step"], "value": hres["value"], "unit": "iter/s",
+                               "workload": hres["config"]["workload"], "nnzL": hres["config"]["nnzL"],
+                               "flops_chol": hres["config"]["flops_chol"], "frac_step": hres["frac_step"],
+                               "residual_inf": hres["config"]["residual_inf"], "ms_analyse": hres["config"]["ms_analyse"]}
+            for k in ("roofline", "solve_roofline", "kernel_ms", "host_abi"):
+                if k in hres:
+                    out["headline"][k] = hres[k]
+        except Exception as e:          # the headline leg must never cost the main line
+            out["headline"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c3":
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, A, row_block, args.blocks if args.workload == "c4" else 100)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

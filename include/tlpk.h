@@ -76,8 +76,11 @@ typedef struct tlpk_stats {
     double  ms_last_solve;     /* device time of the last solve */
     int32_t n_local_blocks, n_blocks;
     int64_t root_panel_len;    /* doubles in the root (linking) panel reduced across ranks */
-    double  flops_update;      /* algorithmic flops of the fp64-MFMA update kernel per factorisation:
-                                  2*K*(lower-triangle target entries), summed over its launches */
+    double  flops_update;      /* flops EXECUTED by the fp64-MFMA update kernel per factorisation on the amalgamated
+                                  (zero-padded) structure: 2*K*(lower-triangle target entries), summed over its launches */
+    double  flops_update_alg;  /* ALGORITHMIC flops of that kernel: the share of flops_chol = sum_j l_j^2 whose target
+                                  column lies outside column j's own 256-wide block column, sum_j (l_j - r_j)^2 with the
+                                  true column counts l_j (no amalgamation zeros); <= flops_chol, <= flops_update */
 } tlpk_stats;
 
 /* per-kernel-class timing, filled when options.profile = 1 */

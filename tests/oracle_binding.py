@@ -225,3 +225,114 @@ class OracleK2:
         if getattr(self, "_h", None):
             _lib2().k2o_free(self._h)
             self._h = None
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU supernodal comparator: oracle/k1_supernodal.c (CHOLMOD-class speed baseline + second checker)
+# ------------------------------------------------------------------------------------------------
+_LIB3 = None
+
+
+def openblas_path():
+    """The OpenBLAS shared library that ships inside the SciPy wheel (symbols prefixed `scipy_`)."""
+    import glob
+    import scipy
+    base = os.path.dirname(os.path.dirname(os.path.abspath(scipy.__file__)))
+    hits = sorted(glob.glob(os.path.join(base, "scipy.libs", "libscipy_openblas*.so")))
+    if not hits:
+        raise RuntimeError("SciPy's bundled OpenBLAS not found (scipy.libs/libscipy_openblas*.so)")
+    return hits[0]
+
+
+def _lib3():
+    global _LIB3
+    if _LIB3 is None:
+        path = os.path.join(_ORACLE_DIR, "libk1sn.so")
+        if not os.path.exists(path):
+            build_oracle()
+        lib = C.CDLL(path)
+        p64, pd, vp = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p
+        i64 = C.c_int64
+        lib.k1sn_create.argtypes = ([C.POINTER(vp), C.c_char_p, i64, i64, p64, p64, pd, p64, i64] + [p64] * 9 +
+                                    [i64, p64, i64, p64, i64, p64, i64, p64, p64, p64, p64, pd, i64, C.c_int])
+        lib.k1sn_create.restype = C.c_int
+        lib.k1sn_update.argtypes = [vp, pd, pd, pd]; lib.k1sn_update.restype = C.c_int
+        lib.k1sn_solve.argtypes = [vp, pd, pd, pd, pd]; lib.k1sn_solve.restype = C.c_int
+        lib.k1sn_free.argtypes = [vp]; lib.k1sn_free.restype = None
+        lib.k1sn_fail_col.argtypes = [vp]; lib.k1sn_fail_col.restype = C.c_int64
+        lib.k1sn_threads.argtypes = [vp]; lib.k1sn_threads.restype = C.c_int
+        lib.k1sn_times.argtypes = [vp, pd]; lib.k1sn_times.restype = None
+        lib.k1sn_get_factor.argtypes = [vp, pd, i64]; lib.k1sn_get_factor.restype = C.c_int
+        _LIB3 = lib
+    return _LIB3
+
+
+class SupernodalK1:
+    """CPU supernodal multifrontal Cholesky (OpenBLAS + OpenMP) on the symbolic structure of a libtlpk
+    handle `kkt` (an analyse-only handle is enough): same ordering, same supernodes, same panel
+    layout as the device factor.  threads = 0: all cores."""
+
+    def __init__(self, A, kkt, threads=0):
+        lib = _lib3()
+        from tulip_jl_amd import _lib as tl
+        A = A.tocsc(); A.sort_indices()
+        self.m, self.n = A.shape
+        g = kkt.symbolic
+        c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)   # noqa: E731
+        Ap, Ai, Ax = c64(A.indptr), c64(A.indices), np.ascontiguousarray(A.data, dtype=np.float64)
+        perm = c64(g("perm"))
+        fr = [c64(g(k)) for k in ("front_f", "front_ns", "front_col0", "front_loff", "front_rowoff", "front_reloff",
+                                   "front_child_ptr", "front_nchild", "depth")]
+        rowidx, rel, children = c64(g("rowidx")), c64(g("rel")), c64(g("children"))
+        s_target, s_diag, pair_ptr, pair_j = c64(g("s_target")), c64(g("s_diag_row")), c64(g("pair_ptr")), c64(g("pair_j"))
+        pair_w = np.ascontiguousarray(tl.symbolic_array_f64(kkt._h, "pair_w"))
+        if pair_w.size != pair_ptr[-1]:
+            raise RuntimeError("the handle has released its host assembly lists (device handles do): pass an analyse-only handle")
+        self.lval_len = int(kkt.stats()["nnzL_stored"])
+        self._h = C.c_void_p()
+        rc = lib.k1sn_create(C.byref(self._h), openblas_path().encode(), self.m, self.n, _p64(Ap), _p64(Ai), _pd(Ax), _p64(perm),
+                             len(fr[0]), *[_p64(a) for a in fr], rowidx.size, _p64(rowidx), rel.size, _p64(rel),
+                             children.size, _p64(children), s_target.size, _p64(s_target), _p64(s_diag), _p64(pair_ptr),
+                             _p64(pair_j), _pd(pair_w), self.lval_len, int(threads))
+        if rc != OK:
+            raise RuntimeError(f"k1sn_create rc={rc}")
+        self.threads = int(lib.k1sn_threads(self._h))
+
+    def update(self, theta, regP, regD):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (theta, regP, regD)]
+        rc = _lib3().k1sn_update(self._h, _pd(a[0]), _pd(a[1]), _pd(a[2]))
+        if rc == NOT_POSDEF:
+            raise OraclePosDefError(int(_lib3().k1sn_fail_col(self._h)))
+        if rc != OK:
+            raise RuntimeError(f"k1sn_update rc={rc}")
+
+    def solve(self, xi_p, xi_d):
+        xp = np.ascontiguousarray(xi_p, dtype=np.float64); xd = np.ascontiguousarray(xi_d, dtype=np.float64)
+        dx = np.empty(self.n); dy = np.empty(self.m)
+        rc = _lib3().k1sn_solve(self._h, _pd(dx), _pd(dy), _pd(xp), _pd(xd))
+        if rc != OK:
+            raise RuntimeError(f"k1sn_solve rc={rc}")
+        return dx, dy
+
+    def times(self):
+        t = np.zeros(3)
+        _lib3().k1sn_times(self._h, _pd(t))
+        return {"assemble_s": t[0], "factor_s": t[1], "solve_s": t[2]}
+
+    def factor_panels(self):
+        buf = np.empty(max(self.lval_len, 1))
+        rc = _lib3().k1sn_get_factor(self._h, _pd(buf), buf.size)
+        if rc != OK:
+            raise RuntimeError(f"k1sn_get_factor rc={rc}")
+        return buf[: self.lval_len]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib3().k1sn_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from helpers import SQRT_EPS, ipm_like_data, kkt_residuals, load_golden, random_lp_matrix
+from helpers import SQRT_EPS, golden_tol, ipm_like_data, kkt_residuals, load_golden, random_lp_matrix
 from oracle_binding import OracleK1, OraclePosDefError
 
 
@@ -221,3 +221,76 @@ def test_k2_signed_cholesky_design():
     y = np.linalg.solve(L, b)
     x = np.linalg.solve(L.T, s * y)
     np.testing.assert_allclose(Kp @ x, b, atol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU supernodal comparator (oracle/k1_supernodal.c): pinned against the simplicial oracle, the
+# reference fixture and the golden vectors before bench.py may use it as cpu_baseline
+# ---------------------------------------------------------------------------------------------
+def _analyse_only(A, **kw):
+    import tulip_jl_amd as tk
+    return tk.setup(A, tk.K1(), tk.Backend(device=-1, **kw))
+
+
+def test_supernodal_reference_fixture():
+    from oracle_binding import SupernodalK1
+    A = sp.csc_matrix(np.array([[1.0, 0, 1, 0], [0, 1, 0, 1]]))
+    sn = SupernodalK1(A, _analyse_only(A))
+    sn.update(np.ones(4), np.ones(4), np.ones(2))
+    dx, dy = sn.solve(np.ones(2), np.ones(4))
+    np.testing.assert_allclose(dy, [1.0, 1.0], atol=1e-15)
+    np.testing.assert_allclose(dx, 0.0, atol=1e-15)
+
+
+@pytest.mark.parametrize("g", load_golden(), ids=lambda g: g["name"])
+def test_supernodal_golden_vectors(g):
+    from oracle_binding import SupernodalK1
+    sn = SupernodalK1(g["A_csc"], _analyse_only(g["A_csc"]))
+    sn.update(g["theta_inv"], g["regP"], g["regD"])
+    dx, dy = sn.solve(g["xi_p"], g["xi_d"])
+    scale = max(np.abs(g["dx"]).max(), np.abs(g["dy"]).max(), 1.0)
+    assert np.abs(dx - g["dx"]).max() <= golden_tol(g) * scale
+    assert np.abs(dy - g["dy"]).max() <= golden_tol(g) * scale
+
+
+@pytest.mark.parametrize("threads", [1, 0])
+@pytest.mark.parametrize("seed", range(3))
+def test_supernodal_matches_simplicial_oracle(seed, threads):
+    """L entry by entry, dx, dy: two independent CPU factorisations (simplicial left-looking C vs
+    multifrontal on LAPACK/BLAS) of the same permuted matrix; block-angular structure on seed 2."""
+    from emulate import panels_to_dense_L
+    from helpers import block_angular
+    from oracle_binding import OracleK1, SupernodalK1
+    if seed == 2:
+        A, rb = block_angular(nblocks=5, mk=120, nk=260, m0=30, nnz_in=3, link_prob=0.5, seed=3)
+        kk = _analyse_only(A, row_block=rb)
+    else:
+        A = random_lp_matrix(250 + 400 * seed, 700 + 600 * seed, 3 + 2 * seed, 40 + seed, slack=(seed == 1))
+        kk = _analyse_only(A)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
+    orc = OracleK1(A, kk.perm()); orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    sn = SupernodalK1(A, kk, threads=threads)
+    sn.update(th, rp, rd)
+    dx, dy = sn.solve(xp, xd)
+    L = panels_to_dense_L(kk, sn.factor_panels()); Lo = orc.get_L().toarray()
+    assert np.abs(L - Lo).max() <= 1e-12 * np.abs(Lo).max()
+    assert np.abs(dy - dyo).max() <= 1e-10 * max(1.0, np.abs(dyo).max())
+    assert np.abs(dx - dxo).max() <= 1e-10 * max(1.0, np.abs(dxo).max())
+
+
+def test_supernodal_not_posdef_and_reuse():
+    from oracle_binding import OraclePosDefError, SupernodalK1
+    A = random_lp_matrix(50, 120, 3, 2)
+    sn = SupernodalK1(A, _analyse_only(A))
+    th, rp, rd, xp, xd = ipm_like_data(50, 120, 0)
+    bad = rd.copy(); bad[7] = -1e6
+    with pytest.raises(OraclePosDefError):
+        sn.update(th, rp, bad)
+    with pytest.raises(RuntimeError):
+        sn.solve(xp, xd)
+    sn.update(th, rp, rd)
+    dx, dy = sn.solve(xp, xd)
+    r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+    assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp).max(), np.abs(xd).max()))

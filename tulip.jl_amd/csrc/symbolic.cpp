@@ -747,6 +747,23 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         S.flops_panel += k * k * k / 3.0 + (f - k) * k * k + (f - k) * (f - k) * k;
     }
 
+    // Algorithmic flops of the left-looking MFMA update (k_update), in the CHOLMOD `fl` convention that
+    // defines flops_chol = sum_j l_j^2 (l_j = true nnz of column j of L, no amalgamation zeros): column
+    // j's l_j^2 flops update the l_j trailing rows; the part whose TARGET column lies in the same
+    // NB_OUT-wide block column of the front is done by the potrf / trsm kernels, the rest -- targets in
+    // later block columns and in the update matrix, (l_j - r_j)^2 with r_j = columns left in j's block
+    // column, itself included -- by k_update.  This is the numerator of bench.py's roofline.frac.
+    S.flops_update_alg = 0;
+    for (i32 s = 0; s < ns_total; ++s) {
+        const FrontDesc &w = S.fronts[s];
+        if (!S.front_local[s]) continue;
+        for (i32 c = 0; c < w.ns; ++c) {
+            const i32 r = std::min((c / NB_OUT + 1) * NB_OUT, w.ns) - c;
+            const double l = (double)S.colcount[w.col0 + c] - (double)r;
+            if (l > 0) S.flops_update_alg += l * l;
+        }
+    }
+
     pt.mark("relative indices");
     // ---- 13. relative indices (below-rows of each front -> position in the parent front) ----
     {

@@ -44,6 +44,7 @@ struct tlpk_handle {
     double *d_theta = nullptr, *d_regP = nullptr, *d_regD = nullptr, *d_D = nullptr;
     double *d_xip = nullptr, *d_xid = nullptr, *d_dx = nullptr, *d_dy = nullptr;
     int *h_info = nullptr;
+    double *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-pointer entry points (lazily allocated)
     bool factored = false, local_done = false, solve_local_done = false, solve_timed = false;
     i64 fail_col = -1;
     double ms_analyse = 0, ms_update = 0, ms_solve = 0;
@@ -392,6 +393,8 @@ void tlpk_destroy(tlpk_handle *h) {
         if (h->stream) hipStreamSynchronize(h->stream);
         for (void *p : h->allocs) hipFree(p);
         if (h->h_info) hipHostFree(h->h_info);
+        if (h->pin_in) hipHostFree(h->pin_in);
+        if (h->pin_out) hipHostFree(h->pin_out);
         for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
@@ -495,15 +498,33 @@ int tlpk_update_device(tlpk_handle *h, const double *d_theta, const double *d_re
     return tlpk_update_finish(h);
 }
 
+// Host-pointer entry points: the caller's vectors are ordinary pageable memory (Julia arrays).  They go
+// through pinned staging buffers owned by the handle: vector k+1 is copied into the staging area by the
+// CPU while vector k travels over PCIe (hipMemcpyAsync from pageable memory is synchronous and runs at
+// a fraction of the link rate).  Nothing of the caller's is referenced after the call returns.
+static int ensure_pinned(tlpk_handle *h) {
+    if (h->pin_in) return TLPK_OK;
+    const size_t nin = (size_t)std::max<i64>(2 * h->S.n + h->S.m, 1), nout = (size_t)std::max<i64>(h->S.n + h->S.m, 1);
+    HIPCHK(h, hipHostMalloc((void **)&h->pin_in, nin * 8, hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&h->pin_out, nout * 8, hipHostMallocDefault));
+    return TLPK_OK;
+}
+
 int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
     if (!h || !theta || !regP || !regD) return TLPK_BADARG;
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (int g = sharded_needs_split(h, "tlpk_update")) return g;
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = ensure_pinned(h)) return rc;
     const Symbolic &S = h->S;
-    HIPCHK(h, hipMemcpyAsync(h->d_theta, theta, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_regP, regP, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_regD, regD, (size_t)S.m * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));          // the staging area may still feed an earlier call's copies
+    double *p0 = h->pin_in, *p1 = p0 + S.n, *p2 = p1 + S.n;
+    std::memcpy(p0, theta, (size_t)S.n * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_theta, p0, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(p1, regP, (size_t)S.n * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_regP, p1, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(p2, regD, (size_t)S.m * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_regD, p2, (size_t)S.m * 8, hipMemcpyHostToDevice, h->stream));
     return tlpk_update_device(h, h->d_theta, h->d_regP, h->d_regD);
 }
 
@@ -578,14 +599,24 @@ int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const
     if (!h->factored) return TLPK_NOT_FACTORED;
     if (int g = sharded_needs_split(h, "tlpk_solve")) return g;
     HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = ensure_pinned(h)) return rc;
     const Symbolic &S = h->S;
-    HIPCHK(h, hipMemcpyAsync(h->d_xip, xi_p, (size_t)S.m * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_xid, xi_d, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double *pi0 = h->pin_in, *pi1 = pi0 + S.m;
+    std::memcpy(pi0, xi_p, (size_t)S.m * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_xip, pi0, (size_t)S.m * 8, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(pi1, xi_d, (size_t)S.n * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_xid, pi1, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
     int rc = tlpk_solve_device(h, h->d_dx, h->d_dy, h->d_xip, h->d_xid);
     if (rc != TLPK_OK) return rc;
-    HIPCHK(h, hipMemcpyAsync(dx, h->d_dx, (size_t)S.n * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(dy, h->d_dy, (size_t)S.m * 8, hipMemcpyDeviceToHost, h->stream));
-    return tlpk_sync(h);
+    double *po0 = h->pin_out, *po1 = po0 + S.m;
+    HIPCHK(h, hipMemcpyAsync(po0, h->d_dy, (size_t)S.m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(po1, h->d_dx, (size_t)S.n * 8, hipMemcpyDeviceToHost, h->stream));
+    rc = tlpk_sync(h);
+    if (rc != TLPK_OK) return rc;
+    std::memcpy(dy, po0, (size_t)S.m * 8);
+    std::memcpy(dx, po1, (size_t)S.n * 8);
+    return TLPK_OK;
 }
 
 // ---- introspection ----
@@ -606,6 +637,7 @@ int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
     out->ms_analyse = h->ms_analyse; out->ms_last_update = h->ms_update; out->ms_last_solve = h->ms_solve;
     out->n_local_blocks = S.n_local_blocks; out->n_blocks = S.nblocks;
     out->flops_update = S.flops_update;
+    out->flops_update_alg = S.flops_update_alg;
     out->root_panel_len = (S.root_front >= 0) ? (i64)S.fronts[S.root_front].f * S.fronts[S.root_front].ns : 0;
     return TLPK_OK;
 }

@@ -117,7 +117,7 @@ struct Symbolic {
     std::vector<char> s_local;             // entry assembled by this rank
     // sizes
     i64 nnzS = 0, nnzL = 0, lval_len = 0, ubuf_len[2] = {0, 0}, uc_len = 0, max_front = 0, dinv_len = 0;
-    double flops_chol = 0, flops_panel = 0, flops_update = 0;
+    double flops_chol = 0, flops_panel = 0, flops_update = 0, flops_update_alg = 0;
     // schedules
     std::vector<PotrfTask> potrf_tasks; std::vector<TrsmTask> trsm_tasks;
     std::vector<UpdateTask> update_tasks, reduce_tasks; std::vector<EaTask> ea_tasks;

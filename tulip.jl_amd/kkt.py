@@ -190,6 +190,10 @@ class HIPNormalEquations:
     def sync(self):
         _raise_for(_lib.lib().tlpk_sync(self._h), self._h)
 
+    def stream_ptr(self):
+        """hipStream_t of the handle (an integer address), e.g. for torch.cuda.ExternalStream."""
+        return _lib.lib().tlpk_stream(self._h) or 0
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().tlpk_destroy(self._h)
