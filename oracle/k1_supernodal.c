@@ -212,12 +212,12 @@ static void factor_front(k1sn *h, i64 s, i64 *fail) {
     }
 }
 
-/* levels with at least `nthreads` fronts: one front per thread (BLAS single-threaded);
+/* levels with at least nthreads/2 fronts: one front per thread (BLAS single-threaded);
  * others: one front at a time with the BLAS on all threads */
 #define FOR_LEVEL_FRONTS(h, d, BODY)                                                              \
     do {                                                                                          \
         const i64 a_ = (h)->level_ptr[d], b_ = (h)->level_ptr[(d) + 1];                          \
-        if (b_ - a_ >= (i64)(h)->nthreads && (h)->nthreads > 1) {                                 \
+        if (2 * (b_ - a_) >= (i64)(h)->nthreads && (h)->nthreads > 1) {                                 \
             (h)->setnt(1);                                                                        \
             _Pragma("omp parallel for schedule(dynamic, 1) num_threads((h)->nthreads)")           \
             for (i64 t_ = a_; t_ < b_; ++t_) { const i64 s = (h)->level_fronts[t_]; BODY; }       \

@@ -342,3 +342,42 @@ def test_mpc_starting_point_pattern():
         dxo, dyo = orc.solve(xp, xd)
         assert np.abs(dy - dyo).max() <= 1e-8 * max(1.0, np.abs(dyo).max())
         assert np.abs(dx - dxo).max() <= 1e-8 * max(1.0, np.abs(dxo).max())
+
+
+def test_c4_scale_factor_entrywise_vs_cpu_supernodal():
+    """BASELINE configs[3] at 16 of its 64 diagonal blocks + the 1000 linking rows (m = 81 000,
+    nnz(L) = 1.5e8, 16 fronts of ~4500 x 3500 and the 1000 x 1000 root): the device factor against an
+    independent CPU factorisation of the same permuted matrix with the same supernodes (multifrontal on
+    LAPACK/BLAS, oracle/k1_supernodal.c, itself pinned against the simplicial oracle) -- EVERY stored
+    entry of L, and dx, dy.  Tolerance: 1e-10 x max|L| (fronts are ~26 blocked steps deep)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle_binding import SupernodalK1
+    from workloads import block_angular_lp, kernel_inputs
+    A, row_block = block_angular_lp(blocks=list(range(16)))
+    m, n = A.shape
+    th, rp, rd, xp, xd = kernel_inputs(m, n, 7, "mid")
+    kkt = gpu_setup(A, row_block=row_block)
+    tk.update(kkt, th, rp, rd)
+    dx = np.zeros(n); dy = np.zeros(m)
+    tk.solve(dx, dy, kkt, xp, xd)
+    ana = tk.setup(A, tk.K1(), tk.Backend(device=-1, row_block=row_block))     # host lists for the CPU comparator
+    assert (ana.perm() == kkt.perm()).all()
+    sn = SupernodalK1(A, ana)
+    sn.update(th, rp, rd)
+    dxc, dyc = sn.solve(xp, xd)
+    Lg, Lc = kkt.factor_panels(), sn.factor_panels()
+    f, ns, loff = kkt.symbolic("front_f"), kkt.symbolic("front_ns"), kkt.symbolic("front_loff")
+    lmax = 0.0; worst = 0.0; checked = 0
+    for s in range(len(f)):
+        a = Lg[loff[s]: loff[s] + f[s] * ns[s]].reshape((f[s], ns[s]), order="F")
+        b = Lc[loff[s]: loff[s] + f[s] * ns[s]].reshape((f[s], ns[s]), order="F")
+        mask = np.tril(np.ones((f[s], ns[s]), dtype=bool))                     # stored entries: row >= column
+        lmax = max(lmax, float(np.abs(b[mask]).max()))
+        worst = max(worst, float(np.abs(a[mask] - b[mask]).max()))
+        checked += int(mask.sum())
+    print(f"c4/16 blocks: {checked} factor entries compared, max |L_gpu - L_cpu| = {worst:.3e}, max|L| = {lmax:.3e}")
+    assert checked >= kkt.stats()["nnzL"]
+    assert worst <= 1e-10 * lmax
+    assert np.abs(dy - dyc).max() <= 1e-9 * max(1.0, np.abs(dyc).max())
+    assert np.abs(dx - dxc).max() <= 1e-9 * max(1.0, np.abs(dxc).max())
