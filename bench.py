@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-headline", action="store_true", help="skip the extra north-star headline run (N=1, workload c4 only)")
     ap.add_argument("--no-host-abi", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child-process mode of the cpu_baseline leg
     return ap.parse_args()
 
 
@@ -152,8 +153,29 @@ def build_workload(args, workload):
     return A, row_block, text
 
 
+def cpu_baseline_subprocess(args):
+    """The CPU comparator runs in a child process: its OpenMP / OpenBLAS thread pools stay out of the
+    process that owns the HIP runtime, and a crash of the CPU leg can never cost the GPU line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
+           "--solves", str(args.solves), "--blocks", str(args.blocks), "--mk", str(args.mk), "--nk", str(args.nk),
+           "--m0", str(args.m0), "--nnz-col", str(args.nnz_col), "--regime", args.regime, "--cpu-seconds", str(args.cpu_seconds)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "cpu_baseline child failed rc=%d: %s" % (r.returncode, (r.stderr or "")[-400:])}
+        return json.loads(lines[-1])
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        A, row_block, _ = build_workload(args, args.workload)
+        print(json.dumps(cpu_baseline(args, A, row_block, args.blocks if args.workload == "c4" else 100)))
+        return
     import torch
     import tulip_jl_amd as tk
     from workloads import kernel_inputs
@@ -365,11 +387,9 @@ def main():
         except Exception as e:          # the headline leg must never cost the main line
             out["headline"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c3":
-        try:
-            out["cpu_baseline"] = cpu_baseline(args, A, row_block, args.blocks if args.workload == "c4" else 100)
+        out["cpu_baseline"] = cpu_baseline_subprocess(args)
+        if "value" in out["cpu_baseline"]:
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        except Exception as e:
-            out["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -55,6 +55,7 @@ typedef void (*dgemv_t)(const char *, const blasint *, const blasint *, const do
 typedef void (*dtrsv_t)(const char *, const char *, const char *, const blasint *, const double *, const blasint *,
                         double *, const blasint *);
 typedef void (*setnt_t)(int);
+typedef int (*getnt_t)(void);
 
 typedef struct k1sn {
     i64 m, n, nnzA, nf, nnzS, lval_len, nlevels;
@@ -131,6 +132,15 @@ int k1sn_create(k1sn **out, const char *blas_path, i64 m, i64 n, const i64 *Ap, 
 #else
     h->nthreads = 1; (void)nthreads;
 #endif
+    {
+        /* The OpenBLAS inside the SciPy wheel is compiled for a fixed maximum number of threads (64 in this
+         * image): more concurrent callers than that corrupt its buffer table (observed on a 256-thread host:
+         * "precompiled NUM_THREADS exceeded" followed by heap corruption).  At load time
+         * openblas_get_num_threads() = min(compiled maximum, cores): never run more threads than that. */
+        getnt_t getnt; *(void **)&getnt = dlsym(h->blas, "scipy_openblas_get_num_threads");
+        const int cap = getnt ? getnt() : 1;
+        if (cap >= 1 && h->nthreads > cap) h->nthreads = cap;
+    }
     h->Ap = dup64(Ap, n + 1); h->Ai = dup64(Ai, h->nnzA); h->Ax = dupd(Ax, h->nnzA); h->perm = dup64(perm, m);
     h->f = dup64(f, nf); h->ns = dup64(ns, nf); h->col0 = dup64(col0, nf); h->loff = dup64(loff, nf);
     h->rowoff = dup64(rowoff, nf); h->reloff = dup64(reloff, nf); h->child_ptr = dup64(child_ptr, nf);
