@@ -8,7 +8,7 @@ import numpy as np
 
 LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
           BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12,
-          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17)
+          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17, FWD_SWEEP=18, BWD_SWEEP=19)
 
 
 class Emulator:
@@ -43,7 +43,10 @@ class Emulator:
             LK["BWD_UPDATE"]: g("bwd_update_tasks").reshape(-1, 6),
             LK["FWD_SMALL"]: g("fwd_small_tasks").reshape(-1, 6),
             LK["BWD_SMALL"]: g("bwd_small_tasks").reshape(-1, 6),
+            LK["FWD_SWEEP"]: g("fwd_sweep_tasks").reshape(-1, 6),
+            LK["BWD_SWEEP"]: g("bwd_sweep_tasks").reshape(-1, 6),
         }
+        self.flagoff = g("front_flagoff")
         self.factor_launches = g("factor_launches").reshape(-1, 3)
         self.fwd_launches = g("fwd_launches").reshape(-1, 3)
         self.bwd_launches = g("bwd_launches").reshape(-1, 3)
@@ -344,6 +347,54 @@ class Emulator:
                 assert pos == f, (front, k0, seen)
                 L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
                 self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11.T, self.xw[c0 + k0: c0 + k0 + nb], lower=False)
+
+    # Persistent sweeps: the items of a launch are executed in LIST order = ticket order.  The device hands
+    # them to workgroups in that order, and an item may only wait for items with a smaller ticket (otherwise
+    # the sweep could deadlock): every block an item consumes must already be published when its turn comes.
+    def _k18(self, T):     # forward sweep
+        import scipy.linalg as sla
+        pub = set()
+        for front, k0, nb, _r0, pivot, nin in T:
+            P = self.panel(front); c0 = int(self.col0[front])
+            f, ns = int(self.f[front]), int(self.ns[front])
+            assert self.flagoff[front] >= 0
+            acc = np.zeros(nb)
+            for j in range(nin):                                  # consumed blocks, ascending
+                assert (int(front), j) in pub, ("forward sweep item waits for a later ticket", front, k0, j)
+                w = min(128, ns - 128 * j)
+                acc += P[k0:k0 + nb, 128 * j:128 * j + w] @ self.xw[c0 + 128 * j: c0 + 128 * j + w]
+            if pivot:
+                assert k0 % 128 == 0 and nin == k0 // 128 and k0 + nb <= ns
+                rhs = self.xw[c0 + k0: c0 + k0 + nb] - acc
+                L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
+                self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11, rhs, lower=True)
+                pub.add((int(front), k0 // 128))
+            else:
+                assert k0 >= ns and nin == (ns + 127) // 128
+                uo = int(self.ucoff[front])
+                self.ucflat[uo + k0 - ns: uo + k0 - ns + nb] -= acc
+        self._fwd_pub = getattr(self, "_fwd_pub", set()) | pub
+
+    def _k19(self, T):     # backward sweep
+        import scipy.linalg as sla
+        pub = set()
+        for front, k0, nb, row0, nrows, nlater in T:
+            P = self.panel(front); c0 = int(self.col0[front])
+            f, ns = int(self.f[front]), int(self.ns[front])
+            rows = self.rows(front)
+            nblk = (ns + 127) // 128
+            assert row0 == ns and nrows == f - ns and k0 % 128 == 0 and nlater == nblk - 1 - k0 // 128
+            acc = np.zeros(nb)
+            if nrows > 0:                                         # rows below the pivot block: ancestors' values
+                acc += P[ns:f, k0:k0 + nb].T @ self.xw[rows[ns:]]
+            for q in range(nlater):                               # later blocks, last first
+                j = nblk - 1 - q
+                assert (int(front), j) in pub, ("backward sweep item waits for a later ticket", front, k0, j)
+                w = min(128, ns - 128 * j)
+                acc += P[128 * j:128 * j + w, k0:k0 + nb].T @ self.xw[c0 + 128 * j: c0 + 128 * j + w]
+            L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
+            self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11.T, self.xw[c0 + k0: c0 + k0 + nb] - acc, lower=False)
+            pub.add((int(front), k0 // 128))
 
     # dense L in permuted numbering, from the panels
     def dense_L(self):

@@ -381,3 +381,63 @@ def test_c4_scale_factor_entrywise_vs_cpu_supernodal():
     assert worst <= 1e-10 * lmax
     assert np.abs(dy - dyc).max() <= 1e-9 * max(1.0, np.abs(dyc).max())
     assert np.abs(dx - dxc).max() <= 1e-9 * max(1.0, np.abs(dxc).max())
+
+
+def test_persistent_sweeps_hand_over_stress(monkeypatch):
+    """The solve sweeps hand solved blocks from workgroup to workgroup inside one launch (flags +
+    agent-scope atomics).  A wrong hand-over shows up as a stale or torn block, typically only under
+    load and not in every run: 40 solves of a block-angular LP with 24 fronts of ~1000 pivot columns
+    (8 chained blocks each, several hundred workgroups in flight) must all be BITWISE identical to the
+    first one, agree with the oracle, and agree with the launch-per-block schedule (TLPK_SWEEP=0) to
+    rounding (different summation grouping)."""
+    A, row_block = block_angular(nblocks=24, mk=1500, nk=3000, m0=300, nnz_in=4, link_prob=0.5, seed=77)
+    m, n = A.shape
+    kkt = gpu_setup(A, row_block=row_block)
+    assert len(kkt.symbolic("fwd_sweep_tasks")) > 0 and len(kkt.symbolic("bwd_sweep_tasks")) > 0
+    assert kkt.symbolic("front_ns").max() > 700
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 5)
+    tk.update(kkt, th, rp, rd)
+    first = None
+    rng = np.random.default_rng(1)
+    for it in range(40):
+        dx = np.full(n, np.nan); dy = np.full(m, np.nan)
+        tk.solve(dx, dy, kkt, xp, xd)
+        if first is None:
+            first = (dx.copy(), dy.copy())
+        assert (dx == first[0]).all() and (dy == first[1]).all(), f"solve {it} differs from solve 0"
+        if it % 8 == 3:                                   # other right-hand sides in between: the flags must not leak
+            tk.solve(np.empty(n), np.empty(m), kkt, rng.standard_normal(m), rng.standard_normal(n))
+    orc = OracleK1(A, kkt.perm()); orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    assert np.abs(first[1] - dyo).max() <= 1e-9 * max(1.0, np.abs(dyo).max())
+    assert np.abs(first[0] - dxo).max() <= 1e-9 * max(1.0, np.abs(dxo).max())
+    monkeypatch.setenv("TLPK_SWEEP", "0")
+    k0 = gpu_setup(A, row_block=row_block)
+    assert len(k0.symbolic("fwd_sweep_tasks")) == 0
+    tk.update(k0, th, rp, rd)
+    dx0 = np.zeros(n); dy0 = np.zeros(m)
+    tk.solve(dx0, dy0, k0, xp, xd)
+    assert np.abs(dy0 - first[1]).max() <= 1e-11 * max(1.0, np.abs(dyo).max())
+
+
+def test_persistent_sweeps_long_chain_single_front():
+    """General sparse shape (one dense front of ~2400 pivot columns = a chain of 19 hand-overs, ragged
+    last block) solved repeatedly; compared with the oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from workloads import general_sparse_lp
+    A = general_sparse_lp(2500)
+    m, n = A.shape
+    kkt = gpu_setup(A)
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 6)
+    tk.update(kkt, th, rp, rd)
+    orc = OracleK1(A, kkt.perm()); orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    ref = None
+    for _ in range(10):
+        dx = np.zeros(n); dy = np.zeros(m)
+        tk.solve(dx, dy, kkt, xp, xd)
+        ref = ref or (dx.copy(), dy.copy())
+        assert (dx == ref[0]).all() and (dy == ref[1]).all()
+    assert np.abs(dy - dyo).max() <= 1e-8 * max(1.0, np.abs(dyo).max())
+    assert np.abs(dx - dxo).max() <= 1e-8 * max(1.0, np.abs(dxo).max())

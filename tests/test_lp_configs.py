@@ -113,7 +113,12 @@ def test_c2_equivalent_hip_vs_oracle_and_highs(alg):
     hg, sg = solve_lp(lp, lambda A: HipBackend(A, device=0), algorithm=alg)
     perm = hg.kkt.kkt.perm()
     hc, sc = solve_lp(lp, lambda A: OracleBackend(A, perm), algorithm=alg)
-    assert_backends_agree(hg, sg, hc, sc)
+    # Objectives to 1e-7 here, not 1e-8: the loop stops at a relative gap of sqrt(eps) = 1.5e-8, and on this
+    # instance (coefficients over five decades, free and boxed columns) the point it stops at moves by
+    # ~2e-8 relative in the objective under ANY change of rounding -- the CPU oracle run with the natural
+    # ordering instead of AMD differs from itself by 1.7e-8 (measured: -17964.58659835 vs -17964.58629092).
+    # Status, iteration count (+-1), residual norms and HiGHS's optimum (1e-6) are asserted as everywhere.
+    assert_backends_agree(hg, sg, hc, sc, obj_tol=1e-7)
     assert hg.timers["n_bump"] == hc.timers["n_bump"] == 0
     assert abs(sg["z_primal"] - STAIR25_OPT) <= 1e-6 * (1 + abs(STAIR25_OPT))
 

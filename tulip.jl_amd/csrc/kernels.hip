@@ -1005,6 +1005,39 @@ __global__ __launch_bounds__(256) void k_fwd_gather(const SolveTask *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Hand-over of a solved block between workgroups of ONE launch (persistent sweeps below).
+// /opt/skills/guides/cdna_hip_programming.md Guideline 16, the "8-byte agent-scope atomics on both
+// sides" form: the payload (<= 128 doubles) is stored with relaxed agent-scope atomic stores
+// (write-through `sc1` stores), every storing wave drains its stores (s_waitcnt vmcnt(0)), a
+// barrier, then ONE lane stores the flag (relaxed, agent scope).  The consumer polls the flag with
+// relaxed agent-scope loads from one lane (s_sleep between polls), a barrier, then reads the
+// payload with relaxed agent-scope atomic loads (`sc1`: never served from the reading CU's L1).
+// No fences, nothing depends on placement.  Round 1's attempt failed exactly where the guide says it
+// must: plain payload stores + relaxed flag (stale half the time), or __threadfence() per workgroup.
+// Every spin is bounded: a workgroup that waits longer than ~2 s sets info[1] and everybody leaves
+// (the host reports TLPK_INTERNAL) -- a scheduling bug must never hang the device.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane: wait until *flag == epoch; false = aborted (timeout here or elsewhere)
+__device__ __forceinline__ bool wait_flag(const unsigned *flag, unsigned epoch, int *info) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (spins > (1u << 21)) { __hip_atomic_store(info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        }
+    }
+    asm volatile("" ::: "memory");        // nothing that follows may be scheduled above the poll
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
 // Diagonal blocks of the triangular solves (nb <= SOLVE_NB = 2 sub-blocks of NB_IN) with the
 // inverted 64 x 64 sub-blocks written by k_potrf*:
 //   forward   y1 = Wa b1 ;  y2 = Wb (b2 - L21 y1)
@@ -1028,7 +1061,7 @@ constexpr int FWD_DIAG_SCRATCH = 2 * SOLVE_NB + 4 * NB_IN;     // doubles of LDS
 template <bool BACKWARD, int WHICH>
 __device__ __forceinline__ void load_frag(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb, double (&w)[16]) {
     const i32 f = fd.f, na = min(nb, NB_IN), nb2 = nb - na;
-    const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int i = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const double *M; i64 ld; i32 nr, nc;                   // matrix, leading dimension, rows, columns
     if (WHICH == 0) { M = front_dinv(c, fd, bk0); ld = na; nr = na; nc = na; }
     else if (WHICH == 1) { M = c.Lval + fd.loff + (i64)(bk0 + NB_IN) + (i64)bk0 * f; ld = f; nr = nb2; nc = na; }
@@ -1060,27 +1093,36 @@ __device__ __forceinline__ double dot4(const double (&w)[16], const double *v, i
 
 // scratch layout: vin[SOLVE_NB] (rhs of the block, zero beyond nb, filled by the caller, then a
 // barrier) | vout[SOLVE_NB] | ps[4][NB_IN].  The result is written to xw[col0 + bk0 ..).
+// PUBLISH: the result is stored with agent-scope (write-through) stores for a hand-over inside the launch.
+// The three operand fragments are requested before the first product: one memory round trip instead of three
+// on the sweep's serial chain.
+template <bool PUBLISH = false>
 __device__ __forceinline__ void fwd_diag_solve(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb, double *scratch) {
     double *bs = scratch, *ys = scratch + SOLVE_NB;
     double (*ps)[NB_IN] = reinterpret_cast<double (*)[NB_IN]>(scratch + 2 * SOLVE_NB);
     const i32 na = min(nb, NB_IN), nb2 = nb - na;
     const int tid = threadIdx.x, i = tid & 63, part = tid >> 6;
-    double w[16];
+    double w[16], w1[16], w2[16];
     load_frag<false, 0>(c, fd, bk0, nb, w);
+    if (nb2 > 0) {                                             // workgroup-uniform
+        load_frag<false, 1>(c, fd, bk0, nb, w1);
+        load_frag<false, 2>(c, fd, bk0, nb, w2);
+    }
     const double y = dot4(w, bs, i, part, ps);                 // y1 = Wa b1
     if (part == 0) ys[i] = y;                                  // zero for i >= na (masked fragment)
     __syncthreads();
     if (nb2 > 0) {
-        load_frag<false, 1>(c, fd, bk0, nb, w);
-        const double sl = dot4(w, ys, i, part, ps);            // L21 y1
+        const double sl = dot4(w1, ys, i, part, ps);           // L21 y1
         if (part == 0) bs[NB_IN + i] -= sl;
         __syncthreads();
-        load_frag<false, 2>(c, fd, bk0, nb, w);
-        const double y2 = dot4(w, bs + NB_IN, i, part, ps);    // y2 = Wb (b2 - L21 y1)
+        const double y2 = dot4(w2, bs + NB_IN, i, part, ps);   // y2 = Wb (b2 - L21 y1)
         if (part == 0) ys[NB_IN + i] = y2;
         __syncthreads();
     }
-    if (tid < nb) c.xw[fd.col0 + bk0 + tid] = ys[tid];
+    if (tid < nb) {
+        if (PUBLISH) st_agent(c.xw + fd.col0 + bk0 + tid, ys[tid]);
+        else c.xw[fd.col0 + bk0 + tid] = ys[tid];
+    }
 }
 
 // column sums over the 64 lanes (rows k) of 16 products per lane; lane 0 ends up with the 16 sums
@@ -1093,34 +1135,35 @@ __device__ __forceinline__ void reduce16(double (&p)[16]) {
 }
 
 // scratch layout: t[SOLVE_NB] (rhs, zero beyond nb) | x[SOLVE_NB]
+template <bool PUBLISH = false>
 __device__ __forceinline__ void bwd_diag_solve(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb, double *scratch) {
     double *ts = scratch, *xo = scratch + SOLVE_NB;
     const i32 na = min(nb, NB_IN), nb2 = nb - na;
     const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
-    double w[16];
+    double w[16], w1[16], w2[16];
+    load_frag<true, 0>(c, fd, bk0, nb, w);                         // all fragments requested up front
     if (nb2 > 0) {
-        load_frag<true, 2>(c, fd, bk0, nb, w);
+        load_frag<true, 2>(c, fd, bk0, nb, w2);
+        load_frag<true, 1>(c, fd, bk0, nb, w1);
         const double t2 = ts[NB_IN + lane];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) w[kk] *= t2;               // x2[ci] = sum_k Wb[k][ci] t2[k]
-        reduce16(w);
+        for (int kk = 0; kk < 16; ++kk) w2[kk] *= t2;              // x2[ci] = sum_k Wb[k][ci] t2[k]
+        reduce16(w2);
         if (lane == 0) {
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) xo[NB_IN + 16 * part + kk] = w[kk];     // zero for ci >= nb2
+            for (int kk = 0; kk < 16; ++kk) xo[NB_IN + 16 * part + kk] = w2[kk];     // zero for ci >= nb2
         }
         __syncthreads();
-        load_frag<true, 1>(c, fd, bk0, nb, w);
         const double x2 = xo[NB_IN + lane];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) w[kk] *= x2;               // sum_k L21[k][ci] x2[k]
-        reduce16(w);
+        for (int kk = 0; kk < 16; ++kk) w1[kk] *= x2;              // sum_k L21[k][ci] x2[k]
+        reduce16(w1);
         if (lane == 0) {
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) ts[16 * part + kk] -= w[kk];
+            for (int kk = 0; kk < 16; ++kk) ts[16 * part + kk] -= w1[kk];
         }
         __syncthreads();
     }
-    load_frag<true, 0>(c, fd, bk0, nb, w);
     const double t1 = ts[lane];
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) w[kk] *= t1;                   // x1[ci] = sum_k Wa[k][ci] t1[k]
@@ -1130,7 +1173,10 @@ __device__ __forceinline__ void bwd_diag_solve(const DevCtx &c, const FrontDesc 
         for (int kk = 0; kk < 16; ++kk) xo[16 * part + kk] = w[kk];
     }
     __syncthreads();
-    if (tid < nb) c.xw[fd.col0 + bk0 + tid] = xo[tid];
+    if (tid < nb) {
+        if (PUBLISH) st_agent(c.xw + fd.col0 + bk0 + tid, xo[tid]);
+        else c.xw[fd.col0 + bk0 + tid] = xo[tid];
+    }
 }
 
 // first block of every front of a level: nothing to overlap with
@@ -1289,6 +1335,194 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
 }
 
 // ------------------------------------------------------------------------------------------
+// Persistent sweeps: the whole forward (backward) substitution of every non-small front of a tree
+// level in ONE launch.  The block steps of a front are a serial chain (26 steps for a 3300-column
+// front, 380 for the 48 000-column front of the general sparse benchmark); with one launch per step
+// the chain costs ~25 us per step (launch + a diagonal workgroup that starts cold), and every
+// launch ends with a tail.  Here a workgroup owns a 128-row chunk (forward) or a 128-column block
+// (backward) of one front for the whole sweep, keeps its partial sums in registers / LDS, streams its
+// part of L exactly once, and receives each solved block through a flag (hand-over protocol above).
+//   * items are handed out through a ticket counter in an order in which an item only waits for items
+//     with SMALLER tickets (symbolic.cpp): those are held by workgroups that already run, so the
+//     sweep cannot deadlock whatever the dispatch order or residency;
+//   * L is static: the panel columns of the NEXT block are requested before the wait for its flag, so
+//     behind a flag there is one x read, the arithmetic, the diagonal solve and the publish;
+//   * fixed summation order per item => bitwise deterministic, independent of scheduling.
+// ------------------------------------------------------------------------------------------
+constexpr int SW_B = 16;                    // forward: panel columns per batch per thread
+
+__global__ __launch_bounds__(256, 4) void k_fwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
+    __shared__ double xs[2][SOLVE_NB];               // solved blocks, double-buffered by block parity
+    __shared__ double scratch[FWD_DIAG_SCRATCH];
+    __shared__ unsigned s_item;
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) - a.base); s_ok = 1; }
+    __syncthreads();
+    const SolveTask t = tasks[s_item];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns;
+    const int r = tid & (SOLVE_NB - 1);                        // row of the chunk
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 7);    // column half of a block: wave-uniform
+    // addresses = wave-uniform column base (scalar registers) + 32-bit lane offset: no 64-bit address pair per load
+    const char *Lb = reinterpret_cast<const char *>(c.Lval + fd.loff);
+    const unsigned roff = (unsigned)min(t.k0 + r, f - 1) * 8u;  // clamped row: its result is never stored
+    unsigned *flags = a.flags + fd.flagoff;
+    const i32 nin = t.nslot, nsteps = 4 * nin;                 // a block = 4 batches of SW_B columns per half
+    double acc = 0.0;
+    double b0[SW_B], b1[SW_B];
+    auto issue = [&](double (&b)[SW_B], const i32 step) {
+        const i32 c0 = (step >> 2) * SOLVE_NB + 64 * h + SW_B * (step & 3);
+#pragma unroll
+        for (int j = 0; j < SW_B; ++j)                          // clamped column: x is zero beyond the block
+            b[j] = *reinterpret_cast<const double *>(Lb + (size_t)min(c0 + j, ns - 1) * (size_t)f * 8u + roff);
+    };
+    auto consume = [&](const double (&b)[SW_B], const double *x) {
+#pragma unroll
+        for (int j = 0; j < SW_B; ++j) acc += b[j] * x[j];
+    };
+    if (nsteps > 0) { issue(b0, 0); issue(b1, 1); }
+    for (i32 j = 0; j < nin; ++j) {
+        if (tid < 64) {                                        // wave 0: wait for block j, stage it
+            int ok = 1;
+            if (tid == 0) ok = wait_flag(flags + j, a.epoch, c.info) ? 1 : 0;
+            ok = __shfl(ok, 0);
+            if (!ok) { if (tid == 0) s_ok = 0; }
+            else {
+                const i32 wj = min(SOLVE_NB, ns - j * SOLVE_NB);
+                const double *xg = c.xw + fd.col0 + j * SOLVE_NB;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int idx = tid + 64 * u;
+                    const double v = ld_agent(xg + min(idx, wj - 1));
+                    xs[j & 1][idx] = (idx < wj) ? v : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        if (!s_ok) return;
+        const double *x = xs[j & 1] + 64 * h;
+        const i32 st = 4 * j;
+        // unconditional prefetch (the step is clamped: the last two batches of an item are requested again
+        // and dropped) -- a guarded prefetch makes the compiler keep both versions of the buffer alive
+        const i32 last = nsteps - 1;
+        consume(b0, x);            issue(b0, min(st + 2, last));
+        consume(b1, x + SW_B);     issue(b1, min(st + 3, last));
+        consume(b0, x + 2 * SW_B); issue(b0, min(st + 4, last));
+        consume(b1, x + 3 * SW_B); issue(b1, min(st + 5, last));
+    }
+    // the two column halves of a row, in fixed order
+    double *red = scratch + 2 * SOLVE_NB;
+    if (h == 1) red[r] = acc;
+    __syncthreads();
+    const double total = (h == 0) ? acc + red[r] : 0.0;
+    if (t.slot == 0) {                                         // rows below the pivot block: contribution vector
+        if (h == 0 && r < t.nb) { double *dst = c.uc + fd.ucoff + (t.k0 + r - ns); *dst = *dst - total; }
+        return;
+    }
+    if (tid < SOLVE_NB) scratch[tid] = (tid < t.nb) ? c.xw[fd.col0 + t.k0 + min(tid, t.nb - 1)] - total : 0.0;
+    __syncthreads();
+    fwd_diag_solve<true>(c, fd, t.k0, t.nb, scratch);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + t.k0 / SOLVE_NB, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Backward: item = column block [k0, k0 + nb) of a front.  t[k0 + j] = b - sum_r L[r, k0 + j] x[r] over the
+// rows below the pivot block (values of the ancestors, known at launch) and over the LATER pivot blocks of
+// the front, consumed as they are published (last block first); then the diagonal solve and the publish.
+// Lanes run along the contiguous rows, a wave owns a quarter of the columns (batches of 8, next batch in
+// flight while the current one is reduced by shuffles), sums per column accumulate in LDS in fixed order.
+__global__ __launch_bounds__(256, 4) void k_bwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
+    __shared__ double scratch[FWD_DIAG_SCRATCH];
+    __shared__ double tacc[SOLVE_NB];
+    __shared__ unsigned s_item;
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) { s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) - a.base); s_ok = 1; }
+    if (tid < SOLVE_NB) tacc[tid] = 0.0;
+    __syncthreads();
+    const SolveTask t = tasks[s_item];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 f = fd.f, ns = fd.ns, nb = t.nb;
+    const i32 *rows = c.rowidx + fd.rowoff;
+    unsigned *flags = a.flags + fd.flagoff;
+    const i32 nblk = (ns + SOLVE_NB - 1) / SOLVE_NB;
+    const i32 nbelow = (t.slot + BWD_ROWS - 1) / BWD_ROWS;      // tiles of rows below the pivot block
+    const i32 ntiles = nbelow + t.nslot;
+    const char *P0b = reinterpret_cast<const char *>(c.Lval + fd.loff + (i64)t.k0 * f);
+    constexpr int CB = 8, RPL = BWD_ROWS / 64;
+    for (i32 q = 0; q < ntiles; ++q) {
+        const bool below = q < nbelow;
+        const i32 jb = below ? 0 : nblk - 1 - (q - nbelow);     // pivot block consumed by this tile
+        const i32 r0 = below ? t.row0 + q * BWD_ROWS : jb * SOLVE_NB;
+        const i32 nr = below ? min(BWD_ROWS, t.row0 + t.slot - r0) : min(SOLVE_NB, ns - r0);
+        i32 ro[RPL];
+        unsigned rb[RPL];
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) { ro[u] = min(lane + 64 * u, nr - 1); rb[u] = (unsigned)(r0 + ro[u]) * 8u; }   // clamped: the matching x is zeroed
+        double cur[CB][RPL], nxt[CB][RPL];
+        auto fetch = [&](double (&dst)[CB][RPL], const i32 j0) {
+#pragma unroll
+            for (int jj = 0; jj < CB; ++jj) {
+                const char *col = P0b + (size_t)min(j0 + jj, nb - 1) * (size_t)f * 8u;   // wave-uniform; clamped: extra columns are dropped below
+#pragma unroll
+                for (int u = 0; u < RPL; ++u) dst[jj][u] = *reinterpret_cast<const double *>(col + rb[u]);
+            }
+        };
+        fetch(cur, wave * CB);                                  // static data: requested before the wait
+        double xr[RPL];
+        if (below) {
+            i32 gi[RPL];
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) gi[u] = rows[r0 + ro[u]];
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) { const double xv = c.xw[gi[u]]; xr[u] = (lane + 64 * u < nr) ? xv : 0.0; }
+        } else {
+            if (tid == 0 && !wait_flag(flags + jb, a.epoch, c.info)) s_ok = 0;
+            __syncthreads();
+            if (!s_ok) return;
+            const double *xg = c.xw + fd.col0 + r0;
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) { const double xv = ld_agent(xg + ro[u]); xr[u] = (lane + 64 * u < nr) ? xv : 0.0; }
+        }
+#pragma unroll 1
+        for (i32 j0 = wave * CB; j0 < nb; j0 += 4 * CB) {
+            fetch(nxt, j0 + 4 * CB);                            // unconditional (clamped columns)
+            double accv[CB];
+#pragma unroll
+            for (int jj = 0; jj < CB; ++jj) {
+                double s_ = 0.0;
+#pragma unroll
+                for (int u = 0; u < RPL; ++u) s_ += cur[jj][u] * xr[u];
+                accv[jj] = s_;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+                for (int jj = 0; jj < CB; ++jj) accv[jj] += __shfl_down(accv[jj], off);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int jj = 0; jj < CB; ++jj) if (j0 + jj < nb) tacc[j0 + jj] += accv[jj];
+            }
+#pragma unroll
+            for (int jj = 0; jj < CB; ++jj)
+#pragma unroll
+                for (int u = 0; u < RPL; ++u) cur[jj][u] = nxt[jj][u];
+        }
+    }
+    __syncthreads();
+    if (tid < SOLVE_NB) scratch[tid] = (tid < nb) ? c.xw[fd.col0 + t.k0 + min(tid, nb - 1)] - tacc[tid] : 0.0;
+    __syncthreads();
+    bwd_diag_solve<true>(c, fd, t.k0, nb, scratch);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + t.k0 / SOLVE_NB, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------
 // Small fronts (ns <= SMALL_NS pivot columns, any number of rows below): one WAVE per front does a
 // whole sweep step of the front -- the leaf levels hold most of the fronts, and a 256-thread
 // workgroup per front in two or three kernels per level is nearly all fixed latency.  Four fronts per
@@ -1435,7 +1669,7 @@ void launch_single_solve(hipStream_t st, const DevArrays &a) {
         hipLaunchKernelGGL(k_single_solve, dim3(nblk(a.n_single, 256)), dim3(256), 0, st, a.n_single, a.single_dinvoff, a.single_col,
                            a.ctx.dinv, a.ctx.xw);
 }
-void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
+void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const SweepArgs *sw) {
     if (L.count <= 0) return;
     const dim3 g((unsigned)L.count);
     switch (L.kind) {
@@ -1453,6 +1687,8 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L) {
     case LK_BWD_UPDATE: hipLaunchKernelGGL(k_bwd_update, g, dim3(256), 0, st, a.bwd_update_tasks + L.first, a.ctx); break;
     case LK_FWD_SMALL: hipLaunchKernelGGL(k_fwd_small, g, dim3(256), 0, st, a.fwd_small_tasks + L.first, a.ctx); break;
     case LK_BWD_SMALL: hipLaunchKernelGGL(k_bwd_small, g, dim3(256), 0, st, a.bwd_small_tasks + L.first, a.ctx); break;
+    case LK_FWD_SWEEP: if (sw) hipLaunchKernelGGL(k_fwd_sweep, g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw); break;
+    case LK_BWD_SWEEP: if (sw) hipLaunchKernelGGL(k_bwd_sweep, g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw); break;
     default: break;
     }
 }

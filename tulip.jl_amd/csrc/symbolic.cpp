@@ -1130,6 +1130,19 @@ static void build_schedule(Symbolic &S) {
     // ---------------- forward solve: deepest level first ----------------
     // (thin but TALL fronts keep the workgroup-per-row-chunk kernels: one wave walking 1000 rows is slower)
     auto is_small = [&](i32 s) { return S.fronts[s].ns <= SMALL_NS && S.fronts[s].f - S.fronts[s].ns <= SMALL_ROWS && s != S.root_front; };
+    // Persistent sweeps (default): the block steps of a level's triangular solves run inside ONE launch per
+    // direction; a solved SOLVE_NB-wide block is handed to the workgroups that need it through a flag word
+    // per (front, block).  TLPK_SWEEP=0 keeps one launch per block step (the round-1 schedule).
+    S.sweep = true;
+    if (const char *e = std::getenv("TLPK_SWEEP")) S.sweep = std::atoi(e) != 0;
+    S.n_sweep_flags = 0;
+    for (size_t s = 0; s < S.fronts.size(); ++s) {
+        FrontDesc &w = S.fronts[s];
+        w.flagoff = -1;
+        if (!S.front_local[s] || S.front_single[s] || is_small((i32)s)) continue;
+        w.flagoff = (i32)S.n_sweep_flags;
+        S.n_sweep_flags += (w.ns + SOLVE_NB - 1) / SOLVE_NB;
+    }
     auto fwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
         const bool root_level = (d == 0 && S.root_front >= 0);
@@ -1161,6 +1174,34 @@ static void build_schedule(Symbolic &S) {
         }
         i32 max_ns = 0;
         for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t]) && !is_small(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
+        if (S.sweep) {
+            // Items in hand-out order (workgroups draw them from a ticket counter): chunk index first, front
+            // second, so that an item only ever waits for items with a smaller ticket -- those are held by
+            // workgroups that are already running, whatever the dispatch order (no deadlock), and the fronts of
+            // the level advance side by side.
+            const i64 first = (i64)S.fwd_sweep_tasks.size();
+            i32 max_chunks = 0;
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (!in_scope(s) || is_small(s)) continue;
+                const FrontDesc &w = S.fronts[s];
+                max_chunks = std::max(max_chunks, (w.ns + SOLVE_NB - 1) / SOLVE_NB + (w.f - w.ns + SOLVE_NB - 1) / SOLVE_NB);
+            }
+            for (i32 ci = 0; ci < max_chunks; ++ci)
+                for (i32 t = t0; t < t1; ++t) {
+                    const i32 s = S.level_fronts[t];
+                    if (!in_scope(s) || is_small(s)) continue;
+                    const FrontDesc &w = S.fronts[s];
+                    const i32 nblk = (w.ns + SOLVE_NB - 1) / SOLVE_NB;
+                    if (ci < nblk) S.fwd_sweep_tasks.push_back(SolveTask{s, ci * SOLVE_NB, std::min(SOLVE_NB, w.ns - ci * SOLVE_NB), 0, 1, ci, 0, 0});
+                    else {
+                        const i32 r0 = w.ns + (ci - nblk) * SOLVE_NB;
+                        if (r0 < w.f) S.fwd_sweep_tasks.push_back(SolveTask{s, r0, std::min(SOLVE_NB, w.f - r0), 0, 0, nblk, 0, 0});
+                    }
+                }
+            push_launch(S.fwd_launches, LK_FWD_SWEEP, first, (i64)S.fwd_sweep_tasks.size() - first);
+            max_ns = 0;        // no per-block launches
+        }
         for (i32 kb = 0; kb < max_ns; kb += SOLVE_NB) {
             const i64 f_diag = (i64)S.fwd_diag_tasks.size(), f_upd = (i64)S.fwd_update_tasks.size();
             // pass 0: the look-ahead workgroups (first row chunk: they also solve the next diagonal
@@ -1207,7 +1248,24 @@ static void build_schedule(Symbolic &S) {
         }
         i32 max_ns = 0;
         for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t]) && !is_small(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
-        const i32 nblk = (max_ns + SOLVE_NB - 1) / SOLVE_NB;
+        i32 nblk = (max_ns + SOLVE_NB - 1) / SOLVE_NB;
+        if (S.sweep) {
+            // hand-out order: distance of the column block from the END of its front first (a block waits for the
+            // later blocks of its own front only), front second
+            const i64 first = (i64)S.bwd_sweep_tasks.size();
+            for (i32 dd = 0; dd < nblk; ++dd)
+                for (i32 t = t0; t < t1; ++t) {
+                    const i32 s = S.level_fronts[t];
+                    if (!in_scope(s) || is_small(s)) continue;
+                    const FrontDesc &w = S.fronts[s];
+                    const i32 my_nblk = (w.ns + SOLVE_NB - 1) / SOLVE_NB;
+                    if (dd >= my_nblk) continue;
+                    const i32 kb = my_nblk - 1 - dd;
+                    S.bwd_sweep_tasks.push_back(SolveTask{s, kb * SOLVE_NB, std::min(SOLVE_NB, w.ns - kb * SOLVE_NB), w.ns, w.f - w.ns, dd, 0, 0});
+                }
+            push_launch(S.bwd_launches, LK_BWD_SWEEP, first, (i64)S.bwd_sweep_tasks.size() - first);
+            nblk = 0;
+        }
         for (i32 b = 0; b < nblk; ++b) {
             const i64 f_upd = (i64)S.bwd_update_tasks.size();
             // pass 0: the workgroups that also solve a diagonal block (critical path) start first

@@ -51,6 +51,10 @@ struct tlpk_handle {
     tlpk_kernel_times kt{};
     size_t factor_marker = 0, fwd_marker = 0;   // index of the LK_ALLREDUCE_ROOT launch (or size)
     i64 first_link = 0, nlink = 0;
+    // persistent sweeps: ticket-counter slot and number of runs of every sweep launch, flag epoch
+    std::vector<i32> sweep_slot_fwd, sweep_slot_bwd;
+    std::vector<unsigned long long> sweep_runs_fwd, sweep_runs_bwd;
+    unsigned long long solve_epoch = 0;
     std::string last_error;
 };
 
@@ -97,7 +101,7 @@ int kind_class(i32 kind) {
     case LK_TRSM: case LK_TRSM_THIN: return TLPK_KC_TRSM;
     case LK_UPDATE: return TLPK_KC_UPDATE;
     case LK_UPDATE_REDUCE: return TLPK_KC_UPDATE_REDUCE;
-    case LK_FWD_GATHER: case LK_FWD_DIAG: case LK_FWD_UPDATE: case LK_FWD_SMALL: return TLPK_KC_SOLVE_FWD;
+    case LK_FWD_GATHER: case LK_FWD_DIAG: case LK_FWD_UPDATE: case LK_FWD_SMALL: case LK_FWD_SWEEP: return TLPK_KC_SOLVE_FWD;
     default: return TLPK_KC_SOLVE_BWD;
     }
 }
@@ -153,7 +157,8 @@ void join_groups(tlpk_handle *h) {
     h->forked = false;
 }
 
-void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, size_t to) {
+// dir: 0 = forward-solve schedule, 1 = backward-solve schedule, -1 = factorisation (no sweeps)
+void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, size_t to, int dir = -1) {
     size_t skip_update = (size_t)-1;
     for (size_t i = from; i < to; ++i) {
         if (L[i].group < 0) join_groups(h);
@@ -194,7 +199,16 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
             }
         }
         ProfScope ps(h, kind_class(cur.kind), st);
-        launch_tasks(st, h->d, cur);
+        if (cur.kind == LK_FWD_SWEEP || cur.kind == LK_BWD_SWEEP) {
+            std::vector<unsigned long long> &runs = dir == 0 ? h->sweep_runs_fwd : h->sweep_runs_bwd;
+            const i32 slot = (dir == 0 ? h->sweep_slot_fwd : h->sweep_slot_bwd)[i];
+            SweepArgs sw{h->d.sweep_tickets + slot, runs[i] * (unsigned long long)cur.count,
+                         dir == 0 ? h->d.sweep_flags_fwd : h->d.sweep_flags_bwd,
+                         (unsigned)((h->solve_epoch - 1) % 0xFFFFFFFFull) + 1u};
+            runs[i] += 1;
+            launch_tasks(st, h->d, cur, &sw);
+        } else
+            launch_tasks(st, h->d, cur);
     }
     join_groups(h);
 }
@@ -251,6 +265,7 @@ int upload_all(tlpk_handle *h) {
     UP(d.fwd_gather_tasks, S.fwd_gather_tasks); UP(d.fwd_diag_tasks, S.fwd_diag_tasks);
     UP(d.fwd_update_tasks, S.fwd_update_tasks); UP(d.bwd_update_tasks, S.bwd_update_tasks);
     UP(d.fwd_small_tasks, S.fwd_small_tasks); UP(d.bwd_small_tasks, S.bwd_small_tasks);
+    UP(d.fwd_sweep_tasks, S.fwd_sweep_tasks); UP(d.bwd_sweep_tasks, S.bwd_sweep_tasks);
 #undef UP
 #define AL(dst, cnt) if ((rc = dev_alloc(h, &(dst), (cnt))) != TLPK_OK) return rc
     AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
@@ -258,7 +273,23 @@ int upload_all(tlpk_handle *h) {
     AL(h->d_theta, S.n); AL(h->d_regP, S.n); AL(h->d_regD, S.m); AL(h->d_D, S.n);
     AL(h->d_xip, S.m); AL(h->d_xid, S.n); AL(h->d_dx, S.n); AL(h->d_dy, S.m);
 #undef AL
+    {
+        // persistent sweeps: one ticket counter per sweep launch, one flag word per (front, pivot block) and direction
+        i32 nslots = 0;
+        h->sweep_slot_fwd.assign(S.fwd_launches.size(), -1); h->sweep_slot_bwd.assign(S.bwd_launches.size(), -1);
+        for (size_t i = 0; i < S.fwd_launches.size(); ++i) if (S.fwd_launches[i].kind == LK_FWD_SWEEP) h->sweep_slot_fwd[i] = nslots++;
+        for (size_t i = 0; i < S.bwd_launches.size(); ++i) if (S.bwd_launches[i].kind == LK_BWD_SWEEP) h->sweep_slot_bwd[i] = nslots++;
+        h->sweep_runs_fwd.assign(S.fwd_launches.size(), 0); h->sweep_runs_bwd.assign(S.bwd_launches.size(), 0);
+        if ((rc = dev_alloc(h, &d.sweep_tickets, (i64)nslots)) != TLPK_OK) return rc;
+        if ((rc = dev_alloc(h, &d.sweep_flags_fwd, S.n_sweep_flags)) != TLPK_OK) return rc;
+        if ((rc = dev_alloc(h, &d.sweep_flags_bwd, S.n_sweep_flags)) != TLPK_OK) return rc;
+        HIPCHK(h, hipMemset(d.sweep_tickets, 0, (size_t)std::max<i64>(nslots, 1) * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(d.sweep_flags_fwd, 0, (size_t)std::max<i64>(S.n_sweep_flags, 1) * sizeof(unsigned)));
+        HIPCHK(h, hipMemset(d.sweep_flags_bwd, 0, (size_t)std::max<i64>(S.n_sweep_flags, 1) * sizeof(unsigned)));
+        HIPCHK(h, hipMemset(d.ctx.info, 0, 4 * sizeof(int)));
+    }
     HIPCHK(h, hipHostMalloc((void **)&h->h_info, 4 * sizeof(int), hipHostMallocDefault));
+    h->h_info[0] = h->h_info[1] = h->h_info[2] = h->h_info[3] = 0;
     // free host-side copies that are only needed on the device
     std::vector<double>().swap(S.pair_w); std::vector<i32>().swap(S.pair_j);
     return TLPK_OK;
@@ -538,7 +569,8 @@ int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
     h->solve_timed = false;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     { ProfScope ps(h, TLPK_KC_SPMV); launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank); launch_single_solve(h->stream, h->d); }
-    run_launches(h, h->S.fwd_launches, 0, h->fwd_marker);
+    h->solve_epoch += 1;
+    run_launches(h, h->S.fwd_launches, 0, h->fwd_marker, 0);
     HIPCHK(h, hipGetLastError());
     h->solve_local_done = true;
     return TLPK_OK;
@@ -559,10 +591,11 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     if (!h->solve_local_done) { h->last_error = "tlpk_solve_finish without a preceding tlpk_solve_local"; return TLPK_BADARG; }
     h->solve_local_done = false;
     HIPCHK(h, hipSetDevice(h->device));
-    run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size());
-    run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size());
+    run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size(), 0);
+    run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1);
     { ProfScope ps(h, TLPK_KC_SPMV); launch_unpermute(h->stream, h->d, d_dy); }
     { ProfScope ps(h, TLPK_KC_SPMV); launch_dx(h->stream, h->d, h->d_D, d_dy, d_xid, d_dx); }
+    if (h->S.sweep) HIPCHK(h, hipMemcpyAsync(h->h_info + 1, h->d.ctx.info + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
     h->solve_timed = true;
@@ -588,6 +621,10 @@ int tlpk_sync(tlpk_handle *h) {
     }
     (void)hipGetLastError();
     prof_collect(h);
+    if (h->h_info[1] != 0) {
+        h->last_error = "a solve sweep gave up waiting for a block hand-over (internal scheduling error); results are invalid";
+        return TLPK_INTERNAL;
+    }
     return TLPK_OK;
 }
 
@@ -704,12 +741,16 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "front_single") tmp.assign(S.front_single.begin(), S.front_single.end());
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); } }
-    else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks" || w == "fwd_small_tasks" || w == "bwd_small_tasks") {
+    else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks" || w == "fwd_small_tasks" || w == "bwd_small_tasks" ||
+             w == "fwd_sweep_tasks" || w == "bwd_sweep_tasks") {
         const std::vector<SolveTask> &v = (w == "fwd_gather_tasks") ? S.fwd_gather_tasks : (w == "fwd_diag_tasks") ? S.fwd_diag_tasks :
                                           (w == "fwd_update_tasks") ? S.fwd_update_tasks : (w == "bwd_update_tasks") ? S.bwd_update_tasks :
-                                          (w == "fwd_small_tasks") ? S.fwd_small_tasks : S.bwd_small_tasks;
+                                          (w == "fwd_small_tasks") ? S.fwd_small_tasks : (w == "bwd_small_tasks") ? S.bwd_small_tasks :
+                                          (w == "fwd_sweep_tasks") ? S.fwd_sweep_tasks : S.bwd_sweep_tasks;
         for (auto &t : v) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.slot); tmp.push_back(t.nslot); }
     }
+    else if (w == "front_flagoff") field([](const FrontDesc &f) { return f.flagoff; });
+    else if (w == "n_sweep_flags") tmp.assign(1, S.n_sweep_flags);
     else if (w == "front_ucoff") field([](const FrontDesc &f) { return f.ucoff; });
     else if (w == "front_uoff") field([](const FrontDesc &f) { return f.uoff; });
     else if (w == "front_ubuf") field([](const FrontDesc &f) { return f.ubuf; });

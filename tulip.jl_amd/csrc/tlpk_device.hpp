@@ -19,7 +19,15 @@ struct DevCtx {
     double *xw;         // permuted right-hand side / solution
     double *dinv;       // inverses of the NB_IN x NB_IN diagonal blocks of L (written by k_potrf)
     double *spart;      // split-K scratch: one TILE x TILE partial product per slot
-    int *info;          // info[0] = smallest failing pivot column (INT_MAX = none)
+    int *info;          // info[0] = smallest failing pivot column (INT_MAX = none); info[1] != 0: a sweep gave up waiting
+};
+
+// per-launch arguments of the persistent sweep kernels
+struct SweepArgs {
+    unsigned long long *ticket;   // hand-out counter of this launch (monotonic over the life of the handle)
+    unsigned long long base;      // its value before this launch: item = ticket - base
+    unsigned *flags;              // one word per (front, pivot block): == epoch once the block is solved in this sweep
+    unsigned epoch;               // never 0; changes with every solve
 };
 
 struct DevArrays {
@@ -39,12 +47,15 @@ struct DevArrays {
     UpdateTask *update_tasks = nullptr, *reduce_tasks = nullptr;
     i64 n_single = 0; i64 *single_loff = nullptr, *single_dinvoff = nullptr; i32 *single_col = nullptr;   // isolated 1 x 1 fronts
     SolveTask *fwd_gather_tasks = nullptr, *fwd_diag_tasks = nullptr, *fwd_update_tasks = nullptr,
-              *bwd_update_tasks = nullptr, *fwd_small_tasks = nullptr, *bwd_small_tasks = nullptr;
+              *bwd_update_tasks = nullptr, *fwd_small_tasks = nullptr, *bwd_small_tasks = nullptr,
+              *fwd_sweep_tasks = nullptr, *bwd_sweep_tasks = nullptr;
+    unsigned long long *sweep_tickets = nullptr;      // one counter per sweep launch of the schedules
+    unsigned *sweep_flags_fwd = nullptr, *sweep_flags_bwd = nullptr;
 };
 
 void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D);
 void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD);
-void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L);
+void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const SweepArgs *sw = nullptr);
 void launch_single_factor(hipStream_t st, const DevArrays &a);
 void launch_single_solve(hipStream_t st, const DevArrays &a);
 void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank);

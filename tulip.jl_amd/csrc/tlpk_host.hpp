@@ -40,7 +40,7 @@ struct FrontDesc {
     i32 ubuf;      // which ping-pong buffer holds U (depth & 1)
     i32 parent;    // parent front or -1
     i32 child_ptr, nchild;   // children in `children[child_ptr .. child_ptr+nchild)`
-    i32 pad;
+    i32 flagoff;   // first word of the front's sweep flags (one per SOLVE_NB-wide pivot block), or -1
 };
 static_assert(sizeof(FrontDesc) == 80, "FrontDesc layout");
 
@@ -50,7 +50,10 @@ struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; }; // pad1 = s
 // in reduce_tasks: k0 = first slot, kw = number of parts
 //  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
 struct EaTask    { i32 front, j0, j1, pad; };                        // parent columns [j0, j1)
-struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };  // forward: nslot = width of the next diagonal block solved by this workgroup (0 = none);
+struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };
+// sweep items (LK_FWD_SWEEP): k0/nb = first row / rows of the chunk, slot = 1 pivot block (solve + publish) | 0 rows below,
+//   nslot = solved blocks to consume (0 .. nslot-1, ascending); (LK_BWD_SWEEP): k0/nb = column block, row0/slot = first row /
+//   number of rows below the pivot block (values of the ancestors), nslot = later blocks to consume (descending from the last)  // forward: nslot = width of the next diagonal block solved by this workgroup (0 = none);
 // backward: k0/nb = target column block, row0/slot = first source row / number of source rows, nslot != 0 = also solve the diagonal block
 
 enum LaunchKind : i32 {
@@ -63,7 +66,9 @@ enum LaunchKind : i32 {
     LK_UPDATE_REDUCE,   // applies the split-K partial tiles of the preceding LK_UPDATE launch to their targets
     LK_TRSM_THIN,       // block columns of <= TRSM_THIN_W columns: one thread per row (no MFMA strips)
     LK_FWD_SMALL, LK_BWD_SMALL,  // whole fronts of <= SMALL_NS pivot columns: one wave per front and sweep
-    LK_POTRF_SMALL      // pivot blocks of fronts with <= SMALL_NS pivot columns: one wave per front
+    LK_POTRF_SMALL,     // pivot blocks of fronts with <= SMALL_NS pivot columns: one wave per front
+    LK_FWD_SWEEP,       // whole forward substitution of every (non-small) front of a level in ONE launch: workgroups
+    LK_BWD_SWEEP        // own row chunks / column blocks and hand solved blocks over through flags (k_fwd_sweep / k_bwd_sweep)
 };
 struct Launch { i32 kind; i32 group; i64 first; i64 count; i32 side = 0; i32 pad = 0; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
 
@@ -123,6 +128,9 @@ struct Symbolic {
     std::vector<UpdateTask> update_tasks, reduce_tasks; std::vector<EaTask> ea_tasks;
     i64 spart_len = 0;                     // split-K scratch: TILE x TILE doubles per partial tile
     std::vector<SolveTask> fwd_gather_tasks, fwd_diag_tasks, fwd_update_tasks, bwd_update_tasks, fwd_small_tasks, bwd_small_tasks;
+    std::vector<SolveTask> fwd_sweep_tasks, bwd_sweep_tasks;
+    i64 n_sweep_flags = 0;                 // words in each of the two flag arrays (forward / backward)
+    bool sweep = true;                     // persistent sweep kernels (TLPK_SWEEP=0: one launch per 128-column block step)
     std::vector<Launch> factor_launches, fwd_launches, bwd_launches;
     std::string error;
 };
