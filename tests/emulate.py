@@ -351,7 +351,7 @@ class Emulator:
     # Persistent sweeps: the items of a launch are executed in LIST order = ticket order.  The device hands
     # them to workgroups in that order, and an item may only wait for items with a smaller ticket (otherwise
     # the sweep could deadlock): every block an item consumes must already be published when its turn comes.
-    def _k18(self, T):     # forward sweep
+    def _k18(self, T, SW=64):     # forward sweep: SWEEP_NB-wide pivot blocks
         import scipy.linalg as sla
         pub = set()
         for front, k0, nb, _r0, pivot, nin in T:
@@ -361,40 +361,39 @@ class Emulator:
             acc = np.zeros(nb)
             for j in range(nin):                                  # consumed blocks, ascending
                 assert (int(front), j) in pub, ("forward sweep item waits for a later ticket", front, k0, j)
-                w = min(128, ns - 128 * j)
-                acc += P[k0:k0 + nb, 128 * j:128 * j + w] @ self.xw[c0 + 128 * j: c0 + 128 * j + w]
+                w = min(SW, ns - SW * j)
+                acc += P[k0:k0 + nb, SW * j:SW * j + w] @ self.xw[c0 + SW * j: c0 + SW * j + w]
             if pivot:
-                assert k0 % 128 == 0 and nin == k0 // 128 and k0 + nb <= ns
+                assert k0 % SW == 0 and nin == k0 // SW and k0 + nb <= ns and nb <= SW
                 rhs = self.xw[c0 + k0: c0 + k0 + nb] - acc
                 L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
                 self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11, rhs, lower=True)
-                pub.add((int(front), k0 // 128))
+                pub.add((int(front), k0 // SW))
             else:
-                assert k0 >= ns and nin == (ns + 127) // 128
+                assert k0 >= ns and nin == (ns + SW - 1) // SW and nb <= 128
                 uo = int(self.ucoff[front])
                 self.ucflat[uo + k0 - ns: uo + k0 - ns + nb] -= acc
-        self._fwd_pub = getattr(self, "_fwd_pub", set()) | pub
 
-    def _k19(self, T):     # backward sweep
+    def _k19(self, T, SW=64):     # backward sweep
         import scipy.linalg as sla
         pub = set()
         for front, k0, nb, row0, nrows, nlater in T:
             P = self.panel(front); c0 = int(self.col0[front])
             f, ns = int(self.f[front]), int(self.ns[front])
             rows = self.rows(front)
-            nblk = (ns + 127) // 128
-            assert row0 == ns and nrows == f - ns and k0 % 128 == 0 and nlater == nblk - 1 - k0 // 128
+            nblk = (ns + SW - 1) // SW
+            assert row0 == ns and nrows == f - ns and k0 % SW == 0 and nlater == nblk - 1 - k0 // SW and nb <= SW
             acc = np.zeros(nb)
             if nrows > 0:                                         # rows below the pivot block: ancestors' values
                 acc += P[ns:f, k0:k0 + nb].T @ self.xw[rows[ns:]]
             for q in range(nlater):                               # later blocks, last first
                 j = nblk - 1 - q
                 assert (int(front), j) in pub, ("backward sweep item waits for a later ticket", front, k0, j)
-                w = min(128, ns - 128 * j)
-                acc += P[128 * j:128 * j + w, k0:k0 + nb].T @ self.xw[c0 + 128 * j: c0 + 128 * j + w]
+                w = min(SW, ns - SW * j)
+                acc += P[SW * j:SW * j + w, k0:k0 + nb].T @ self.xw[c0 + SW * j: c0 + SW * j + w]
             L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
             self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11.T, self.xw[c0 + k0: c0 + k0 + nb] - acc, lower=False)
-            pub.add((int(front), k0 // 128))
+            pub.add((int(front), k0 // SW))
 
     # dense L in permuted numbering, from the panels
     def dense_L(self):

@@ -127,15 +127,17 @@ def test_c2_equivalent_hip_vs_oracle_and_highs(alg):
 @pytest.mark.parametrize("alg", ["hsd", "mpc"])
 def test_retry_loop_fires_on_hip_backend(alg):
     """n_bump > 0 inside an IPM run on the device: TLPK_NOT_POSDEF -> PosDefException -> regs x100 ->
-    retry on the SAME handle.  Which pivot fails is decided by rounding, so the two backends may bump
-    at different iterations: iteration counts are compared loosely, the optimum against HiGHS."""
+    retry on the SAME handle.  Which pivot fails -- and therefore when the regularisations jump by 100 and
+    how many iterations the run needs -- is decided by rounding: on this LP the CPU oracle alone needs 9
+    iterations with the AMD ordering and 35 with the natural one.  Iteration counts are therefore NOT
+    compared here; status, the optimum (HiGHS) and the residual norms are."""
     lp = read_free_mps(os.path.join(GOLDEN, "bump.mps"))
     hg, sg = solve_lp(lp, lambda A: HipBackend(A, device=0), algorithm=alg)
     hc, sc = solve_lp(lp, lambda A: OracleBackend(A, hg.kkt.kkt.perm()), algorithm=alg)
     assert hg.timers["n_bump"] > 0 and hc.timers["n_bump"] > 0
     assert sg["status"] == sc["status"] == "Trm_Optimal"
-    assert abs(hg.niter - hc.niter) <= 5
     assert abs(sg["z_primal"] - BUMP_OPT) <= 1e-6 * (1 + abs(BUMP_OPT))
+    assert abs(sc["z_primal"] - BUMP_OPT) <= 1e-6 * (1 + abs(BUMP_OPT))
     assert max(sg["rho"]) <= SQRT_EPS
 
 

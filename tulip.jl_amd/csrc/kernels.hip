@@ -1336,190 +1336,247 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
 
 // ------------------------------------------------------------------------------------------
 // Persistent sweeps: the whole forward (backward) substitution of every non-small front of a tree
-// level in ONE launch.  The block steps of a front are a serial chain (26 steps for a 3300-column
-// front, 380 for the 48 000-column front of the general sparse benchmark); with one launch per step
-// the chain costs ~25 us per step (launch + a diagonal workgroup that starts cold), and every
-// launch ends with a tail.  Here a workgroup owns a 128-row chunk (forward) or a 128-column block
-// (backward) of one front for the whole sweep, keeps its partial sums in registers / LDS, streams its
-// part of L exactly once, and receives each solved block through a flag (hand-over protocol above).
+// level in ONE launch.  The block steps of a front are a serial chain (56 steps of 64 columns for a
+// 3500-column front, 760 for the 48 000-column front of the general sparse benchmark); with one launch
+// per step the chain costs ~25 us per step (launch + a diagonal workgroup that starts cold + three
+// dependent memory round trips in it), and every launch ends with a tail.  Here a workgroup owns a
+// chunk of rows (forward) or a block of columns (backward) of one front for the whole sweep, keeps its
+// partial sums in registers, streams its part of L exactly once, and receives each solved 64-wide
+// block from the workgroup that solved it:
+//   * hand-over words: one double per pivot column in a buffer that the host fills with a sentinel (all
+//     ones, a NaN no computation produces) before every solve.  The producer stores its 64 results with
+//     agent-scope atomic stores (write-through), a consumer WAVE polls the words it needs with agent-scope
+//     atomic loads until none is the sentinel -- the data is its own flag (8-byte stores are not torn),
+//     one memory round trip per hand-over, no fence, nothing placement-dependent
+//     (/opt/skills/guides/cdna_hip_programming.md Guideline 16, forms R2 / "agent atomics both sides");
+//   * waves stream independently (no workgroup barrier per block): a wave polls only the words of ITS
+//     columns and broadcasts them from lane registers;
+//   * L is static: the panel entries for the next two blocks are requested before the wait for the
+//     current one, and the workgroup of a pivot block holds its inverted diagonal block in registers from
+//     the start, so behind the last hand-over of a pivot block there are 16 multiply-adds, two LDS
+//     reductions and the stores;
 //   * items are handed out through a ticket counter in an order in which an item only waits for items
 //     with SMALLER tickets (symbolic.cpp): those are held by workgroups that already run, so the
 //     sweep cannot deadlock whatever the dispatch order or residency;
-//   * L is static: the panel columns of the NEXT block are requested before the wait for its flag, so
-//     behind a flag there is one x read, the arithmetic, the diagonal solve and the publish;
-//   * fixed summation order per item => bitwise deterministic, independent of scheduling.
+//   * fixed summation order per item => bitwise deterministic, independent of scheduling;
+//   * every spin is bounded (~2 s): a wave that gives up sets info[1], everybody stops waiting, the host
+//     reports TLPK_INTERNAL.  A scheduling bug must never hang the device.
 // ------------------------------------------------------------------------------------------
-constexpr int SW_B = 16;                    // forward: panel columns per batch per thread
+constexpr unsigned long long SW_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
+
+// one wave: wait until the words xh[0 .. cnt) (cnt <= 64) hold results; lane l returns word min(l, cnt-1)
+__device__ __forceinline__ double poll_block(const double *xh, const int cnt, const int lane, int *info, bool &dead) {
+    const unsigned long long *p = reinterpret_cast<const unsigned long long *>(xh) + min(lane, cnt - 1);
+    unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (!dead && !__all(v != SW_SENTINEL)) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((++spins & 127u) == 0u) {
+            if (__hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
+            else if (spins > (1u << 21)) { __hip_atomic_store(info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
+        }
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("" ::: "memory");        // nothing that follows may be scheduled above the poll
+    return __longlong_as_double((long long)v);
+}
+__device__ __forceinline__ double readlane_f64(const double v, const int l) {      // l wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// PIVOT item: rows [k0, k0 + nb) (nb <= 64) are a pivot block; lane = row, wave = quarter of the 64 columns of a
+// consumed block.  BELOW item: <= 128 rows below the pivot block; waves 0/1 = rows 0..63 / 64..127 of the chunk
+// for columns 0..31 of a block, waves 2/3 the same rows for columns 32..63.
+template <bool PIVOT>
+__device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDesc &fd, const DevCtx &c, const double *xh, double *scratch) {
+    constexpr int NBATCH = PIVOT ? 1 : 2;                      // batches of 16 columns per wave and block
+    constexpr int WCOLS = 16 * NBATCH;                         // columns of a block handled by a wave
+    const i32 f = fd.f, ns = fd.ns;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rloc = PIVOT ? lane : lane + 64 * (wave & 1);    // row of the chunk
+    const int cp0 = PIVOT ? 16 * wave : 32 * (wave >> 1);      // first column of the wave inside a block
+    const char *Lb = reinterpret_cast<const char *>(c.Lval + fd.loff);
+    const unsigned roff = (unsigned)min(t.k0 + rloc, f - 1) * 8u;     // clamped row: its result is never stored
+    const double *xhf = xh + fd.col0;
+    const i32 nin = t.nslot;
+    double w[16];
+    if (PIVOT) load_frag<false, 0>(c, fd, t.k0, t.nb, w);      // inverted diagonal block, held from the start
+    double acc = 0.0;
+    double b0[16], b1[16];
+    bool dead = false;
+    auto issue = [&](double (&b)[16], const i32 j, const int q) {          // block j (clamped), batch q
+        const i32 c0 = min(j, nin - 1) * SWEEP_NB + cp0 + 16 * q;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)                             // clamped column: x is zero beyond the block
+            b[u] = *reinterpret_cast<const double *>(Lb + (size_t)min(c0 + u, ns - 1) * (size_t)f * 8u + roff);
+    };
+    auto consume = [&](const double (&b)[16], const double xv, const int q) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += b[u] * readlane_f64(xv, 16 * q + u);
+    };
+    auto wait_block = [&](const i32 j) -> double {             // this wave's columns of block j (zero beyond its width)
+        const i32 cnt = min(WCOLS, min(SWEEP_NB, ns - j * SWEEP_NB) - cp0);
+        if (cnt <= 0) return 0.0;
+        const double v = poll_block(xhf + j * SWEEP_NB + cp0, cnt, lane, c.info, dead);
+        return (lane < cnt) ? v : 0.0;
+    };
+    if (nin > 0) {
+        if (PIVOT) { issue(b0, 0, 0); issue(b1, 1, 0); }
+        else { issue(b0, 0, 0); issue(b1, 0, 1); }
+    }
+    if (PIVOT) {
+        for (i32 j = 0; j < nin; j += 2) {
+            double xv = wait_block(j);
+            consume(b0, xv, 0); issue(b0, j + 2, 0);
+            if (j + 1 < nin) {                                  // wave-uniform
+                xv = wait_block(j + 1);
+                consume(b1, xv, 0); issue(b1, j + 3, 0);
+            }
+        }
+    } else {
+        for (i32 j = 0; j < nin; ++j) {
+            const double xv = wait_block(j);
+            consume(b0, xv, 0); issue(b0, j + 1, 0);
+            consume(b1, xv, 1); issue(b1, j + 1, 1);
+        }
+    }
+    double (*ps)[NB_IN] = reinterpret_cast<double (*)[NB_IN]>(scratch + 2 * SOLVE_NB);      // 4 x 64 doubles
+    if (PIVOT) {
+        double *bs = scratch;
+        ps[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            const double total = ((ps[0][lane] + ps[1][lane]) + ps[2][lane]) + ps[3][lane];
+            bs[lane] = (lane < t.nb) ? c.xw[fd.col0 + t.k0 + min(lane, t.nb - 1)] - total : 0.0;
+        }
+        __syncthreads();
+        const double y = dot4(w, bs, lane, wave, ps);           // y = W (b - sum); valid in wave 0
+        if (wave == 0 && lane < t.nb) {
+            c.xw[fd.col0 + t.k0 + lane] = y;
+            st_agent(const_cast<double *>(xhf) + t.k0 + lane, y);     // hand-over: the data is its own flag
+        }
+    } else {
+        double *red = &ps[0][0];                                // 256 doubles: [column half][row]
+        if (wave >= 2) red[rloc] = acc;
+        __syncthreads();
+        if (wave < 2 && rloc < t.nb) {
+            double *dst = c.uc + fd.ucoff + (t.k0 + rloc - ns);
+            *dst = *dst - (acc + red[rloc]);
+        }
+    }
+}
 
 __global__ __launch_bounds__(256, 4) void k_fwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
-    __shared__ double xs[2][SOLVE_NB];               // solved blocks, double-buffered by block parity
     __shared__ double scratch[FWD_DIAG_SCRATCH];
     __shared__ unsigned s_item;
-    __shared__ int s_ok;
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) - a.base); s_ok = 1; }
+    if (threadIdx.x == 0) s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) - a.base);
     __syncthreads();
     const SolveTask t = tasks[s_item];
     const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, ns = fd.ns;
-    const int r = tid & (SOLVE_NB - 1);                        // row of the chunk
-    const int h = __builtin_amdgcn_readfirstlane(tid >> 7);    // column half of a block: wave-uniform
-    // addresses = wave-uniform column base (scalar registers) + 32-bit lane offset: no 64-bit address pair per load
-    const char *Lb = reinterpret_cast<const char *>(c.Lval + fd.loff);
-    const unsigned roff = (unsigned)min(t.k0 + r, f - 1) * 8u;  // clamped row: its result is never stored
-    unsigned *flags = a.flags + fd.flagoff;
-    const i32 nin = t.nslot, nsteps = 4 * nin;                 // a block = 4 batches of SW_B columns per half
-    double acc = 0.0;
-    double b0[SW_B], b1[SW_B];
-    auto issue = [&](double (&b)[SW_B], const i32 step) {
-        const i32 c0 = (step >> 2) * SOLVE_NB + 64 * h + SW_B * (step & 3);
-#pragma unroll
-        for (int j = 0; j < SW_B; ++j)                          // clamped column: x is zero beyond the block
-            b[j] = *reinterpret_cast<const double *>(Lb + (size_t)min(c0 + j, ns - 1) * (size_t)f * 8u + roff);
-    };
-    auto consume = [&](const double (&b)[SW_B], const double *x) {
-#pragma unroll
-        for (int j = 0; j < SW_B; ++j) acc += b[j] * x[j];
-    };
-    if (nsteps > 0) { issue(b0, 0); issue(b1, 1); }
-    for (i32 j = 0; j < nin; ++j) {
-        if (tid < 64) {                                        // wave 0: wait for block j, stage it
-            int ok = 1;
-            if (tid == 0) ok = wait_flag(flags + j, a.epoch, c.info) ? 1 : 0;
-            ok = __shfl(ok, 0);
-            if (!ok) { if (tid == 0) s_ok = 0; }
-            else {
-                const i32 wj = min(SOLVE_NB, ns - j * SOLVE_NB);
-                const double *xg = c.xw + fd.col0 + j * SOLVE_NB;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int idx = tid + 64 * u;
-                    const double v = ld_agent(xg + min(idx, wj - 1));
-                    xs[j & 1][idx] = (idx < wj) ? v : 0.0;
-                }
-            }
-        }
-        __syncthreads();
-        if (!s_ok) return;
-        const double *x = xs[j & 1] + 64 * h;
-        const i32 st = 4 * j;
-        // unconditional prefetch (the step is clamped: the last two batches of an item are requested again
-        // and dropped) -- a guarded prefetch makes the compiler keep both versions of the buffer alive
-        const i32 last = nsteps - 1;
-        consume(b0, x);            issue(b0, min(st + 2, last));
-        consume(b1, x + SW_B);     issue(b1, min(st + 3, last));
-        consume(b0, x + 2 * SW_B); issue(b0, min(st + 4, last));
-        consume(b1, x + 3 * SW_B); issue(b1, min(st + 5, last));
-    }
-    // the two column halves of a row, in fixed order
-    double *red = scratch + 2 * SOLVE_NB;
-    if (h == 1) red[r] = acc;
-    __syncthreads();
-    const double total = (h == 0) ? acc + red[r] : 0.0;
-    if (t.slot == 0) {                                         // rows below the pivot block: contribution vector
-        if (h == 0 && r < t.nb) { double *dst = c.uc + fd.ucoff + (t.k0 + r - ns); *dst = *dst - total; }
-        return;
-    }
-    if (tid < SOLVE_NB) scratch[tid] = (tid < t.nb) ? c.xw[fd.col0 + t.k0 + min(tid, t.nb - 1)] - total : 0.0;
-    __syncthreads();
-    fwd_diag_solve<true>(c, fd, t.k0, t.nb, scratch);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(flags + t.k0 / SOLVE_NB, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t.slot) fwd_sweep_item<true>(t, fd, c, a.xh, scratch);          // workgroup-uniform
+    else fwd_sweep_item<false>(t, fd, c, a.xh, scratch);
 }
 
-// Backward: item = column block [k0, k0 + nb) of a front.  t[k0 + j] = b - sum_r L[r, k0 + j] x[r] over the
-// rows below the pivot block (values of the ancestors, known at launch) and over the LATER pivot blocks of
-// the front, consumed as they are published (last block first); then the diagonal solve and the publish.
-// Lanes run along the contiguous rows, a wave owns a quarter of the columns (batches of 8, next batch in
-// flight while the current one is reduced by shuffles), sums per column accumulate in LDS in fixed order.
-__global__ __launch_bounds__(256, 4) void k_bwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
-    __shared__ double scratch[FWD_DIAG_SCRATCH];
-    __shared__ double tacc[SOLVE_NB];
+// Backward: item = column block [k0, k0 + nb) (nb <= 64) of a front.  t[k0 + j] = b - sum_r L[r, k0 + j] x[r] over the
+// rows below the pivot block (values of the ancestors, known at launch) and over the LATER pivot blocks of the
+// front, consumed as they are published (last block first); then x = W' t and the publish.  Lanes run along the 64
+// contiguous rows of a tile, a wave owns 16 of the columns and keeps per-lane partial sums over ALL tiles (one
+// shuffle reduction at the end).
+__global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
+    __shared__ double ts[NB_IN], xo[NB_IN];
     __shared__ unsigned s_item;
-    __shared__ int s_ok;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) { s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) - a.base); s_ok = 1; }
-    if (tid < SOLVE_NB) tacc[tid] = 0.0;
+    if (tid == 0) s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) - a.base);
     __syncthreads();
     const SolveTask t = tasks[s_item];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, nb = t.nb;
     const i32 *rows = c.rowidx + fd.rowoff;
-    unsigned *flags = a.flags + fd.flagoff;
-    const i32 nblk = (ns + SOLVE_NB - 1) / SOLVE_NB;
-    const i32 nbelow = (t.slot + BWD_ROWS - 1) / BWD_ROWS;      // tiles of rows below the pivot block
+    const double *xhf = a.xh + fd.col0;
+    const i32 nblk = (ns + SWEEP_NB - 1) / SWEEP_NB;
+    const i32 nbelow = (t.slot + 63) / 64;                      // 64-row tiles below the pivot block
     const i32 ntiles = nbelow + t.nslot;
-    const char *P0b = reinterpret_cast<const char *>(c.Lval + fd.loff + (i64)t.k0 * f);
-    constexpr int CB = 8, RPL = BWD_ROWS / 64;
-    for (i32 q = 0; q < ntiles; ++q) {
-        const bool below = q < nbelow;
-        const i32 jb = below ? 0 : nblk - 1 - (q - nbelow);     // pivot block consumed by this tile
-        const i32 r0 = below ? t.row0 + q * BWD_ROWS : jb * SOLVE_NB;
-        const i32 nr = below ? min(BWD_ROWS, t.row0 + t.slot - r0) : min(SOLVE_NB, ns - r0);
-        i32 ro[RPL];
-        unsigned rb[RPL];
+    // this wave's columns: wave-uniform bases (scalar registers) + 32-bit lane offsets
+    const char *Pb = reinterpret_cast<const char *>(c.Lval + fd.loff + (i64)t.k0 * f);
+    size_t coloff[1];
+    (void)coloff;
+    double w[16];
+    load_frag<true, 0>(c, fd, t.k0, nb, w);                     // W[k = lane][16 wave + kk], held from the start
+    double acc[16];
 #pragma unroll
-        for (int u = 0; u < RPL; ++u) { ro[u] = min(lane + 64 * u, nr - 1); rb[u] = (unsigned)(r0 + ro[u]) * 8u; }   // clamped: the matching x is zeroed
-        double cur[CB][RPL], nxt[CB][RPL];
-        auto fetch = [&](double (&dst)[CB][RPL], const i32 j0) {
+    for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+    bool dead = false;
+    auto tile_r0 = [&](const i32 q) { const i32 qc = min(q, ntiles - 1); return qc < nbelow ? t.row0 + 64 * qc : (nblk - 1 - (qc - nbelow)) * SWEEP_NB; };
+    auto tile_nr = [&](const i32 q) { const i32 qc = min(q, ntiles - 1); const i32 r0 = tile_r0(qc); return qc < nbelow ? min(64, f - r0) : min(SWEEP_NB, ns - r0); };
+    auto issue = [&](double (&b)[16], const i32 q) {           // tile q (clamped): 64 rows x this wave's 16 columns
+        const i32 r0 = tile_r0(q), nr = tile_nr(q);
+        const unsigned rb = (unsigned)(r0 + min(lane, nr - 1)) * 8u;            // clamped row: its x is zeroed
 #pragma unroll
-            for (int jj = 0; jj < CB; ++jj) {
-                const char *col = P0b + (size_t)min(j0 + jj, nb - 1) * (size_t)f * 8u;   // wave-uniform; clamped: extra columns are dropped below
+        for (int u = 0; u < 16; ++u)
+            b[u] = *reinterpret_cast<const double *>(Pb + (size_t)min(16 * wave + u, nb - 1) * (size_t)f * 8u + rb);   // clamped column: dropped below
+    };
+    auto row_index = [&](const i32 q) -> i32 {                  // global index of this lane's row in a tile below the pivot block
+        const i32 qc = min(q, max(nbelow - 1, 0));
+        const i32 r0 = t.row0 + 64 * qc, nr = min(64, f - r0);
+        return (nbelow > 0) ? rows[r0 + min(lane, max(nr - 1, 0))] : 0;
+    };
+    auto consume = [&](const double (&b)[16], const double xr) {
 #pragma unroll
-                for (int u = 0; u < RPL; ++u) dst[jj][u] = *reinterpret_cast<const double *>(col + rb[u]);
-            }
-        };
-        fetch(cur, wave * CB);                                  // static data: requested before the wait
-        double xr[RPL];
-        if (below) {
-            i32 gi[RPL];
-#pragma unroll
-            for (int u = 0; u < RPL; ++u) gi[u] = rows[r0 + ro[u]];
-#pragma unroll
-            for (int u = 0; u < RPL; ++u) { const double xv = c.xw[gi[u]]; xr[u] = (lane + 64 * u < nr) ? xv : 0.0; }
+        for (int u = 0; u < 16; ++u) acc[u] += b[u] * xr;
+    };
+    double b0[16], b1[16];
+    if (ntiles > 0) { issue(b0, 0); issue(b1, 1); }
+    // rows below the pivot block: x of the ancestors through the row indices -- indices two tiles ahead, values one
+    i32 gi0 = row_index(0), gi1 = row_index(1);
+    double xn = (nbelow > 0) ? c.xw[gi0] : 0.0;                 // x of tile 0
+    auto tile_x = [&](const i32 q) -> double {                  // x[row of this lane] for tile q
+        const i32 nr = tile_nr(q);
+        double xv;
+        if (q < nbelow) {
+            xv = xn;                                            // requested one tile ago
+            xn = c.xw[gi1];                                     // tile q + 1 (index loaded two tiles ago)
+            gi1 = row_index(q + 2);
         } else {
-            if (tid == 0 && !wait_flag(flags + jb, a.epoch, c.info)) s_ok = 0;
-            __syncthreads();
-            if (!s_ok) return;
-            const double *xg = c.xw + fd.col0 + r0;
-#pragma unroll
-            for (int u = 0; u < RPL; ++u) { const double xv = ld_agent(xg + ro[u]); xr[u] = (lane + 64 * u < nr) ? xv : 0.0; }
+            const i32 jb = nblk - 1 - (q - nbelow);
+            xv = poll_block(xhf + jb * SWEEP_NB, nr, lane, c.info, dead);
         }
-#pragma unroll 1
-        for (i32 j0 = wave * CB; j0 < nb; j0 += 4 * CB) {
-            fetch(nxt, j0 + 4 * CB);                            // unconditional (clamped columns)
-            double accv[CB];
-#pragma unroll
-            for (int jj = 0; jj < CB; ++jj) {
-                double s_ = 0.0;
-#pragma unroll
-                for (int u = 0; u < RPL; ++u) s_ += cur[jj][u] * xr[u];
-                accv[jj] = s_;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-                for (int jj = 0; jj < CB; ++jj) accv[jj] += __shfl_down(accv[jj], off);
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int jj = 0; jj < CB; ++jj) if (j0 + jj < nb) tacc[j0 + jj] += accv[jj];
-            }
-#pragma unroll
-            for (int jj = 0; jj < CB; ++jj)
-#pragma unroll
-                for (int u = 0; u < RPL; ++u) cur[jj][u] = nxt[jj][u];
+        return (lane < nr) ? xv : 0.0;
+    };
+    for (i32 q = 0; q < ntiles; q += 2) {
+        double xr = tile_x(q);
+        consume(b0, xr); issue(b0, q + 2);
+        if (q + 1 < ntiles) {                                   // workgroup-uniform
+            xr = tile_x(q + 1);
+            consume(b1, xr); issue(b1, q + 3);
         }
     }
+    (void)gi0;
+    // column sums over the 64 lanes, fixed tree; lane 0 holds the 16 sums of this wave's columns
+    reduce16(acc);
+    if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xo[16 * wave + u] = acc[u];
+    }
     __syncthreads();
-    if (tid < SOLVE_NB) scratch[tid] = (tid < nb) ? c.xw[fd.col0 + t.k0 + min(tid, nb - 1)] - tacc[tid] : 0.0;
+    if (tid < NB_IN) ts[tid] = (tid < nb) ? c.xw[fd.col0 + t.k0 + min(tid, nb - 1)] - xo[tid] : 0.0;
     __syncthreads();
-    bwd_diag_solve<true>(c, fd, t.k0, nb, scratch);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(flags + t.k0 / SOLVE_NB, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double t1 = ts[lane];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) w[kk] *= t1;                // x[ci] = sum_k W[k][ci] t[k], ci = 16 wave + kk
+    reduce16(w);
+    if (lane == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const i32 ci = 16 * wave + kk;
+            if (ci < nb) {
+                c.xw[fd.col0 + t.k0 + ci] = w[kk];
+                st_agent(const_cast<double *>(xhf) + t.k0 + ci, w[kk]);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

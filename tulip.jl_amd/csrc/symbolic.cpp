@@ -1140,8 +1140,8 @@ static void build_schedule(Symbolic &S) {
         FrontDesc &w = S.fronts[s];
         w.flagoff = -1;
         if (!S.front_local[s] || S.front_single[s] || is_small((i32)s)) continue;
-        w.flagoff = (i32)S.n_sweep_flags;
-        S.n_sweep_flags += (w.ns + SOLVE_NB - 1) / SOLVE_NB;
+        w.flagoff = 0;                       // handled by the sweep kernels (hand-over words are indexed by column)
+        S.n_sweep_flags += 1;
     }
     auto fwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
@@ -1185,15 +1185,15 @@ static void build_schedule(Symbolic &S) {
                 const i32 s = S.level_fronts[t];
                 if (!in_scope(s) || is_small(s)) continue;
                 const FrontDesc &w = S.fronts[s];
-                max_chunks = std::max(max_chunks, (w.ns + SOLVE_NB - 1) / SOLVE_NB + (w.f - w.ns + SOLVE_NB - 1) / SOLVE_NB);
+                max_chunks = std::max(max_chunks, (w.ns + SWEEP_NB - 1) / SWEEP_NB + (w.f - w.ns + SOLVE_NB - 1) / SOLVE_NB);
             }
             for (i32 ci = 0; ci < max_chunks; ++ci)
                 for (i32 t = t0; t < t1; ++t) {
                     const i32 s = S.level_fronts[t];
                     if (!in_scope(s) || is_small(s)) continue;
                     const FrontDesc &w = S.fronts[s];
-                    const i32 nblk = (w.ns + SOLVE_NB - 1) / SOLVE_NB;
-                    if (ci < nblk) S.fwd_sweep_tasks.push_back(SolveTask{s, ci * SOLVE_NB, std::min(SOLVE_NB, w.ns - ci * SOLVE_NB), 0, 1, ci, 0, 0});
+                    const i32 nblk = (w.ns + SWEEP_NB - 1) / SWEEP_NB;
+                    if (ci < nblk) S.fwd_sweep_tasks.push_back(SolveTask{s, ci * SWEEP_NB, std::min(SWEEP_NB, w.ns - ci * SWEEP_NB), 0, 1, ci, 0, 0});
                     else {
                         const i32 r0 = w.ns + (ci - nblk) * SOLVE_NB;
                         if (r0 < w.f) S.fwd_sweep_tasks.push_back(SolveTask{s, r0, std::min(SOLVE_NB, w.f - r0), 0, 0, nblk, 0, 0});
@@ -1253,15 +1253,16 @@ static void build_schedule(Symbolic &S) {
             // hand-out order: distance of the column block from the END of its front first (a block waits for the
             // later blocks of its own front only), front second
             const i64 first = (i64)S.bwd_sweep_tasks.size();
-            for (i32 dd = 0; dd < nblk; ++dd)
+            const i32 nblk64 = (max_ns + SWEEP_NB - 1) / SWEEP_NB;
+            for (i32 dd = 0; dd < nblk64; ++dd)
                 for (i32 t = t0; t < t1; ++t) {
                     const i32 s = S.level_fronts[t];
                     if (!in_scope(s) || is_small(s)) continue;
                     const FrontDesc &w = S.fronts[s];
-                    const i32 my_nblk = (w.ns + SOLVE_NB - 1) / SOLVE_NB;
+                    const i32 my_nblk = (w.ns + SWEEP_NB - 1) / SWEEP_NB;
                     if (dd >= my_nblk) continue;
                     const i32 kb = my_nblk - 1 - dd;
-                    S.bwd_sweep_tasks.push_back(SolveTask{s, kb * SOLVE_NB, std::min(SOLVE_NB, w.ns - kb * SOLVE_NB), w.ns, w.f - w.ns, dd, 0, 0});
+                    S.bwd_sweep_tasks.push_back(SolveTask{s, kb * SWEEP_NB, std::min(SWEEP_NB, w.ns - kb * SWEEP_NB), w.ns, w.f - w.ns, dd, 0, 0});
                 }
             push_launch(S.bwd_launches, LK_BWD_SWEEP, first, (i64)S.bwd_sweep_tasks.size() - first);
             nblk = 0;

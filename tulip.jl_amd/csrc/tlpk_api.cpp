@@ -203,8 +203,7 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
             std::vector<unsigned long long> &runs = dir == 0 ? h->sweep_runs_fwd : h->sweep_runs_bwd;
             const i32 slot = (dir == 0 ? h->sweep_slot_fwd : h->sweep_slot_bwd)[i];
             SweepArgs sw{h->d.sweep_tickets + slot, runs[i] * (unsigned long long)cur.count,
-                         dir == 0 ? h->d.sweep_flags_fwd : h->d.sweep_flags_bwd,
-                         (unsigned)((h->solve_epoch - 1) % 0xFFFFFFFFull) + 1u};
+                         h->d.sweep_xh + (dir == 0 ? 0 : h->S.m)};
             runs[i] += 1;
             launch_tasks(st, h->d, cur, &sw);
         } else
@@ -274,18 +273,15 @@ int upload_all(tlpk_handle *h) {
     AL(h->d_xip, S.m); AL(h->d_xid, S.n); AL(h->d_dx, S.n); AL(h->d_dy, S.m);
 #undef AL
     {
-        // persistent sweeps: one ticket counter per sweep launch, one flag word per (front, pivot block) and direction
+        // persistent sweeps: one ticket counter per sweep launch, one hand-over word per column and direction
         i32 nslots = 0;
         h->sweep_slot_fwd.assign(S.fwd_launches.size(), -1); h->sweep_slot_bwd.assign(S.bwd_launches.size(), -1);
         for (size_t i = 0; i < S.fwd_launches.size(); ++i) if (S.fwd_launches[i].kind == LK_FWD_SWEEP) h->sweep_slot_fwd[i] = nslots++;
         for (size_t i = 0; i < S.bwd_launches.size(); ++i) if (S.bwd_launches[i].kind == LK_BWD_SWEEP) h->sweep_slot_bwd[i] = nslots++;
         h->sweep_runs_fwd.assign(S.fwd_launches.size(), 0); h->sweep_runs_bwd.assign(S.bwd_launches.size(), 0);
         if ((rc = dev_alloc(h, &d.sweep_tickets, (i64)nslots)) != TLPK_OK) return rc;
-        if ((rc = dev_alloc(h, &d.sweep_flags_fwd, S.n_sweep_flags)) != TLPK_OK) return rc;
-        if ((rc = dev_alloc(h, &d.sweep_flags_bwd, S.n_sweep_flags)) != TLPK_OK) return rc;
+        if ((rc = dev_alloc(h, &d.sweep_xh, 2 * S.m)) != TLPK_OK) return rc;
         HIPCHK(h, hipMemset(d.sweep_tickets, 0, (size_t)std::max<i64>(nslots, 1) * sizeof(unsigned long long)));
-        HIPCHK(h, hipMemset(d.sweep_flags_fwd, 0, (size_t)std::max<i64>(S.n_sweep_flags, 1) * sizeof(unsigned)));
-        HIPCHK(h, hipMemset(d.sweep_flags_bwd, 0, (size_t)std::max<i64>(S.n_sweep_flags, 1) * sizeof(unsigned)));
         HIPCHK(h, hipMemset(d.ctx.info, 0, 4 * sizeof(int)));
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_info, 4 * sizeof(int), hipHostMallocDefault));
@@ -568,7 +564,12 @@ int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
     prof_begin(h, false);
     h->solve_timed = false;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    { ProfScope ps(h, TLPK_KC_SPMV); launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank); launch_single_solve(h->stream, h->d); }
+    {
+        ProfScope ps(h, TLPK_KC_SPMV);
+        // hand-over words of both sweeps back to the sentinel (all ones): the data is its own flag
+        if (h->S.sweep && h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_xh, 0xFF, (size_t)(2 * h->S.m) * 8, h->stream));
+        launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank); launch_single_solve(h->stream, h->d);
+    }
     h->solve_epoch += 1;
     run_launches(h, h->S.fwd_launches, 0, h->fwd_marker, 0);
     HIPCHK(h, hipGetLastError());

@@ -26,8 +26,7 @@ struct DevCtx {
 struct SweepArgs {
     unsigned long long *ticket;   // hand-out counter of this launch (monotonic over the life of the handle)
     unsigned long long base;      // its value before this launch: item = ticket - base
-    unsigned *flags;              // one word per (front, pivot block): == epoch once the block is solved in this sweep
-    unsigned epoch;               // never 0; changes with every solve
+    double *xh;                   // hand-over words of this direction, one per permuted column, sentinel-filled before the solve
 };
 
 struct DevArrays {
@@ -50,7 +49,7 @@ struct DevArrays {
               *bwd_update_tasks = nullptr, *fwd_small_tasks = nullptr, *bwd_small_tasks = nullptr,
               *fwd_sweep_tasks = nullptr, *bwd_sweep_tasks = nullptr;
     unsigned long long *sweep_tickets = nullptr;      // one counter per sweep launch of the schedules
-    unsigned *sweep_flags_fwd = nullptr, *sweep_flags_bwd = nullptr;
+    double *sweep_xh = nullptr;                       // hand-over words: [0, m) forward sweep, [m, 2m) backward sweep
 };
 
 void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D);

@@ -23,6 +23,7 @@ constexpr int TRSM_THIN_W = 32;    // widest block column handled by k_trsm_thin
 constexpr int TRSM_WG_ROWS = 64;   // rows per k_trsm workgroup (4 waves x 16 rows x whole block column)
 constexpr int EA_COLS = 16;   // parent columns per extend-add workgroup
 constexpr int SOLVE_NB = 128; // block width of the triangular-solve kernels (two NB_IN sub-blocks)
+constexpr int SWEEP_NB = NB_IN;  // width of a pivot block handed from workgroup to workgroup in the persistent sweeps
 constexpr int MAX_GROUPS = 8;    // concurrent streams for independent diagonal blocks
 constexpr int SOLVE_ROWS = 256; // rows per forward-update workgroup
 constexpr int BWD_ROWS = 128;   // rows per backward-update workgroup (partial sums, reduced in fixed order)
@@ -40,7 +41,7 @@ struct FrontDesc {
     i32 ubuf;      // which ping-pong buffer holds U (depth & 1)
     i32 parent;    // parent front or -1
     i32 child_ptr, nchild;   // children in `children[child_ptr .. child_ptr+nchild)`
-    i32 flagoff;   // first word of the front's sweep flags (one per SOLVE_NB-wide pivot block), or -1
+    i32 flagoff;   // >= 0: the front's triangular solves run in the persistent sweep kernels; -1: small / single / not local
 };
 static_assert(sizeof(FrontDesc) == 80, "FrontDesc layout");
 
@@ -51,9 +52,10 @@ struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; }; // pad1 = s
 //  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
 struct EaTask    { i32 front, j0, j1, pad; };                        // parent columns [j0, j1)
 struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };
-// sweep items (LK_FWD_SWEEP): k0/nb = first row / rows of the chunk, slot = 1 pivot block (solve + publish) | 0 rows below,
-//   nslot = solved blocks to consume (0 .. nslot-1, ascending); (LK_BWD_SWEEP): k0/nb = column block, row0/slot = first row /
-//   number of rows below the pivot block (values of the ancestors), nslot = later blocks to consume (descending from the last)  // forward: nslot = width of the next diagonal block solved by this workgroup (0 = none);
+// sweep items (LK_FWD_SWEEP): k0/nb = first row / rows of the chunk (<= SWEEP_NB pivot rows or <= SOLVE_NB rows below),
+//   slot = 1 pivot block (solve + publish) | 0 rows below, nslot = SWEEP_NB-wide solved blocks to consume (0 .. nslot-1);
+//   (LK_BWD_SWEEP): k0/nb = column block (<= SWEEP_NB), row0/slot = first row / number of rows below the pivot block
+//   (values of the ancestors), nslot = later blocks to consume (descending from the last)  // forward: nslot = width of the next diagonal block solved by this workgroup (0 = none);
 // backward: k0/nb = target column block, row0/slot = first source row / number of source rows, nslot != 0 = also solve the diagonal block
 
 enum LaunchKind : i32 {
@@ -129,7 +131,7 @@ struct Symbolic {
     i64 spart_len = 0;                     // split-K scratch: TILE x TILE doubles per partial tile
     std::vector<SolveTask> fwd_gather_tasks, fwd_diag_tasks, fwd_update_tasks, bwd_update_tasks, fwd_small_tasks, bwd_small_tasks;
     std::vector<SolveTask> fwd_sweep_tasks, bwd_sweep_tasks;
-    i64 n_sweep_flags = 0;                 // words in each of the two flag arrays (forward / backward)
+    i64 n_sweep_flags = 0;                 // number of fronts handled by the sweep kernels
     bool sweep = true;                     // persistent sweep kernels (TLPK_SWEEP=0: one launch per 128-column block step)
     std::vector<Launch> factor_launches, fwd_launches, bwd_launches;
     std::string error;
