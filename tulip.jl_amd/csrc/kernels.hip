@@ -1364,13 +1364,17 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
 // ------------------------------------------------------------------------------------------
 constexpr unsigned long long SW_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
 
-// one wave: wait until the words xh[0 .. cnt) (cnt <= 64) hold results; lane l returns word min(l, cnt-1)
-__device__ __forceinline__ double poll_block(const double *xh, const int cnt, const int lane, int *info, bool &dead) {
+// one wave: wait until the words xh[0 .. cnt) (cnt <= 64) hold results; lane l returns word min(l, cnt-1).
+// Polls back off: the first `nfast` polls come every ~`fast` x 27 ns (a block that is about to be published: the
+// chain of pivot blocks), later ones every ~`slow` x 27 ns (blocks that are many steps away: hundreds of waiting
+// waves must not flood the L2 / fabric with coherent reads).
+__device__ __forceinline__ double poll_block(const double *xh, const int cnt, const int lane, int *info, bool &dead, const SweepArgs &a) {
     const unsigned long long *p = reinterpret_cast<const unsigned long long *>(xh) + min(lane, cnt - 1);
     unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
     while (!dead && !__all(v != SW_SENTINEL)) {
-        __builtin_amdgcn_s_sleep(8);
+        const int naps = (spins < (unsigned)a.poll_nfast) ? a.poll_fast : a.poll_slow;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(1);
         if ((++spins & 127u) == 0u) {
             if (__hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
             else if (spins > (1u << 21)) { __hip_atomic_store(info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
@@ -1389,7 +1393,8 @@ __device__ __forceinline__ double readlane_f64(const double v, const int l) {   
 // consumed block.  BELOW item: <= 128 rows below the pivot block; waves 0/1 = rows 0..63 / 64..127 of the chunk
 // for columns 0..31 of a block, waves 2/3 the same rows for columns 32..63.
 template <bool PIVOT>
-__device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDesc &fd, const DevCtx &c, const double *xh, double *scratch) {
+__device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDesc &fd, const DevCtx &c, const SweepArgs &a, double *scratch) {
+    const double *xh = a.xh;
     constexpr int NBATCH = PIVOT ? 1 : 2;                      // batches of 16 columns per wave and block
     constexpr int WCOLS = 16 * NBATCH;                         // columns of a block handled by a wave
     const i32 f = fd.f, ns = fd.ns;
@@ -1419,7 +1424,7 @@ __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDe
     auto wait_block = [&](const i32 j) -> double {             // this wave's columns of block j (zero beyond its width)
         const i32 cnt = min(WCOLS, min(SWEEP_NB, ns - j * SWEEP_NB) - cp0);
         if (cnt <= 0) return 0.0;
-        const double v = poll_block(xhf + j * SWEEP_NB + cp0, cnt, lane, c.info, dead);
+        const double v = poll_block(xhf + j * SWEEP_NB + cp0, cnt, lane, c.info, dead, a);
         return (lane < cnt) ? v : 0.0;
     };
     if (nin > 0) {
@@ -1475,8 +1480,8 @@ __global__ __launch_bounds__(256, 4) void k_fwd_sweep(const SolveTask *__restric
     __syncthreads();
     const SolveTask t = tasks[s_item];
     const FrontDesc fd = c.fronts[t.front];
-    if (t.slot) fwd_sweep_item<true>(t, fd, c, a.xh, scratch);          // workgroup-uniform
-    else fwd_sweep_item<false>(t, fd, c, a.xh, scratch);
+    if (t.slot) fwd_sweep_item<true>(t, fd, c, a, scratch);             // workgroup-uniform
+    else fwd_sweep_item<false>(t, fd, c, a, scratch);
 }
 
 // Backward: item = column block [k0, k0 + nb) (nb <= 64) of a front.  t[k0 + j] = b - sum_r L[r, k0 + j] x[r] over the
@@ -1541,7 +1546,7 @@ __global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restric
             gi1 = row_index(q + 2);
         } else {
             const i32 jb = nblk - 1 - (q - nbelow);
-            xv = poll_block(xhf + jb * SWEEP_NB, nr, lane, c.info, dead);
+            xv = poll_block(xhf + jb * SWEEP_NB, nr, lane, c.info, dead, a);
         }
         return (lane < nr) ? xv : 0.0;
     };

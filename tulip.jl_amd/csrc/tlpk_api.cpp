@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <climits>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -55,6 +56,7 @@ struct tlpk_handle {
     std::vector<i32> sweep_slot_fwd, sweep_slot_bwd;
     std::vector<unsigned long long> sweep_runs_fwd, sweep_runs_bwd;
     unsigned long long solve_epoch = 0;
+    int poll[3] = {8, 16, 32};          // TLPK_POLL=fast,nfast,slow (tuning knob of the sweep kernels' polling back-off)
     std::string last_error;
 };
 
@@ -203,7 +205,7 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
             std::vector<unsigned long long> &runs = dir == 0 ? h->sweep_runs_fwd : h->sweep_runs_bwd;
             const i32 slot = (dir == 0 ? h->sweep_slot_fwd : h->sweep_slot_bwd)[i];
             SweepArgs sw{h->d.sweep_tickets + slot, runs[i] * (unsigned long long)cur.count,
-                         h->d.sweep_xh + (dir == 0 ? 0 : h->S.m)};
+                         h->d.sweep_xh + (dir == 0 ? 0 : h->S.m), h->poll[0], h->poll[1], h->poll[2]};
             runs[i] += 1;
             launch_tasks(st, h->d, cur, &sw);
         } else
@@ -348,6 +350,7 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
         }
         h->profile = def.profile != 0;
         if (const char *e = std::getenv("TLPK_SERIAL")) h->serial = std::atoi(e) != 0;
+        if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
         const auto t0 = std::chrono::steady_clock::now();
         rc = analyse(h->S, m, n, colptr, rowval, nzval, index_base, h->opt);
         h->ms_analyse = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

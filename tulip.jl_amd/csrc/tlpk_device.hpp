@@ -27,6 +27,7 @@ struct SweepArgs {
     unsigned long long *ticket;   // hand-out counter of this launch (monotonic over the life of the handle)
     unsigned long long base;      // its value before this launch: item = ticket - base
     double *xh;                   // hand-over words of this direction, one per permuted column, sentinel-filled before the solve
+    int poll_fast, poll_nfast, poll_slow;   // polling back-off (units of s_sleep 1 = 64 clocks): first poll_nfast polls every poll_fast, then every poll_slow
 };
 
 struct DevArrays {
