@@ -156,6 +156,35 @@ int64_t tlpk_symbolic_get_f64(const tlpk_handle *h, const char *what, double *bu
 /* Copy the numeric factor panels (device -> host), nnzL_stored doubles. */
 int tlpk_get_factor(tlpk_handle *h, double *lval, int64_t cap);
 
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident HSD iterate: an OPTIONAL extension for callers that keep the
+ * interior-point vectors in HBM.  The drop-in interface above moves 16 (m + n) bytes over PCIe per
+ * solve and leaves every right-hand side to the host; here one call runs one routine of
+ * /root/reference/src/IPM/HSD/{HSD.jl, step.jl} on device vectors owned by the handle and returns only
+ * scalars.  The host keeps tau, kappa, the regularisation scalars and the control flow
+ * (tulip.jl_amd/hsd_device.py mirrors HSD.jl:203-350).  Single-rank handles only.
+ * --------------------------------------------------------------------------------------------- */
+/* b (m), c (n), l, u (n; +-Inf allowed) of the standard form (ipmdata.jl:64-173); sets the HSD starting point
+ * (HSD.jl:238-247).  tlpk_ipm_reset restores the starting point. */
+int tlpk_ipm_load(tlpk_handle *h, const double *b, const double *c, const double *l, const double *u);
+int tlpk_ipm_reset(tlpk_handle *h);
+/* HSD.jl:77-128, 136-196.  out[13] = { |rp|inf, |rl|inf, |ru|inf, |rd|inf, c'x, b'y, lz'zl, uz'zu, xl'zl + xu'zu,
+ *                                      |Ax|inf, |(x-xl) lflag|inf, |(x+xu) uflag|inf, |A'y + zl lflag - zu uflag|inf } */
+int tlpk_ipm_residuals(tlpk_handle *h, double tau, double *out);
+/* step.jl:24-51: theta_inv from the iterate, uniform regP / regD, KKT.update!; TLPK_NOT_POSDEF -> retry with larger values */
+int tlpk_ipm_factor(tlpk_handle *h, double regP, double regD);
+/* step.jl:56-76: h-system; out[0] = lz'(lz th_l) + uz'(uz th_u) - (c + th_l lz + th_u uz)'hx + b'hy */
+int tlpk_ipm_hsolve(tlpk_handle *h, double *out);
+/* step.jl:325-364: centrality targets from the accepted direction; out[2] = { sum(vl), sum(vu) } */
+int tlpk_ipm_targets(tlpk_handle *h, double a_, double mu_l, double mu_u, double *out);
+/* step.jl:198-266 + 294-306: one Newton system.  mode 0 predictor | 1 corrector | 2 centrality corrector;
+ * sc[8] = { tau, kappa, h0, xi_g, xi_tk, eta, gamma*mu, delta }; out[3] = { dtau, dkappa, max step to the boundary } */
+int tlpk_ipm_newton(tlpk_handle *h, int mode, const double *sc, double *out);
+int tlpk_ipm_accept(tlpk_handle *h);                         /* step.jl:112-118: candidate -> accepted direction */
+int tlpk_ipm_advance(tlpk_handle *h, double alpha, double *out);   /* step.jl:139-148; out[0] = xl'zl + xu'zu */
+/* what = 0 x, 1 xl, 2 xu, 3 zl, 4 zu (n), 5 y (m) */
+int tlpk_ipm_get(tlpk_handle *h, int what, double *host, int64_t len);
+
 const char *tlpk_strerror(int code);
 const char *tlpk_last_error(const tlpk_handle *h);
 const char *tlpk_backend_name(void);         /* "HIP (gfx950)" */

@@ -58,6 +58,8 @@ EXPORTS = [
     "tlpk_solve_finish", "tlpk_info", "tlpk_kernel_timing", "tlpk_get_perm", "tlpk_symbolic_get",
     "tlpk_symbolic_get_f64", "tlpk_set_profile", "tlpk_root_copy", "tlpk_get_factor", "tlpk_strerror", "tlpk_last_error",
     "tlpk_backend_name", "tlpk_system_name", "tlpk_device_count",
+    "tlpk_ipm_load", "tlpk_ipm_reset", "tlpk_ipm_residuals", "tlpk_ipm_factor", "tlpk_ipm_hsolve", "tlpk_ipm_targets",
+    "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get",
 ]
 
 
@@ -109,6 +111,19 @@ def lib():
     L.tlpk_backend_name.restype = C.c_char_p
     L.tlpk_system_name.restype = C.c_char_p
     L.tlpk_device_count.restype = C.c_int
+    L.tlpk_ipm_load.argtypes = [vp, pd, pd, pd, pd]
+    L.tlpk_ipm_reset.argtypes = [vp]
+    L.tlpk_ipm_residuals.argtypes = [vp, C.c_double, pd]
+    L.tlpk_ipm_factor.argtypes = [vp, C.c_double, C.c_double]
+    L.tlpk_ipm_hsolve.argtypes = [vp, pd]
+    L.tlpk_ipm_targets.argtypes = [vp, C.c_double, C.c_double, C.c_double, pd]
+    L.tlpk_ipm_newton.argtypes = [vp, C.c_int, pd, pd]
+    L.tlpk_ipm_accept.argtypes = [vp]
+    L.tlpk_ipm_advance.argtypes = [vp, C.c_double, pd]
+    L.tlpk_ipm_get.argtypes = [vp, C.c_int, pd, C.c_int64]
+    for name in ("tlpk_ipm_load", "tlpk_ipm_reset", "tlpk_ipm_residuals", "tlpk_ipm_factor", "tlpk_ipm_hsolve",
+                 "tlpk_ipm_targets", "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get"):
+        getattr(L, name).restype = C.c_int
     for name in ("tlpk_create", "tlpk_update", "tlpk_solve", "tlpk_update_device", "tlpk_solve_device",
                  "tlpk_sync", "tlpk_update_local", "tlpk_root_panel", "tlpk_update_finish",
                  "tlpk_solve_local", "tlpk_root_rhs", "tlpk_solve_finish", "tlpk_info",

@@ -1490,7 +1490,9 @@ __global__ __launch_bounds__(256, 4) void k_fwd_sweep(const SolveTask *__restric
 // contiguous rows of a tile, a wave owns 16 of the columns and keeps per-lane partial sums over ALL tiles (one
 // shuffle reduction at the end).
 __global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
-    __shared__ double ts[NB_IN], xo[NB_IN];
+    __shared__ double red[NB_IN][NB_IN + 1];        // per-lane partial sums of the 64 columns, transposed reduction
+    __shared__ double ts[NB_IN], bsh[NB_IN];
+    __shared__ double ps[4][NB_IN];
     __shared__ unsigned s_item;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1508,8 +1510,21 @@ __global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restric
     const char *Pb = reinterpret_cast<const char *>(c.Lval + fd.loff + (i64)t.k0 * f);
     size_t coloff[1];
     (void)coloff;
+    // Held from the start, off the chain: this block's right-hand side and the fragment of the inverted diagonal
+    // block for x[ci] = sum_k W[k][ci] t[k]: thread (ci = lane, part = wave) keeps W[16 part + kk][ci] (W is stored
+    // column-major: 16 consecutive doubles per lane)
+    if (tid < NB_IN) bsh[tid] = (tid < nb) ? c.xw[fd.col0 + t.k0 + min(tid, nb - 1)] : 0.0;
     double w[16];
-    load_frag<true, 0>(c, fd, t.k0, nb, w);                     // W[k = lane][16 wave + kk], held from the start
+    {
+        const double *W = front_dinv(c, fd, t.k0);              // nb x nb, column-major, ld = nb, upper part zero
+        const i32 ci = min(lane, nb - 1);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const i32 k = 16 * wave + kk;
+            const double v = W[(i64)min(k, nb - 1) + (i64)ci * nb];
+            w[kk] = (lane < nb && k < nb && k >= lane) ? v : 0.0;
+        }
+    }
     double acc[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc[u] = 0.0;
@@ -1559,28 +1574,31 @@ __global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restric
         }
     }
     (void)gi0;
-    // column sums over the 64 lanes, fixed tree; lane 0 holds the 16 sums of this wave's columns
-    reduce16(acc);
-    if (lane == 0) {
+    // column sums over the 64 lanes (rows) through LDS: thread (col = tid / 4, sub = tid % 4) adds 16 lanes' partial
+    // sums, the four subs are combined by two quad shuffles -- fixed order, ~40 LDS accesses on the chain instead of
+    // two 96-shuffle trees
 #pragma unroll
-        for (int u = 0; u < 16; ++u) xo[16 * wave + u] = acc[u];
+    for (int u = 0; u < 16; ++u) red[16 * wave + u][lane] = acc[u];
+    __syncthreads();
+    {
+        const int col = tid >> 2, sub = tid & 3;
+        double s_ = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_ += red[col][16 * sub + i];
+        s_ += __shfl_xor(s_, 1);
+        s_ += __shfl_xor(s_, 2);
+        if (sub == 0) ts[col] = bsh[col] - s_;                  // zero beyond nb (clamped duplicate columns are dropped by w)
     }
     __syncthreads();
-    if (tid < NB_IN) ts[tid] = (tid < nb) ? c.xw[fd.col0 + t.k0 + min(tid, nb - 1)] - xo[tid] : 0.0;
+    double xs_ = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) xs_ += w[kk] * ts[16 * wave + kk];
+    ps[wave][lane] = xs_;
     __syncthreads();
-    const double t1 = ts[lane];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) w[kk] *= t1;                // x[ci] = sum_k W[k][ci] t[k], ci = 16 wave + kk
-    reduce16(w);
-    if (lane == 0) {
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const i32 ci = 16 * wave + kk;
-            if (ci < nb) {
-                c.xw[fd.col0 + t.k0 + ci] = w[kk];
-                st_agent(const_cast<double *>(xhf) + t.k0 + ci, w[kk]);
-            }
-        }
+    if (wave == 0 && lane < nb) {
+        const double x = ((ps[0][lane] + ps[1][lane]) + ps[2][lane]) + ps[3][lane];
+        c.xw[fd.col0 + t.k0 + lane] = x;
+        st_agent(const_cast<double *>(xhf) + t.k0 + lane, x);   // hand-over: the data is its own flag
     }
 }
 

@@ -18,83 +18,15 @@
 
 #include "../../include/tlpk.h"
 #include "tlpk_device.hpp"
+#include "tlpk_handle.hpp"
 
 using namespace tlpk;
-
-struct tlpk_handle {
-    Symbolic S;
-    Options opt;
-    std::vector<i64> row_block_copy, user_perm_copy;
-    int device = -1;
-    bool has_device = false;
-    bool profile = false;
-    bool serial = false;          // TLPK_SERIAL=1: every launch on the main stream (what profile mode does), for external profilers
-    hipStream_t stream = nullptr;                 // main stream (= group 0)
-    hipStream_t gstream[MAX_GROUPS] = {};         // gstream[0] == stream; others: concurrent subtree groups
-    hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
-    hipStream_t sstream[MAX_GROUPS] = {};         // side stream of each group: diagonal-block chains overlap the bulk update
-    hipEvent_t ev_side[MAX_GROUPS] = {};
-    bool forked = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<hipEvent_t> ev_pool;
-    std::vector<int> ev_class;            // class of each recorded pair in the current call
-    size_t ev_used = 0;
-    DevArrays d;
-    std::vector<void *> allocs;
-    i64 device_bytes = 0;
-    double *d_theta = nullptr, *d_regP = nullptr, *d_regD = nullptr, *d_D = nullptr;
-    double *d_xip = nullptr, *d_xid = nullptr, *d_dx = nullptr, *d_dy = nullptr;
-    int *h_info = nullptr;
-    double *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-pointer entry points (lazily allocated)
-    bool factored = false, local_done = false, solve_local_done = false, solve_timed = false;
-    i64 fail_col = -1;
-    double ms_analyse = 0, ms_update = 0, ms_solve = 0;
-    tlpk_kernel_times kt{};
-    size_t factor_marker = 0, fwd_marker = 0;   // index of the LK_ALLREDUCE_ROOT launch (or size)
-    i64 first_link = 0, nlink = 0;
-    // persistent sweeps: ticket-counter slot and number of runs of every sweep launch, flag epoch
-    std::vector<i32> sweep_slot_fwd, sweep_slot_bwd;
-    std::vector<unsigned long long> sweep_runs_fwd, sweep_runs_bwd;
-    unsigned long long solve_epoch = 0;
-    int poll[3] = {8, 16, 32};          // TLPK_POLL=fast,nfast,slow (tuning knob of the sweep kernels' polling back-off)
-    std::string last_error;
-};
 
 namespace {
 
 // GPU_MAX_HW_QUEUES (more hardware queues than the runtime's default 4) is a tuning knob of the HOST
 // process: the Python and Julia glue set it before the HIP runtime initialises (tulip.jl_amd/__init__.py,
 // julia/libtlpk.jl).  The library itself never touches the environment.
-
-int hip_fail(tlpk_handle *h, hipError_t e, const char *what) {
-    h->last_error = std::string(what) + ": " + hipGetErrorString(e);
-    return (e == hipErrorOutOfMemory) ? TLPK_OOM : TLPK_HIPERR;
-}
-#define HIPCHK(h, call)                                                   \
-    do {                                                                  \
-        hipError_t e_ = (call);                                           \
-        if (e_ != hipSuccess) return hip_fail((h), e_, #call);            \
-    } while (0)
-
-template <class T>
-int dev_alloc(tlpk_handle *h, T **out, i64 count) {
-    *out = nullptr;
-    const size_t bytes = (size_t)std::max<i64>(count, 1) * sizeof(T);
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return hip_fail(h, e, "hipMalloc");
-    h->allocs.push_back(p);
-    h->device_bytes += (i64)bytes;
-    *out = (T *)p;
-    return TLPK_OK;
-}
-template <class T>
-int dev_upload(tlpk_handle *h, T **out, const std::vector<T> &v) {
-    int rc = dev_alloc(h, out, (i64)v.size());
-    if (rc != TLPK_OK) return rc;
-    if (!v.empty()) HIPCHK(h, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    return TLPK_OK;
-}
 
 int kind_class(i32 kind) {
     switch (kind) {
@@ -421,6 +353,7 @@ void tlpk_destroy(tlpk_handle *h) {
     if (h->device >= 0) {
         hipSetDevice(h->device);
         if (h->stream) hipStreamSynchronize(h->stream);
+        ipm_free(h);
         for (void *p : h->allocs) hipFree(p);
         if (h->h_info) hipHostFree(h->h_info);
         if (h->pin_in) hipHostFree(h->pin_in);

@@ -1,0 +1,44 @@
+// tlpk_ipm.hpp -- device-resident interior-point state: views shared by
+// ipm_kernels.hip and tlpk_ipm.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "tlpk_host.hpp"
+
+namespace tlpk {
+
+constexpr int IPM_SLOTS = 16;      // reduction results per kernel
+constexpr int IPM_BLOCKS = 1024;   // workgroups of the grid-stride kernels (per-block partials, fixed combination order)
+
+// search direction (or any vector of the iterate's shape)
+struct IpmDir { double *x, *xl, *xu, *zl, *zu /* n */, *y /* m */; };
+
+// everything the kernels read; passed by value
+struct IpmVecs {
+    i64 m, n;
+    const i64 *Ap; const i32 *Ai; const double *Ax;       // A, CSC (the handle's copy)
+    const i64 *Tp; const i32 *Tj; const double *Tx;       // A, CSR
+    const double *b, *c, *lz, *uz, *lflag, *uflag;        // problem data: l .* lflag, u .* uflag, flags as 0 / 1
+    double *x, *xl, *xu, *zl, *zu, *y;                    // the iterate (point.jl)
+    double *rp, *rl, *ru, *rd;                            // residuals (HSD.jl:83-110)
+    double *thl, *thu;                                    // zl ./ xl, zu ./ xu on bounded entries
+    double *hx, *hy;                                      // solution of the h-system (step.jl:56-66)
+    double *xil, *xiu, *xzl, *xzu, *xid, *xip;            // right-hand sides of the current Newton system
+};
+
+void ipm_launch_init(hipStream_t st, const IpmVecs &v);
+void ipm_launch_finalize(hipStream_t st, int nblocks, int nsum, int nmax, int nmin, const double *partials, double *out);
+int ipm_launch_res_cols(hipStream_t st, const IpmVecs &v, double tau, double *partials);
+int ipm_launch_res_rows(hipStream_t st, const IpmVecs &v, double tau, double *partials);
+void ipm_launch_theta(hipStream_t st, const IpmVecs &v, double *theta, double *regP, double *regD, double rP, double rD);
+void ipm_launch_hrhs(hipStream_t st, const IpmVecs &v);
+int ipm_launch_hdots(hipStream_t st, const IpmVecs &v, double *partials);
+int ipm_launch_targets(hipStream_t st, const IpmVecs &v, const IpmDir &D, double a_, double mu_l, double mu_u, double *partials);
+int ipm_launch_newton_pre(hipStream_t st, const IpmVecs &v, const IpmDir &D, int mode, double eta, double gmu, double delta, double *partials);
+void ipm_launch_newton_dots(hipStream_t st, const IpmVecs &v, const IpmDir &D, int nblocks, double *partials);
+int ipm_launch_newton_post(hipStream_t st, const IpmVecs &v, const IpmDir &D, const IpmDir &Add, int add, double dtau, double *partials);
+int ipm_launch_advance(hipStream_t st, const IpmVecs &v, const IpmDir &D, double alpha, double *partials);
+
+}  // namespace tlpk
