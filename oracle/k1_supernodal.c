@@ -22,7 +22,7 @@
  *
  * The symbolic structure (ordering, supernodes/fronts, relative indices, assembly lists of
  * A*D*A') is NOT recomputed here: the caller passes the arrays of an analyse-only libtlpk handle
- * (tlpk_symbolic_get), so that the CPU and GPU paths factorise the same permuted matrix with the
+ * (tlpk_symbolic_get; panels are f x ns column-major with leading dimension lda >= f), so that the CPU and GPU paths factorise the same permuted matrix with the
  * same supernode partition => same nnz(L), same flops, and the factor panels can be compared entry
  * by entry at full benchmark size (tests/test_gpu_parity.py).  The numeric code is independent of
  * the HIP kernels (LAPACK-style unblocked-by-us calls vs hand-written MFMA tiles).
@@ -63,7 +63,7 @@ typedef struct k1sn {
     i64 *Ap, *Ai; double *Ax;
     i64 *perm;                                    /* perm[new] = old */
     /* fronts */
-    i64 *f, *ns, *col0, *loff, *rowoff, *reloff, *child_ptr, *nchild, *depth;
+    i64 *f, *ns, *col0, *loff, *rowoff, *reloff, *child_ptr, *nchild, *depth, *lda;
     i64 *rowidx, *rel, *children;
     i64 *level_ptr, *level_fronts;                /* fronts by depth, heaviest first inside a level */
     i64 *ucoff; i64 uc_len;
@@ -95,7 +95,7 @@ void k1sn_free(k1sn *h) {
     if (!h) return;
     free(h->Ap); free(h->Ai); free(h->Ax); free(h->perm);
     free(h->f); free(h->ns); free(h->col0); free(h->loff); free(h->rowoff); free(h->reloff);
-    free(h->child_ptr); free(h->nchild); free(h->depth); free(h->rowidx); free(h->rel); free(h->children);
+    free(h->child_ptr); free(h->nchild); free(h->depth); free(h->lda); free(h->rowidx); free(h->rel); free(h->children);
     free(h->level_ptr); free(h->level_fronts); free(h->ucoff);
     free(h->s_target); free(h->s_diag_row); free(h->pair_ptr); free(h->pair_j); free(h->pair_w);
     free(h->theta); free(h->regP); free(h->regD); free(h->D); free(h->Lval); free(h->uc); free(h->xw);
@@ -112,7 +112,7 @@ static int cmp_wk(const void *a, const void *b) { const double x = ((const wk_t 
  * returns 0 ok, 2 bad argument / BLAS not found, 3 out of memory */
 int k1sn_create(k1sn **out, const char *blas_path, i64 m, i64 n, const i64 *Ap, const i64 *Ai, const double *Ax,
                 const i64 *perm, i64 nf, const i64 *f, const i64 *ns, const i64 *col0, const i64 *loff,
-                const i64 *rowoff, const i64 *reloff, const i64 *child_ptr, const i64 *nchild, const i64 *depth,
+                const i64 *rowoff, const i64 *reloff, const i64 *child_ptr, const i64 *nchild, const i64 *depth, const i64 *lda,
                 i64 n_rowidx, const i64 *rowidx, i64 n_rel, const i64 *rel, i64 n_children, const i64 *children,
                 i64 nnzS, const i64 *s_target, const i64 *s_diag_row, const i64 *pair_ptr, const i64 *pair_j,
                 const double *pair_w, i64 lval_len, int nthreads) {
@@ -144,7 +144,7 @@ int k1sn_create(k1sn **out, const char *blas_path, i64 m, i64 n, const i64 *Ap, 
     h->Ap = dup64(Ap, n + 1); h->Ai = dup64(Ai, h->nnzA); h->Ax = dupd(Ax, h->nnzA); h->perm = dup64(perm, m);
     h->f = dup64(f, nf); h->ns = dup64(ns, nf); h->col0 = dup64(col0, nf); h->loff = dup64(loff, nf);
     h->rowoff = dup64(rowoff, nf); h->reloff = dup64(reloff, nf); h->child_ptr = dup64(child_ptr, nf);
-    h->nchild = dup64(nchild, nf); h->depth = dup64(depth, nf);
+    h->nchild = dup64(nchild, nf); h->depth = dup64(depth, nf); h->lda = dup64(lda, nf);
     h->rowidx = dup64(rowidx, n_rowidx); h->rel = dup64(rel, n_rel); h->children = dup64(children, n_children);
     h->s_target = dup64(s_target, nnzS); h->s_diag_row = dup64(s_diag_row, nnzS); h->pair_ptr = dup64(pair_ptr, nnzS + 1);
     h->pair_j = dup64(pair_j, pair_ptr[nnzS]); h->pair_w = dupd(pair_w, pair_ptr[nnzS]);
@@ -155,7 +155,7 @@ int k1sn_create(k1sn **out, const char *blas_path, i64 m, i64 n, const i64 *Ap, 
     h->xw = (double *)calloc((size_t)(m > 0 ? m : 1), 8);
     h->ucoff = (i64 *)malloc((size_t)(nf > 0 ? nf : 1) * sizeof(i64));
     if (!h->Ap || !h->Ai || !h->Ax || !h->perm || !h->f || !h->ns || !h->col0 || !h->loff || !h->rowoff || !h->reloff ||
-        !h->child_ptr || !h->nchild || !h->depth || !h->rowidx || !h->rel || !h->children || !h->s_target || !h->s_diag_row ||
+        !h->child_ptr || !h->nchild || !h->depth || !h->lda || !h->rowidx || !h->rel || !h->children || !h->s_target || !h->s_diag_row ||
         !h->pair_ptr || !h->pair_j || !h->pair_w || !h->theta || !h->regP || !h->regD || !h->D || !h->Lval || !h->U || !h->xw || !h->ucoff) {
         k1sn_free(h); return 3;
     }
@@ -189,7 +189,7 @@ int k1sn_create(k1sn **out, const char *blas_path, i64 m, i64 n, const i64 *Ap, 
 
 /* one front: extend-add of the children's update matrices, dense partial factorisation */
 static void factor_front(k1sn *h, i64 s, i64 *fail) {
-    const i64 f = h->f[s], ns = h->ns[s], rs = f - ns;
+    const i64 f = h->f[s], ns = h->ns[s], rs = f - ns, ld = h->lda[s];       /* panel: f x ns, leading dimension ld >= f */
     double *P = h->Lval + h->loff[s];
     double *Us = NULL;
     if (rs > 0) { Us = (double *)calloc((size_t)(rs * rs), 8); h->U[s] = Us; if (!Us) { *fail = -2; return; } }
@@ -202,12 +202,12 @@ static void factor_front(k1sn *h, i64 s, i64 *fail) {
         for (i64 q = 0; q < rsc; ++q) {
             const i64 tc = relc[q];
             const double *src = Uc + q * rsc;
-            if (tc < ns) { double *dst = P + tc * f; for (i64 r = q; r < rsc; ++r) dst[relc[r]] += src[r]; }
+            if (tc < ns) { double *dst = P + tc * ld; for (i64 r = q; r < rsc; ++r) dst[relc[r]] += src[r]; }
             else { double *dst = Us + (tc - ns) * rs - ns; for (i64 r = q; r < rsc; ++r) dst[relc[r]] += src[r]; }
         }
         free(h->U[c]); h->U[c] = NULL;
     }
-    blasint info = 0, bn = (blasint)ns, bf = (blasint)f, brs = (blasint)rs;
+    blasint info = 0, bn = (blasint)ns, bf = (blasint)ld, brs = (blasint)rs;
     h->dpotrf("L", &bn, P, &bf, &info);
     if (info != 0) {                                       /* not positive definite: spd.jl:46-47 */
         const i64 col = h->col0[s] + (info > 0 ? info - 1 : 0);
@@ -277,7 +277,7 @@ static void fwd_front(k1sn *h, i64 s) {
         const double *ucc = h->uc + h->ucoff[c];
         for (i64 r = 0; r < rsc; ++r) { const i64 pos = relc[r]; if (pos < ns) x[pos] += ucc[r]; else ucs[pos - ns] += ucc[r]; }
     }
-    const blasint bn = (blasint)ns, bf = (blasint)f, brs = (blasint)rs, inc = 1;
+    const blasint bn = (blasint)ns, bf = (blasint)h->lda[s], brs = (blasint)rs, inc = 1;
     h->dtrsv("L", "N", "N", &bn, P, &bf, x, &inc);
     if (rs > 0) { const double mone = -1.0, one = 1.0; h->dgemv("N", &brs, &bn, &mone, P + ns, &bf, x, &inc, &one, ucs, &inc); }
 }
@@ -286,7 +286,7 @@ static void bwd_front(k1sn *h, i64 s) {
     const double *P = h->Lval + h->loff[s];
     double *x = h->xw + h->col0[s], *xb = h->uc + h->ucoff[s];     /* the contribution vector is free again: reuse it */
     const i64 *rows = h->rowidx + h->rowoff[s] + ns;
-    const blasint bn = (blasint)ns, bf = (blasint)f, brs = (blasint)rs, inc = 1;
+    const blasint bn = (blasint)ns, bf = (blasint)h->lda[s], brs = (blasint)rs, inc = 1;
     if (rs > 0) {
         for (i64 r = 0; r < rs; ++r) xb[r] = h->xw[rows[r]];
         const double mone = -1.0, one = 1.0;

@@ -17,7 +17,7 @@ class Emulator:
         self.kkt = kkt
         self.m, self.n = kkt.m, kkt.n
         self.perm = g("perm")
-        self.f = g("front_f"); self.ns = g("front_ns"); self.col0 = g("front_col0")
+        self.f = g("front_f"); self.ns = g("front_ns"); self.col0 = g("front_col0"); self.lda = g("front_lda")
         self.parent = g("front_parent"); self.loff = g("front_loff"); self.rowoff = g("front_rowoff")
         self.reloff = g("front_reloff"); self.child_ptr = g("front_child_ptr"); self.nchild = g("front_nchild")
         self.local = g("front_local")
@@ -59,8 +59,8 @@ class Emulator:
 
     # views
     def panel(self, s):
-        f, ns = int(self.f[s]), int(self.ns[s])
-        return self.Lval[self.loff[s]: self.loff[s] + f * ns].reshape((f, ns), order="F")
+        f, ns, lda = int(self.f[s]), int(self.ns[s]), int(self.lda[s])
+        return self.Lval[self.loff[s]: self.loff[s] + lda * ns].reshape((lda, ns), order="F")[:f]
 
     def rows(self, s):
         return self.rowidx[self.rowoff[s]: self.rowoff[s] + self.f[s]]
@@ -110,7 +110,7 @@ class Emulator:
         s = self.root_front
         if s < 0:
             return self.Lval[:0]
-        return self.Lval[self.loff[s]: self.loff[s] + self.f[s] * self.ns[s]]
+        return self.Lval[self.loff[s]: self.loff[s] + self.lda[s] * self.ns[s]]
 
     def update_finish(self):
         self._run(self.factor_launches, False, start=self._resume)
@@ -193,11 +193,11 @@ class Emulator:
 
     def _k2(self, T, rows_per_task=64):      # trsm: rows below the diagonal block of a block column, whole width
         import scipy.linalg as sla
-        for front, k0, nb, row0, *_ in T:
+        for front, k0, nb, row0, _kprev, rowlim in T:
             P = self.panel(front)
             f = int(self.f[front])
-            r1 = min(row0 + rows_per_task, f)
-            assert row0 >= k0 + nb
+            r1 = int(rowlim)                                      # rows [row0, rowlim) belong to the task
+            assert row0 >= k0 + nb and row0 < r1 <= f and r1 - row0 <= rows_per_task
             L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
             P[row0:r1, k0:k0 + nb] = sla.solve_triangular(L11, P[row0:r1, k0:k0 + nb].T, lower=True).T
 
@@ -412,7 +412,7 @@ def panels_to_dense_L(kkt, lval):
     em = Emulator.__new__(Emulator)
     g = kkt.symbolic
     em.m = kkt.m
-    em.f = g("front_f"); em.ns = g("front_ns"); em.col0 = g("front_col0"); em.loff = g("front_loff")
+    em.f = g("front_f"); em.ns = g("front_ns"); em.col0 = g("front_col0"); em.loff = g("front_loff"); em.lda = g("front_lda")
     em.rowoff = g("front_rowoff"); em.rowidx = g("rowidx"); em.local = g("front_local")
     em.Lval = lval
     return em.dense_L()

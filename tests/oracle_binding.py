@@ -253,7 +253,7 @@ def _lib3():
         lib = C.CDLL(path)
         p64, pd, vp = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p
         i64 = C.c_int64
-        lib.k1sn_create.argtypes = ([C.POINTER(vp), C.c_char_p, i64, i64, p64, p64, pd, p64, i64] + [p64] * 9 +
+        lib.k1sn_create.argtypes = ([C.POINTER(vp), C.c_char_p, i64, i64, p64, p64, pd, p64, i64] + [p64] * 10 +
                                     [i64, p64, i64, p64, i64, p64, i64, p64, p64, p64, p64, pd, i64, C.c_int])
         lib.k1sn_create.restype = C.c_int
         lib.k1sn_update.argtypes = [vp, pd, pd, pd]; lib.k1sn_update.restype = C.c_int
@@ -282,7 +282,7 @@ class SupernodalK1:
         Ap, Ai, Ax = c64(A.indptr), c64(A.indices), np.ascontiguousarray(A.data, dtype=np.float64)
         perm = c64(g("perm"))
         fr = [c64(g(k)) for k in ("front_f", "front_ns", "front_col0", "front_loff", "front_rowoff", "front_reloff",
-                                   "front_child_ptr", "front_nchild", "depth")]
+                                   "front_child_ptr", "front_nchild", "depth", "front_lda")]
         rowidx, rel, children = c64(g("rowidx")), c64(g("rel")), c64(g("children"))
         s_target, s_diag, pair_ptr, pair_j = c64(g("s_target")), c64(g("s_diag_row")), c64(g("pair_ptr")), c64(g("pair_j"))
         pair_w = np.ascontiguousarray(tl.symbolic_array_f64(kkt._h, "pair_w"))

@@ -367,11 +367,11 @@ def test_c4_scale_factor_entrywise_vs_cpu_supernodal():
     sn.update(th, rp, rd)
     dxc, dyc = sn.solve(xp, xd)
     Lg, Lc = kkt.factor_panels(), sn.factor_panels()
-    f, ns, loff = kkt.symbolic("front_f"), kkt.symbolic("front_ns"), kkt.symbolic("front_loff")
+    f, ns, loff, lda = kkt.symbolic("front_f"), kkt.symbolic("front_ns"), kkt.symbolic("front_loff"), kkt.symbolic("front_lda")
     lmax = 0.0; worst = 0.0; checked = 0
     for s in range(len(f)):
-        a = Lg[loff[s]: loff[s] + f[s] * ns[s]].reshape((f[s], ns[s]), order="F")
-        b = Lc[loff[s]: loff[s] + f[s] * ns[s]].reshape((f[s], ns[s]), order="F")
+        a = Lg[loff[s]: loff[s] + lda[s] * ns[s]].reshape((lda[s], ns[s]), order="F")[: f[s]]
+        b = Lc[loff[s]: loff[s] + lda[s] * ns[s]].reshape((lda[s], ns[s]), order="F")[: f[s]]
         mask = np.tril(np.ones((f[s], ns[s]), dtype=bool))                     # stored entries: row >= column
         lmax = max(lmax, float(np.abs(b[mask]).max()))
         worst = max(worst, float(np.abs(a[mask] - b[mask]).max()))

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
     const EaTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     double *P = c.Lval + fd.loff;
     double *Up = front_u(c, fd);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
                 const i32 tc = relc[q];
                 if (((tc - t.j0) & 3) != wave) continue;
                 const double *__restrict__ src = Uc + (i64)q * rsc;
-                double *__restrict__ dst = (tc < ns) ? (P + (i64)tc * f) : (Up + (i64)(tc - ns) * rs - ns);
+                double *__restrict__ dst = (tc < ns) ? (P + (i64)tc * lda) : (Up + (i64)(tc - ns) * rs - ns);
                 // targets of one column are distinct rows: batches of 4 independent read-modify-writes
                 i32 r = q + lane;
                 for (; r + 192 < rsc; r += 256) {
@@ -186,7 +187,8 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
     double (*rowbuf)[NB_IN] = colbuf + 2;
     double *dg = scratch + NB_IN * (NB_IN + 1) + 4 * NB_IN;
     const i32 f = fd.f;
-    double *P = c.Lval + fd.loff + (i64)bk0 + (i64)bk0 * f;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
+    double *P = c.Lval + fd.loff + (i64)bk0 + (i64)bk0 * lda;
     const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
     const bool rok = r < nb;
     double av[16], wv[16];
@@ -197,7 +199,7 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
     const i32 Kp = bk0 - kprev;
     if (Kp > 0) {
         const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-        const double *X = c.Lval + fd.loff + (i64)bk0 + (i64)kprev * f;     // X[rr][k] = X[rr + k*f]
+        const double *X = c.Lval + fd.loff + (i64)bk0 + (i64)kprev * lda;     // X[rr][k] = X[rr + k*f]
         v4f64 dacc[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) dacc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -213,7 +215,7 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
             double bq[4], aq[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const i64 coff = (i64)(ks + 4 * u + lk) * f;
+                const i64 coff = (i64)(ks + 4 * u + lk) * lda;
                 bq[u] = X[(i64)rr_c + coff];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) aq[u][a] = X[(i64)cr_c[a] + coff];
@@ -237,7 +239,7 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
         // clamped address + select instead of a guarded load: a branch around each load makes it wait
         // for the previous one (16 dependent L2 round trips on the factorisation's serial chain)
         const bool mine = rok && col < nb && r >= col;
-        const double pv = P[(i64)min(r, nb - 1) + (i64)min(col, nb - 1) * f];
+        const double pv = P[(i64)min(r, nb - 1) + (i64)min(col, nb - 1) * lda];
         const double dv = (Kp > 0) ? Ds[col * (NB_IN + 1) + r] : 0.0;
         av[q] = mine ? (pv - dv) : 0.0;
         wv[q] = (r == col) ? 1.0 : 0.0;
@@ -302,7 +304,7 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
         for (int q = 0; q < 16; ++q) {
             const i32 col = cg + 4 * q;
             if (col < nb) {
-                if (r >= col) P[(i64)r + (i64)col * f] = av[q];
+                if (r >= col) P[(i64)r + (i64)col * lda] = av[q];
                 W[(i64)r + (i64)col * nb] = (r >= col) ? wv[q] * idg : 0.0;   // L^{-1} = diag(1/L_ii) L~^{-1}
             }
         }
@@ -332,12 +334,13 @@ __global__ __launch_bounds__(256) void k_potrf_small(const PotrfTask *__restrict
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     double *P = c.Lval + fd.loff;
     const i32 ic = min(lane, ns - 1);
     double a[SMALL_NS], w[SMALL_NS];
 #pragma unroll
     for (int j = 0; j < SMALL_NS; ++j) {
-        const double v = P[(i64)ic + (i64)min(j, ns - 1) * f];           // clamped, unconditional
+        const double v = P[(i64)ic + (i64)min(j, ns - 1) * lda];           // clamped, unconditional
         a[j] = (lane < ns && j < ns && j <= lane) ? v : 0.0;
         w[j] = (j == lane) ? 1.0 : 0.0;
     }
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(256) void k_potrf_small(const PotrfTask *__restrict
 #pragma unroll
         for (int j = 0; j < SMALL_NS; ++j) {
             if (j < ns) {
-                if (j <= lane) P[(i64)lane + (i64)j * f] = a[j];
+                if (j <= lane) P[(i64)lane + (i64)j * lda] = a[j];
                 W[(i64)lane + (i64)j * ns] = (j <= lane) ? w[j] * ili : 0.0;
             }
         }
@@ -392,6 +395,7 @@ __global__ __launch_bounds__(256) void k_potrf_small(const PotrfTask *__restrict
 __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, const i32 k0, const i32 nb,
                                           const i32 row0, const i32 rowlim, const i32 kprev, double *Ws) {
     const i32 f = fd.f;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     double *P = c.Lval + fd.loff;
     const double *W = front_dinv(c, fd, k0);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -411,7 +415,7 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const i32 k = 4 * ks + lk;
-            const double v = P[(i64)rowc[b] + (i64)(k0 + min(k, nb - 1)) * f];      // clamped, not guarded
+            const double v = P[(i64)rowc[b] + (i64)(k0 + min(k, nb - 1)) * lda];      // clamped, not guarded
             bf[b][ks] = (k < nb) ? v : 0.0;
         }
     v4f64 acc[4][NBR];
@@ -420,7 +424,7 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
         __syncthreads();
         for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
             const int cc = idx & (NB_IN - 1), k = idx >> 6;
-            const double v = P[(i64)(k0 + min(cc, nb - 1)) + (i64)(kprev + c0 + k) * f];
+            const double v = P[(i64)(k0 + min(cc, nb - 1)) + (i64)(kprev + c0 + k) * lda];
             Ws[k * LDW + cc] = (cc < nb) ? v : 0.0;
         }
         __syncthreads();
@@ -430,7 +434,7 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
             for (int b = 0; b < NBR; ++b)
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
-                    xf[b][ks] = P[(i64)rowc[b] + (i64)(kprev + c0 + 4 * ks + lk) * f];
+                    xf[b][ks] = P[(i64)rowc[b] + (i64)(kprev + c0 + 4 * ks + lk) * lda];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -485,7 +489,7 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const i32 cc = a * 16 + lk + 4 * q;
-                    if (row < rowlim && cc < nb) P[(i64)row + (i64)(k0 + cc) * f] = acc[a][b][q];
+                    if (row < rowlim && cc < nb) P[(i64)row + (i64)(k0 + cc) * lda] = acc[a][b][q];
                 }
             }
     }
@@ -527,26 +531,28 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, k0 = t.k0, w = t.nb;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     double *P = c.Lval + fd.loff;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
     const i32 rbase = t.row0 + wave * 16;
-    const bool active = rbase < f;
-    const i32 rowc = min(rbase + lr, f - 1);        // clamped, stores are guarded
+    const i32 rlim = t.pad1;                        // rows [row0, rlim) belong to this task
+    const bool active = rbase < rlim;
+    const i32 rowc = min(rbase + lr, rlim - 1);     // clamped, stores are guarded
     double bf[4][16];                               // bf[i][ks] = B[row][k0 + 64 i + 4 ks + lk]
     if (w == NB_OUT) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) bf[i][ks] = P[(i64)rowc + (i64)(k0 + 64 * i + 4 * ks + lk) * f];
+            for (int ks = 0; ks < 16; ++ks) bf[i][ks] = P[(i64)rowc + (i64)(k0 + 64 * i + 4 * ks + lk) * lda];
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const i32 col = 64 * i + 4 * ks + lk;
-                const double v = P[(i64)rowc + (i64)(k0 + min(col, w - 1)) * f];
+                const double v = P[(i64)rowc + (i64)(k0 + min(col, w - 1)) * lda];
                 bf[i][ks] = (col < w) ? v : 0.0;
             }
     }
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int idx = tid + 256 * u, cc = idx & (NB_IN - 1), k = idx >> 6;
-                pre[u] = (cc < nbi) ? P[(i64)(k0 + 64 * i + cc) + (i64)(k0 + 64 * j + k) * f] : 0.0;
+                pre[u] = (cc < nbi) ? P[(i64)(k0 + 64 * i + cc) + (i64)(k0 + 64 * j + k) * lda] : 0.0;
             }
         } else {
             const double *W = front_dinv(c, fd, k0 + 64 * i);
@@ -626,14 +632,14 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
             }
         }
     }
-    if (active && rbase + lr < f) {
+    if (active && rbase + lr < rlim) {
         const i32 row = rbase + lr;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const i32 col = 64 * i + 4 * ks + lk;
-                if (col < w) P[(i64)row + (i64)(k0 + col) * f] = bf[i][ks];
+                if (col < w) P[(i64)row + (i64)(k0 + col) * lda] = bf[i][ks];
             }
     }
 }
@@ -646,22 +652,23 @@ __global__ __launch_bounds__(256) void k_trsm_thin(const TrsmTask *__restrict__ 
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, w = t.nb;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *W = front_dinv(c, fd, t.k0);          // w x w, column-major, ld = w, upper part zero
     for (int idx = threadIdx.x; idx < w * w; idx += 256) Wl[idx] = W[idx];
     __syncthreads();
     const i32 r = t.row0 + threadIdx.x;
-    if (r >= f) return;
-    double *P = c.Lval + fd.loff + (i64)r + (i64)t.k0 * f;
+    if (r >= t.pad1) return;                           // rows [row0, pad1) belong to this task
+    double *P = c.Lval + fd.loff + (i64)r + (i64)t.k0 * lda;
     double b[TRSM_THIN_W];
 #pragma unroll
-    for (int k = 0; k < TRSM_THIN_W; ++k) b[k] = P[(i64)min(k, w - 1) * f];          // clamped, used only for k < w
+    for (int k = 0; k < TRSM_THIN_W; ++k) b[k] = P[(i64)min(k, w - 1) * lda];          // clamped, used only for k < w
 #pragma unroll
     for (int cc = 0; cc < TRSM_THIN_W; ++cc) {
         if (cc < w) {                                    // workgroup-uniform
             double x = 0.0;
 #pragma unroll
             for (int k = 0; k <= cc; ++k) x += Wl[cc + k * w] * b[k];
-            P[(i64)cc * f] = x;
+            P[(i64)cc * lda] = x;
         }
     }
 }
@@ -688,6 +695,7 @@ template <bool FULL>
 __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc &fd, const DevCtx &c,
                                             double (*As)[UPD_KT * UPD_LD], double (*Bs)[UPD_KT * UPD_LD]) {
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *P = c.Lval + fd.loff;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
@@ -718,23 +726,23 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
     const int sr = tid & 127, sk0 = tid >> 7;       // staging: row sr, k = sk0 + 2*it
     const i32 ra = t.i0 + sr, rb_ = t.j0 + sr;
     const bool raok = FULL || (ra < f), rbok = FULL || ((rb_ < f) && !diag_tile);
-    const double *Pa = P + (i64)(t.k0 + sk0) * f + ra;
-    const double *Pb = P + (i64)(t.k0 + sk0) * f + rb_;
+    const double *Pa = P + (i64)(t.k0 + sk0) * lda + ra;
+    const double *Pb = P + (i64)(t.k0 + sk0) * lda + rb_;
     double pa[UPD_NLD], pb[UPD_NLD];
 
     auto load_slab = [&](i32 kk, bool full_k) {
         if (FULL && full_k) {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                pa[it] = Pa[(i64)(kk + 2 * it) * f];
-                pb[it] = Pb[(i64)(kk + 2 * it) * f];
+                pa[it] = Pa[(i64)(kk + 2 * it) * lda];
+                pb[it] = Pb[(i64)(kk + 2 * it) * lda];
             }
         } else {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
                 const bool kok = (kk + sk0 + 2 * it) < t.kw;
-                pa[it] = (kok && raok) ? Pa[(i64)(kk + 2 * it) * f] : 0.0;
-                pb[it] = (kok && rbok) ? Pb[(i64)(kk + 2 * it) * f] : 0.0;
+                pa[it] = (kok && raok) ? Pa[(i64)(kk + 2 * it) * lda] : 0.0;
+                pb[it] = (kok && rbok) ? Pb[(i64)(kk + 2 * it) * lda] : 0.0;
             }
         }
     };
@@ -757,9 +765,9 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         // the last row of the front (a clamped row only feeds outputs that the guarded epilogue
         // never stores), all 16 MFMA blocks of an active wave are computed, the epilogue masks.
         const i32 rac = min(t.i0 + sr, f - 1), rbc = min(t.j0 + sr, f - 1);
-        const double *pa_ptr = P + (i64)(t.k0 + sk0) * f + rac;
-        const double *pb_ptr = P + (i64)(t.k0 + sk0) * f + rbc;
-        const i64 step = (i64)UPD_KT * f, two_f = 2 * (i64)f;
+        const double *pa_ptr = P + (i64)(t.k0 + sk0) * lda + rac;
+        const double *pb_ptr = P + (i64)(t.k0 + sk0) * lda + rbc;
+        const i64 step = (i64)UPD_KT * lda, two_f = 2 * (i64)lda;
         auto ld_a = [&]() {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) pa[it] = pa_ptr[it * two_f];
@@ -816,8 +824,8 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         }
         if (t.kw % UPD_KT) {                              // K tail: one zero-filled slab
             const i32 kk = nrounds * UPD_KT;
-            pa_ptr = P + (i64)(t.k0 + kk + sk0) * f + rac;
-            pb_ptr = P + (i64)(t.k0 + kk + sk0) * f + rbc;
+            pa_ptr = P + (i64)(t.k0 + kk + sk0) * lda + rac;
+            pb_ptr = P + (i64)(t.k0 + kk + sk0) * lda + rbc;
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
                 const bool kok = (kk + sk0 + 2 * it) < t.kw;
@@ -907,7 +915,7 @@ epilogue:
             for (int q = 0; q < 4; ++q) {
                 const i32 col = jbase + a * 16 + lk + 4 * q;
                 if (FULL || (row < f && col < t.jlim && row >= col)) {
-                    if (col < ns) Pw[(i64)row + (i64)col * f] -= acc[a][b][q];
+                    if (col < ns) Pw[(i64)row + (i64)col * lda] -= acc[a][b][q];
                     else {
                         double *dst = Uw + (i64)(row - ns) + (i64)(col - ns) * rs;
                         *dst = t.beta0 ? -acc[a][b][q] : (*dst - acc[a][b][q]);
@@ -943,6 +951,7 @@ __global__ __launch_bounds__(256) void k_update_reduce(const UpdateTask *__restr
     const UpdateTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *Sp = c.spart + (i64)t.k0 * (TILE * TILE);
     double *Pw = c.Lval + fd.loff;
     double *Uw = front_u(c, fd);
@@ -951,7 +960,7 @@ __global__ __launch_bounds__(256) void k_update_reduce(const UpdateTask *__restr
         if (row >= f || col >= t.jlim || row < col) continue;
         double sum = Sp[e];
         for (i32 sp = 1; sp < t.kw; ++sp) sum += Sp[(i64)sp * (TILE * TILE) + e];
-        if (col < ns) Pw[(i64)row + (i64)col * f] -= sum;
+        if (col < ns) Pw[(i64)row + (i64)col * lda] -= sum;
         else {
             double *dst = Uw + (i64)(row - ns) + (i64)(col - ns) * rs;
             *dst = t.beta0 ? -sum : (*dst - sum);
@@ -1061,10 +1070,11 @@ constexpr int FWD_DIAG_SCRATCH = 2 * SOLVE_NB + 4 * NB_IN;     // doubles of LDS
 template <bool BACKWARD, int WHICH>
 __device__ __forceinline__ void load_frag(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb, double (&w)[16]) {
     const i32 f = fd.f, na = min(nb, NB_IN), nb2 = nb - na;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const int i = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const double *M; i64 ld; i32 nr, nc;                   // matrix, leading dimension, rows, columns
     if (WHICH == 0) { M = front_dinv(c, fd, bk0); ld = na; nr = na; nc = na; }
-    else if (WHICH == 1) { M = c.Lval + fd.loff + (i64)(bk0 + NB_IN) + (i64)bk0 * f; ld = f; nr = nb2; nc = na; }
+    else if (WHICH == 1) { M = c.Lval + fd.loff + (i64)(bk0 + NB_IN) + (i64)bk0 * lda; ld = lda; nr = nb2; nc = na; }
     else { M = front_dinv(c, fd, bk0 + NB_IN); ld = nb2; nr = nb2; nc = nb2; }
     const i32 ir = min(i, nr - 1);
     double v[16];
@@ -1200,13 +1210,14 @@ __global__ __launch_bounds__(256) void k_fwd_update(const SolveTask *__restrict_
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, nb = t.nb;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const bool fused = t.nslot > 0;                      // workgroup-uniform
-    const double *P = c.Lval + fd.loff + (i64)t.k0 * f;
+    const double *P = c.Lval + fd.loff + (i64)t.k0 * lda;
     const i32 r = t.row0 + threadIdx.x, rc = min(r, f - 1);
     // the first panel columns travel while the solved block is staged
     double pv[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) pv[j] = P[(i64)rc + (i64)min(j, nb - 1) * f];
+    for (int j = 0; j < 16; ++j) pv[j] = P[(i64)rc + (i64)min(j, nb - 1) * lda];
     if (threadIdx.x < SOLVE_NB) ys[threadIdx.x] = (threadIdx.x < nb) ? c.xw[fd.col0 + t.k0 + threadIdx.x] : 0.0;
     __syncthreads();
     double acc = 0.0;
@@ -1217,7 +1228,7 @@ __global__ __launch_bounds__(256) void k_fwd_update(const SolveTask *__restrict_
     // beyond nb
     for (i32 jb = 16; jb < nb; jb += 16) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) pv[j] = P[(i64)rc + (i64)min(jb + j, nb - 1) * f];
+        for (int j = 0; j < 16; ++j) pv[j] = P[(i64)rc + (i64)min(jb + j, nb - 1) * lda];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc += pv[j] * ys[jb + j];
     }
@@ -1252,12 +1263,13 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, nb = t.nb, nrows = t.slot;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const bool fused = t.nslot != 0;                     // workgroup-uniform
     const i32 *rows = c.rowidx + fd.rowoff;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < SOLVE_NB) tacc[threadIdx.x] = 0.0;
     __syncthreads();
-    const double *P0 = c.Lval + fd.loff + (i64)t.k0 * f;
+    const double *P0 = c.Lval + fd.loff + (i64)t.k0 * lda;
     for (i32 rc = t.row0; rc < t.row0 + nrows; rc += BWD_ROWS) {
         const i32 nr = min(BWD_ROWS, t.row0 + nrows - rc);
         double xr[BWD_ROWS / 64];
@@ -1284,7 +1296,7 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
         auto fetch = [&](double (&dst)[CB][BWD_ROWS / 64], const i32 j0) {
 #pragma unroll
             for (int jj = 0; jj < CB; ++jj) {
-                const double *col = P + (i64)min(j0 + jj, nb - 1) * f;      // clamped: extra columns are dropped below
+                const double *col = P + (i64)min(j0 + jj, nb - 1) * lda;      // clamped: extra columns are dropped below
 #pragma unroll
                 for (int u = 0; u < BWD_ROWS / 64; ++u) dst[jj][u] = col[ro[u]];
             }
@@ -1398,6 +1410,7 @@ __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDe
     constexpr int NBATCH = PIVOT ? 1 : 2;                      // batches of 16 columns per wave and block
     constexpr int WCOLS = 16 * NBATCH;                         // columns of a block handled by a wave
     const i32 f = fd.f, ns = fd.ns;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rloc = PIVOT ? lane : lane + 64 * (wave & 1);    // row of the chunk
@@ -1415,7 +1428,7 @@ __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDe
         const i32 c0 = min(j, nin - 1) * SWEEP_NB + cp0 + 16 * q;
 #pragma unroll
         for (int u = 0; u < 16; ++u)                             // clamped column: x is zero beyond the block
-            b[u] = *reinterpret_cast<const double *>(Lb + (size_t)min(c0 + u, ns - 1) * (size_t)f * 8u + roff);
+            b[u] = *reinterpret_cast<const double *>(Lb + (size_t)min(c0 + u, ns - 1) * (size_t)lda * 8u + roff);
     };
     auto consume = [&](const double (&b)[16], const double xv, const int q) {
 #pragma unroll
@@ -1501,13 +1514,14 @@ __global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restric
     const SolveTask t = tasks[s_item];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, nb = t.nb;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const i32 *rows = c.rowidx + fd.rowoff;
     const double *xhf = a.xh + fd.col0;
     const i32 nblk = (ns + SWEEP_NB - 1) / SWEEP_NB;
-    const i32 nbelow = (t.slot + 63) / 64;                      // 64-row tiles below the pivot block
+    const i32 nbelow = (t.slot > 0) ? (f + 63) / 64 - ns / 64 : 0;   // tiles below the pivot block, ENDING on multiples of 64 rows (line-aligned loads)
     const i32 ntiles = nbelow + t.nslot;
     // this wave's columns: wave-uniform bases (scalar registers) + 32-bit lane offsets
-    const char *Pb = reinterpret_cast<const char *>(c.Lval + fd.loff + (i64)t.k0 * f);
+    const char *Pb = reinterpret_cast<const char *>(c.Lval + fd.loff + (i64)t.k0 * lda);
     size_t coloff[1];
     (void)coloff;
     // Held from the start, off the chain: this block's right-hand side and the fragment of the inverted diagonal
@@ -1529,18 +1543,18 @@ __global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restric
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc[u] = 0.0;
     bool dead = false;
-    auto tile_r0 = [&](const i32 q) { const i32 qc = min(q, ntiles - 1); return qc < nbelow ? t.row0 + 64 * qc : (nblk - 1 - (qc - nbelow)) * SWEEP_NB; };
-    auto tile_nr = [&](const i32 q) { const i32 qc = min(q, ntiles - 1); const i32 r0 = tile_r0(qc); return qc < nbelow ? min(64, f - r0) : min(SWEEP_NB, ns - r0); };
+    auto tile_r0 = [&](const i32 q) { const i32 qc = min(q, ntiles - 1); return qc < nbelow ? (qc == 0 ? ns : (ns / 64 + qc) * 64) : (nblk - 1 - (qc - nbelow)) * SWEEP_NB; };
+    auto tile_nr = [&](const i32 q) { const i32 qc = min(q, ntiles - 1); const i32 r0 = tile_r0(qc); return qc < nbelow ? min(f, (ns / 64 + qc + 1) * 64) - r0 : min(SWEEP_NB, ns - r0); };
     auto issue = [&](double (&b)[16], const i32 q) {           // tile q (clamped): 64 rows x this wave's 16 columns
         const i32 r0 = tile_r0(q), nr = tile_nr(q);
         const unsigned rb = (unsigned)(r0 + min(lane, nr - 1)) * 8u;            // clamped row: its x is zeroed
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            b[u] = *reinterpret_cast<const double *>(Pb + (size_t)min(16 * wave + u, nb - 1) * (size_t)f * 8u + rb);   // clamped column: dropped below
+            b[u] = *reinterpret_cast<const double *>(Pb + (size_t)min(16 * wave + u, nb - 1) * (size_t)lda * 8u + rb);   // clamped column: dropped below
     };
     auto row_index = [&](const i32 q) -> i32 {                  // global index of this lane's row in a tile below the pivot block
         const i32 qc = min(q, max(nbelow - 1, 0));
-        const i32 r0 = t.row0 + 64 * qc, nr = min(64, f - r0);
+        const i32 r0 = (qc == 0) ? ns : (ns / 64 + qc) * 64, nr = min(f, (ns / 64 + qc + 1) * 64) - r0;
         return (nbelow > 0) ? rows[r0 + min(lane, max(nr - 1, 0))] : 0;
     };
     auto consume = [&](const double (&b)[16], const double xr) {
@@ -1617,6 +1631,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *__restrict__ W = front_dinv(c, fd, 0);          // ns x ns, column-major, ld = ns, upper part zero
     const double *__restrict__ P = c.Lval + fd.loff;
     double *xs = c.xw + fd.col0;
@@ -1636,7 +1651,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__
         const i32 rr = min(lane + 64 * u, max(rs - 1, 0));         // row below, clamped (rs may be 0: stays inside the panel)
         uv[u] = (rs > 0) ? uc[rr] : 0.0;
 #pragma unroll
-        for (int k = 0; k < SMALL_NS; ++k) lv[u][k] = P[(i64)min(ns + rr, f - 1) + (i64)min(k, ns - 1) * f];
+        for (int k = 0; k < SMALL_NS; ++k) lv[u][k] = P[(i64)min(ns + rr, f - 1) + (i64)min(k, ns - 1) * lda];
     }
     double y = 0.0;
 #pragma unroll
@@ -1660,6 +1675,7 @@ __global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *__restrict__ P = c.Lval + fd.loff;
     const double *__restrict__ W = front_dinv(c, fd, 0);
     const i32 *__restrict__ rows = c.rowidx + fd.rowoff;
@@ -1679,7 +1695,7 @@ __global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__
     for (int u = 0; u < SMALL_RPL; ++u) {
         const i32 r = min(ns + lane + 64 * u, f - 1);
 #pragma unroll
-        for (int k = 0; k < SMALL_NS; ++k) lv[u][k] = P[(i64)r + (i64)min(k, ns - 1) * f];
+        for (int k = 0; k < SMALL_NS; ++k) lv[u][k] = P[(i64)r + (i64)min(k, ns - 1) * lda];
         const double xv = c.xw[gi[u]];
         xr[u] = (lane + 64 * u < rs) ? xv : 0.0;
     }

@@ -708,8 +708,13 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     for (i32 s = 0; s < ns_total; ++s) {
         FrontDesc &w = S.fronts[s];
         w.ubuf = S.depth[s] & 1;
-        if (!S.front_local[s]) { w.loff = -1; w.uoff = -1; w.ucoff = -1; w.dinvoff = -1; continue; }
-        w.loff = S.lval_len; S.lval_len += (i64)w.f * w.ns;
+        if (!S.front_local[s]) { w.lda = w.f; w.loff = -1; w.uoff = -1; w.ucoff = -1; w.dinvoff = -1; continue; }
+        // Panel columns of the larger fronts start on 128-byte lines: the kernels stream 64..256 contiguous rows of a
+        // column per load, and a misaligned 512-byte segment touches 5 lines instead of 4 (measured: 28 % more
+        // fabric traffic in the solve sweeps than algorithmic bytes with ld = f).
+        w.lda = (w.f >= LDA_PAD_MIN_F) ? (w.f + 15) / 16 * 16 : w.f;
+        if (w.lda != w.f || w.f >= LDA_PAD_MIN_F) S.lval_len = (S.lval_len + 15) / 16 * 16;
+        w.loff = S.lval_len; S.lval_len += (i64)w.lda * w.ns;
         w.ucoff = S.uc_len; S.uc_len += (w.f - w.ns);
         w.dinvoff = S.dinv_len;
         S.dinv_len += (w.ns >= NB_IN) ? (i64)((w.ns + NB_IN - 1) / NB_IN) * NB_IN * NB_IN : (i64)w.ns * w.ns;
@@ -859,7 +864,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
                     if (!pass) {
                         for (i64 e = S.Sp[kk]; e < S.Sp[kk + 1]; ++e) {
                             const i32 ii = S.Si[e];
-                            S.s_target[e] = w.loff + pos_in_front[ii] + (i64)(kk - w.col0) * w.f;
+                            S.s_target[e] = w.loff + pos_in_front[ii] + (i64)(kk - w.col0) * w.lda;
                             S.s_local[e] = 1;
                         }
                         if (!is_root || opt.rank == 0) S.s_diag_row[S.Sp[kk]] = k;
@@ -1099,7 +1104,13 @@ static void build_schedule(Symbolic &S) {
                     const i32 no = std::min(NB_OUT, w.ns - ko);
                     if ((no <= TRSM_THIN_W) != (thin == 1)) return;
                     const i32 step = thin ? 256 : TRSM_WG_ROWS;
-                    for (i32 r0 = ko + no; r0 < w.f; r0 += step) S.trsm_tasks.push_back(TrsmTask{s, ko, no, r0, ko, 0, 0, 0});
+                    // row ranges END on multiples of `step` rows (16-row strips then sit on 128-byte lines of the
+                    // line-aligned panel); pad1 = row limit of the task
+                    for (i32 r0 = ko + no; r0 < w.f;) {
+                        const i32 r1 = std::min(w.f, (r0 / step + 1) * step);
+                        S.trsm_tasks.push_back(TrsmTask{s, ko, no, r0, ko, 0, r1, 0});
+                        r0 = r1;
+                    }
                 });
                 push_launch(S.factor_launches, thin ? LK_TRSM_THIN : LK_TRSM, f_trsm, (i64)S.trsm_tasks.size() - f_trsm);
             }
@@ -1185,7 +1196,7 @@ static void build_schedule(Symbolic &S) {
                 const i32 s = S.level_fronts[t];
                 if (!in_scope(s) || is_small(s)) continue;
                 const FrontDesc &w = S.fronts[s];
-                max_chunks = std::max(max_chunks, (w.ns + SWEEP_NB - 1) / SWEEP_NB + (w.f - w.ns + SOLVE_NB - 1) / SOLVE_NB);
+                max_chunks = std::max(max_chunks, (w.ns + SWEEP_NB - 1) / SWEEP_NB + (w.f > w.ns ? (w.f + SOLVE_NB - 1) / SOLVE_NB - w.ns / SOLVE_NB : 0));
             }
             for (i32 ci = 0; ci < max_chunks; ++ci)
                 for (i32 t = t0; t < t1; ++t) {
@@ -1195,8 +1206,12 @@ static void build_schedule(Symbolic &S) {
                     const i32 nblk = (w.ns + SWEEP_NB - 1) / SWEEP_NB;
                     if (ci < nblk) S.fwd_sweep_tasks.push_back(SolveTask{s, ci * SWEEP_NB, std::min(SWEEP_NB, w.ns - ci * SWEEP_NB), 0, 1, ci, 0, 0});
                     else {
-                        const i32 r0 = w.ns + (ci - nblk) * SOLVE_NB;
-                        if (r0 < w.f) S.fwd_sweep_tasks.push_back(SolveTask{s, r0, std::min(SOLVE_NB, w.f - r0), 0, 0, nblk, 0, 0});
+                        // rows below the pivot block in chunks that END on multiples of SOLVE_NB rows (line-aligned loads;
+                        // only the first chunk of a front is ragged)
+                        const i32 q = ci - nblk;
+                        const i32 r0 = (q == 0) ? w.ns : (w.ns / SOLVE_NB + q) * SOLVE_NB;
+                        const i32 r1 = std::min(w.f, (w.ns / SOLVE_NB + q + 1) * SOLVE_NB);
+                        if (r0 < w.f) S.fwd_sweep_tasks.push_back(SolveTask{s, r0, r1 - r0, 0, 0, nblk, 0, 0});
                     }
                 }
             push_launch(S.fwd_launches, LK_FWD_SWEEP, first, (i64)S.fwd_sweep_tasks.size() - first);

@@ -409,7 +409,7 @@ int tlpk_root_panel(tlpk_handle *h, double **d_ptr, int64_t *count) {
     if (h->S.root_front < 0) { *d_ptr = nullptr; *count = 0; return TLPK_OK; }
     const FrontDesc &fd = h->S.fronts[h->S.root_front];
     *d_ptr = h->d.ctx.Lval + fd.loff;
-    *count = (i64)fd.f * fd.ns;
+    *count = (i64)fd.lda * fd.ns;            // whole panel incl. the alignment rows (they stay zero)
     return TLPK_OK;
 }
 
@@ -612,7 +612,7 @@ int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
     out->n_local_blocks = S.n_local_blocks; out->n_blocks = S.nblocks;
     out->flops_update = S.flops_update;
     out->flops_update_alg = S.flops_update_alg;
-    out->root_panel_len = (S.root_front >= 0) ? (i64)S.fronts[S.root_front].f * S.fronts[S.root_front].ns : 0;
+    out->root_panel_len = (S.root_front >= 0) ? (i64)S.fronts[S.root_front].lda * S.fronts[S.root_front].ns : 0;
     return TLPK_OK;
 }
 
@@ -663,6 +663,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "col_local") tmp.assign(S.col_local.begin(), S.col_local.end());
     else if (w == "row_local") tmp.assign(S.row_local.begin(), S.row_local.end());
     else if (w == "front_f") field([](const FrontDesc &f) { return f.f; });
+    else if (w == "front_lda") field([](const FrontDesc &f) { return f.lda; });
     else if (w == "front_ns") field([](const FrontDesc &f) { return f.ns; });
     else if (w == "front_col0") field([](const FrontDesc &f) { return f.col0; });
     else if (w == "front_parent") field([](const FrontDesc &f) { return f.parent; });
@@ -673,7 +674,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "front_nchild") field([](const FrontDesc &f) { return f.nchild; });
     else if (w == "root_front") tmp.assign(1, S.root_front);
     else if (w == "potrf_tasks") { for (auto &t : S.potrf_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.kprev); } }
-    else if (w == "trsm_tasks") { for (auto &t : S.trsm_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.kprev); tmp.push_back(t.fuse_nb); } }
+    else if (w == "trsm_tasks") { for (auto &t : S.trsm_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.kprev); tmp.push_back(t.pad1); } }
     else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "front_single") tmp.assign(S.front_single.begin(), S.front_single.end());
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }

@@ -25,12 +25,13 @@ constexpr int EA_COLS = 16;   // parent columns per extend-add workgroup
 constexpr int SOLVE_NB = 128; // block width of the triangular-solve kernels (two NB_IN sub-blocks)
 constexpr int SWEEP_NB = NB_IN;  // width of a pivot block handed from workgroup to workgroup in the persistent sweeps
 constexpr int MAX_GROUPS = 8;    // concurrent streams for independent diagonal blocks
+constexpr int LDA_PAD_MIN_F = 64;   // fronts with at least this many rows get a line-aligned panel (lda multiple of 16)
 constexpr int SOLVE_ROWS = 256; // rows per forward-update workgroup
 constexpr int BWD_ROWS = 128;   // rows per backward-update workgroup (partial sums, reduced in fixed order)
 
 // ---- device-visible descriptors (plain structs, uploaded as arrays) ----
 struct FrontDesc {
-    i64 loff;      // offset of the panel (f x ns, ld = f, column-major) in Lval
+    i64 loff;      // offset of the panel (f x ns, column-major, leading dimension lda >= f) in Lval
     i64 uoff;      // offset of the update matrix (rs x rs, ld = rs) in its ping-pong buffer
     i64 rowoff;    // offset into rowidx (f entries, first ns are the pivot columns)
     i64 reloff;    // offset into rel (rs entries: position of each below-row in the parent front)
@@ -42,11 +43,14 @@ struct FrontDesc {
     i32 parent;    // parent front or -1
     i32 child_ptr, nchild;   // children in `children[child_ptr .. child_ptr+nchild)`
     i32 flagoff;   // >= 0: the front's triangular solves run in the persistent sweep kernels; -1: small / single / not local
+    i32 lda;       // leading dimension of the panel: f rounded up to 16 doubles (one 128-byte line) for fronts of >= LDA_PAD_MIN_F
+                   // rows, so that every panel column starts on a cache-line boundary (loff is then a multiple of 16 too)
+    i32 pad2;
 };
-static_assert(sizeof(FrontDesc) == 80, "FrontDesc layout");
+static_assert(sizeof(FrontDesc) == 88, "FrontDesc layout");
 
 struct PotrfTask { i32 front, k0, nb, kprev; };              // diagonal block of a block column: columns [k0, k0 + nb), nb <= NB_OUT; kprev = k0
-struct TrsmTask  { i32 front, k0, nb, row0, kprev, fuse_nb, pad1, pad2; };   // rows [row0, ..) below the diagonal block [k0, k0 + nb) of a block column; kprev = k0, fuse_nb = 0 (unused)
+struct TrsmTask  { i32 front, k0, nb, row0, kprev, fuse_nb, pad1, pad2; };   // rows [row0, pad1) below the diagonal block [k0, k0 + nb) of a block column; kprev = k0, fuse_nb = 0 (unused)
 struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; }; // pad1 = slot + 1: split-K part, the raw tile goes to scratch slot `slot`;
 // in reduce_tasks: k0 = first slot, kw = number of parts
 //  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
