@@ -37,6 +37,12 @@ typedef struct tlpk_handle tlpk_handle;
 #define TLPK_NOT_FACTORED 7 /* solve before a successful update */
 #define TLPK_INTERNAL 8
 
+/* linear system (KKT.jl:37-56 / systems.jl) */
+#define TLPK_SYSTEM_K1 0     /* normal equations  A D A' + Rd, Cholesky            (Cholmod/spd.jl) */
+#define TLPK_SYSTEM_K2 1     /* augmented system [-(Theta^-1+Rp) A'; A Rd], signed Cholesky L S L' = the LDL' of a
+                                quasi-definite matrix without pivoting (Cholmod/sqd.jl, LDLFactorizations/ldlfact.jl);
+                                single GPU, no row_block */
+
 /* ordering selector */
 #define TLPK_ORDER_AMD 0
 #define TLPK_ORDER_NATURAL 1
@@ -55,6 +61,8 @@ typedef struct tlpk_options {
                                   row; NULL = general sparse.  Blocks are ordered independently,
                                   linking rows last as one dense root supernode. */
     int64_t mem_budget_bytes;  /* 0 = 90 % of the device's free memory (or unlimited if device=-1) */
+    int32_t system;            /* TLPK_SYSTEM_K1 (default) | TLPK_SYSTEM_K2 */
+    int32_t reserved;
 } tlpk_options;
 
 typedef struct tlpk_stats {
@@ -189,6 +197,7 @@ const char *tlpk_strerror(int code);
 const char *tlpk_last_error(const tlpk_handle *h);
 const char *tlpk_backend_name(void);         /* "HIP (gfx950)" */
 const char *tlpk_system_name(void);          /* "Normal equations (K1)" */
+const char *tlpk_linear_system(const tlpk_handle *h);   /* KKT.linear_system of this handle: "... (K1)" | "Augmented system (K2)" */
 int tlpk_device_count(void);
 
 #ifdef __cplusplus

@@ -17,6 +17,9 @@ class Emulator:
         self.kkt = kkt
         self.m, self.n = kkt.m, kkt.n
         self.perm = g("perm")
+        # K2 (augmented system): the factored matrix has order n + m; S = diag(sign) with -1 on variable nodes
+        self.k2 = getattr(kkt, "system", 0) == 1
+        self.sign = np.where(self.perm < self.n, -1.0, 1.0) if self.k2 else None
         self.f = g("front_f"); self.ns = g("front_ns"); self.col0 = g("front_col0"); self.lda = g("front_lda")
         self.parent = g("front_parent"); self.loff = g("front_loff"); self.rowoff = g("front_rowoff")
         self.reloff = g("front_reloff"); self.child_ptr = g("front_child_ptr"); self.nchild = g("front_nchild")
@@ -78,7 +81,7 @@ class Emulator:
 
     # ---- update! ----
     def update(self, theta, regP, regD, stop_at_marker=False):
-        self.D = 1.0 / (theta + regP)
+        self.D = np.concatenate([theta + regP, [1.0]]) if self.k2 else 1.0 / (theta + regP)   # K2: D2 = [theta + regP ; 1]
         self.regD = np.asarray(regD, dtype=float)
         self.Lval[:] = 0.0
         contrib = self.pair_w * self.D[self.pair_j]
@@ -96,11 +99,12 @@ class Emulator:
         self.fail_col = None
         for s_ in np.nonzero(self.single & (self.local != 0))[0]:      # k_single_factor
             d = self.Lval[self.loff[s_]]
-            if not d > 0:
+            sj = self.sign[self.col0[s_]] if self.k2 else 1.0
+            if not sj * d > 0:
                 col = int(self.col0[s_])
                 self.fail_col = col if self.fail_col is None else min(self.fail_col, col)
                 d = 1.0
-            self.Lval[self.loff[s_]] = np.sqrt(d)
+            self.Lval[self.loff[s_]] = np.sqrt(abs(d))
         self._resume = self._run(self.factor_launches, True)
         if not stop_at_marker:
             self.update_finish()
@@ -180,15 +184,16 @@ class Emulator:
         for front, k0, nb, _ in T:
             P = self.panel(front)
             blk = np.tril(P[k0:k0 + nb, k0:k0 + nb])
+            sg = self.sign[self.col0[front] + k0: self.col0[front] + k0 + nb] if self.k2 else np.ones(nb)
             for j in range(nb):
                 d = blk[j, j]
-                if not d > 0:
+                if not sg[j] * d > 0:
                     col = int(self.col0[front] + k0 + j)
                     self.fail_col = col if self.fail_col is None else min(self.fail_col, col)
-                    d = 1.0
+                    d = sg[j]
                 blk[j + 1:, j + 1:] -= np.tril(np.outer(blk[j + 1:, j], blk[j + 1:, j]) / d)
-                blk[j, j] = np.sqrt(d)
-                blk[j + 1:, j] /= blk[j, j]
+                blk[j, j] = np.sqrt(abs(d))
+                blk[j + 1:, j] /= sg[j] * blk[j, j]                    # K = L S L': L_ij = a_ij / (s_j L_jj)
             P[k0:k0 + nb, k0:k0 + nb] = blk
 
     def _k2(self, T, rows_per_task=64):      # trsm: rows below the diagonal block of a block column, whole width
@@ -199,7 +204,10 @@ class Emulator:
             r1 = int(rowlim)                                      # rows [row0, rowlim) belong to the task
             assert row0 >= k0 + nb and row0 < r1 <= f and r1 - row0 <= rows_per_task
             L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
-            P[row0:r1, k0:k0 + nb] = sla.solve_triangular(L11, P[row0:r1, k0:k0 + nb].T, lower=True).T
+            X = sla.solve_triangular(L11, P[row0:r1, k0:k0 + nb].T, lower=True).T
+            if self.k2:
+                X = X * self.sign[self.col0[front] + k0: self.col0[front] + k0 + nb][None, :]     # L21 = A21 L11^-T S11
+            P[row0:r1, k0:k0 + nb] = X
 
     def _k3(self, T):      # update
         TILE = 128
@@ -209,7 +217,10 @@ class Emulator:
             i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)
             if i1 <= i0 or j1 <= j0:
                 continue
-            G = P[i0:i1, k0:k0 + kw] @ P[j0:j1, k0:k0 + kw].T
+            Pj = P[j0:j1, k0:k0 + kw]
+            if self.k2:
+                Pj = Pj * self.sign[self.col0[front] + k0: self.col0[front] + k0 + kw][None, :]      # X S X'
+            G = P[i0:i1, k0:k0 + kw] @ Pj.T
             if slot1:            # split-K part: raw tile to its scratch slot (each slot written exactly once)
                 assert int(slot1) - 1 not in self.spart
                 self.spart[int(slot1) - 1] = G
@@ -256,12 +267,15 @@ class Emulator:
 
     # ---- solve! ----
     def solve_local(self, xi_p, xi_d, A):
-        # k_rhs: a rank sums only its own columns; only rank 0 adds xi_p on linking rows
-        Aloc = A @ __import__("scipy.sparse").sparse.diags(self.col_local.astype(float))
-        xi = Aloc @ (self.D * xi_d)
-        rl = self.row_local
-        xi = np.where(rl == 0, 0.0, xi + np.where((rl == 2) & (self.rank != 0), 0.0, xi_p))
-        self.xw = xi[self.perm].copy()
+        if self.k2:                                                     # k_k2_rhs: [xi_d ; xi_p] permuted
+            self.xw = np.concatenate([xi_d, xi_p])[self.perm].copy()
+        else:
+            # k_rhs: a rank sums only its own columns; only rank 0 adds xi_p on linking rows
+            Aloc = A @ __import__("scipy.sparse").sparse.diags(self.col_local.astype(float))
+            xi = Aloc @ (self.D * xi_d)
+            rl = self.row_local
+            xi = np.where(rl == 0, 0.0, xi + np.where((rl == 2) & (self.rank != 0), 0.0, xi_p))
+            self.xw = xi[self.perm].copy()
         for s_ in np.nonzero(self.single & (self.local != 0))[0]:          # k_single_solve
             l = self.Lval[self.loff[s_]]
             self.xw[self.col0[s_]] = self.xw[self.col0[s_]] / l / l
@@ -277,7 +291,13 @@ class Emulator:
     def solve_finish(self, xi_d, A):
         self._run(self.fwd_launches, False, start=self._resume_fwd)
         self._bwd_seen = {}
+        if self.k2:
+            self.xw *= self.sign                                        # k_apply_signs: L S L' x = b
         self._run(self.bwd_launches)
+        if self.k2:                                                     # k_k2_out
+            sol = np.zeros(self.m + self.n)
+            sol[self.perm] = self.xw
+            return sol[: self.n], sol[self.n:]
         dy = np.zeros(self.m)
         dy[self.perm] = self.xw
         dy[self.row_local == 0] = 0.0

@@ -18,6 +18,6 @@ import os as _os
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _lib  # noqa: F401,E402
-from .kkt import (K1, Backend, DimensionMismatch, HIPNormalEquations, OutOfMemoryError,  # noqa: F401,E402
+from .kkt import (K1, K2, Backend, DimensionMismatch, HIPNormalEquations, OutOfMemoryError,  # noqa: F401,E402
                   PosDefException, arithmetic, backend, linear_system, run_ls_tests, setup,
                   solve, update)

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libtlpk.so")
 
 OK, NOT_POSDEF, BADARG, OOM, HIPERR, NO_DEVICE, TOO_LARGE, NOT_FACTORED, INTERNAL = range(9)
 ORDER_AMD, ORDER_NATURAL, ORDER_USER = 0, 1, 2
+SYSTEM_K1, SYSTEM_K2 = 0, 1
 KC_NAMES = ["assemble", "extend_add", "potrf", "trsm", "update", "solve_fwd", "solve_bwd", "spmv", "update_reduce"]
 
 p64 = C.POINTER(C.c_int64)
@@ -24,7 +25,8 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("ordering", C.c_int32),
                 ("relax", C.c_int32), ("profile", C.c_int32), ("rank", C.c_int32),
                 ("nranks", C.c_int32), ("streams", C.c_int32),
-                ("user_perm", p64), ("row_block", p64), ("mem_budget_bytes", C.c_int64)]
+                ("user_perm", p64), ("row_block", p64), ("mem_budget_bytes", C.c_int64),
+                ("system", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -57,7 +59,7 @@ EXPORTS = [
     "tlpk_root_panel", "tlpk_update_finish", "tlpk_solve_local", "tlpk_root_rhs",
     "tlpk_solve_finish", "tlpk_info", "tlpk_kernel_timing", "tlpk_get_perm", "tlpk_symbolic_get",
     "tlpk_symbolic_get_f64", "tlpk_set_profile", "tlpk_root_copy", "tlpk_get_factor", "tlpk_strerror", "tlpk_last_error",
-    "tlpk_backend_name", "tlpk_system_name", "tlpk_device_count",
+    "tlpk_backend_name", "tlpk_system_name", "tlpk_linear_system", "tlpk_device_count",
     "tlpk_ipm_load", "tlpk_ipm_reset", "tlpk_ipm_residuals", "tlpk_ipm_factor", "tlpk_ipm_hsolve", "tlpk_ipm_targets",
     "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get",
 ]
@@ -110,6 +112,8 @@ def lib():
     L.tlpk_last_error.restype = C.c_char_p
     L.tlpk_backend_name.restype = C.c_char_p
     L.tlpk_system_name.restype = C.c_char_p
+    L.tlpk_linear_system.argtypes = [vp]
+    L.tlpk_linear_system.restype = C.c_char_p
     L.tlpk_device_count.restype = C.c_int
     L.tlpk_ipm_load.argtypes = [vp, pd, pd, pd, pd]
     L.tlpk_ipm_reset.argtypes = [vp]

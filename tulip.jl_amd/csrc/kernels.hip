@@ -77,12 +77,17 @@ __global__ void k_assemble(i64 nent, const i64 *__restrict__ target, const i32 *
 
 // Isolated 1 x 1 fronts, one thread each: L = sqrt(s), and the whole solve x = b / s in one step
 // (nothing else reads or writes their entries).
+// csign != nullptr (K2): the pivot must carry the sign of its node; L = sqrt|d|.  The solve below stays x = b / |d|,
+// the sign is applied with everybody else's between the sweeps (k_apply_signs).
 __global__ void k_single_factor(i64 n, const i64 *__restrict__ loff, const i64 *__restrict__ dinvoff,
-                                const i32 *__restrict__ col, double *__restrict__ Lval, double *__restrict__ dinv, int *info) {
+                                const i32 *__restrict__ col, double *__restrict__ Lval, double *__restrict__ dinv, int *info,
+                                const double *__restrict__ csign) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double d = Lval[loff[i]];
-    if (!(d > 0.0)) { atomicMin(info, col[i]); d = 1.0; }      // same convention as potrf_block
+    const double sj = csign ? csign[col[i]] : 1.0;
+    if (!(sj * d > 0.0)) { atomicMin(info, col[i]); d = 1.0; }      // same convention as potrf_block
+    d = fabs(d);
     const double l = sqrt(d);
     Lval[loff[i]] = l;
     dinv[dinvoff[i]] = 1.0 / l;
@@ -177,8 +182,14 @@ __device__ __forceinline__ double *front_dinv(const DevCtx &c, const FrontDesc &
 
 constexpr int POTRF_SCRATCH = NB_IN * (NB_IN + 1) + 5 * NB_IN;   // doubles of LDS scratch
 
+// SIGNED (augmented system K2): P K P' = L S L' with S = diag(c.csign) = +-1 known per column.  The unit-lower
+// eliminations a_rc -= a_rj a_cj / d are sign-agnostic; a pivot must have the sign of its node (otherwise the
+// matrix is not quasi-definite: reported like a non-positive pivot), the column is scaled by s_j / sqrt|d|, and
+// products of two factor blocks carry S of the contracted columns (X S X').
+template <bool SIGNED = false>
 __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb,
                                             const i32 kprev, double *scratch) {
+    const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
     // Register-resident: thread (r, cg) owns A[r][col] and W[r][col] for col = cg + 4q, q = 0..15.
     // Per step only the pivot column of A and the pivot row of W go through LDS (double-buffered
     // by step parity => one barrier per column and no dependent LDS read-modify-write chains).
@@ -217,6 +228,7 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
             for (int u = 0; u < 4; ++u) {
                 const i64 coff = (i64)(ks + 4 * u + lk) * lda;
                 bq[u] = X[(i64)rr_c + coff];
+                if (SIGNED) bq[u] *= sg[kprev + ks + 4 * u + lk];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) aq[u][a] = X[(i64)cr_c[a] + coff];
             }
@@ -258,18 +270,21 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
         }
         __syncthreads();
         double d = colbuf[pb][j];
-        if (!(d > 0.0)) {
+        const double sj = SIGNED ? sg[bk0 + j] : 1.0;
+        if (!(sj * d > 0.0)) {
             if (tid == 0) atomicMin(c.info, fd.col0 + bk0 + j);
-            d = 1.0;
+            d = sj;
         }
+        if (SIGNED) d = fabs(d);
         // pivot arithmetic off one reciprocal square root (hardware estimate + 2 Newton steps, then a
-        // final correction of the square root): isq = d^-1/2, sq = d^1/2, inv2 = 1/d = isq^2
+        // final correction of the square root): isq = |d|^-1/2, sq = |d|^1/2, inv2 = 1/|d| = isq^2
         double isq = __builtin_amdgcn_rsq(d);
         isq = isq * (1.5 - 0.5 * d * isq * isq);
         isq = isq * (1.5 - 0.5 * d * isq * isq);
         double sq = d * isq;
         sq = fma(0.5 * isq, fma(-sq, sq, d), sq);
-        const double inv2 = isq * isq;
+        const double inv2 = SIGNED ? isq * isq * sj : isq * isq;            // 1 / (signed pivot)
+        if (SIGNED) isq *= sj;                                              // column scale s_j / sqrt|d|
         const double arj = (rok && r > j) ? colbuf[pb][r] * inv2 : 0.0;    // multiplier L~[r][j]
         // all LDS reads first (independent), then branch-free predicated updates
         double cv[16], rv[16];
@@ -328,11 +343,13 @@ static_assert(NB_IN * LDW >= POTRF_SCRATCH, "the trsm LDS block doubles as the p
 // columns travel by shuffles.  Same algorithm as potrf_block: unit-lower eliminations applied to
 // [A | I], columns scaled by 1/sqrt(d), inverse rows scaled by 1/L_ii; a non-positive pivot records
 // its column and is replaced by 1.
+template <bool SIGNED>
 __global__ __launch_bounds__(256) void k_potrf_small(const PotrfTask *__restrict__ tasks, DevCtx c) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const PotrfTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
+    const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
     const i32 f = fd.f, ns = fd.ns;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     double *P = c.Lval + fd.loff;
@@ -348,16 +365,19 @@ __global__ __launch_bounds__(256) void k_potrf_small(const PotrfTask *__restrict
     for (int k = 0; k < SMALL_NS; ++k) {
         if (k < ns) {                                                   // wave-uniform
             double d = __shfl(a[k], k);
-            if (!(d > 0.0)) {
+            const double sk = SIGNED ? sg[k] : 1.0;
+            if (!(sk * d > 0.0)) {
                 if (lane == 0) atomicMin(c.info, fd.col0 + k);
-                d = 1.0;
+                d = sk;
             }
+            if (SIGNED) d = fabs(d);
             double isq = __builtin_amdgcn_rsq(d);
             isq = isq * (1.5 - 0.5 * d * isq * isq);
             isq = isq * (1.5 - 0.5 * d * isq * isq);
             double sq = d * isq;
             sq = fma(0.5 * isq, fma(-sq, sq, d), sq);
-            const double m = (lane > k) ? a[k] * (isq * isq) : 0.0;      // multiplier a_ik / d
+            const double m = (lane > k) ? a[k] * (isq * isq) * sk : 0.0; // multiplier a_ik / d
+            if (SIGNED) isq *= sk;
 #pragma unroll
             for (int j = k + 1; j < SMALL_NS; ++j) {
                 const double ajk = __shfl(a[k], j);                     // a_jk from lane j
@@ -392,8 +412,10 @@ __global__ __launch_bounds__(256) void k_potrf_small(const PotrfTask *__restrict
 // block of a block column: B -= X_prev * L[k0.., kprev..k0)' first (left-looking), then the
 // solve.  One wave = 16 rows (keeps the kernel within 256 registers: its workgroup must fit
 // next to a k_update workgroup on the same CU).  In place: a wave only overwrites its own rows, after all of its loads.
+template <bool SIGNED = false>
 __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, const i32 k0, const i32 nb,
                                           const i32 row0, const i32 rowlim, const i32 kprev, double *Ws) {
+    const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
     const i32 f = fd.f;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     double *P = c.Lval + fd.loff;
@@ -434,7 +456,7 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
             for (int b = 0; b < NBR; ++b)
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
-                    xf[b][ks] = P[(i64)rowc[b] + (i64)(kprev + c0 + 4 * ks + lk) * lda];
+                    xf[b][ks] = P[(i64)rowc[b] + (i64)(kprev + c0 + 4 * ks + lk) * lda] * (SIGNED ? sg[kprev + c0 + 4 * ks + lk] : 1.0);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -489,7 +511,7 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const i32 cc = a * 16 + lk + 4 * q;
-                    if (row < rowlim && cc < nb) P[(i64)row + (i64)(k0 + cc) * lda] = acc[a][b][q];
+                    if (row < rowlim && cc < nb) P[(i64)row + (i64)(k0 + cc) * lda] = SIGNED ? acc[a][b][q] * sg[k0 + cc] : acc[a][b][q];
                 }
             }
     }
@@ -499,25 +521,27 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 // already been applied by the left-looking k_update): 64-wide steps, each a potrf of the step's
 // diagonal block followed by the trsm of the rows below it INSIDE the block -- one workgroup runs
 // the whole chain, so the factorisation's critical path costs one launch per block column.
+template <bool SIGNED>
 __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {      // t.nb <= NB_IN
     __shared__ double scratch[POTRF_SCRATCH];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    potrf_block(c, fd, t.k0, t.nb, t.k0, scratch);
+    potrf_block<SIGNED>(c, fd, t.k0, t.nb, t.k0, scratch);
 }
+template <bool SIGNED>
 __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restrict__ tasks, DevCtx c) {
     __shared__ double Ws[NB_IN * LDW];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
-    potrf_block(c, fd, k0, min(w, NB_IN), k0, Ws);
+    potrf_block<SIGNED>(c, fd, k0, min(w, NB_IN), k0, Ws);
     for (i32 ks = k0; ks + NB_IN < kend; ks += NB_IN) {          // step ks is factored: rows below, next diagonal block
         for (i32 r0 = ks + NB_IN; r0 < kend; r0 += NB_IN) {
             __syncthreads();                                     // own global stores visible, Ws free
-            trsm_rows(c, fd, ks, NB_IN, r0, kend, k0, Ws);
+            trsm_rows<SIGNED>(c, fd, ks, NB_IN, r0, kend, k0, Ws);
         }
         __syncthreads();
-        potrf_block(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
+        potrf_block<SIGNED>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
     }
 }
 
@@ -526,6 +550,9 @@ __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restri
 // 64-wide steps: B_i -= sum_{j<i} X_j L_ij' ; X_i = B_i Linv_ii'.  The panel is read once and
 // written once (the stepwise variant re-read the solved steps of the block column from HBM for
 // every following step).
+// SIGNED: the registers keep B Linv' = X S (what the later steps of the block column need: B_i -= sum_j X_j S_j L_ij');
+// the stored factor block X gets its column signs only at the final store.
+template <bool SIGNED>
 __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
     __shared__ double Ws[NB_IN * LDW];              // staged operand: Ws[k*LDW + c]
     const TrsmTask t = tasks[blockIdx.x];
@@ -639,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const i32 col = 64 * i + 4 * ks + lk;
-                if (col < w) P[(i64)row + (i64)(k0 + col) * lda] = bf[i][ks];
+                if (col < w) P[(i64)row + (i64)(k0 + col) * lda] = SIGNED ? bf[i][ks] * c.csign[fd.col0 + k0 + col] : bf[i][ks];
             }
     }
 }
@@ -647,6 +674,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
 // Thin block columns (w <= TRSM_THIN_W: the small fronts of the leaf levels): X = B * L11^{-T} with
 // one thread per row -- the row's w entries in registers, the inverted block broadcast from LDS;
 // consecutive threads touch consecutive rows of each column (coalesced).
+template <bool SIGNED>
 __global__ __launch_bounds__(256) void k_trsm_thin(const TrsmTask *__restrict__ tasks, DevCtx c) {
     __shared__ double Wl[TRSM_THIN_W * TRSM_THIN_W];
     const TrsmTask t = tasks[blockIdx.x];
@@ -668,7 +696,7 @@ __global__ __launch_bounds__(256) void k_trsm_thin(const TrsmTask *__restrict__ 
             double x = 0.0;
 #pragma unroll
             for (int k = 0; k <= cc; ++k) x += Wl[cc + k * w] * b[k];
-            P[(i64)cc * lda] = x;
+            P[(i64)cc * lda] = SIGNED ? x * c.csign[fd.col0 + t.k0 + cc] : x;
         }
     }
 }
@@ -691,9 +719,11 @@ constexpr int UPD_NLD = UPD_KT / 2;        // staging loads per thread per opera
 // the diagonal and inside the column limit, so every 16x16 block is a target and no load needs a
 // guard except the K tail.  The hot loop is then straight-line code: 16 unguarded staging loads,
 // 4 x (8 LDS reads + 16 MFMAs).  Edge and diagonal tiles take the guarded generic path.
-template <bool FULL>
+// SIGNED (K2): T -= P[I,K] S_K P[J,K]': the column-tile operand is multiplied by the signs of its K columns while it is staged.
+template <bool FULL, bool SIGNED = false>
 __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc &fd, const DevCtx &c,
                                             double (*As)[UPD_KT * UPD_LD], double (*Bs)[UPD_KT * UPD_LD]) {
+    const double *sgk = SIGNED ? c.csign + fd.col0 + t.k0 : nullptr;          // sign of K column k: sgk[k]
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *P = c.Lval + fd.loff;
@@ -702,7 +732,7 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
     const int wr = wave >> 1, wc = wave & 1;        // 2 x 2 waves, each a 64 x 64 sub-tile
     const i32 ibase = t.i0 + wr * 64;               // target rows of this wave
     const i32 jbase = t.j0 + wc * 64;               // target cols of this wave
-    const bool diag_tile = !FULL && (t.i0 == t.j0);
+    const bool diag_tile = !FULL && !SIGNED && (t.i0 == t.j0);       // unsigned: the column tile IS the row tile (one staging buffer)
 
     bool valid[4][4];
     bool any = FULL;
@@ -736,6 +766,7 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
             for (int it = 0; it < UPD_NLD; ++it) {
                 pa[it] = Pa[(i64)(kk + 2 * it) * lda];
                 pb[it] = Pb[(i64)(kk + 2 * it) * lda];
+                if (SIGNED) pb[it] *= sgk[kk + sk0 + 2 * it];
             }
         } else {
 #pragma unroll
@@ -743,6 +774,7 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
                 const bool kok = (kk + sk0 + 2 * it) < t.kw;
                 pa[it] = (kok && raok) ? Pa[(i64)(kk + 2 * it) * lda] : 0.0;
                 pb[it] = (kok && rbok) ? Pb[(i64)(kk + 2 * it) * lda] : 0.0;
+                if (SIGNED) pb[it] *= sgk[min(kk + sk0 + 2 * it, t.kw - 1)];
             }
         }
     };
@@ -772,9 +804,11 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) pa[it] = pa_ptr[it * two_f];
         };
+        i32 kb_idx = 0;                                   // first K column of the slab ld_b loads next (SIGNED)
         auto ld_b = [&]() {
 #pragma unroll
-            for (int it = 0; it < UPD_NLD; ++it) pb[it] = pb_ptr[it * two_f];
+            for (int it = 0; it < UPD_NLD; ++it) { pb[it] = pb_ptr[it * two_f]; if (SIGNED) pb[it] *= sgk[kb_idx + sk0 + 2 * it]; }
+            kb_idx += UPD_KT;
         };
         auto st_ab = [&](int buf) {
 #pragma unroll
@@ -831,6 +865,7 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
                 const bool kok = (kk + sk0 + 2 * it) < t.kw;
                 pa[it] = kok ? pa_ptr[it * two_f] : 0.0;
                 pb[it] = kok ? pb_ptr[it * two_f] : 0.0;
+                if (SIGNED) pb[it] *= sgk[min(kk + sk0 + 2 * it, t.kw - 1)];
             }
             st_ab(cur);
             __syncthreads();
@@ -925,6 +960,7 @@ epilogue:
         }
 }
 
+template <bool SIGNED>
 __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict__ tasks, DevCtx c) {
     // double-buffered K-slabs: slab t+1 travels global -> registers while slab t is multiplied
     __shared__ double As[2][UPD_KT * UPD_LD];  // As[.][k][r] = P[i0 + r, k0 + kk + k]  (row tile)
@@ -939,8 +975,8 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
 #endif
     const FrontDesc fd = c.fronts[t.front];
     const bool full = (t.i0 + TILE <= fd.f) && (t.j0 + TILE <= t.jlim) && (t.i0 >= t.j0 + TILE);
-    if (full) update_tile<true>(t, fd, c, As, Bs);
-    else update_tile<false>(t, fd, c, As, Bs);
+    if (full) update_tile<true, SIGNED>(t, fd, c, As, Bs);
+    else update_tile<false, SIGNED>(t, fd, c, As, Bs);
 }
 
 // Split-K: when an update launch has too few tiles to fill the chip, the K range of every tile is
@@ -1743,6 +1779,38 @@ __global__ void k_dx(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Augmented system (K2): K = [-(Theta^-1 + Rp) A'; A Rd], nodes 0..n-1 = variables, n..n+m-1 = constraints
+// (/root/reference/src/KKT/Cholmod/sqd.jl:24-74)
+// ------------------------------------------------------------------------------------------
+// D2 = [theta_inv + regP ; 1]: the vector the assembly lists refer to (diagonal of a variable node: -1 * D2[j];
+// an off-diagonal entry A[i,j] * D2[n])                                                            sqd.jl:44-50
+__global__ void k_k2_diag(i64 n, const double *__restrict__ theta, const double *__restrict__ regP, double *__restrict__ D2) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) D2[j] = theta[j] + regP[j];
+    else if (j == n) D2[j] = 1.0;
+}
+// permuted right-hand side [xi_d ; xi_p]                                                          sqd.jl:62-66
+__global__ void k_k2_rhs(i64 N, i64 n, const i32 *__restrict__ perm, const double *__restrict__ xi_p, const double *__restrict__ xi_d,
+                         double *__restrict__ xw) {
+    const i64 kk = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (kk >= N) return;
+    const i32 v = perm[kk];
+    xw[kk] = (v < n) ? xi_d[v] : xi_p[v - n];
+}
+// between the sweeps of L S L' x = b:  z = S y
+__global__ void k_apply_signs(i64 N, const double *__restrict__ csign, double *__restrict__ xw) {
+    const i64 kk = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (kk < N) xw[kk] *= csign[kk];
+}
+// [dx ; dy] = P' x                                                                                 sqd.jl:69-72
+__global__ void k_k2_out(i64 N, i64 n, const i32 *__restrict__ perm, const double *__restrict__ xw, double *__restrict__ dx, double *__restrict__ dy) {
+    const i64 kk = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (kk >= N) return;
+    const i32 v = perm[kk];
+    if (v < n) dx[v] = xw[kk]; else dy[v - n] = xw[kk];
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 static inline unsigned nblk(i64 n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -1758,7 +1826,7 @@ void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const 
 void launch_single_factor(hipStream_t st, const DevArrays &a) {
     if (a.n_single > 0)
         hipLaunchKernelGGL(k_single_factor, dim3(nblk(a.n_single, 256)), dim3(256), 0, st, a.n_single, a.single_loff, a.single_dinvoff,
-                           a.single_col, a.ctx.Lval, a.ctx.dinv, a.ctx.info);
+                           a.single_col, a.ctx.Lval, a.ctx.dinv, a.ctx.info, a.ctx.csign);
 }
 void launch_single_solve(hipStream_t st, const DevArrays &a) {
     if (a.n_single > 0)
@@ -1768,14 +1836,17 @@ void launch_single_solve(hipStream_t st, const DevArrays &a) {
 void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const SweepArgs *sw) {
     if (L.count <= 0) return;
     const dim3 g((unsigned)L.count);
+    const bool sgn = a.ctx.csign != nullptr;                  // K2: signed Cholesky
+#define TLPK_LAUNCH_S(KERNEL, TASKS) do { if (sgn) hipLaunchKernelGGL(KERNEL<true>, g, dim3(256), 0, st, TASKS + L.first, a.ctx); \
+                                          else hipLaunchKernelGGL(KERNEL<false>, g, dim3(256), 0, st, TASKS + L.first, a.ctx); } while (0)
     switch (L.kind) {
     case LK_EXTEND_ADD: hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, a.ea_tasks + L.first, a.ctx); break;
-    case LK_POTRF: hipLaunchKernelGGL(k_potrf, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
-    case LK_POTRF_WIDE: hipLaunchKernelGGL(k_potrf_wide, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
-    case LK_POTRF_SMALL: hipLaunchKernelGGL(k_potrf_small, g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); break;
-    case LK_TRSM: hipLaunchKernelGGL(k_trsm, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
-    case LK_TRSM_THIN: hipLaunchKernelGGL(k_trsm_thin, g, dim3(256), 0, st, a.trsm_tasks + L.first, a.ctx); break;
-    case LK_UPDATE: hipLaunchKernelGGL(k_update, g, dim3(256), 0, st, a.update_tasks + L.first, a.ctx); break;
+    case LK_POTRF: TLPK_LAUNCH_S(k_potrf, a.potrf_tasks); break;
+    case LK_POTRF_WIDE: TLPK_LAUNCH_S(k_potrf_wide, a.potrf_tasks); break;
+    case LK_POTRF_SMALL: TLPK_LAUNCH_S(k_potrf_small, a.potrf_tasks); break;
+    case LK_TRSM: TLPK_LAUNCH_S(k_trsm, a.trsm_tasks); break;
+    case LK_TRSM_THIN: TLPK_LAUNCH_S(k_trsm_thin, a.trsm_tasks); break;
+    case LK_UPDATE: TLPK_LAUNCH_S(k_update, a.update_tasks); break;
     case LK_UPDATE_REDUCE: hipLaunchKernelGGL(k_update_reduce, g, dim3(256), 0, st, a.reduce_tasks + L.first, a.ctx); break;
     case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;
     case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(256), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
@@ -1787,6 +1858,19 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
     case LK_BWD_SWEEP: if (sw) hipLaunchKernelGGL(k_bwd_sweep, g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw); break;
     default: break;
     }
+#undef TLPK_LAUNCH_S
+}
+void launch_k2_diag(hipStream_t st, i64 n, const double *theta, const double *regP, double *D2) {
+    hipLaunchKernelGGL(k_k2_diag, dim3(nblk(n + 1, 256)), dim3(256), 0, st, n, theta, regP, D2);
+}
+void launch_k2_rhs(hipStream_t st, const DevArrays &a, i64 n, const double *xi_p, const double *xi_d) {
+    if (a.m > 0) hipLaunchKernelGGL(k_k2_rhs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, n, a.perm, xi_p, xi_d, a.ctx.xw);
+}
+void launch_apply_signs(hipStream_t st, const DevArrays &a) {
+    if (a.m > 0) hipLaunchKernelGGL(k_apply_signs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.ctx.csign, a.ctx.xw);
+}
+void launch_k2_out(hipStream_t st, const DevArrays &a, i64 n, double *dx, double *dy) {
+    if (a.m > 0) hipLaunchKernelGGL(k_k2_out, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, n, a.perm, a.ctx.xw, dx, dy);
 }
 void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank) {
     if (a.m > 0)

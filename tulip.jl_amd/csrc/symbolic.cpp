@@ -867,7 +867,30 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
                             S.s_target[e] = w.loff + pos_in_front[ii] + (i64)(kk - w.col0) * w.lda;
                             S.s_local[e] = 1;
                         }
-                        if (!is_root || opt.rank == 0) S.s_diag_row[S.Sp[kk]] = k;
+                        if (opt.system == 1) { if (k >= opt.k2_n) S.s_diag_row[S.Sp[kk]] = k - (i32)opt.k2_n; }   // constraint node: regD
+                        else if (!is_root || opt.rank == 0) S.s_diag_row[S.Sp[kk]] = k;
+                    }
+                    if (opt.system == 1) {
+                        // Augmented system: the diagonal of a variable node is -(theta + regP) = -1 * D2[k]; an
+                        // off-diagonal entry is the constant A[i,j] = A[i,j] * D2[k2_n] with D2[k2_n] = 1 (the columns
+                        // of the incidence matrix carry (1, A[i,j]) on the variable / constraint node).
+                        if (k < opt.k2_n) {
+                            const i64 e = S.Sp[kk];
+                            if (!pass) S.pair_ptr[e + 1]++;
+                            else { const i64 c = cursor[e]++; S.pair_w[c] = -1.0; S.pair_j[c] = k; }
+                        }
+                        for (i64 q = S.Tp[k]; q < S.Tp[k + 1]; ++q) {
+                            const i32 j = S.Tj[q];
+                            const double akj = S.Ax[S.Tpos[q]];
+                            for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
+                                const i32 ii = S.iperm[S.Ai[p]];
+                                if (ii <= kk) continue;
+                                const i64 e = epos[ii];
+                                if (!pass) S.pair_ptr[e + 1]++;
+                                else { const i64 c = cursor[e]++; S.pair_w[c] = akj * S.Ax[p]; S.pair_j[c] = (i32)opt.k2_n; }
+                            }
+                        }
+                        continue;
                     }
                     for (i64 q = S.Tp[k]; q < S.Tp[k + 1]; ++q) {
                         const i32 j = S.Tj[q];
@@ -889,6 +912,47 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     pt.mark("schedule");
     build_schedule(S);
     pt.mark(nullptr);
+    return TLPK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: the augmented system K = [-(Theta^-1 + Rp)  A'; A  Rd] of order N = n + m
+// (/root/reference/src/KKT/KKT.jl:70-75, src/KKT/Cholmod/sqd.jl:5-74, src/KKT/LDLFactorizations/ldlfact.jl:63-139).
+// K is symmetric quasi-definite: any symmetric permutation has a factorisation P K P' = L S L' with
+// S = diag(+-1) known in advance (-1 for a variable node, +1 for a constraint node) and no pivoting
+// (Vanderbei 1995), i.e. a "signed Cholesky" that runs on the same supernodal machinery.  The graph
+// of K is the graph of B B' for the N x nnz(A) incidence matrix B whose column p holds 1 on the
+// variable node and A[i,j] on the constraint node of the p-th nonzero of A: the whole analyse phase is
+// reused on B, only the assembly lists differ (see step 14).
+// ---------------------------------------------------------------------------------------------
+int analyse_k2(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
+               int base, const Options &opt_in) {
+    if (m < 0 || n < 0 || (base != 0 && base != 1) || !colptr) return fail(S, TLPK_BADARG, "bad dimensions or index base");
+    if (opt_in.row_block || opt_in.nranks > 1) return fail(S, TLPK_BADARG, "the augmented system (K2) is single-GPU and takes no row_block");
+    if (opt_in.ordering == TLPK_ORDER_USER) return fail(S, TLPK_BADARG, "user_perm is not supported for K2");
+    const i64 nnz = colptr[n] - base;
+    if (nnz < 0 || m + n >= ((i64)1 << 31) || nnz >= ((i64)1 << 30)) return fail(S, TLPK_TOO_LARGE, "augmented system exceeds int32");
+    if (nnz > 0 && (!rowval || !nzval)) return fail(S, TLPK_BADARG, "null rowval/nzval");
+    std::vector<i64> bp((size_t)nnz + 1), bi((size_t)(2 * nnz));
+    std::vector<double> bx((size_t)(2 * nnz));
+    for (i64 j = 0; j < n; ++j) {
+        if (colptr[j] - base < 0 || colptr[j + 1] < colptr[j] || colptr[j + 1] - base > nnz) return fail(S, TLPK_BADARG, "colptr not monotone");
+        for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; ++p) {
+            const i64 r = rowval[p] - base;
+            if (r < 0 || r >= m) return fail(S, TLPK_BADARG, "row index out of range");
+            bp[(size_t)p] = 2 * p;
+            bi[(size_t)(2 * p)] = j; bx[(size_t)(2 * p)] = 1.0;                  // variable node
+            bi[(size_t)(2 * p + 1)] = n + r; bx[(size_t)(2 * p + 1)] = nzval[p];   // constraint node
+        }
+    }
+    bp[(size_t)nnz] = 2 * nnz;
+    Options opt = opt_in;
+    opt.system = 1; opt.k2_n = n;
+    const int rc = analyse(S, m + n, nnz, bp.data(), bi.data(), bx.data(), 0, opt);
+    if (rc != TLPK_OK) return rc;
+    S.system = 1; S.k2_n = n; S.k2_m = m;
+    S.csign.resize((size_t)(m + n));
+    for (i64 kk = 0; kk < m + n; ++kk) S.csign[(size_t)kk] = (S.perm[(size_t)kk] < n) ? -1.0 : 1.0;
     return TLPK_OK;
 }
 

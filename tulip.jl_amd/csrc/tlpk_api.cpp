@@ -203,8 +203,11 @@ int upload_all(tlpk_handle *h) {
 #define AL(dst, cnt) if ((rc = dev_alloc(h, &(dst), (cnt))) != TLPK_OK) return rc
     AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
     AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4); AL(d.ctx.dinv, S.dinv_len); AL(d.ctx.spart, S.spart_len);
-    AL(h->d_theta, S.n); AL(h->d_regP, S.n); AL(h->d_regD, S.m); AL(h->d_D, S.n);
-    AL(h->d_xip, S.m); AL(h->d_xid, S.n); AL(h->d_dx, S.n); AL(h->d_dy, S.m);
+    const i64 nn = std::max<i64>(S.n, S.k2_n + 1);             // K2: user vectors have k2_n entries, D2 one more
+    AL(h->d_theta, nn); AL(h->d_regP, nn); AL(h->d_regD, S.m); AL(h->d_D, nn);
+    AL(h->d_xip, S.m); AL(h->d_xid, nn); AL(h->d_dx, nn); AL(h->d_dy, S.m);
+    d.ctx.csign = nullptr;
+    if (S.system == 1) { double *p; if ((rc = dev_upload(h, &p, S.csign)) != TLPK_OK) return rc; d.ctx.csign = p; }
 #undef AL
     {
         // persistent sweeps: one ticket counter per sweep launch, one hand-over word per column and direction
@@ -233,6 +236,10 @@ void find_markers(tlpk_handle *h) {
     for (size_t i = 0; i < h->S.fwd_launches.size(); ++i)
         if (h->S.fwd_launches[i].kind == LK_ALLREDUCE_ROOT) h->fwd_marker = i;
 }
+
+// user-visible dimensions: for K2 the Symbolic describes the augmented matrix (order n + m)
+inline i64 user_n(const tlpk_handle *h) { return h->S.system == 1 ? h->S.k2_n : h->S.n; }
+inline i64 user_m(const tlpk_handle *h) { return h->S.system == 1 ? h->S.k2_m : h->S.m; }
 
 }  // namespace
 
@@ -271,6 +278,7 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
         h->opt.ordering = def.ordering; h->opt.relax = def.relax;
         h->opt.rank = def.rank; h->opt.nranks = def.nranks < 1 ? 1 : def.nranks;
         h->opt.streams = def.streams;
+        h->opt.system = (def.system == TLPK_SYSTEM_K2) ? 1 : 0;
         if (def.row_block && m > 0) {
             h->row_block_copy.assign(def.row_block, def.row_block + m);
             h->opt.row_block = h->row_block_copy.data();
@@ -284,7 +292,8 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
         if (const char *e = std::getenv("TLPK_SERIAL")) h->serial = std::atoi(e) != 0;
         if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
         const auto t0 = std::chrono::steady_clock::now();
-        rc = analyse(h->S, m, n, colptr, rowval, nzval, index_base, h->opt);
+        rc = (h->opt.system == 1) ? analyse_k2(h->S, m, n, colptr, rowval, nzval, index_base, h->opt)
+                                  : analyse(h->S, m, n, colptr, rowval, nzval, index_base, h->opt);
         h->ms_analyse = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         h->last_error = h->S.error;
         if (rc == TLPK_OK) {
@@ -385,12 +394,17 @@ int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_reg
     prof_begin(h, true);
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     // stored copies (spd.jl:36-38): the caller may mutate its vectors right after the call
-    if (d_theta != h->d_theta) HIPCHK(h, hipMemcpyAsync(h->d_theta, d_theta, (size_t)S.n * 8, hipMemcpyDeviceToDevice, h->stream));
-    if (d_regP != h->d_regP) HIPCHK(h, hipMemcpyAsync(h->d_regP, d_regP, (size_t)S.n * 8, hipMemcpyDeviceToDevice, h->stream));
-    if (d_regD != h->d_regD) HIPCHK(h, hipMemcpyAsync(h->d_regD, d_regD, (size_t)S.m * 8, hipMemcpyDeviceToDevice, h->stream));
+    const i64 un = user_n(h), um = user_m(h);
+    if (d_theta != h->d_theta) HIPCHK(h, hipMemcpyAsync(h->d_theta, d_theta, (size_t)un * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (d_regP != h->d_regP) HIPCHK(h, hipMemcpyAsync(h->d_regP, d_regP, (size_t)un * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (d_regD != h->d_regD) HIPCHK(h, hipMemcpyAsync(h->d_regD, d_regD, (size_t)um * 8, hipMemcpyDeviceToDevice, h->stream));
     h->h_info[0] = INT_MAX;
     HIPCHK(h, hipMemcpyAsync(h->d.ctx.info, h->h_info, sizeof(int), hipMemcpyHostToDevice, h->stream));
-    { ProfScope ps(h, TLPK_KC_ASSEMBLE); launch_compute_d(h->stream, S.n, h->d_theta, h->d_regP, h->d_D); }
+    {
+        ProfScope ps(h, TLPK_KC_ASSEMBLE);
+        if (S.system == 1) launch_k2_diag(h->stream, un, h->d_theta, h->d_regP, h->d_D);      // D2 = [theta + regP ; 1]  (sqd.jl:44-50)
+        else launch_compute_d(h->stream, S.n, h->d_theta, h->d_regP, h->d_D);
+    }
     {
         ProfScope ps(h, TLPK_KC_ASSEMBLE);
         if (S.lval_len > 0) HIPCHK(h, hipMemsetAsync(h->d.ctx.Lval, 0, (size_t)S.lval_len * 8, h->stream));
@@ -467,7 +481,7 @@ int tlpk_update_device(tlpk_handle *h, const double *d_theta, const double *d_re
 // a fraction of the link rate).  Nothing of the caller's is referenced after the call returns.
 static int ensure_pinned(tlpk_handle *h) {
     if (h->pin_in) return TLPK_OK;
-    const size_t nin = (size_t)std::max<i64>(2 * h->S.n + h->S.m, 1), nout = (size_t)std::max<i64>(h->S.n + h->S.m, 1);
+    const size_t nin = (size_t)std::max<i64>(2 * user_n(h) + user_m(h), 1), nout = (size_t)std::max<i64>(user_n(h) + user_m(h), 1);
     HIPCHK(h, hipHostMalloc((void **)&h->pin_in, nin * 8, hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc((void **)&h->pin_out, nout * 8, hipHostMallocDefault));
     return TLPK_OK;
@@ -479,15 +493,15 @@ int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const d
     if (int g = sharded_needs_split(h, "tlpk_update")) return g;
     HIPCHK(h, hipSetDevice(h->device));
     if (int rc = ensure_pinned(h)) return rc;
-    const Symbolic &S = h->S;
     HIPCHK(h, hipStreamSynchronize(h->stream));          // the staging area may still feed an earlier call's copies
-    double *p0 = h->pin_in, *p1 = p0 + S.n, *p2 = p1 + S.n;
-    std::memcpy(p0, theta, (size_t)S.n * 8);
-    HIPCHK(h, hipMemcpyAsync(h->d_theta, p0, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
-    std::memcpy(p1, regP, (size_t)S.n * 8);
-    HIPCHK(h, hipMemcpyAsync(h->d_regP, p1, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
-    std::memcpy(p2, regD, (size_t)S.m * 8);
-    HIPCHK(h, hipMemcpyAsync(h->d_regD, p2, (size_t)S.m * 8, hipMemcpyHostToDevice, h->stream));
+    const i64 un = user_n(h), um = user_m(h);
+    double *p0 = h->pin_in, *p1 = p0 + un, *p2 = p1 + un;
+    std::memcpy(p0, theta, (size_t)un * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_theta, p0, (size_t)un * 8, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(p1, regP, (size_t)un * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_regP, p1, (size_t)un * 8, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(p2, regD, (size_t)um * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_regD, p2, (size_t)um * 8, hipMemcpyHostToDevice, h->stream));
     return tlpk_update_device(h, h->d_theta, h->d_regP, h->d_regD);
 }
 
@@ -504,7 +518,9 @@ int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
         ProfScope ps(h, TLPK_KC_SPMV);
         // hand-over words of both sweeps back to the sentinel (all ones): the data is its own flag
         if (h->S.sweep && h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_xh, 0xFF, (size_t)(2 * h->S.m) * 8, h->stream));
-        launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank); launch_single_solve(h->stream, h->d);
+        if (h->S.system == 1) launch_k2_rhs(h->stream, h->d, h->S.k2_n, d_xip, d_xid);        // [xi_d ; xi_p] permuted (sqd.jl:62-66)
+        else launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank);
+        launch_single_solve(h->stream, h->d);
     }
     h->solve_epoch += 1;
     run_launches(h, h->S.fwd_launches, 0, h->fwd_marker, 0);
@@ -529,9 +545,13 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     h->solve_local_done = false;
     HIPCHK(h, hipSetDevice(h->device));
     run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size(), 0);
+    if (h->S.system == 1) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d); }     // L S L' x = b: z = S y between the sweeps
     run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1);
-    { ProfScope ps(h, TLPK_KC_SPMV); launch_unpermute(h->stream, h->d, d_dy); }
-    { ProfScope ps(h, TLPK_KC_SPMV); launch_dx(h->stream, h->d, h->d_D, d_dy, d_xid, d_dx); }
+    if (h->S.system == 1) { ProfScope ps(h, TLPK_KC_SPMV); launch_k2_out(h->stream, h->d, h->S.k2_n, d_dx, d_dy); }
+    else {
+        { ProfScope ps(h, TLPK_KC_SPMV); launch_unpermute(h->stream, h->d, d_dy); }
+        { ProfScope ps(h, TLPK_KC_SPMV); launch_dx(h->stream, h->d, h->d_D, d_dy, d_xid, d_dx); }
+    }
     if (h->S.sweep) HIPCHK(h, hipMemcpyAsync(h->h_info + 1, h->d.ctx.info + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
@@ -574,22 +594,22 @@ int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const
     if (int g = sharded_needs_split(h, "tlpk_solve")) return g;
     HIPCHK(h, hipSetDevice(h->device));
     if (int rc = ensure_pinned(h)) return rc;
-    const Symbolic &S = h->S;
+    const i64 un = user_n(h), um = user_m(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    double *pi0 = h->pin_in, *pi1 = pi0 + S.m;
-    std::memcpy(pi0, xi_p, (size_t)S.m * 8);
-    HIPCHK(h, hipMemcpyAsync(h->d_xip, pi0, (size_t)S.m * 8, hipMemcpyHostToDevice, h->stream));
-    std::memcpy(pi1, xi_d, (size_t)S.n * 8);
-    HIPCHK(h, hipMemcpyAsync(h->d_xid, pi1, (size_t)S.n * 8, hipMemcpyHostToDevice, h->stream));
+    double *pi0 = h->pin_in, *pi1 = pi0 + um;
+    std::memcpy(pi0, xi_p, (size_t)um * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_xip, pi0, (size_t)um * 8, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(pi1, xi_d, (size_t)un * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_xid, pi1, (size_t)un * 8, hipMemcpyHostToDevice, h->stream));
     int rc = tlpk_solve_device(h, h->d_dx, h->d_dy, h->d_xip, h->d_xid);
     if (rc != TLPK_OK) return rc;
-    double *po0 = h->pin_out, *po1 = po0 + S.m;
-    HIPCHK(h, hipMemcpyAsync(po0, h->d_dy, (size_t)S.m * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(po1, h->d_dx, (size_t)S.n * 8, hipMemcpyDeviceToHost, h->stream));
+    double *po0 = h->pin_out, *po1 = po0 + um;
+    HIPCHK(h, hipMemcpyAsync(po0, h->d_dy, (size_t)um * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(po1, h->d_dx, (size_t)un * 8, hipMemcpyDeviceToHost, h->stream));
     rc = tlpk_sync(h);
     if (rc != TLPK_OK) return rc;
-    std::memcpy(dy, po0, (size_t)S.m * 8);
-    std::memcpy(dx, po1, (size_t)S.n * 8);
+    std::memcpy(dy, po0, (size_t)um * 8);
+    std::memcpy(dx, po1, (size_t)un * 8);
     return TLPK_OK;
 }
 
@@ -598,7 +618,7 @@ int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
     if (!h || !out) return TLPK_BADARG;
     const Symbolic &S = h->S;
     std::memset(out, 0, sizeof(*out));
-    out->m = S.m; out->n = S.n; out->nnzA = S.nnzA; out->nnzS = S.nnzS; out->nnzL = S.nnzL;
+    out->m = user_m(h); out->n = user_n(h); out->nnzA = (S.system == 1) ? S.n : S.nnzA; out->nnzS = S.nnzS; out->nnzL = S.nnzL;
     out->nnzL_stored = S.lval_len; out->flops_chol = S.flops_chol; out->flops_panel = S.flops_panel;
     out->n_supernodes = S.nsuper; out->n_levels = S.nlevels; out->max_front = S.max_front;
     out->n_pairs = S.pair_ptr.empty() ? 0 : S.pair_ptr.back();
@@ -741,5 +761,6 @@ const char *tlpk_strerror(int code) {
 const char *tlpk_last_error(const tlpk_handle *h) { return h ? h->last_error.c_str() : ""; }
 const char *tlpk_backend_name(void) { return "HIP (gfx950)"; }
 const char *tlpk_system_name(void) { return "Normal equations (K1)"; }
+const char *tlpk_linear_system(const tlpk_handle *h) { return (h && h->S.system == 1) ? "Augmented system (K2)" : "Normal equations (K1)"; }
 
 }  // extern "C"

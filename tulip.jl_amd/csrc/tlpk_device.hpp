@@ -20,6 +20,7 @@ struct DevCtx {
     double *dinv;       // inverses of the NB_IN x NB_IN diagonal blocks of L (written by k_potrf)
     double *spart;      // split-K scratch: one TILE x TILE partial product per slot
     int *info;          // info[0] = smallest failing pivot column (INT_MAX = none); info[1] != 0: a sweep gave up waiting
+    const double *csign;   // K2 (augmented system): +1 / -1 per permuted column, the S of P K P' = L S L'; nullptr for K1
 };
 
 // per-launch arguments of the persistent sweep kernels
@@ -61,5 +62,9 @@ void launch_single_solve(hipStream_t st, const DevArrays &a);
 void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank);
 void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy);
 void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx);
+void launch_k2_diag(hipStream_t st, i64 n, const double *theta, const double *regP, double *D2);
+void launch_k2_rhs(hipStream_t st, const DevArrays &a, i64 n, const double *xi_p, const double *xi_d);
+void launch_apply_signs(hipStream_t st, const DevArrays &a);
+void launch_k2_out(hipStream_t st, const DevArrays &a, i64 n, double *dx, double *dy);
 
 }  // namespace tlpk

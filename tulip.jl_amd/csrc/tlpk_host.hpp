@@ -80,12 +80,16 @@ struct Launch { i32 kind; i32 group; i64 first; i64 count; i32 side = 0; i32 pad
 
 struct Options {
     i32 ordering = 0, relax = 1, rank = 0, nranks = 1, streams = 0;
+    i32 system = 0;                   // 0 = K1 normal equations, 1 = K2 augmented system (signed Cholesky)
+    i64 k2_n = 0;                     // K2, internal: number of variable nodes (nodes [0, k2_n) are variables, the rest constraints)
     const i64 *user_perm = nullptr;   // 0-based here
     const i64 *row_block = nullptr;
 };
 
 struct Symbolic {
-    i64 m = 0, n = 0, nnzA = 0;
+    i64 m = 0, n = 0, nnzA = 0;          // K2: m = order of the augmented matrix (n_var + m_con), n / nnzA those of the incidence matrix below
+    i32 system = 0; i64 k2_n = 0, k2_m = 0;   // K2: user dimensions (variables, constraints)
+    std::vector<double> csign;           // K2: +1 / -1 per permuted column (constraint / variable node)
     // A, CSC and CSR (0-based, int32 indices); csr_pos[q] = CSC position of the CSR entry q
     std::vector<i64> Ap; std::vector<i32> Ai; std::vector<double> Ax;
     std::vector<i64> Tp; std::vector<i32> Tj; std::vector<i32> Tpos;
@@ -144,8 +148,11 @@ struct Symbolic {
 // amd.cpp
 void amd_order(i32 n, const std::vector<i64> &xadj, const std::vector<i32> &adj, std::vector<i32> &order);
 
-// symbolic.cpp : returns a TLPK_* code
+// symbolic.cpp : returns a TLPK_* code.  analyse_k2 builds the structures of the augmented system
+// [-(Theta^-1 + Rp) A'; A Rd] (order n + m) from the same machinery.
 int analyse(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
             int index_base, const Options &opt);
+int analyse_k2(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
+               int index_base, const Options &opt);
 
 }  // namespace tlpk

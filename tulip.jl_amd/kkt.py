@@ -19,6 +19,12 @@ class K1:
     """Normal-equations system, /root/reference/src/KKT/systems.jl:34-54."""
 
 
+class K2:
+    """Augmented system, /root/reference/src/KKT/systems.jl:12-31 -- the reference's default for Float64
+    (KKT.jl:134-141, Cholmod/sqd.jl).  On the device: signed Cholesky P K P' = L S L' of the quasi-definite
+    matrix [-(Theta^-1 + Rp) A'; A Rd]."""
+
+
 class DimensionMismatch(ValueError):
     """Julia's DimensionMismatch (spd.jl:26-34)."""
 
@@ -78,7 +84,7 @@ class HIPNormalEquations:
     """`HIPNormalEquations <: AbstractKKTSolver{Float64}` -- the counterpart of
     `CholmodSolver{Float64,K1}` (/root/reference/src/KKT/Cholmod/cholmod.jl:46-60)."""
 
-    def __init__(self, A, backend_):
+    def __init__(self, A, backend_, system=_lib.SYSTEM_K1):
         import scipy.sparse as sp
         if not sp.issparse(A):
             A = sp.csc_matrix(np.asarray(A, dtype=np.float64))     # cholmod.jl:65 convert(SparseMatrixCSC, A)
@@ -96,6 +102,8 @@ class HIPNormalEquations:
         opt.rank, opt.nranks = backend_.rank, backend_.nranks
         opt.mem_budget_bytes = backend_.mem_budget_bytes
         opt.streams = backend_.streams
+        opt.system = system
+        self.system = system
         self._keep = []
         if backend_.row_block is not None:
             if backend_.row_block.shape != (self.m,):
@@ -165,7 +173,9 @@ class HIPNormalEquations:
         return (p.value or 0), n.value
 
     def perm(self):
-        p = np.empty(self.m, dtype=np.int64)
+        """perm[new] = old.  K1: the m rows of S; K2: the n + m nodes of the augmented matrix (variables 0..n-1,
+        constraints n..n+m-1)."""
+        p = np.empty(self.m + self.n if self.system == _lib.SYSTEM_K2 else self.m, dtype=np.int64)
         _lib.lib().tlpk_get_perm(self._h, _lib.as_p64(p))
         return p
 
@@ -210,9 +220,11 @@ def setup(A, system=None, backend_=None):
     """KKT.setup(A, ::K1, ::TlpHIP.Backend)  (KKT.jl:59, spd.jl:5-20).  Runs the analyse phase on
     the host and uploads the symbolic structures; skips the throw-away numeric factorisation of
     spd.jl:14-17."""
-    if system is not None and not isinstance(system, K1) and system is not K1:
-        raise TypeError("the HIP backend solves the normal equations (K1) only")
-    return HIPNormalEquations(A, backend_ or Backend())
+    if system is None or isinstance(system, K1) or system is K1:
+        return HIPNormalEquations(A, backend_ or Backend())
+    if isinstance(system, K2) or system is K2:
+        return HIPNormalEquations(A, backend_ or Backend(), system=_lib.SYSTEM_K2)
+    raise TypeError("the HIP backend solves the normal equations (K1) or the augmented system (K2)")
 
 
 def _vec(x, name, length, what):
@@ -263,7 +275,7 @@ def backend(kkt):
 
 def linear_system(kkt):
     """KKT.linear_system (KKT.jl:121; spd.jl:3)."""
-    return _lib.lib().tlpk_system_name().decode()
+    return _lib.lib().tlpk_linear_system(kkt._h if kkt is not None else None).decode()
 
 
 def run_ls_tests(A, kkt, atol=SQRT_EPS):
