@@ -150,6 +150,15 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
  * own the memory it reduces (torch.distributed tensors). */
 int tlpk_root_copy(tlpk_handle *h, int which, int dir, double *d_buf);
 
+/* Single-process multi-GPU (block-angular LPs only): ONE handle, driven by one host thread, shards the diagonal
+ * blocks over `ngpus` devices of this node -- what a Julia process needs (`TlpHIP.Backend(row_block = rb, ngpus = 8)`).
+ * `opt->row_block` is required, `opt->system` must be K1.  devices: ngpus HIP ordinals, or NULL for 0 .. ngpus-1
+ * (an ordinal may repeat: several shards on one device, for testing).  The two reductions of a Newton step (root
+ * panel, root right-hand side) are done inside the library over peer-to-peer copies, stream-ordered; results are
+ * gathered on devices[0].  The handle accepts tlpk_update / tlpk_solve / tlpk_info / tlpk_get_perm / tlpk_destroy. */
+int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                      const double *nzval, int index_base, const tlpk_options *opt, int ngpus, const int32_t *devices);
+
 /* Introspection */
 int tlpk_info(const tlpk_handle *h, tlpk_stats *out);
 int tlpk_kernel_timing(const tlpk_handle *h, tlpk_kernel_times *out);

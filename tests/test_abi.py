@@ -121,3 +121,16 @@ def test_plain_c_caller_drives_setup_update_solve_on_device(tmp_path):
     out = subprocess.run([exe, _lib.LIB_PATH, "gpu"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi_smoke gpu ok" in out.stdout
+
+
+def test_multi_device_create_rejects_what_it_cannot_do():
+    """tlpk_create_multi needs a block-angular K1 problem; without a GPU the shards fail with TLPK_NO_DEVICE."""
+    sys.path.insert(0, HERE)
+    from helpers import block_angular, random_lp_matrix
+    A = random_lp_matrix(20, 40, 3, 1)
+    with pytest.raises(tk.DimensionMismatch):                       # no row_block
+        tk.setup(A, tk.K1(), tk.Backend(device=0, ngpus=2, devices=[0, 0]))
+    A, rb = block_angular(nblocks=4, mk=20, nk=40, m0=6, nnz_in=3, link_prob=0.5, seed=2)
+    if _lib.lib().tlpk_device_count() == 0:
+        with pytest.raises(RuntimeError):
+            tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb, ngpus=2, devices=[0, 0]))

@@ -441,3 +441,38 @@ def test_persistent_sweeps_long_chain_single_front():
         assert (dx == ref[0]).all() and (dy == ref[1]).all()
     assert np.abs(dy - dyo).max() <= 1e-8 * max(1.0, np.abs(dyo).max())
     assert np.abs(dx - dxo).max() <= 1e-8 * max(1.0, np.abs(dxo).max())
+
+
+@pytest.mark.parametrize("ngpus", [2, 3])
+def test_single_process_multi_device_mode(ngpus):
+    """tlpk_create_multi: ONE handle, one host thread, `ngpus` shards -- here all on this box's single GPU
+    (the ordinal may repeat).  Same sharding, root-panel / root-rhs reductions inside the library (peer copies
+    + ordered sum), results gathered on the lead device.  Every solve must equal the oracle's; the handle
+    reports the failing pivot of any shard and stays usable (PosDef retry contract)."""
+    A, row_block = block_angular(nblocks=7, mk=300, nk=600, m0=70, nnz_in=3, link_prob=0.5, seed=13)
+    m, n = A.shape
+    kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=row_block, ngpus=ngpus, devices=[0] * ngpus))
+    st = kkt.stats()
+    assert st["n_blocks"] == 7 and st["n_local_blocks"] == 7          # summed over the shards
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 13)
+    orc = OracleK1(A, kkt.perm()); orc.update(th, rp, rd)
+    for it in range(3):
+        tk.update(kkt, th, rp, rd)
+        dx = np.full(n, np.nan); dy = np.full(m, np.nan)
+        tk.solve(dx, dy, kkt, xp, xd)
+        dxo, dyo = orc.solve(xp, xd)
+        assert np.abs(dx - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max())
+        assert np.abs(dy - dyo).max() <= 1e-9 * max(1, np.abs(dyo).max())
+        xp = xp[::-1].copy()                                          # another right-hand side on the same factor
+    bad = rd.copy(); bad[5] = -1e6                                    # a block row of the first shard
+    with pytest.raises(tk.PosDefException):
+        tk.update(kkt, th, rp, bad)
+    bad = rd.copy(); bad[m - 3] = -1e9                                # a linking row: fails in the replicated root
+    with pytest.raises(tk.PosDefException):
+        tk.update(kkt, th, rp, bad)
+    tk.update(kkt, th, rp, rd)
+    dx = np.zeros(n); dy = np.zeros(m)
+    tk.solve(dx, dy, kkt, xp, xd)
+    r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+    assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp).max(), np.abs(xd).max()))
+    tk.run_ls_tests(A, kkt)

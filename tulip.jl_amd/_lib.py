@@ -60,7 +60,7 @@ EXPORTS = [
     "tlpk_solve_finish", "tlpk_info", "tlpk_kernel_timing", "tlpk_get_perm", "tlpk_symbolic_get",
     "tlpk_symbolic_get_f64", "tlpk_set_profile", "tlpk_root_copy", "tlpk_get_factor", "tlpk_strerror", "tlpk_last_error",
     "tlpk_backend_name", "tlpk_system_name", "tlpk_linear_system", "tlpk_device_count",
-    "tlpk_ipm_load", "tlpk_ipm_reset", "tlpk_ipm_residuals", "tlpk_ipm_factor", "tlpk_ipm_hsolve", "tlpk_ipm_targets",
+    "tlpk_create_multi", "tlpk_ipm_load", "tlpk_ipm_reset", "tlpk_ipm_residuals", "tlpk_ipm_factor", "tlpk_ipm_hsolve", "tlpk_ipm_targets",
     "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get",
 ]
 
@@ -79,6 +79,8 @@ def lib():
     L.tlpk_default_options.argtypes = [C.POINTER(Options)]
     L.tlpk_default_options.restype = None
     L.tlpk_create.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, p64, p64, pd, C.c_int, C.POINTER(Options)]
+    L.tlpk_create_multi.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, p64, p64, pd, C.c_int, C.POINTER(Options), C.c_int, C.POINTER(C.c_int32)]
+    L.tlpk_create_multi.restype = C.c_int
     L.tlpk_destroy.argtypes = [vp]
     L.tlpk_destroy.restype = None
     L.tlpk_update.argtypes = [vp, pd, pd, pd]

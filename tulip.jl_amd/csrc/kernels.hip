@@ -1757,25 +1757,40 @@ __global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__
     if (lane < ns) xs[lane] = x;
 }
 
+// dy_shared != nullptr (single-process multi-device mode): the rows this rank OWNS (its block rows; the linking rows
+// on rank 0) are also written into the job-wide result vector, which may live on a peer device (P2P stores).
 __global__ void k_unpermute(i64 m, const i32 *__restrict__ perm, const char *__restrict__ row_local,
-                            const double *__restrict__ xw, double *__restrict__ dy) {
+                            const double *__restrict__ xw, double *__restrict__ dy, double *__restrict__ dy_shared, int rank) {
     const i64 ii = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (ii >= m) return;
     const i32 i = perm[ii];
-    dy[i] = row_local[i] ? xw[ii] : 0.0;
+    const char rl = row_local[i];
+    const double v = rl ? xw[ii] : 0.0;
+    dy[i] = v;
+    if (dy_shared && (rl == 1 || (rl == 2 && rank == 0))) dy_shared[i] = v;
 }
 
-// dx_j = D_j (A[:,j]' dy - xi_d[j]);  columns of other ranks give 0.
+// dx_j = D_j (A[:,j]' dy - xi_d[j]);  columns of other ranks give 0 (local_only: are left alone -- dx is then the
+// job-wide vector that every rank fills with its own columns).
 __global__ void k_dx(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ Ai,
                      const double *__restrict__ Ax, const double *__restrict__ D,
                      const double *__restrict__ dy, const double *__restrict__ xi_d,
-                     const char *__restrict__ col_local, double *__restrict__ dx) {
+                     const char *__restrict__ col_local, double *__restrict__ dx, int local_only) {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    if (!col_local[j]) { dx[j] = 0.0; return; }
+    if (!col_local[j]) { if (!local_only) dx[j] = 0.0; return; }
     double s = 0.0;
     for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) s += Ax[p] * dy[Ai[p]];
     dx[j] = D[j] * (s - xi_d[j]);
+}
+
+// dst += src[0] + src[1] + ... (fixed order): the root-panel / root-rhs reduction of the multi-device mode
+__global__ void k_sum_into(i64 len, double *__restrict__ dst, const double *__restrict__ src, int nsrc, i64 stride) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    double v = dst[i];
+    for (int r = 0; r < nsrc; ++r) v += src[(i64)r * stride + i];
+    dst[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1877,11 +1892,14 @@ void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const doubl
         hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, D, xi_p, xi_d,
                            a.row_local, a.col_local, rank, a.ctx.xw);
 }
-void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy) {
-    if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw, dy);
+void launch_sum_into(hipStream_t st, i64 len, double *dst, const double *src, int nsrc, i64 stride) {
+    if (len > 0 && nsrc > 0) hipLaunchKernelGGL(k_sum_into, dim3(nblk(len, 256)), dim3(256), 0, st, len, dst, src, nsrc, stride);
 }
-void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx) {
-    if (a.n > 0) hipLaunchKernelGGL(k_dx, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, D, dy, xi_d, a.col_local, dx);
+void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy_shared, int rank) {
+    if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw, dy, dy_shared, rank);
+}
+void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx, int local_only) {
+    if (a.n > 0) hipLaunchKernelGGL(k_dx, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, D, dy, xi_d, a.col_local, dx, local_only);
 }
 
 }  // namespace tlpk

@@ -359,6 +359,14 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
 
 void tlpk_destroy(tlpk_handle *h) {
     if (!h) return;
+    if (!h->sub.empty() || h->multi_tmp) {                // multi-device parent: owns its per-device handles, nothing else
+        for (tlpk_handle *c : h->sub) tlpk_destroy(c);
+        if (h->multi_tmp) { hipSetDevice(h->device); hipFree(h->multi_tmp); }
+        if (h->multi_done) hipEventDestroy(h->multi_done);
+        for (int r = 0; r < MAX_DEVICES; ++r) if (h->multi_ev[r]) hipEventDestroy(h->multi_ev[r]);
+        delete h;
+        return;
+    }
     if (h->device >= 0) {
         hipSetDevice(h->device);
         if (h->stream) hipStreamSynchronize(h->stream);
@@ -387,6 +395,7 @@ void tlpk_destroy(tlpk_handle *h) {
 // ---- update ----
 int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_regP, const double *d_regD) {
     if (!h || !d_theta || !d_regP || !d_regD) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     HIPCHK(h, hipSetDevice(h->device));
     const Symbolic &S = h->S;
@@ -419,6 +428,7 @@ int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_reg
 
 int tlpk_root_panel(tlpk_handle *h, double **d_ptr, int64_t *count) {
     if (!h || !d_ptr || !count) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (h->S.root_front < 0) { *d_ptr = nullptr; *count = 0; return TLPK_OK; }
     const FrontDesc &fd = h->S.fronts[h->S.root_front];
@@ -440,6 +450,7 @@ int tlpk_root_copy(tlpk_handle *h, int which, int dir, double *d_buf) {
 
 int tlpk_update_finish(tlpk_handle *h) {
     if (!h) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->local_done) return TLPK_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -459,6 +470,10 @@ int tlpk_update_finish(tlpk_handle *h) {
 
 // The composed entry points run both halves back to back WITHOUT the all-reduce of the root panel /
 // root rhs: on a sharded handle that would factorise this rank's partial sum and return TLPK_OK.
+namespace {
+int multi_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD);
+int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const double *xi_d);
+}
 static int sharded_needs_split(tlpk_handle *h, const char *what) {
     if (h && h->opt.nranks > 1 && h->S.root_front >= 0) {
         h->last_error = std::string(what) + ": handle is sharded over " + std::to_string(h->opt.nranks) +
@@ -489,6 +504,7 @@ static int ensure_pinned(tlpk_handle *h) {
 
 int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
     if (!h || !theta || !regP || !regD) return TLPK_BADARG;
+    if (!h->sub.empty()) return multi_update(h, theta, regP, regD);
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (int g = sharded_needs_split(h, "tlpk_update")) return g;
     HIPCHK(h, hipSetDevice(h->device));
@@ -508,6 +524,7 @@ int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const d
 // ---- solve ----
 int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
     if (!h || !d_xip || !d_xid) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->factored) return TLPK_NOT_FACTORED;
     HIPCHK(h, hipSetDevice(h->device));
@@ -531,6 +548,7 @@ int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
 
 int tlpk_root_rhs(tlpk_handle *h, double **d_ptr, int64_t *count) {
     if (!h || !d_ptr || !count) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     *d_ptr = h->nlink ? h->d.ctx.xw + h->first_link : nullptr;
     *count = h->nlink;
@@ -539,6 +557,7 @@ int tlpk_root_rhs(tlpk_handle *h, double **d_ptr, int64_t *count) {
 
 int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xid) {
     if (!h || !d_dx || !d_dy || !d_xid) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->factored) return TLPK_NOT_FACTORED;
     if (!h->solve_local_done) { h->last_error = "tlpk_solve_finish without a preceding tlpk_solve_local"; return TLPK_BADARG; }
@@ -549,8 +568,8 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1);
     if (h->S.system == 1) { ProfScope ps(h, TLPK_KC_SPMV); launch_k2_out(h->stream, h->d, h->S.k2_n, d_dx, d_dy); }
     else {
-        { ProfScope ps(h, TLPK_KC_SPMV); launch_unpermute(h->stream, h->d, d_dy); }
-        { ProfScope ps(h, TLPK_KC_SPMV); launch_dx(h->stream, h->d, h->d_D, d_dy, d_xid, d_dx); }
+        { ProfScope ps(h, TLPK_KC_SPMV); launch_unpermute(h->stream, h->d, d_dy, h->shared_dy, h->opt.rank); }
+        { ProfScope ps(h, TLPK_KC_SPMV); launch_dx(h->stream, h->d, h->d_D, d_dy, d_xid, d_dx, h->dx_local_only ? 1 : 0); }
     }
     if (h->S.sweep) HIPCHK(h, hipMemcpyAsync(h->h_info + 1, h->d.ctx.info + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
@@ -568,6 +587,7 @@ int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *
 
 int tlpk_sync(tlpk_handle *h) {
     if (!h) return TLPK_BADARG;
+    if (!h->sub.empty()) { int w = TLPK_OK; for (tlpk_handle *c : h->sub) { const int rc = tlpk_sync(c); if (rc != TLPK_OK) w = rc; } return w; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -585,10 +605,11 @@ int tlpk_sync(tlpk_handle *h) {
     return TLPK_OK;
 }
 
-void *tlpk_stream(tlpk_handle *h) { return h ? (void *)h->stream : nullptr; }
+void *tlpk_stream(tlpk_handle *h) { return h ? (void *)(h->sub.empty() ? h->stream : h->sub[0]->stream) : nullptr; }
 
 int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const double *xi_d) {
     if (!h || !dx || !dy || !xi_p || !xi_d) return TLPK_BADARG;
+    if (!h->sub.empty()) return multi_solve(h, dx, dy, xi_p, xi_d);
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->factored) return TLPK_NOT_FACTORED;
     if (int g = sharded_needs_split(h, "tlpk_solve")) return g;
@@ -613,9 +634,171 @@ int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const
     return TLPK_OK;
 }
 
+// ---- single-process multi-device mode (block-angular LPs; SURVEY.md 8e "one-process-8-devices") ----
+// One handle drives `ngpus` devices from one host thread (what a Julia process needs): internally one sharded
+// handle per device (rank r of ngpus, same split-phase schedule as the one-process-per-GPU mode).  The two
+// reductions of a Newton step -- the root (linking) panel after the local factorisations, the root right-hand
+// side inside every solve -- are done by the library over peer-to-peer copies: gather on the lead device, add in
+// rank order (deterministic), copy back; stream-ordered through events, no host synchronisation between the
+// halves.  Results are written by every rank straight into the lead device's dx / dy (P2P stores of the entries
+// it owns) and leave through one pinned copy.
+namespace {
+
+int multi_allreduce(tlpk_handle *h, bool panel) {
+    tlpk_handle *lead = h->sub[0];
+    double *p0 = nullptr; int64_t cnt = 0;
+    int rc = panel ? tlpk_root_panel(lead, &p0, &cnt) : tlpk_root_rhs(lead, &p0, &cnt);
+    if (rc != TLPK_OK || cnt == 0) return rc;
+    const int N = (int)h->sub.size();
+    for (int r = 1; r < N; ++r) {                        // gather: every peer sends on its own stream, after its local work
+        tlpk_handle *c = h->sub[r];
+        double *pr = nullptr; int64_t cr = 0;
+        rc = panel ? tlpk_root_panel(c, &pr, &cr) : tlpk_root_rhs(c, &pr, &cr);
+        if (rc != TLPK_OK || cr != cnt) { h->last_error = "root buffers of the ranks differ"; return TLPK_INTERNAL; }
+        HIPCHK(h, hipSetDevice(c->device));
+        HIPCHK(h, hipMemcpyPeerAsync(h->multi_tmp + (size_t)(r - 1) * (size_t)cnt, lead->device, pr, c->device, (size_t)cnt * 8, c->stream));
+        HIPCHK(h, hipEventRecord(h->multi_ev[r], c->stream));
+    }
+    HIPCHK(h, hipSetDevice(lead->device));
+    for (int r = 1; r < N; ++r) HIPCHK(h, hipStreamWaitEvent(lead->stream, h->multi_ev[r], 0));
+    launch_sum_into(lead->stream, cnt, p0, h->multi_tmp, N - 1, cnt);          // rank order: deterministic
+    HIPCHK(h, hipEventRecord(h->multi_done, lead->stream));
+    for (int r = 1; r < N; ++r) {                        // copy back, on the peer's stream
+        tlpk_handle *c = h->sub[r];
+        double *pr = nullptr; int64_t cr = 0;
+        rc = panel ? tlpk_root_panel(c, &pr, &cr) : tlpk_root_rhs(c, &pr, &cr);
+        HIPCHK(h, hipSetDevice(c->device));
+        HIPCHK(h, hipStreamWaitEvent(c->stream, h->multi_done, 0));
+        HIPCHK(h, hipMemcpyPeerAsync(pr, c->device, p0, lead->device, (size_t)cnt * 8, c->stream));
+    }
+    return TLPK_OK;
+}
+
+int multi_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
+    tlpk_handle *lead = h->sub[0];
+    const i64 n = h->S.n, m = h->S.m;
+    HIPCHK(h, hipSetDevice(lead->device));
+    if (int rc = ensure_pinned(lead)) { h->last_error = lead->last_error; return rc; }
+    for (tlpk_handle *c : h->sub) { HIPCHK(h, hipSetDevice(c->device)); HIPCHK(h, hipStreamSynchronize(c->stream)); }   // staging area free again
+    double *p0 = lead->pin_in, *p1 = p0 + n, *p2 = p1 + n;
+    std::memcpy(p0, theta, (size_t)n * 8); std::memcpy(p1, regP, (size_t)n * 8); std::memcpy(p2, regD, (size_t)m * 8);
+    for (tlpk_handle *c : h->sub) {
+        HIPCHK(h, hipSetDevice(c->device));
+        HIPCHK(h, hipMemcpyAsync(c->d_theta, p0, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(h, hipMemcpyAsync(c->d_regP, p1, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(h, hipMemcpyAsync(c->d_regD, p2, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        const int rc = tlpk_update_local(c, c->d_theta, c->d_regP, c->d_regD);
+        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    }
+    if (int rc = multi_allreduce(h, true)) return rc;
+    int worst = TLPK_OK; h->fail_col = -1;
+    for (tlpk_handle *c : h->sub) {
+        const int rc = tlpk_update_finish(c);
+        if (rc == TLPK_NOT_POSDEF) { if (h->fail_col < 0 || c->fail_col < h->fail_col) h->fail_col = c->fail_col; if (worst == TLPK_OK) worst = rc; }
+        else if (rc != TLPK_OK) { h->last_error = c->last_error; worst = rc; }
+    }
+    h->factored = (worst == TLPK_OK);
+    return worst;
+}
+
+int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const double *xi_d) {
+    if (!h->factored) return TLPK_NOT_FACTORED;
+    tlpk_handle *lead = h->sub[0];
+    const i64 n = h->S.n, m = h->S.m;
+    HIPCHK(h, hipSetDevice(lead->device));
+    if (int rc = ensure_pinned(lead)) { h->last_error = lead->last_error; return rc; }
+    for (tlpk_handle *c : h->sub) { HIPCHK(h, hipSetDevice(c->device)); HIPCHK(h, hipStreamSynchronize(c->stream)); }
+    double *pi0 = lead->pin_in, *pi1 = pi0 + m;
+    std::memcpy(pi0, xi_p, (size_t)m * 8); std::memcpy(pi1, xi_d, (size_t)n * 8);
+    for (tlpk_handle *c : h->sub) {
+        HIPCHK(h, hipSetDevice(c->device));
+        HIPCHK(h, hipMemcpyAsync(c->d_xip, pi0, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(h, hipMemcpyAsync(c->d_xid, pi1, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        const int rc = tlpk_solve_local(c, c->d_xip, c->d_xid);
+        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    }
+    if (int rc = multi_allreduce(h, false)) return rc;
+    for (size_t r = 0; r < h->sub.size(); ++r) {
+        tlpk_handle *c = h->sub[r];
+        // every rank fills its own entries of the lead device's dx / dy (P2P stores); its local dy feeds its k_dx
+        c->shared_dy = lead->d_dy; c->dx_local_only = true;
+        const int rc = tlpk_solve_finish(c, lead->d_dx, r == 0 ? h->multi_tmp + h->multi_dy0_off : c->d_dy, c->d_xid);
+        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+        HIPCHK(h, hipSetDevice(c->device));
+        if (r > 0) HIPCHK(h, hipEventRecord(h->multi_ev[r], c->stream));
+    }
+    HIPCHK(h, hipSetDevice(lead->device));
+    for (size_t r = 1; r < h->sub.size(); ++r) HIPCHK(h, hipStreamWaitEvent(lead->stream, h->multi_ev[r], 0));
+    double *po0 = lead->pin_out, *po1 = po0 + m;
+    HIPCHK(h, hipMemcpyAsync(po0, lead->d_dy, (size_t)m * 8, hipMemcpyDeviceToHost, lead->stream));
+    HIPCHK(h, hipMemcpyAsync(po1, lead->d_dx, (size_t)n * 8, hipMemcpyDeviceToHost, lead->stream));
+    int worst = TLPK_OK;
+    for (tlpk_handle *c : h->sub) { const int rc = tlpk_sync(c); if (rc != TLPK_OK) { h->last_error = c->last_error; worst = rc; } }
+    if (worst != TLPK_OK) return worst;
+    std::memcpy(dy, po0, (size_t)m * 8); std::memcpy(dx, po1, (size_t)n * 8);
+    return TLPK_OK;
+}
+
+}  // namespace
+
+int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                      int index_base, const tlpk_options *uopt, int ngpus, const int32_t *devices) {
+    if (!out) return TLPK_BADARG;
+    *out = nullptr;
+    if (!uopt || uopt->struct_size != (int32_t)sizeof(tlpk_options) || ngpus < 1 || ngpus > MAX_DEVICES || !uopt->row_block ||
+        uopt->system == TLPK_SYSTEM_K2)
+        return TLPK_BADARG;                              // block-angular K1 only (general sparse LPs stay single-GPU)
+    tlpk_handle *h = new (std::nothrow) tlpk_handle();
+    if (!h) return TLPK_OOM;
+    int rc = TLPK_OK;
+    try {
+        for (int r = 0; r < ngpus && rc == TLPK_OK; ++r) {
+            tlpk_options o = *uopt;
+            o.device = devices ? devices[r] : r;
+            o.rank = r; o.nranks = ngpus;
+            tlpk_handle *c = nullptr;
+            rc = tlpk_create(&c, m, n, colptr, rowval, nzval, index_base, &o);
+            if (rc != TLPK_OK) { if (c) { h->last_error = c->last_error; tlpk_destroy(c); } break; }
+            h->sub.push_back(c);
+        }
+    } catch (...) { rc = TLPK_OOM; }
+    if (rc == TLPK_OK) {
+        tlpk_handle *lead = h->sub[0];
+        h->S.m = m; h->S.n = n; h->has_device = true; h->device = lead->device; h->opt.nranks = 1;
+        double *p = nullptr; int64_t cnt = 0;
+        tlpk_root_panel(lead, &p, &cnt);
+        const i64 tmp_len = (i64)(ngpus - 1) * cnt + m;                      // staging of the peers' root buffers + the lead's rank-local dy
+        h->multi_dy0_off = (i64)(ngpus - 1) * cnt;
+        hipError_t e = hipSetDevice(lead->device);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->multi_tmp, (size_t)std::max<i64>(tmp_len, 1) * 8);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->multi_done, hipEventDisableTiming);
+        for (int r = 1; r < ngpus && e == hipSuccess; ++r) {
+            e = hipSetDevice(h->sub[r]->device);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->multi_ev[r], hipEventDisableTiming);
+            if (e == hipSuccess && h->sub[r]->device != lead->device) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(lead->device, 0);      // this rank stores into the lead's dx / dy
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) e = pe;
+                (void)hipGetLastError();
+            }
+        }
+        if (e != hipSuccess) rc = hip_fail(h, e, "multi-device init");
+    }
+    if (rc != TLPK_OK) { tlpk_destroy(h); return rc; }
+    *out = h;
+    return TLPK_OK;
+}
+
 // ---- introspection ----
 int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
     if (!h || !out) return TLPK_BADARG;
+    if (!h->sub.empty()) {                                  // multi-device handle: the lead's view of the job
+        const int rc = tlpk_info(h->sub[0], out);
+        out->fail_col = h->fail_col;
+        i64 bytes = 0; i32 nloc = 0;
+        for (const tlpk_handle *c : h->sub) { bytes += c->device_bytes; nloc += c->S.n_local_blocks; }
+        out->device_bytes = bytes; out->n_local_blocks = nloc;
+        return rc;
+    }
     const Symbolic &S = h->S;
     std::memset(out, 0, sizeof(*out));
     out->m = user_m(h); out->n = user_n(h); out->nnzA = (S.system == 1) ? S.n : S.nnzA; out->nnzS = S.nnzS; out->nnzL = S.nnzL;
@@ -652,12 +835,14 @@ int tlpk_set_profile(tlpk_handle *h, int on) {
 
 int tlpk_get_perm(const tlpk_handle *h, int64_t *perm) {
     if (!h || !perm) return TLPK_BADARG;
+    if (!h->sub.empty()) return tlpk_get_perm(h->sub[0], perm);
     for (i64 i = 0; i < h->S.m; ++i) perm[i] = h->S.perm[(size_t)i];
     return TLPK_OK;
 }
 
 int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, int64_t cap) {
     if (!h || !what) return -1;
+    if (!h->sub.empty()) return tlpk_symbolic_get(h->sub[0], what, buf, cap);
     const Symbolic &S = h->S;
     std::vector<i64> tmp;
     const std::string w(what);
@@ -736,6 +921,7 @@ int64_t tlpk_symbolic_get_f64(const tlpk_handle *h, const char *what, double *bu
 
 int tlpk_get_factor(tlpk_handle *h, double *lval, int64_t cap) {
     if (!h || !lval) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (cap < h->S.lval_len) return TLPK_BADARG;
     HIPCHK(h, hipSetDevice(h->device));

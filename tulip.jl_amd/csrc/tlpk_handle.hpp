@@ -12,6 +12,7 @@
 using namespace tlpk;
 
 struct IpmState;        // tlpk_ipm.cpp
+constexpr int MAX_DEVICES = 16;
 
 struct tlpk_handle {
     Symbolic S;
@@ -49,6 +50,13 @@ struct tlpk_handle {
     std::vector<unsigned long long> sweep_runs_fwd, sweep_runs_bwd;
     unsigned long long solve_epoch = 0;
     int poll[3] = {8, 16, 32};          // TLPK_POLL=fast,nfast,slow (tuning knob of the sweep kernels' polling back-off)
+    // single-process multi-device mode (tlpk_create_multi): the parent owns one sharded handle per device
+    std::vector<tlpk_handle *> sub;
+    double *multi_tmp = nullptr;        // device 0: staging of the peers' root panels / root rhs for the reduction
+    i64 multi_dy0_off = 0;              // ... followed by the lead's rank-local dy
+    hipEvent_t multi_ev[MAX_DEVICES] = {}; hipEvent_t multi_done = nullptr;
+    double *shared_dy = nullptr;        // child: job-wide dy on the lead device (P2P), filled with the rows this rank owns
+    bool dx_local_only = false;         // child: dx is the job-wide vector, leave the other ranks' columns alone
     IpmState *ipm = nullptr;            // device-resident interior-point vectors (tlpk_ipm_load), freed by tlpk_destroy
     std::string last_error;
 };

@@ -51,7 +51,7 @@ class Backend:
     """
 
     def __init__(self, device=0, ordering="amd", relax=True, row_block=None, user_perm=None,
-                 profile=False, rank=0, nranks=1, mem_budget_bytes=0, streams=0):
+                 profile=False, rank=0, nranks=1, mem_budget_bytes=0, streams=0, ngpus=1, devices=None):
         self.device = device
         self.ordering = {"amd": _lib.ORDER_AMD, "natural": _lib.ORDER_NATURAL, "user": _lib.ORDER_USER}[ordering]
         self.relax = bool(relax)
@@ -61,6 +61,9 @@ class Backend:
         self.rank, self.nranks = int(rank), int(nranks)
         self.mem_budget_bytes = int(mem_budget_bytes)
         self.streams = int(streams)            # 0 = auto (2 concurrent block groups), 1 = single group
+        # single-process multi-GPU (block-angular LPs): one handle shards the diagonal blocks over `ngpus` devices
+        self.ngpus = int(ngpus)
+        self.devices = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
 
 
 def _raise_for(code, handle=None, what=""):
@@ -117,8 +120,15 @@ class HIPNormalEquations:
         rowval = np.ascontiguousarray(A.indices, dtype=np.int64)
         nzval = np.ascontiguousarray(A.data, dtype=np.float64)
         self._h = C.c_void_p()
-        rc = L.tlpk_create(C.byref(self._h), self.m, self.n, _lib.as_p64(colptr), _lib.as_p64(rowval),
-                           _lib.as_pd(nzval), 0, C.byref(opt))
+        if backend_.ngpus > 1:
+            if backend_.devices is not None and backend_.devices.shape != (backend_.ngpus,):
+                raise DimensionMismatch("devices must list ngpus ordinals")
+            dv = None if backend_.devices is None else backend_.devices.ctypes.data_as(C.POINTER(C.c_int32))
+            rc = L.tlpk_create_multi(C.byref(self._h), self.m, self.n, _lib.as_p64(colptr), _lib.as_p64(rowval),
+                                     _lib.as_pd(nzval), 0, C.byref(opt), backend_.ngpus, dv)
+        else:
+            rc = L.tlpk_create(C.byref(self._h), self.m, self.n, _lib.as_p64(colptr), _lib.as_p64(rowval),
+                               _lib.as_pd(nzval), 0, C.byref(opt))
         if rc != _lib.OK:
             h = self._h if self._h else None
             try:
