@@ -134,3 +134,34 @@ def test_multi_device_create_rejects_what_it_cannot_do():
     if _lib.lib().tlpk_device_count() == 0:
         with pytest.raises(RuntimeError):
             tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb, ngpus=2, devices=[0, 0]))
+
+
+def test_julia_glue_matches_the_header_textually():
+    """Julia is not in the image, so the glue cannot be executed; what CAN be checked is that the
+    `Options` mirror in julia/libtlpk.jl has the fields of `tlpk_options` in the same order with the same
+    widths, that every `ccall` names an exported symbol, and that hip.jl reaches the module the way
+    Tulip's include order makes it reachable (/root/reference/src/Tulip.jl:18-27)."""
+    jl = open(os.path.join(ROOT, "tulip.jl_amd", "julia", "libtlpk.jl")).read()
+    hdr = open(os.path.join(ROOT, "include", "tlpk.h")).read()
+    body = re.search(r"typedef struct tlpk_options \{(.*?)\} tlpk_options;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    cfields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype = "ptr" if "*" in decl else ("i64" if "int64_t" in decl else "i32")
+        for name in decl.replace("*", " ").split()[-1:] if ctype == "ptr" else decl.split(None, 1)[1].split(","):
+            cfields.append((name.strip(), ctype))
+    jbody = re.search(r"mutable struct Options(.*?)\nend", jl, flags=re.S).group(1)
+    jfields = []
+    for line in jbody.splitlines():
+        mm = re.match(r"\s*(\w+)::(\S+)", line)
+        if mm:
+            t = mm.group(2)
+            jfields.append((mm.group(1), "ptr" if t.startswith("Ptr") else ("i64" if t == "Int64" else "i32")))
+    assert jfields == cfields, (jfields, cfields)
+    for sym in re.findall(r"ccall\(\(:(\w+),", jl):
+        assert hasattr(_lib.lib(), sym), sym
+    hip = open(os.path.join(ROOT, "tulip.jl_amd", "julia", "hip.jl")).read()
+    assert "using ...TLPLinearAlgebra.LibTLPK" in hip and "using ...LibTLPK" not in hip.replace("using ...TLPLinearAlgebra.LibTLPK", "")

@@ -1784,13 +1784,15 @@ __global__ void k_dx(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ 
     dx[j] = D[j] * (s - xi_d[j]);
 }
 
-// dst += src[0] + src[1] + ... (fixed order): the root-panel / root-rhs reduction of the multi-device mode
-__global__ void k_sum_into(i64 len, double *__restrict__ dst, const double *__restrict__ src, int nsrc, i64 stride) {
+// out = own + src[0] + src[1] + ... (fixed order): the root-panel / root-rhs reduction of the multi-device mode.
+// NOT in place: the ranks copy the result out of `out` at their own pace while the lead already factorises / solves
+// its own copy.
+__global__ void k_sum_to(i64 len, double *__restrict__ out, const double *__restrict__ own, const double *__restrict__ src, int nsrc, i64 stride) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
-    double v = dst[i];
+    double v = own[i];
     for (int r = 0; r < nsrc; ++r) v += src[(i64)r * stride + i];
-    dst[i] = v;
+    out[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1892,8 +1894,8 @@ void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const doubl
         hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, D, xi_p, xi_d,
                            a.row_local, a.col_local, rank, a.ctx.xw);
 }
-void launch_sum_into(hipStream_t st, i64 len, double *dst, const double *src, int nsrc, i64 stride) {
-    if (len > 0 && nsrc > 0) hipLaunchKernelGGL(k_sum_into, dim3(nblk(len, 256)), dim3(256), 0, st, len, dst, src, nsrc, stride);
+void launch_sum_to(hipStream_t st, i64 len, double *out, const double *own, const double *src, int nsrc, i64 stride) {
+    if (len > 0) hipLaunchKernelGGL(k_sum_to, dim3(nblk(len, 256)), dim3(256), 0, st, len, out, own, src, nsrc, stride);
 }
 void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy_shared, int rank) {
     if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw, dy, dy_shared, rank);

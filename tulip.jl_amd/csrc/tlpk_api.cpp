@@ -661,15 +661,20 @@ int multi_allreduce(tlpk_handle *h, bool panel) {
     }
     HIPCHK(h, hipSetDevice(lead->device));
     for (int r = 1; r < N; ++r) HIPCHK(h, hipStreamWaitEvent(lead->stream, h->multi_ev[r], 0));
-    launch_sum_into(lead->stream, cnt, p0, h->multi_tmp, N - 1, cnt);          // rank order: deterministic
+    // The sum goes to its own buffer: the lead continues with ITS copy (it factorises / solves the root in place)
+    // while the peers still read the result.  The buffer is reused by the next reduction, which every peer enters
+    // only after its copy below (stream order) and the lead only after all peers' gathers (events).
+    double *red = h->multi_tmp + h->multi_red_off;
+    launch_sum_to(lead->stream, cnt, red, p0, h->multi_tmp, N - 1, cnt);        // rank order: deterministic
     HIPCHK(h, hipEventRecord(h->multi_done, lead->stream));
+    HIPCHK(h, hipMemcpyAsync(p0, red, (size_t)cnt * 8, hipMemcpyDeviceToDevice, lead->stream));
     for (int r = 1; r < N; ++r) {                        // copy back, on the peer's stream
         tlpk_handle *c = h->sub[r];
         double *pr = nullptr; int64_t cr = 0;
         rc = panel ? tlpk_root_panel(c, &pr, &cr) : tlpk_root_rhs(c, &pr, &cr);
         HIPCHK(h, hipSetDevice(c->device));
         HIPCHK(h, hipStreamWaitEvent(c->stream, h->multi_done, 0));
-        HIPCHK(h, hipMemcpyPeerAsync(pr, c->device, p0, lead->device, (size_t)cnt * 8, c->stream));
+        HIPCHK(h, hipMemcpyPeerAsync(pr, c->device, red, lead->device, (size_t)cnt * 8, c->stream));
     }
     return TLPK_OK;
 }
@@ -767,8 +772,9 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
         h->S.m = m; h->S.n = n; h->has_device = true; h->device = lead->device; h->opt.nranks = 1;
         double *p = nullptr; int64_t cnt = 0;
         tlpk_root_panel(lead, &p, &cnt);
-        const i64 tmp_len = (i64)(ngpus - 1) * cnt + m;                      // staging of the peers' root buffers + the lead's rank-local dy
-        h->multi_dy0_off = (i64)(ngpus - 1) * cnt;
+        const i64 tmp_len = (i64)ngpus * cnt + m;                            // staging of the peers' root buffers, the reduced buffer, the lead's rank-local dy
+        h->multi_red_off = (i64)(ngpus - 1) * cnt;
+        h->multi_dy0_off = (i64)ngpus * cnt;
         hipError_t e = hipSetDevice(lead->device);
         if (e == hipSuccess) e = hipMalloc((void **)&h->multi_tmp, (size_t)std::max<i64>(tmp_len, 1) * 8);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->multi_done, hipEventDisableTiming);

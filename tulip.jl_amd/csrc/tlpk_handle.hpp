@@ -53,7 +53,7 @@ struct tlpk_handle {
     // single-process multi-device mode (tlpk_create_multi): the parent owns one sharded handle per device
     std::vector<tlpk_handle *> sub;
     double *multi_tmp = nullptr;        // device 0: staging of the peers' root panels / root rhs for the reduction
-    i64 multi_dy0_off = 0;              // ... followed by the lead's rank-local dy
+    i64 multi_red_off = 0, multi_dy0_off = 0;   // ... followed by the reduced buffer and the lead's rank-local dy
     hipEvent_t multi_ev[MAX_DEVICES] = {}; hipEvent_t multi_done = nullptr;
     double *shared_dy = nullptr;        // child: job-wide dy on the lead device (P2P), filled with the rows this rank owns
     bool dx_local_only = false;         // child: dx is the job-wide vector, leave the other ranks' columns alone

@@ -14,7 +14,7 @@ using LinearAlgebra
 using SparseArrays
 
 using ..KKT: AbstractKKTBackend, AbstractKKTSolver
-using ..KKT: AbstractKKTSystem, K1
+using ..KKT: AbstractKKTSystem, K1, K2
 import ..KKT: setup, update!, solve!, backend, linear_system
 
 # libtlpk.jl is included from src/LinearAlgebra/LinearAlgebra.jl, i.e. INSIDE `module TLPLinearAlgebra`
@@ -22,21 +22,29 @@ import ..KKT: setup, update!, solve!, backend, linear_system
 using ...TLPLinearAlgebra.LibTLPK
 
 """
-    Backend(; device=0, row_block=nothing)
+    Backend(; device=0, row_block=nothing, streams=0, ngpus=1, devices=nothing)
 
-HIP (gfx950) backend.  `row_block` is the optional block-angular structure hook
-(length m; block id ≥ 0, or -1 for a linking row).
+HIP (gfx950) backend.  `row_block` is the optional block-angular structure hook (length m; block id ≥ 0, or
+-1 for a linking row).  `ngpus > 1` (block-angular LPs, system `K1`): this ONE Julia process shards the
+diagonal blocks over `ngpus` devices of the node (`devices`: HIP ordinals, default `0:ngpus-1`); the
+linking-block reductions happen inside the library.  `streams`: concurrent stream groups (0 = auto).
 """
 struct Backend <: AbstractKKTBackend
     device::Int
     row_block::Union{Nothing,Vector{Int}}
+    streams::Int
+    ngpus::Int
+    devices::Union{Nothing,Vector{Int32}}
 end
-Backend(; device::Int=0, row_block=nothing) = Backend(device, row_block)
+Backend(; device::Int=0, row_block=nothing, streams::Int=0, ngpus::Int=1, devices=nothing) =
+    Backend(device, row_block, streams, ngpus, devices === nothing ? nothing : Vector{Int32}(devices))
 
 """
     HIPNormalEquations
 
-Normal-equations (K1) solver whose numeric factorisation and solves run on the GPU.
+KKT solver whose numeric factorisation and solves run on the GPU: the normal equations (`K1`, Cholesky of
+`A·D·Aᵀ + Rd`, the counterpart of `Cholmod/spd.jl`) or the augmented system (`K2`, signed Cholesky `L·S·Lᵀ`
+of the quasi-definite matrix, the counterpart of `Cholmod/sqd.jl` / `LDLFactorizations/ldlfact.jl`).
 Supported arithmetic: `Float64`.
 """
 mutable struct HIPNormalEquations <: AbstractKKTSolver{Float64}
@@ -53,7 +61,7 @@ mutable struct HIPNormalEquations <: AbstractKKTSolver{Float64}
 end
 
 backend(::HIPNormalEquations) = LibTLPK.backend_name()        # "HIP (gfx950)"
-linear_system(::HIPNormalEquations) = LibTLPK.system_name()   # "Normal equations (K1)"
+linear_system(kkt::HIPNormalEquations) = LibTLPK.linear_system(kkt.handle)   # "Normal equations (K1)" | "Augmented system (K2)"
 
 # error-code -> exception mapping (SURVEY.md section 5, "Failure detection")
 function _check(rc, handle, what)
@@ -65,11 +73,15 @@ function _check(rc, handle, what)
 end
 
 # Convert to sparse matrix if other type is used (cholmod.jl:65)
-setup(A, system::K1, backend::Backend) = setup(convert(SparseMatrixCSC{Float64,Int}, A), system, backend)
+setup(A, system::Union{K1,K2}, backend::Backend) = setup(convert(SparseMatrixCSC{Float64,Int}, A), system, backend)
 
-function setup(A::SparseMatrixCSC{Float64,Int}, ::K1, b::Backend)
+_system_code(::K1) = LibTLPK.TLPK_SYSTEM_K1
+_system_code(::K2) = LibTLPK.TLPK_SYSTEM_K2
+
+function setup(A::SparseMatrixCSC{Float64,Int}, system::Union{K1,K2}, b::Backend)
     m, n = size(A)
-    rc, h = LibTLPK.create(m, n, A.colptr, A.rowval, A.nzval; device=b.device, row_block=b.row_block)
+    rc, h = LibTLPK.create(m, n, A.colptr, A.rowval, A.nzval; device=b.device, row_block=b.row_block,
+                           system=_system_code(system), streams=b.streams, ngpus=b.ngpus, devices=b.devices)
     rc == LibTLPK.TLPK_OK || (h == C_NULL || LibTLPK.destroy(h); _check(rc, C_NULL, "KKT.setup"))
     return HIPNormalEquations(m, n, A, h)
 end

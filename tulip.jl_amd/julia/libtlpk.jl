@@ -1,7 +1,9 @@
 # libtlpk.jl -- ccall shim over the C ABI of libtlpk.so (include/tlpk.h).
 #
 # Where it goes in Tulip: `src/LinearAlgebra/libtlpk.jl`, included from
-# `src/LinearAlgebra/LinearAlgebra.jl` (reference file: /root/reference/src/LinearAlgebra/LinearAlgebra.jl:1-33).
+# `src/LinearAlgebra/LinearAlgebra.jl` INSIDE `module TLPLinearAlgebra` (reference file:
+# /root/reference/src/LinearAlgebra/LinearAlgebra.jl:1-33), i.e. it becomes `Tulip.TLPLinearAlgebra.LibTLPK`;
+# src/KKT/HIP/hip.jl reaches it with `using ...TLPLinearAlgebra.LibTLPK`.
 # Nothing here touches src/IPM.  No CUDA.jl / AMDGPU.jl: plain `ccall` on a C-ABI shared library.
 #
 # NOTE: Julia is not available in the build or GPU images of this project, so this file has been
@@ -11,6 +13,17 @@ module LibTLPK
 using Libdl
 
 const libtlpk = Ref{String}(get(ENV, "TULIP_LIBTLPK", "libtlpk.so"))
+
+# The library runs up to 4 HIP streams concurrently; the ROCm runtime multiplexes the process's streams onto
+# GPU_MAX_HW_QUEUES hardware queues (4 by default), read at the first HIP call of the process.  A tuning knob of the
+# HOST process (the library never touches the environment): set it here unless the user already did.
+function __init__()
+    haskey(ENV, "GPU_MAX_HW_QUEUES") || (ENV["GPU_MAX_HW_QUEUES"] = "8")
+    return nothing
+end
+
+const TLPK_SYSTEM_K1 = Int32(0)
+const TLPK_SYSTEM_K2 = Int32(1)
 
 # return codes (include/tlpk.h)
 const TLPK_OK = Cint(0)
@@ -35,12 +48,15 @@ Base.@kwdef mutable struct Options
     user_perm::Ptr{Int64} = C_NULL
     row_block::Ptr{Int64} = C_NULL
     mem_budget_bytes::Int64 = 0
+    system::Int32 = 0            # TLPK_SYSTEM_K1 | TLPK_SYSTEM_K2
+    reserved::Int32 = 0
 end
 
 strerror(code::Integer) = unsafe_string(ccall((:tlpk_strerror, libtlpk[]), Cstring, (Cint,), code))
 last_error(h::Ptr{Cvoid}) = unsafe_string(ccall((:tlpk_last_error, libtlpk[]), Cstring, (Ptr{Cvoid},), h))
 backend_name() = unsafe_string(ccall((:tlpk_backend_name, libtlpk[]), Cstring, ()))
 system_name() = unsafe_string(ccall((:tlpk_system_name, libtlpk[]), Cstring, ()))
+linear_system(h::Ptr{Cvoid}) = unsafe_string(ccall((:tlpk_linear_system, libtlpk[]), Cstring, (Ptr{Cvoid},), h))
 
 """
     create(A; device, row_block) -> Ptr{Cvoid}
@@ -49,17 +65,28 @@ system_name() = unsafe_string(ccall((:tlpk_system_name, libtlpk[]), Cstring, ())
 with its 1-based `colptr`/`rowval` (index_base = 1); the library copies everything.
 """
 function create(m::Int, n::Int, colptr::Vector{Int}, rowval::Vector{Int}, nzval::Vector{Float64};
-                device::Integer=0, row_block::Union{Nothing,Vector{Int}}=nothing)
+                device::Integer=0, row_block::Union{Nothing,Vector{Int}}=nothing, system::Int32=TLPK_SYSTEM_K1,
+                streams::Integer=0, ngpus::Integer=1, devices::Union{Nothing,Vector{Int32}}=nothing)
     opt = Options()
     opt.struct_size = Int32(sizeof(Options))
     opt.device = Int32(device)
+    opt.system = system
+    opt.streams = Int32(streams)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rb = row_block === nothing ? Int[] : row_block
-    rc = GC.@preserve colptr rowval nzval rb opt begin
+    dv = devices === nothing ? Int32[] : devices
+    rc = GC.@preserve colptr rowval nzval rb dv opt begin
         row_block === nothing || (opt.row_block = pointer(rb))
-        ccall((:tlpk_create, libtlpk[]), Cint,
-              (Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Ref{Options}),
-              h, m, n, colptr, rowval, nzval, 1, opt)
+        if ngpus > 1
+            # one Julia process, several GPUs: block-angular LPs only (tlpk_create_multi, include/tlpk.h)
+            ccall((:tlpk_create_multi, libtlpk[]), Cint,
+                  (Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Ref{Options}, Cint, Ptr{Int32}),
+                  h, m, n, colptr, rowval, nzval, 1, opt, ngpus, devices === nothing ? Ptr{Int32}(C_NULL) : pointer(dv))
+        else
+            ccall((:tlpk_create, libtlpk[]), Cint,
+                  (Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Ref{Options}),
+                  h, m, n, colptr, rowval, nzval, 1, opt)
+        end
     end
     return rc, h[]
 end
