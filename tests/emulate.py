@@ -383,14 +383,12 @@ class Emulator:
                 assert (int(front), j) in pub, ("forward sweep item waits for a later ticket", front, k0, j)
                 w = min(SW, ns - SW * j)
                 acc += P[k0:k0 + nb, SW * j:SW * j + w] @ self.xw[c0 + SW * j: c0 + SW * j + w]
-            if pivot:                                             # one or two consecutive SW-wide pivot blocks
-                assert k0 % (2 * SW) == 0 and nin == k0 // SW and k0 + nb <= ns and nb <= 2 * SW
+            if pivot:
+                assert k0 % SW == 0 and nin == k0 // SW and k0 + nb <= ns and nb <= SW
                 rhs = self.xw[c0 + k0: c0 + k0 + nb] - acc
                 L11 = np.tril(P[k0:k0 + nb, k0:k0 + nb])
                 self.xw[c0 + k0: c0 + k0 + nb] = sla.solve_triangular(L11, rhs, lower=True)
                 pub.add((int(front), k0 // SW))
-                if nb > SW:
-                    pub.add((int(front), k0 // SW + 1))
             else:
                 assert k0 >= ns and nin == (ns + SW - 1) // SW and nb <= 128
                 uo = int(self.ucoff[front])

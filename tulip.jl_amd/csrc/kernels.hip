@@ -1437,28 +1437,26 @@ __device__ __forceinline__ double readlane_f64(const double v, const int l) {   
     return __hiloint2double(hi, lo);
 }
 
-// An item owns <= 128 rows of a front: waves 0/1 = rows 0..63 / 64..127 of the chunk for columns 0..31 of a
-// consumed block, waves 2/3 the same rows for columns 32..63.  PIVOT item: its rows are one or two consecutive
-// pivot blocks (A = rows 0..63, B = rows 64..127): after the blocks before them have been consumed it solves A with
-// the inverted diagonal block held in registers since the start, publishes A, removes A from B (L_BA and the inverse
-// of B were requested when the streaming ended) and publishes B -- two blocks of the chain per workgroup, one hand-over
-// between workgroups per 128 columns, and twice the bytes in flight per resident workgroup.  BELOW item: rows below
-// the pivot block, result added to the front's contribution vector.
+// PIVOT item: rows [k0, k0 + nb) (nb <= 64) are a pivot block; lane = row, wave = quarter of the 64 columns of a
+// consumed block.  BELOW item: <= 128 rows below the pivot block; waves 0/1 = rows 0..63 / 64..127 of the chunk
+// for columns 0..31 of a block, waves 2/3 the same rows for columns 32..63.
 template <bool PIVOT>
 __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDesc &fd, const DevCtx &c, const SweepArgs &a, double *scratch) {
     const double *xh = a.xh;
+    constexpr int NBATCH = PIVOT ? 1 : 2;                      // batches of 16 columns per wave and block
+    constexpr int WCOLS = 16 * NBATCH;                         // columns of a block handled by a wave
     const i32 f = fd.f, ns = fd.ns;
-    const i32 lda = fd.lda;
+    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rloc = lane + 64 * (wave & 1);                   // row of the chunk
-    const int cp0 = 32 * (wave >> 1);                          // first column of the wave inside a block
+    const int rloc = PIVOT ? lane : lane + 64 * (wave & 1);    // row of the chunk
+    const int cp0 = PIVOT ? 16 * wave : 32 * (wave >> 1);      // first column of the wave inside a block
     const char *Lb = reinterpret_cast<const char *>(c.Lval + fd.loff);
     const unsigned roff = (unsigned)min(t.k0 + rloc, f - 1) * 8u;     // clamped row: its result is never stored
     const double *xhf = xh + fd.col0;
     const i32 nin = t.nslot;
     double w[16];
-    if (PIVOT) load_frag<false, 0>(c, fd, t.k0, t.nb, w);      // inverse of diagonal block A, held from the start
+    if (PIVOT) load_frag<false, 0>(c, fd, t.k0, t.nb, w);      // inverted diagonal block, held from the start
     double acc = 0.0;
     double b0[16], b1[16];
     bool dead = false;
@@ -1473,52 +1471,54 @@ __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDe
         for (int u = 0; u < 16; ++u) acc += b[u] * readlane_f64(xv, 16 * q + u);
     };
     auto wait_block = [&](const i32 j) -> double {             // this wave's columns of block j (zero beyond its width)
-        const i32 cnt = min(32, min(SWEEP_NB, ns - j * SWEEP_NB) - cp0);
+        const i32 cnt = min(WCOLS, min(SWEEP_NB, ns - j * SWEEP_NB) - cp0);
         if (cnt <= 0) return 0.0;
         const double v = poll_block(xhf + j * SWEEP_NB + cp0, cnt, lane, c.info, dead, a);
         return (lane < cnt) ? v : 0.0;
     };
-    if (nin > 0) { issue(b0, 0, 0); issue(b1, 0, 1); }
-    for (i32 j = 0; j < nin; ++j) {
-        const double xv = wait_block(j);
-        consume(b0, xv, 0); issue(b0, j + 1, 0);
-        consume(b1, xv, 1); issue(b1, j + 1, 1);
+    if (nin > 0) {
+        if (PIVOT) { issue(b0, 0, 0); issue(b1, 1, 0); }
+        else { issue(b0, 0, 0); issue(b1, 0, 1); }
     }
-    double *bs = scratch, *ys = scratch + SOLVE_NB;
+    if (PIVOT) {
+        for (i32 j = 0; j < nin; j += 2) {
+            double xv = wait_block(j);
+            consume(b0, xv, 0); issue(b0, j + 2, 0);
+            if (j + 1 < nin) {                                  // wave-uniform
+                xv = wait_block(j + 1);
+                consume(b1, xv, 0); issue(b1, j + 3, 0);
+            }
+        }
+    } else {
+        for (i32 j = 0; j < nin; ++j) {
+            const double xv = wait_block(j);
+            consume(b0, xv, 0); issue(b0, j + 1, 0);
+            consume(b1, xv, 1); issue(b1, j + 1, 1);
+        }
+    }
     double (*ps)[NB_IN] = reinterpret_cast<double (*)[NB_IN]>(scratch + 2 * SOLVE_NB);      // 4 x 64 doubles
-    double *red = &ps[0][0];                                    // 256 doubles: here [row] of the second column half
-    if (wave >= 2) red[rloc] = acc;
-    if (!PIVOT) {
+    if (PIVOT) {
+        double *bs = scratch;
+        ps[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            const double total = ((ps[0][lane] + ps[1][lane]) + ps[2][lane]) + ps[3][lane];
+            bs[lane] = (lane < t.nb) ? c.xw[fd.col0 + t.k0 + min(lane, t.nb - 1)] - total : 0.0;
+        }
+        __syncthreads();
+        const double y = dot4(w, bs, lane, wave, ps);           // y = W (b - sum); valid in wave 0
+        if (wave == 0 && lane < t.nb) {
+            c.xw[fd.col0 + t.k0 + lane] = y;
+            st_agent(const_cast<double *>(xhf) + t.k0 + lane, y);     // hand-over: the data is its own flag
+        }
+    } else {
+        double *red = &ps[0][0];                                // 256 doubles: [column half][row]
+        if (wave >= 2) red[rloc] = acc;
         __syncthreads();
         if (wave < 2 && rloc < t.nb) {
             double *dst = c.uc + fd.ucoff + (t.k0 + rloc - ns);
             *dst = *dst - (acc + red[rloc]);
         }
-        return;
-    }
-    // ---- the two pivot blocks: y_A = W_A t_A ; y_B = W_B (t_B - L_BA y_A) ----
-    const i32 nb = t.nb, na = min(nb, NB_IN), nb2 = nb - na;
-    const int part = wave;
-    double w1[16], w2[16];
-    if (nb2 > 0) {                                              // requested now, needed after A is solved
-        load_frag<false, 1>(c, fd, t.k0, nb, w1);
-        load_frag<false, 2>(c, fd, t.k0, nb, w2);
-    }
-    __syncthreads();
-    if (wave < 2) bs[rloc] = (rloc < nb) ? c.xw[fd.col0 + t.k0 + min(rloc, nb - 1)] - (acc + red[rloc]) : 0.0;
-    __syncthreads();
-    const double y = dot4(w, bs, lane, part, ps);               // valid in wave 0; zero for lane >= na (masked fragment)
-    if (part == 0) {
-        ys[lane] = y;
-        if (lane < na) { c.xw[fd.col0 + t.k0 + lane] = y; st_agent(const_cast<double *>(xhf) + t.k0 + lane, y); }     // hand-over: the data is its own flag
-    }
-    __syncthreads();
-    if (nb2 > 0) {
-        const double sl = dot4(w1, ys, lane, part, ps);         // L_BA y_A
-        if (part == 0) bs[NB_IN + lane] -= sl;
-        __syncthreads();
-        const double y2 = dot4(w2, bs + NB_IN, lane, part, ps);
-        if (part == 0 && lane < nb2) { c.xw[fd.col0 + t.k0 + NB_IN + lane] = y2; st_agent(const_cast<double *>(xhf) + t.k0 + NB_IN + lane, y2); }
     }
 }
 

@@ -1256,25 +1256,23 @@ static void build_schedule(Symbolic &S) {
             // the level advance side by side.
             const i64 first = (i64)S.fwd_sweep_tasks.size();
             i32 max_chunks = 0;
-            // a pivot item = SOLVE_NB rows = two consecutive SWEEP_NB-wide pivot blocks (solved one after the other by the
-            // same workgroup); every item consumes the blocks before its rows in SWEEP_NB-wide pieces
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
                 if (!in_scope(s) || is_small(s)) continue;
                 const FrontDesc &w = S.fronts[s];
-                max_chunks = std::max(max_chunks, (w.ns + SOLVE_NB - 1) / SOLVE_NB + (w.f > w.ns ? (w.f + SOLVE_NB - 1) / SOLVE_NB - w.ns / SOLVE_NB : 0));
+                max_chunks = std::max(max_chunks, (w.ns + SWEEP_NB - 1) / SWEEP_NB + (w.f > w.ns ? (w.f + SOLVE_NB - 1) / SOLVE_NB - w.ns / SOLVE_NB : 0));
             }
             for (i32 ci = 0; ci < max_chunks; ++ci)
                 for (i32 t = t0; t < t1; ++t) {
                     const i32 s = S.level_fronts[t];
                     if (!in_scope(s) || is_small(s)) continue;
                     const FrontDesc &w = S.fronts[s];
-                    const i32 npiv = (w.ns + SOLVE_NB - 1) / SOLVE_NB, nblk = (w.ns + SWEEP_NB - 1) / SWEEP_NB;
-                    if (ci < npiv) S.fwd_sweep_tasks.push_back(SolveTask{s, ci * SOLVE_NB, std::min(SOLVE_NB, w.ns - ci * SOLVE_NB), 0, 1, ci * (SOLVE_NB / SWEEP_NB), 0, 0});
+                    const i32 nblk = (w.ns + SWEEP_NB - 1) / SWEEP_NB;
+                    if (ci < nblk) S.fwd_sweep_tasks.push_back(SolveTask{s, ci * SWEEP_NB, std::min(SWEEP_NB, w.ns - ci * SWEEP_NB), 0, 1, ci, 0, 0});
                     else {
                         // rows below the pivot block in chunks that END on multiples of SOLVE_NB rows (line-aligned loads;
                         // only the first chunk of a front is ragged)
-                        const i32 q = ci - npiv;
+                        const i32 q = ci - nblk;
                         const i32 r0 = (q == 0) ? w.ns : (w.ns / SOLVE_NB + q) * SOLVE_NB;
                         const i32 r1 = std::min(w.f, (w.ns / SOLVE_NB + q + 1) * SOLVE_NB);
                         if (r0 < w.f) S.fwd_sweep_tasks.push_back(SolveTask{s, r0, r1 - r0, 0, 0, nblk, 0, 0});
