@@ -256,52 +256,59 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
         av[q] = mine ? (pv - dv) : 0.0;
         wv[q] = (r == col) ? 1.0 : 0.0;
     }
-    for (i32 j = 0; j < nb; ++j) {
-        const int pb = j & 1, jq = j >> 2;
-        if (cg == (j & 3)) {
-            double v = 0.0;
+    // Column steps.  Thread (r, cg) holds columns cg + 4q: column j = 4 jq + jj belongs to the threads with cg == jj, in
+    // register av[jq].  The loop over jq is unrolled, so every register index below is static, and a step only touches
+    // what can still change: A columns q >= jq (columns before j are final) and W columns q <= jq (row j of the
+    // inverse is zero beyond column j) -- 17 multiply-adds, selects and LDS reads per thread and column instead of 32,
+    // and no 16-way select chains to extract / update av[jq].
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v = (q == jq) ? av[q] : v;
-            colbuf[pb][r] = v;                               // A[r][j]
-        }
-        if (r == j) {
+    for (int jq = 0; jq < 16; ++jq) {
+#pragma unroll 1
+        for (int jj = 0; jj < 4; ++jj) {
+            const i32 j = 4 * jq + jj;
+            if (j >= nb) break;                                  // workgroup-uniform
+            const int pb = j & 1;
+            if (cg == jj) colbuf[pb][r] = av[jq];                // A[r][j]
+            if (r == j) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) rowbuf[pb][cg + 4 * q] = wv[q];   // W[j][:]
-        }
-        __syncthreads();
-        double d = colbuf[pb][j];
-        const double sj = SIGNED ? sg[bk0 + j] : 1.0;
-        if (!(sj * d > 0.0)) {
-            if (tid == 0) atomicMin(c.info, fd.col0 + bk0 + j);
-            d = sj;
-        }
-        if (SIGNED) d = fabs(d);
-        // pivot arithmetic off one reciprocal square root (hardware estimate + 2 Newton steps, then a
-        // final correction of the square root): isq = |d|^-1/2, sq = |d|^1/2, inv2 = 1/|d| = isq^2
-        double isq = __builtin_amdgcn_rsq(d);
-        isq = isq * (1.5 - 0.5 * d * isq * isq);
-        isq = isq * (1.5 - 0.5 * d * isq * isq);
-        double sq = d * isq;
-        sq = fma(0.5 * isq, fma(-sq, sq, d), sq);
-        const double inv2 = SIGNED ? isq * isq * sj : isq * isq;            // 1 / (signed pivot)
-        if (SIGNED) isq *= sj;                                              // column scale s_j / sqrt|d|
-        const double arj = (rok && r > j) ? colbuf[pb][r] * inv2 : 0.0;    // multiplier L~[r][j]
-        // all LDS reads first (independent), then branch-free predicated updates
-        double cv[16], rv[16];
+                for (int q = 0; q <= jq; ++q) rowbuf[pb][cg + 4 * q] = wv[q];   // W[j][0 .. j]
+            }
+            __syncthreads();
+            double d = colbuf[pb][j];
+            const double sj = SIGNED ? sg[bk0 + j] : 1.0;
+            if (!(sj * d > 0.0)) {
+                if (tid == 0) atomicMin(c.info, fd.col0 + bk0 + j);
+                d = sj;
+            }
+            if (SIGNED) d = fabs(d);
+            // pivot arithmetic off one reciprocal square root (hardware estimate + 2 Newton steps, then a
+            // final correction of the square root): isq = |d|^-1/2, sq = |d|^1/2, inv2 = 1/|d| = isq^2
+            double isq = __builtin_amdgcn_rsq(d);
+            isq = isq * (1.5 - 0.5 * d * isq * isq);
+            isq = isq * (1.5 - 0.5 * d * isq * isq);
+            double sq = d * isq;
+            sq = fma(0.5 * isq, fma(-sq, sq, d), sq);
+            const double inv2 = SIGNED ? isq * isq * sj : isq * isq;            // 1 / (signed pivot)
+            if (SIGNED) isq *= sj;                                              // column scale s_j / sqrt|d|
+            const double arj = (rok && r > j) ? colbuf[pb][r] * inv2 : 0.0;    // multiplier L~[r][j]
+            // all LDS reads first (independent), then branch-free predicated updates
+            double cv[16], rv[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { cv[q] = colbuf[pb][cg + 4 * q]; rv[q] = rowbuf[pb][cg + 4 * q]; }
+            for (int q = jq; q < 16; ++q) cv[q] = colbuf[pb][cg + 4 * q];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const i32 col = cg + 4 * q;
-            const double m1 = (col > j && col <= r) ? arj : 0.0;
-            const double m2 = (col <= j) ? arj : 0.0;
-            av[q] = fma(-m1, cv[q], av[q]);
-            wv[q] = fma(-m2, rv[q], wv[q]);
-        }
-        if (cg == (j & 3)) {                                  // finish column j: L[r][j]
+            for (int q = 0; q <= jq; ++q) rv[q] = rowbuf[pb][cg + 4 * q];
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (q == jq) av[q] = (r == j) ? sq : ((r > j) ? av[q] * isq : av[q]);
+            for (int q = jq; q < 16; ++q) {
+                const i32 col = cg + 4 * q;
+                const double m1 = (col > j && col <= r) ? arj : 0.0;
+                av[q] = fma(-m1, cv[q], av[q]);
+            }
+#pragma unroll
+            for (int q = 0; q <= jq; ++q) {
+                const double m2 = (cg + 4 * q <= j) ? arj : 0.0;
+                wv[q] = fma(-m2, rv[q], wv[q]);
+            }
+            if (cg == jj) av[jq] = (r == j) ? sq : ((r > j) ? av[jq] * isq : av[jq]);   // finish column j: L[r][j]
         }
     }
     // diagonal of L for the row scaling of the inverse
