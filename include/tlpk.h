@@ -111,7 +111,9 @@ void tlpk_default_options(tlpk_options *opt);
 
 /* A is m x n CSC with int64 indices (Julia SparseMatrixCSC{Float64,Int}); index_base in {0,1}.
  * A is copied; nothing is retained.  Runs the whole analyse phase and uploads the symbolic
- * structures.  Does NOT perform the throw-away numeric factorisation of spd.jl:14-17. */
+ * structures.  Does NOT perform the throw-away numeric factorisation of spd.jl:14-17.
+ * Return value != TLPK_OK: *out = NULL, EXCEPT for TLPK_TOO_LARGE, which returns a live analyse-only handle
+ * (tlpk_info / tlpk_last_error carry the diagnostics: symbolic nnz(L), bytes needed); the caller destroys it. */
 int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr,
                 const int64_t *rowval, const double *nzval, int index_base,
                 const tlpk_options *opt);
