@@ -13,14 +13,18 @@
 //                     register-resident MFMA pass                                spd.jl:46
 //   solve!   (spd.jl:52-70)
 //     k_rhs           xi = xi_p + A*(D.*xi_d), permuted                          spd.jl:56-57
-//     k_single_solve, k_fwd_gather / k_fwd_diag / k_fwd_update / k_fwd_small, k_bwd_update / k_bwd_small
-//                     supernodal forward / backward substitution                 spd.jl:61
+//     k_single_solve, k_fwd_gather, k_fwd_small / k_bwd_small, k_fwd_sweep / k_bwd_sweep (persistent: one launch per
+//                     tree level and direction; k_fwd_diag / k_fwd_update / k_bwd_update: one launch per block step,
+//                     TLPK_SWEEP=0)   supernodal forward / backward substitution   spd.jl:61
+//   K2 (sqd.jl:24-74): the factor kernels instantiated SIGNED (P K P' = L S L'), k_k2_diag, k_k2_rhs, k_apply_signs, k_k2_out
 //     k_unpermute, k_dx  dy = P' x ;  dx = D.*(A'dy - xi_d)                      spd.jl:64-66
 //
 // Two rules learnt by measurement run through this file: (1) never guard a load that feeds the next
 // instruction (`c ? M[i] : 0`): clamp the address and select afterwards, or every load waits for the
-// previous one; (2) workgroups of one launch never talk to each other (the L2s of the 8 dies are not
-// coherent for ordinary stores inside a kernel): whatever crosses workgroups crosses a launch.
+// previous one; (2) ordinary stores of one workgroup are NOT visible to another workgroup of the same launch
+// (the L2s of the 8 dies are not coherent for them, a CU's L1 never is): whatever crosses workgroups either
+// crosses a launch, or -- the solve sweeps -- goes through relaxed agent-scope atomic stores and loads on both
+// sides with the data as its own flag (cdna_hip_programming.md, Guideline 16).
 //
 // Every kernel is deterministic (no floating-point atomics): sums that cross workgroups are
 // ordered by the static schedule built on the host (symbolic.cpp: build_schedule).
