@@ -807,18 +807,29 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         // Edge and diagonal tiles run the same straight-line loop: their staging rows are clamped to
         // the last row of the front (a clamped row only feeds outputs that the guarded epilogue
         // never stores), all 16 MFMA blocks of an active wave are computed, the epilogue masks.
+        // One address register pair per staging load, advanced in place: when the addresses were recomputed from a
+        // base pointer every round, the compiler recycled the destination registers of loads still in flight as
+        // temporaries and had to wait for them (s_waitcnt vmcnt(3) in the middle of a round: the two-round prefetch
+        // distance shrank to half a round).
         const i32 rac = min(t.i0 + sr, f - 1), rbc = min(t.j0 + sr, f - 1);
-        const double *pa_ptr = P + (i64)(t.k0 + sk0) * lda + rac;
-        const double *pb_ptr = P + (i64)(t.k0 + sk0) * lda + rbc;
         const i64 step = (i64)UPD_KT * lda, two_f = 2 * (i64)lda;
+        const double *qa[UPD_NLD], *qb[UPD_NLD];
+#pragma unroll
+        for (int it = 0; it < UPD_NLD; ++it) {
+            qa[it] = P + (i64)(t.k0 + sk0) * lda + rac + it * two_f;
+            qb[it] = P + (i64)(t.k0 + sk0) * lda + rbc + it * two_f;
+        }
         auto ld_a = [&]() {
 #pragma unroll
-            for (int it = 0; it < UPD_NLD; ++it) pa[it] = pa_ptr[it * two_f];
+            for (int it = 0; it < UPD_NLD; ++it) { pa[it] = *qa[it]; qa[it] += step; }
         };
         i32 kb_idx = 0;                                   // first K column of the slab ld_b loads next (SIGNED)
         auto ld_b = [&]() {
 #pragma unroll
-            for (int it = 0; it < UPD_NLD; ++it) { pb[it] = pb_ptr[it * two_f]; if (SIGNED) pb[it] *= sgk[kb_idx + sk0 + 2 * it]; }
+            for (int it = 0; it < UPD_NLD; ++it) {
+                pb[it] = *qb[it]; qb[it] += step;
+                if (SIGNED) pb[it] *= sgk[kb_idx + sk0 + 2 * it];
+            }
             kb_idx += UPD_KT;
         };
         auto st_ab = [&](int buf) {
@@ -852,7 +863,6 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         };
         ld_a(); ld_b();
         st_ab(0);
-        pa_ptr += step; pb_ptr += step;
         ld_a(); ld_b();                                   // slab 1 in flight
         __syncthreads();
         int cur = 0;
@@ -860,7 +870,7 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         for (i32 rd = 0; rd < nrounds; ++rd) {
             const bool have_next = rd + 1 < nrounds, have_next2 = rd + 2 < nrounds;
             mfma_round(cur, [&](int k4) {
-                if (k4 == 0 && have_next) { st_ab(cur ^ 1); pa_ptr += step; pb_ptr += step; }
+                if (k4 == 0 && have_next) st_ab(cur ^ 1);
                 if (k4 == 4 && have_next2) ld_a();
                 if (k4 == 8 && have_next2) ld_b();
             });
@@ -869,13 +879,14 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         }
         if (t.kw % UPD_KT) {                              // K tail: one zero-filled slab
             const i32 kk = nrounds * UPD_KT;
-            pa_ptr = P + (i64)(t.k0 + kk + sk0) * lda + rac;
-            pb_ptr = P + (i64)(t.k0 + kk + sk0) * lda + rbc;
+            const double *pa_ptr = P + (i64)(t.k0 + kk + sk0) * lda + rac;
+            const double *pb_ptr = P + (i64)(t.k0 + kk + sk0) * lda + rbc;
+            const i64 two_l = 2 * (i64)lda;
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
                 const bool kok = (kk + sk0 + 2 * it) < t.kw;
-                pa[it] = kok ? pa_ptr[it * two_f] : 0.0;
-                pb[it] = kok ? pb_ptr[it * two_f] : 0.0;
+                pa[it] = kok ? pa_ptr[it * two_l] : 0.0;
+                pb[it] = kok ? pb_ptr[it * two_l] : 0.0;
                 if (SIGNED) pb[it] *= sgk[min(kk + sk0 + 2 * it, t.kw - 1)];
             }
             st_ab(cur);
