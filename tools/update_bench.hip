@@ -20,7 +20,8 @@ int main(int argc, char **argv) {
     for (int s = 0; s < nfronts; ++s) {
         fr[s] = FrontDesc{};
         fr[s].loff = loff; fr[s].uoff = uoff; fr[s].f = f; fr[s].ns = ns; fr[s].ubuf = 0; fr[s].parent = -1;
-        loff += (i64)f * ns; uoff += (i64)rs * rs;
+        fr[s].lda = (f + 15) / 16 * 16;
+        loff += (i64)fr[s].lda * ns; uoff += (i64)rs * rs;
     }
     std::vector<UpdateTask> tasks;
     double flops = 0;
@@ -42,6 +43,8 @@ int main(int argc, char **argv) {
             hipMemcpy(L + off, h.data(), sizeof(double) * std::min<i64>((i64)h.size(), loff - off), hipMemcpyHostToDevice);
         hipMemset(U, 0, sizeof(double) * (uoff + 1));
     }
+    c.upd_remap = getenv("TLPK_UPD_REMAP") ? atoi(getenv("TLPK_UPD_REMAP")) : 0;
+    { double *sp; hipMalloc(&sp, tasks.size() * 64 + 64); hipMemset(sp, 0, tasks.size() * 64 + 64); c.spart = sp; }
     c.fronts = dfr; c.Lval = L; c.U0 = U; c.U1 = U; c.info = info;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     // optional 6th arg: number of streams the fronts are split over (concurrent-kernel test)
@@ -65,7 +68,7 @@ int main(int argc, char **argv) {
             hipEventRecord(e0, st[0]);
             for (int g = 1; g < nstreams; ++g) hipStreamWaitEvent(st[g], e0, 0);
             for (int g = 0; g < nstreams; ++g) {
-                hipLaunchKernelGGL(k_update, dim3((unsigned)(cut[g + 1] - cut[g])), dim3(256), 0, st[g], dt + cut[g], c);
+                hipLaunchKernelGGL(k_update<false>, dim3((unsigned)(cut[g + 1] - cut[g])), dim3(256), 0, st[g], dt + cut[g], c);
                 hipEventRecord(done[g], st[g]);
             }
             for (int g = 1; g < nstreams; ++g) hipStreamWaitEvent(st[0], done[g], 0);
@@ -78,17 +81,31 @@ int main(int argc, char **argv) {
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_update, dim3((unsigned)tasks.size()), dim3(256), 0, 0, dt, c);
+        hipLaunchKernelGGL(k_update<false>, dim3((unsigned)tasks.size()), dim3(256), 0, 0, dt, c);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep > 0 && ms < best) best = ms;
     }
-    printf("variant %d%s: fronts=%d f=%d ns=%d kw=%d tiles=%zu : %.3f ms  %.2f TFLOP/s (algorithmic)\n",
+#ifdef UPD_TRACE
+    {
+        std::vector<unsigned long long> tr(tasks.size() * 8);
+        hipMemcpy(tr.data(), c.spart, tr.size() * 8, hipMemcpyDeviceToHost);
+        char nm[256]; snprintf(nm, sizeof nm, "gpurun_out/upd_trace_%d_%d.csv", kw, (int)left);
+        FILE *fp = fopen(nm, "w");
+        if (fp) {
+            fprintf(fp, "wg,t0,t1,t2,t3,hwid,xcc\n");
+            for (size_t i = 0; i < tasks.size(); ++i)
+                fprintf(fp, "%zu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, tr[i*8], tr[i*8+1], tr[i*8+2], tr[i*8+3], tr[i*8+4], tr[i*8+5]);
+            fclose(fp);
+        }
+    }
+#endif
+    printf("variant %d%s: fronts=%d f=%d ns=%d kw=%d tiles=%zu : %.3f ms  %.2f TFLOP/s (algorithmic)  %.2f TFLOP/s (executed)  %.1f us/tile-slot\n",
 #ifdef UPD_VARIANT
            UPD_VARIANT,
 #else
            0,
 #endif
-           left ? " (left-looking)" : "", nfronts, f, ns, kw, tasks.size(), best, flops / best / 1e9);
+           left ? " (left-looking)" : "", nfronts, f, ns, kw, tasks.size(), best, flops / best / 1e9, (double)tasks.size() * 2.0 * TILE * TILE * kw / best / 1e9, best * 1e3 * 512.0 / (double)tasks.size());
     return 0;
 }

@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
                 const double *__restrict__ src = Uc + (i64)q * rsc;
                 double *__restrict__ dst = (tc < ns) ? (P + (i64)tc * lda) : (Up + (i64)(tc - ns) * rs - ns);
                 // targets of one column are distinct rows: batches of 4 independent read-modify-writes
+                // (fire-and-forget L2 adds were tried here: 8.9 vs 7.1 ms, the scattered targets cost the L2 more
+                // than the old-value round trip costs the waves)
                 i32 r = q + lane;
                 for (; r + 192 < rsc; r += 256) {
                     const i32 t0 = relc[r], t1 = relc[r + 64], t2 = relc[r + 128], t3 = relc[r + 192];
@@ -865,6 +867,9 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         st_ab(0);
         ld_a(); ld_b();                                   // slab 1 in flight
         __syncthreads();
+#ifdef UPD_TRACE
+        if (threadIdx.x == 0) ((unsigned long long *)c.spart)[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
+#endif
         int cur = 0;
         const i32 nrounds = t.kw / UPD_KT;
         for (i32 rd = 0; rd < nrounds; ++rd) {
@@ -937,6 +942,9 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
     }
     }
 epilogue:
+#ifdef UPD_TRACE
+    if (threadIdx.x == 0) ((unsigned long long *)c.spart)[(size_t)blockIdx.x * 8 + 2] = wall_clock64();
+#endif
     if (!any) return;
     if (t.pad1) {
         // split-K part: the raw tile goes to its scratch slot, k_update_reduce applies the parts in order
@@ -972,10 +980,15 @@ epilogue:
             for (int q = 0; q < 4; ++q) {
                 const i32 col = jbase + a * 16 + lk + 4 * q;
                 if (FULL || (row < f && col < t.jlim && row >= col)) {
-                    if (col < ns) Pw[(i64)row + (i64)col * lda] -= acc[a][b][q];
+                    // T -= acc as a fire-and-forget fp64 add executed by the L2 (one adder per entry and launch:
+                    // the same IEEE sum as load / subtract / store, bit for bit, without the wave waiting for
+                    // the old value -- the read-modify-write form cost 46 us per tile whatever K, its loads
+                    // serialised behind the stores to the same array)
+                    if (col < ns) unsafeAtomicAdd(Pw + (i64)row + (i64)col * lda, -acc[a][b][q]);
                     else {
                         double *dst = Uw + (i64)(row - ns) + (i64)(col - ns) * rs;
-                        *dst = t.beta0 ? -acc[a][b][q] : (*dst - acc[a][b][q]);
+                        if (t.beta0) *dst = -acc[a][b][q];
+                        else unsafeAtomicAdd(dst, -acc[a][b][q]);
                     }
                 }
             }
@@ -987,18 +1000,33 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
     // double-buffered K-slabs: slab t+1 travels global -> registers while slab t is multiplied
     __shared__ double As[2][UPD_KT * UPD_LD];  // As[.][k][r] = P[i0 + r, k0 + kk + k]  (row tile)
     __shared__ double Bs[2][UPD_KT * UPD_LD];  // Bs[.][k][r] = P[j0 + r, k0 + kk + k]  (column tile)
-#if defined(UPD_VARIANT) && UPD_VARIANT == 3      /* ablation: XCD-contiguous block remap */
-    const unsigned nb_ = gridDim.x, per_ = (nb_ + 7) / 8;
-    const unsigned rb_ = (blockIdx.x % 8) * per_ + blockIdx.x / 8;
-    if (rb_ >= nb_) return;
-    const UpdateTask t = tasks[rb_];
-#else
-    const UpdateTask t = tasks[blockIdx.x];
-#endif
+    // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  upd_remap = 2: XCD x takes runs of 64
+    // consecutive tasks (neighbours in the list share panel slabs: one L2 serves them); 1: one contiguous
+    // eighth of the list per XCD.
+    unsigned b = blockIdx.x;
+    if (c.upd_remap == 2) {
+        const unsigned whole = gridDim.x & ~511u;
+        if (b < whole) b = (b & ~511u) + ((b & 7u) << 6) + ((b >> 3) & 63u);
+    } else if (c.upd_remap == 1) {
+        const unsigned per = gridDim.x >> 3, whole = per << 3;
+        if (b < whole) b = (b & 7u) * per + (b >> 3);
+    }
+    const UpdateTask t = tasks[b];
     const FrontDesc fd = c.fronts[t.front];
     const bool full = (t.i0 + TILE <= fd.f) && (t.j0 + TILE <= t.jlim) && (t.i0 >= t.j0 + TILE);
+#ifdef UPD_TRACE   /* tools/update_bench.hip: per-workgroup time stamps (100 MHz) and placement */
+    unsigned long long *tr = (unsigned long long *)c.spart + (size_t)blockIdx.x * 8;
+    if (threadIdx.x == 0) {
+        tr[0] = wall_clock64();
+        tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+        tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20);       // XCC_ID
+    }
+#endif
     if (full) update_tile<true, SIGNED>(t, fd, c, As, Bs);
     else update_tile<false, SIGNED>(t, fd, c, As, Bs);
+#ifdef UPD_TRACE
+    if (threadIdx.x == 0) tr[3] = wall_clock64();
+#endif
 }
 
 // Split-K: when an update launch has too few tiles to fill the chip, the K range of every tile is

@@ -1016,15 +1016,23 @@ static void build_schedule(Symbolic &S) {
         //       1 = only the tiles below it, 2 = all
         // dry != nullptr: only count the tiles (into *dry), for every front the caller passes
         i64 *dry = nullptr;
+        i32 upd_super = 4;
+        if (const char *e = std::getenv("TLPK_UPD_SUPER")) upd_super = std::max(1, std::atoi(e));   // tuning knob
         auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0, int part) {
             if (kw <= 0 || c0 >= c1) return;
             if (!dry && part != 1) for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * kw * (double)(w.f - cc);
-            for (i32 j0 = c0; j0 < c1; j0 += TILE)
-                for (i32 i0 = j0; i0 < w.f; i0 += TILE) {
-                    const bool diag_blk = i0 < c0 + NB_OUT;
-                    if ((part == 0 && !diag_blk) || (part == 1 && diag_blk)) continue;
-                    if (dry) ++*dry; else S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0});
-                }
+            // tiles in super-tile order (UPD_SUPER x UPD_SUPER tiles): tasks that are neighbours in the list
+            // read the same row / column slabs of the panel, and k_update deals runs of 64 consecutive
+            // tasks to one XCD (one L2)
+            const i32 SUP = upd_super * TILE;
+            for (i32 J0 = c0; J0 < c1; J0 += SUP)
+                for (i32 I0 = J0; I0 < w.f; I0 += SUP)
+                    for (i32 j0 = J0; j0 < std::min(J0 + SUP, c1); j0 += TILE)
+                        for (i32 i0 = std::max(I0, j0); i0 < std::min(I0 + SUP, w.f); i0 += TILE) {
+                            const bool diag_blk = i0 < c0 + NB_OUT;
+                            if ((part == 0 && !diag_blk) || (part == 1 && diag_blk)) continue;
+                            if (dry) ++*dry; else S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0});
+                        }
         };
         auto for_fronts = [&](auto &&fn) {              // dry runs see all of the rank's fronts of the level
             for (i32 t = t0; t < t1; ++t) {

@@ -207,6 +207,8 @@ int upload_all(tlpk_handle *h) {
     AL(h->d_theta, nn); AL(h->d_regP, nn); AL(h->d_regD, S.m); AL(h->d_D, nn);
     AL(h->d_xip, S.m); AL(h->d_xid, nn); AL(h->d_dx, nn); AL(h->d_dy, S.m);
     d.ctx.csign = nullptr;
+    d.ctx.upd_remap = 2;
+    if (const char *e = std::getenv("TLPK_UPD_REMAP")) d.ctx.upd_remap = std::atoi(e);      // tuning knob
     if (S.system == 1) { double *p; if ((rc = dev_upload(h, &p, S.csign)) != TLPK_OK) return rc; d.ctx.csign = p; }
 #undef AL
     {

@@ -20,6 +20,7 @@ struct DevCtx {
     double *dinv;       // inverses of the NB_IN x NB_IN diagonal blocks of L (written by k_potrf)
     double *spart;      // split-K scratch: one TILE x TILE partial product per slot
     int *info;          // info[0] = smallest failing pivot column (INT_MAX = none); info[1] != 0: a sweep gave up waiting
+    int upd_remap;         // k_update blockIdx -> task mapping (0 identity, 1 XCD-contiguous, 2 runs of 64 tasks per XCD)
     const double *csign;   // K2 (augmented system): +1 / -1 per permuted column, the S of P K P' = L S L'; nullptr for K1
 };
 
