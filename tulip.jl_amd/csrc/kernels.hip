@@ -151,22 +151,31 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
             const i32 rsc = s_rsc[ci];
             const double *Uc = (s_ubuf[ci] ? c.U1 : c.U0) + s_uoff[ci];
             const i32 *relc = c.rel + s_reloff[ci];
+            // the parent columns of this child's columns [q0, q1) (at most EA_COLS of them): ONE load per wave,
+            // handed out by readlane (a load per column made every wave wait q1 - q0 round trips per child)
+            static_assert(EA_COLS <= 64, "one lane per column of the range");
+            const i32 tcv = relc[min(q0 + lane, q1 - 1)];
             for (i32 q = q0; q < q1; ++q) {
-                const i32 tc = relc[q];
+                const i32 tc = __builtin_amdgcn_readlane(tcv, q - q0);
                 if (((tc - t.j0) & 3) != wave) continue;
                 const double *__restrict__ src = Uc + (i64)q * rsc;
                 double *__restrict__ dst = (tc < ns) ? (P + (i64)tc * lda) : (Up + (i64)(tc - ns) * rs - ns);
-                // targets of one column are distinct rows: batches of 4 independent read-modify-writes
+                // targets of one column are distinct rows: batches of 4 x 64 independent read-modify-writes, short
+                // columns included (guards instead of a one-by-one tail: every trip is two dependent round trips)
                 // (fire-and-forget L2 adds were tried here: 8.9 vs 7.1 ms, the scattered targets cost the L2 more
                 // than the old-value round trip costs the waves)
-                i32 r = q + lane;
-                for (; r + 192 < rsc; r += 256) {
-                    const i32 t0 = relc[r], t1 = relc[r + 64], t2 = relc[r + 128], t3 = relc[r + 192];
-                    const double v0 = src[r], v1 = src[r + 64], v2 = src[r + 128], v3 = src[r + 192];
-                    const double d0 = dst[t0], d1 = dst[t1], d2 = dst[t2], d3 = dst[t3];
-                    dst[t0] = d0 + v0; dst[t1] = d1 + v1; dst[t2] = d2 + v2; dst[t3] = d3 + v3;
+                for (i32 r = q + lane; r < rsc; r += 256) {
+                    i32 tg[4]; double v[4], d[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const i32 ru = min(r + 64 * u, rsc - 1);
+                        tg[u] = relc[ru]; v[u] = src[ru];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d[u] = dst[tg[u]];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (r + 64 * u < rsc) dst[tg[u]] = d[u] + v[u];
                 }
-                for (; r < rsc; r += 64) dst[relc[r]] += src[r];
             }
         }
     }
