@@ -5,6 +5,7 @@ Only what the hot path needs lives here:
   _lib.py    ctypes binding of libtlpk.so
   kkt.py     host-side mirror of Tulip's KKT interface (setup / update! / solve!)
   hsd_device.py  optional: Tulip's HSD loop with the iterate resident in HBM (tlpk_ipm_*), scalars only over PCIe
+  problem.py / presolve.py / model.py  front end: free-MPS reader, standard form, presolve + scaling + postsolve, Model
   julia/     the Julia glue a Tulip maintainer adds (HIPNormalEquations <: AbstractKKTSolver)
 """
 import os as _os
@@ -21,3 +22,6 @@ from . import _lib  # noqa: F401,E402
 from .kkt import (K1, K2, Backend, DimensionMismatch, HIPNormalEquations, OutOfMemoryError,  # noqa: F401,E402
                   PosDefException, arithmetic, backend, linear_system, run_ls_tests, setup,
                   solve, update)
+from .model import Model  # noqa: F401,E402
+from .presolve import Presolve, PresolveOptions  # noqa: F401,E402
+from .problem import LP, read_free_mps, standard_form  # noqa: F401,E402
