@@ -204,6 +204,18 @@ int tlpk_ipm_advance(tlpk_handle *h, double alpha, double *out);   /* step.jl:13
 /* what = 0 x, 1 xl, 2 xu, 3 zl, 4 zu (n), 5 y (m) */
 int tlpk_ipm_get(tlpk_handle *h, int what, double *host, int64_t len);
 
+/* ---- Mehrotra predictor-corrector with the iterate in HBM (/root/reference/src/IPM/MPC/MPC.jl:218-410,
+ * MPC/step.jl:10-358).  Same vectors as above: tlpk_ipm_load once, tlpk_ipm_residuals with tau = 1 (MPC.jl:101-141),
+ * tlpk_ipm_factor (step.jl:24-51), tlpk_ipm_accept and tlpk_ipm_get are shared. */
+int tlpk_mpc_start(tlpk_handle *h, double *out);               /* MPC.jl:353-410 starting point; out[0] = xl'zl + xu'zu */
+/* mode 0 predictor | 1 corrector (gmu = sigma mu) | 2 centrality corrector; out[0], out[1] = largest primal / dual step
+ * to the boundary of the written direction (inf if unbounded)   MPC/step.jl:164-217 */
+int tlpk_mpc_newton(tlpk_handle *h, int mode, double gmu, double *out);
+/* out[0] = complementarity at the point moved by (ap, ad) along the accepted direction, out[1] = at the point   step.jl:246-258 */
+int tlpk_mpc_gap(tlpk_handle *h, double ap, double ad, double *out);
+int tlpk_mpc_targets(tlpk_handle *h, double ap_, double ad_, double tmin, double tmax);      /* step.jl:329-358 */
+int tlpk_mpc_advance(tlpk_handle *h, double ap, double ad, double *out);                     /* step.jl:112-123; out[0] = xl'zl + xu'zu */
+
 const char *tlpk_strerror(int code);
 const char *tlpk_last_error(const tlpk_handle *h);
 const char *tlpk_backend_name(void);         /* "HIP (gfx950)" */

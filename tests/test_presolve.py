@@ -359,10 +359,11 @@ def test_model_on_device(name, obj):
 
 
 @pytest.mark.gpu
-def test_model_on_device_netlib_class():
+@pytest.mark.parametrize("algorithm", ["hsd", "mpc"])
+def test_model_on_device_netlib_class(algorithm):
     lp = read_free_mps(os.path.join(GOLDEN, "stair25.mps"))
-    m = Model(lp).optimize()
-    ref = Model(lp).optimize(ipm=cpu_ipm())
+    m = Model(lp, algorithm=algorithm).optimize()
+    ref = Model(lp).optimize(ipm=cpu_ipm(algorithm))
     r = highs(lp)
     assert m.status == "Trm_Optimal" and abs(m.objective_value() - r.fun) <= 1e-6 * (1 + abs(r.fun))
     assert abs(m.objective_value() - ref.objective_value()) <= 1e-7 * (1 + abs(r.fun))

@@ -4,7 +4,7 @@ Only what the hot path needs lives here:
   csrc/      hand-written HIP kernels (gfx950) + the C-ABI library (include/tlpk.h)
   _lib.py    ctypes binding of libtlpk.so
   kkt.py     host-side mirror of Tulip's KKT interface (setup / update! / solve!)
-  hsd_device.py  optional: Tulip's HSD loop with the iterate resident in HBM (tlpk_ipm_*), scalars only over PCIe
+  hsd_device.py / mpc_device.py  optional: Tulip's HSD and MPC loops with the iterate resident in HBM (tlpk_ipm_* / tlpk_mpc_*), scalars only over PCIe
   problem.py / presolve.py / model.py  front end: free-MPS reader, standard form, presolve + scaling + postsolve, Model
   julia/     the Julia glue a Tulip maintainer adds (HIPNormalEquations <: AbstractKKTSolver)
 """

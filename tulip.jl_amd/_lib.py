@@ -62,6 +62,7 @@ EXPORTS = [
     "tlpk_backend_name", "tlpk_system_name", "tlpk_linear_system", "tlpk_device_count",
     "tlpk_create_multi", "tlpk_ipm_load", "tlpk_ipm_reset", "tlpk_ipm_residuals", "tlpk_ipm_factor", "tlpk_ipm_hsolve", "tlpk_ipm_targets",
     "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get",
+    "tlpk_mpc_start", "tlpk_mpc_newton", "tlpk_mpc_gap", "tlpk_mpc_targets", "tlpk_mpc_advance",
 ]
 
 
@@ -127,8 +128,14 @@ def lib():
     L.tlpk_ipm_accept.argtypes = [vp]
     L.tlpk_ipm_advance.argtypes = [vp, C.c_double, pd]
     L.tlpk_ipm_get.argtypes = [vp, C.c_int, pd, C.c_int64]
+    L.tlpk_mpc_start.argtypes = [vp, pd]
+    L.tlpk_mpc_newton.argtypes = [vp, C.c_int, C.c_double, pd]
+    L.tlpk_mpc_gap.argtypes = [vp, C.c_double, C.c_double, pd]
+    L.tlpk_mpc_targets.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.tlpk_mpc_advance.argtypes = [vp, C.c_double, C.c_double, pd]
     for name in ("tlpk_ipm_load", "tlpk_ipm_reset", "tlpk_ipm_residuals", "tlpk_ipm_factor", "tlpk_ipm_hsolve",
-                 "tlpk_ipm_targets", "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get"):
+                 "tlpk_ipm_targets", "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get",
+                 "tlpk_mpc_start", "tlpk_mpc_newton", "tlpk_mpc_gap", "tlpk_mpc_targets", "tlpk_mpc_advance"):
         getattr(L, name).restype = C.c_int
     for name in ("tlpk_create", "tlpk_update", "tlpk_solve", "tlpk_update_device", "tlpk_solve_device",
                  "tlpk_sync", "tlpk_update_local", "tlpk_root_panel", "tlpk_update_finish",

@@ -151,14 +151,15 @@ __global__ __launch_bounds__(IPM_T) void k_ipm_hdots(IpmVecs v, double *__restri
 }
 
 // Gondzio targets (step.jl:333-364): v = (x + a dx)(z + a dz) on bounded entries, mapped to the box [mu_l, mu_u];
-// stored in xzl / xzu, sums returned (the host adds the tau-kappa term and forms delta)
-__global__ __launch_bounds__(IPM_T) void k_ipm_targets(IpmVecs v, IpmDir D, double a_, double mu_l, double mu_u, double *__restrict__ partials) {
+// stored in xzl / xzu, sums returned (the host adds the tau-kappa term and forms delta).  HSD trials one step
+// length (a_p = a_d); MPC separate primal and dual ones (MPC/step.jl:329-358)
+__global__ __launch_bounds__(IPM_T) void k_ipm_targets(IpmVecs v, IpmDir D, double a_p, double a_d, double mu_l, double mu_u, double *__restrict__ partials) {
     __shared__ double sh[IPM_T];
     double s0 = 0, s1 = 0;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
-        double vl = ((v.xl[j] + a_ * D.xl[j]) * (v.zl[j] + a_ * D.zl[j])) * v.lflag[j];
-        double vu = ((v.xu[j] + a_ * D.xu[j]) * (v.zu[j] + a_ * D.zu[j])) * v.uflag[j];
+        double vl = ((v.xl[j] + a_p * D.xl[j]) * (v.zl[j] + a_d * D.zl[j])) * v.lflag[j];
+        double vu = ((v.xu[j] + a_p * D.xu[j]) * (v.zu[j] + a_d * D.zu[j])) * v.uflag[j];
         if (v.lflag[j] != 0.0) vl = (vl < mu_l) ? mu_l - vl : ((vl > mu_u) ? mu_u - vl : 0.0);
         if (v.uflag[j] != 0.0) vu = (vu < mu_l) ? mu_l - vu : ((vu > mu_u) ? mu_u - vu : 0.0);
         v.xzl[j] = vl; v.xzu[j] = vu;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(IPM_T) void k_ipm_newton_dots(IpmVecs v, IpmDir D, 
 // the largest step to the boundary (step.jl:274-306) of the resulting direction.
 __global__ __launch_bounds__(IPM_T) void k_ipm_newton_post(IpmVecs v, IpmDir D, IpmDir Add, int add, double dtau, double *__restrict__ partials) {
     __shared__ double sh[IPM_T];
-    double amin = __builtin_inf();
+    double amin_p = __builtin_inf(), amin_d = __builtin_inf();               // primal (xl, xu) and dual (zl, zu) sides
     const i64 stride = (i64)gridDim.x * blockDim.x, t0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     for (i64 j = t0; j < v.n; j += stride) {
         const double lf = v.lflag[j], uf = v.uflag[j];
@@ -224,29 +225,122 @@ __global__ __launch_bounds__(IPM_T) void k_ipm_newton_post(IpmVecs v, IpmDir D, 
         double dzl = (lf != 0.0) ? (v.xzl[j] - v.zl[j] * dxl) / v.xl[j] : 0.0, dzu = (uf != 0.0) ? (v.xzu[j] - v.zu[j] * dxu) / v.xu[j] : 0.0;
         if (add) { dx += Add.x[j]; dxl += Add.xl[j]; dxu += Add.xu[j]; dzl += Add.zl[j]; dzu += Add.zu[j]; }
         D.x[j] = dx; D.xl[j] = dxl; D.xu[j] = dxu; D.zl[j] = dzl; D.zu[j] = dzu;
-        if (dxl < 0.0) amin = fmin(amin, -v.xl[j] / dxl);
-        if (dxu < 0.0) amin = fmin(amin, -v.xu[j] / dxu);
-        if (dzl < 0.0) amin = fmin(amin, -v.zl[j] / dzl);
-        if (dzu < 0.0) amin = fmin(amin, -v.zu[j] / dzu);
+        if (dxl < 0.0) amin_p = fmin(amin_p, -v.xl[j] / dxl);
+        if (dxu < 0.0) amin_p = fmin(amin_p, -v.xu[j] / dxu);
+        if (dzl < 0.0) amin_d = fmin(amin_d, -v.zl[j] / dzl);
+        if (dzu < 0.0) amin_d = fmin(amin_d, -v.zu[j] / dzu);
     }
     for (i64 i = t0; i < v.m; i += stride) { double dy = D.y[i] + dtau * v.hy[i]; if (add) dy += Add.y[i]; D.y[i] = dy; }
-    const double r = blk_min(amin, sh);
+    double r = blk_min(amin_p, sh);
     if (threadIdx.x == 0) partials[(size_t)blockIdx.x * IPM_SLOTS + 0] = r;
+    r = blk_min(amin_d, sh);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * IPM_SLOTS + 1] = r;
 }
 // pt += alpha D (step.jl:139-148); returns xl'zl + xu'zu of the new point for mu (point.jl:45-48)
-__global__ __launch_bounds__(IPM_T) void k_ipm_advance(IpmVecs v, IpmDir D, double alpha, double *__restrict__ partials) {
+// (MPC/step.jl:112-123: primal side by alpha_p, dual side by alpha_d; HSD passes the same value twice)
+__global__ __launch_bounds__(IPM_T) void k_ipm_advance(IpmVecs v, IpmDir D, double alpha, double alpha_d, double *__restrict__ partials) {
     __shared__ double sh[IPM_T];
     double s0 = 0;
     const i64 stride = (i64)gridDim.x * blockDim.x, t0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     for (i64 j = t0; j < v.n; j += stride) {
         v.x[j] += alpha * D.x[j];
-        const double xl = v.xl[j] + alpha * D.xl[j], xu = v.xu[j] + alpha * D.xu[j], zl = v.zl[j] + alpha * D.zl[j], zu = v.zu[j] + alpha * D.zu[j];
+        const double xl = v.xl[j] + alpha * D.xl[j], xu = v.xu[j] + alpha * D.xu[j], zl = v.zl[j] + alpha_d * D.zl[j], zu = v.zu[j] + alpha_d * D.zu[j];
         v.xl[j] = xl; v.xu[j] = xu; v.zl[j] = zl; v.zu[j] = zu;
         s0 += xl * zl + xu * zu;
     }
-    for (i64 i = t0; i < v.m; i += stride) v.y[i] += alpha * D.y[i];
+    for (i64 i = t0; i < v.m; i += stride) v.y[i] += alpha_d * D.y[i];
     const double r = blk_sum(s0, sh);
     if (threadIdx.x == 0) partials[(size_t)blockIdx.x * IPM_SLOTS + 0] = r;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Mehrotra predictor-corrector (the non-homogeneous algorithm, /root/reference/src/IPM/MPC): what the kernels
+// above do not already cover with tau = 1, dtau = 0.
+//   k_mpc_fill            MPC.jl:359             theta_inv = 0, regP = 1, regD = 1e-6 of the starting-point system
+//   k_mpc_start1 .. 4     MPC.jl:365-405         shifts to positive coordinates, balanced complementarity products
+//   k_mpc_gap             MPC/step.jl:246-258, 290-296   complementarity after a trial step (mu_aff, corrector targets)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_mpc_fill(IpmVecs v, double *__restrict__ theta, double *__restrict__ regP, double *__restrict__ regD) {
+    const i64 stride = (i64)gridDim.x * blockDim.x, t0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (i64 j = t0; j < v.n; j += stride) { theta[j] = 0.0; regP[j] = 1.0; v.xid[j] = 0.0; v.hx[j] = 0.0; }
+    for (i64 i = t0; i < v.m; i += stride) { regD[i] = 1e-6; v.xip[i] = 0.0; v.hy[i] = 0.0; }
+}
+// minima of (x - l) lflag and (u - x) uflag (entries without the bound contribute 0, as `false * Inf` does there)
+__global__ __launch_bounds__(IPM_T) void k_mpc_start1(IpmVecs v, double *__restrict__ partials) {
+    __shared__ double sh[IPM_T];
+    double m0 = 0.0, m1 = 0.0;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
+        if (v.lflag[j] != 0.0) m0 = fmin(m0, v.x[j] - v.lz[j]);
+        if (v.uflag[j] != 0.0) m1 = fmin(m1, v.uz[j] - v.x[j]);
+    }
+    double r = blk_min(m0, sh); if (threadIdx.x == 0) partials[(size_t)blockIdx.x * IPM_SLOTS + 0] = r;
+    r = blk_min(m1, sh); if (threadIdx.x == 0) partials[(size_t)blockIdx.x * IPM_SLOTS + 1] = r;
+}
+// xl, xu shifted by dxs; z = c - A'y split over the finite bounds; minima of zl, zu
+__global__ __launch_bounds__(IPM_T) void k_mpc_start2(IpmVecs v, double dxs, double *__restrict__ partials) {
+    __shared__ double sh[IPM_T];
+    double m0 = 0.0, m1 = 0.0;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
+        const double lf = v.lflag[j], uf = v.uflag[j], x = v.x[j];
+        v.xl[j] = (lf != 0.0) ? (x - v.lz[j]) + dxs : 0.0;
+        v.xu[j] = (uf != 0.0) ? (v.uz[j] - x) + dxs : 0.0;
+        double aty = 0.0;
+        for (i64 p = v.Ap[j]; p < v.Ap[j + 1]; ++p) aty += v.Ax[p] * v.y[v.Ai[p]];
+        const double z = v.c[j] - aty, nb = lf + uf;
+        const double zl = (lf != 0.0) ? z / nb : 0.0, zu = (uf != 0.0) ? -z / nb : 0.0;
+        v.zl[j] = zl; v.zu[j] = zu;
+        m0 = fmin(m0, zl); m1 = fmin(m1, zu);
+    }
+    double r = blk_min(m0, sh); if (threadIdx.x == 0) partials[(size_t)blockIdx.x * IPM_SLOTS + 0] = r;
+    r = blk_min(m1, sh); if (threadIdx.x == 0) partials[(size_t)blockIdx.x * IPM_SLOTS + 1] = r;
+}
+// zl, zu shifted by dzs; sums {xl'zl + xu'zu, sum zl + sum zu, sum xl + sum xu}
+__global__ __launch_bounds__(IPM_T) void k_mpc_start3(IpmVecs v, double dzs, double *__restrict__ partials) {
+    __shared__ double sh[IPM_T];
+    double s0 = 0, s1 = 0, s2 = 0;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
+        const double zl = (v.lflag[j] != 0.0) ? v.zl[j] + dzs : v.zl[j], zu = (v.uflag[j] != 0.0) ? v.zu[j] + dzs : v.zu[j];
+        v.zl[j] = zl; v.zu[j] = zu;
+        const double xl = v.xl[j], xu = v.xu[j];
+        s0 += xl * zl + xu * zu; s1 += zl + zu; s2 += xl + xu;
+    }
+    double *P = partials + (size_t)blockIdx.x * IPM_SLOTS;
+    double r = blk_sum(s0, sh); if (threadIdx.x == 0) P[0] = r;
+    r = blk_sum(s1, sh); if (threadIdx.x == 0) P[1] = r;
+    r = blk_sum(s2, sh); if (threadIdx.x == 0) P[2] = r;
+}
+// balanced products: xl, xu += ddx, zl, zu += ddz on the finite bounds; returns xl'zl + xu'zu
+__global__ __launch_bounds__(IPM_T) void k_mpc_start4(IpmVecs v, double ddx, double ddz, double *__restrict__ partials) {
+    __shared__ double sh[IPM_T];
+    double s0 = 0;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
+        double xl = v.xl[j], xu = v.xu[j], zl = v.zl[j], zu = v.zu[j];
+        if (v.lflag[j] != 0.0) { xl += ddx; zl += ddz; }
+        if (v.uflag[j] != 0.0) { xu += ddx; zu += ddz; }
+        v.xl[j] = xl; v.xu[j] = xu; v.zl[j] = zl; v.zu[j] = zu;
+        s0 += xl * zl + xu * zu;
+    }
+    const double r = blk_sum(s0, sh);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * IPM_SLOTS + 0] = r;
+}
+// {((xl + ap dxl) lflag)'(zl + ad dzl) + ((xu + ap dxu) uflag)'(zu + ad dzu), xl'zl + xu'zu}
+__global__ __launch_bounds__(IPM_T) void k_mpc_gap(IpmVecs v, IpmDir D, double ap, double ad, double *__restrict__ partials) {
+    __shared__ double sh[IPM_T];
+    double s0 = 0, s1 = 0;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) {
+        const double xl = v.xl[j], xu = v.xu[j], zl = v.zl[j], zu = v.zu[j];
+        s0 += ((xl + ap * D.xl[j]) * v.lflag[j]) * (zl + ad * D.zl[j]) + ((xu + ap * D.xu[j]) * v.uflag[j]) * (zu + ad * D.zu[j]);
+        s1 += xl * zl + xu * zu;
+    }
+    double *P = partials + (size_t)blockIdx.x * IPM_SLOTS;
+    double r = blk_sum(s0, sh); if (threadIdx.x == 0) P[0] = r;
+    r = blk_sum(s1, sh); if (threadIdx.x == 0) P[1] = r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -263,8 +357,8 @@ void ipm_launch_theta(hipStream_t st, const IpmVecs &v, double *theta, double *r
 }
 void ipm_launch_hrhs(hipStream_t st, const IpmVecs &v) { hipLaunchKernelGGL(k_ipm_hrhs, dim3(ipm_blocks(v.n)), dim3(IPM_T), 0, st, v); }
 int ipm_launch_hdots(hipStream_t st, const IpmVecs &v, double *partials) { const int nb = ipm_blocks(std::max(v.n, v.m)); hipLaunchKernelGGL(k_ipm_hdots, dim3(nb), dim3(IPM_T), 0, st, v, partials); return nb; }
-int ipm_launch_targets(hipStream_t st, const IpmVecs &v, const IpmDir &D, double a_, double mu_l, double mu_u, double *partials) {
-    const int nb = ipm_blocks(v.n); hipLaunchKernelGGL(k_ipm_targets, dim3(nb), dim3(IPM_T), 0, st, v, D, a_, mu_l, mu_u, partials); return nb;
+int ipm_launch_targets(hipStream_t st, const IpmVecs &v, const IpmDir &D, double a_p, double a_d, double mu_l, double mu_u, double *partials) {
+    const int nb = ipm_blocks(v.n); hipLaunchKernelGGL(k_ipm_targets, dim3(nb), dim3(IPM_T), 0, st, v, D, a_p, a_d, mu_l, mu_u, partials); return nb;
 }
 int ipm_launch_newton_pre(hipStream_t st, const IpmVecs &v, const IpmDir &D, int mode, double eta, double gmu, double delta, double *partials) {
     const int nb = ipm_blocks(std::max(v.n, v.m)); hipLaunchKernelGGL(k_ipm_newton_pre, dim3(nb), dim3(IPM_T), 0, st, v, D, mode, eta, gmu, delta, partials); return nb;
@@ -275,8 +369,23 @@ void ipm_launch_newton_dots(hipStream_t st, const IpmVecs &v, const IpmDir &D, i
 int ipm_launch_newton_post(hipStream_t st, const IpmVecs &v, const IpmDir &D, const IpmDir &Add, int add, double dtau, double *partials) {
     const int nb = ipm_blocks(std::max(v.n, v.m)); hipLaunchKernelGGL(k_ipm_newton_post, dim3(nb), dim3(IPM_T), 0, st, v, D, Add, add, dtau, partials); return nb;
 }
-int ipm_launch_advance(hipStream_t st, const IpmVecs &v, const IpmDir &D, double alpha, double *partials) {
-    const int nb = ipm_blocks(std::max(v.n, v.m)); hipLaunchKernelGGL(k_ipm_advance, dim3(nb), dim3(IPM_T), 0, st, v, D, alpha, partials); return nb;
+int ipm_launch_advance(hipStream_t st, const IpmVecs &v, const IpmDir &D, double alpha_p, double alpha_d, double *partials) {
+    const int nb = ipm_blocks(std::max(v.n, v.m)); hipLaunchKernelGGL(k_ipm_advance, dim3(nb), dim3(IPM_T), 0, st, v, D, alpha_p, alpha_d, partials); return nb;
+}
+
+void mpc_launch_fill(hipStream_t st, const IpmVecs &v, double *theta, double *regP, double *regD) {
+    hipLaunchKernelGGL(k_mpc_fill, dim3(ipm_blocks(std::max(v.n, v.m))), dim3(IPM_T), 0, st, v, theta, regP, regD);
+}
+int mpc_launch_start(hipStream_t st, const IpmVecs &v, int stage, double a, double b, double *partials) {
+    const int nb = ipm_blocks(v.n);
+    if (stage == 1) hipLaunchKernelGGL(k_mpc_start1, dim3(nb), dim3(IPM_T), 0, st, v, partials);
+    else if (stage == 2) hipLaunchKernelGGL(k_mpc_start2, dim3(nb), dim3(IPM_T), 0, st, v, a, partials);
+    else if (stage == 3) hipLaunchKernelGGL(k_mpc_start3, dim3(nb), dim3(IPM_T), 0, st, v, a, partials);
+    else hipLaunchKernelGGL(k_mpc_start4, dim3(nb), dim3(IPM_T), 0, st, v, a, b, partials);
+    return nb;
+}
+int mpc_launch_gap(hipStream_t st, const IpmVecs &v, const IpmDir &D, double ap, double ad, double *partials) {
+    const int nb = ipm_blocks(v.n); hipLaunchKernelGGL(k_mpc_gap, dim3(nb), dim3(IPM_T), 0, st, v, D, ap, ad, partials); return nb;
 }
 
 }  // namespace tlpk

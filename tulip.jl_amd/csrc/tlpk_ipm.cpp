@@ -158,7 +158,7 @@ int tlpk_ipm_targets(tlpk_handle *h, double a_, double mu_l, double mu_u, double
     if (!out) return TLPK_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
     IpmState &s = *h->ipm;
-    const int nb = ipm_launch_targets(h->stream, s.v, s.D[s.cur], a_, mu_l, mu_u, s.partials[0]);
+    const int nb = ipm_launch_targets(h->stream, s.v, s.D[s.cur], a_, a_, mu_l, mu_u, s.partials[0]);
     ipm_launch_finalize(h->stream, nb, 2, 0, 0, s.partials[0], s.d_out);
     if (int rc = fetch(h, 2)) return rc;
     out[0] = s.h_out[0]; out[1] = s.h_out[1];
@@ -192,9 +192,9 @@ int tlpk_ipm_newton(tlpk_handle *h, int mode, const double *sc, double *out) {
     const double dtau = (xi_g_ + q[4] - q[5]) / h0;
     const double dkappa = (xi_tk - kappa * dtau) / tau;
     const int nb2 = ipm_launch_newton_post(h->stream, s.v, dst, acc, mode == 2 ? 1 : 0, dtau, s.partials[1]);
-    ipm_launch_finalize(h->stream, nb2, 0, 0, 1, s.partials[1], s.d_out);
-    if ((rc = fetch(h, 1)) != TLPK_OK) return rc;
-    out[0] = dtau; out[1] = dkappa; out[2] = s.h_out[0];
+    ipm_launch_finalize(h->stream, nb2, 0, 0, 2, s.partials[1], s.d_out);
+    if ((rc = fetch(h, 2)) != TLPK_OK) return rc;
+    out[0] = dtau; out[1] = dkappa; out[2] = std::fmin(s.h_out[0], s.h_out[1]);    // one step length for both sides
     return TLPK_OK;
 }
 
@@ -211,7 +211,7 @@ int tlpk_ipm_advance(tlpk_handle *h, double alpha, double *out) {
     if (!out) return TLPK_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
     IpmState &s = *h->ipm;
-    const int nb = ipm_launch_advance(h->stream, s.v, s.D[s.cur], alpha, s.partials[0]);
+    const int nb = ipm_launch_advance(h->stream, s.v, s.D[s.cur], alpha, alpha, s.partials[0]);
     ipm_launch_finalize(h->stream, nb, 1, 0, 0, s.partials[0], s.d_out);
     if (int rc = fetch(h, 1)) return rc;
     out[0] = s.h_out[0];
@@ -229,6 +229,103 @@ int tlpk_ipm_get(tlpk_handle *h, int what, double *host, int64_t len) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (need > 0) HIPCHK(h, hipMemcpy(host, src[what], (size_t)need * 8, hipMemcpyDeviceToHost));
+    return TLPK_OK;
+}
+
+/* ---- Mehrotra predictor-corrector with the iterate in HBM (MPC/MPC.jl, MPC/step.jl) ------------------------
+ * Shares the vectors, tlpk_ipm_load / residuals (tau = 1) / factor / accept / get with the HSD entry points. */
+
+/* MPC.jl:353-410: starting point.  One factorisation of A A' + 1e-6 I, two solves with a zero half of the
+ * right-hand side, shifts to positive coordinates, balanced products.  out[0] = xl'zl + xu'zu. */
+int tlpk_mpc_start(tlpk_handle *h, double *out) {
+    if (int rc = ipm_ready(h)) return rc;
+    if (!out) return TLPK_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    IpmState &s = *h->ipm;
+    const IpmVecs &v = s.v;
+    mpc_launch_fill(h->stream, v, h->d_theta, h->d_regP, h->d_regD);
+    int rc = tlpk_update_device(h, h->d_theta, h->d_regP, h->d_regD);
+    if (rc != TLPK_OK) return rc;
+    if ((rc = tlpk_solve_device(h, s.D[0].x, v.y, v.xip, v.c)) != TLPK_OK) return rc;          // y  (xip == 0 here)
+    if ((rc = tlpk_solve_device(h, v.x, s.D[0].y, v.b, v.xid)) != TLPK_OK) return rc;          // x  (xid == 0 here)
+    int nb = mpc_launch_start(h->stream, v, 1, 0.0, 0.0, s.partials[0]);
+    ipm_launch_finalize(h->stream, nb, 0, 0, 2, s.partials[0], s.d_out);
+    if ((rc = fetch(h, 2)) != TLPK_OK) return rc;
+    if ((rc = tlpk_sync(h)) != TLPK_OK) return rc;
+    const double dxs = 1.0 + std::fmax(0.0, std::fmax(-1.5 * s.h_out[0], -1.5 * s.h_out[1]));
+    nb = mpc_launch_start(h->stream, v, 2, dxs, 0.0, s.partials[0]);
+    ipm_launch_finalize(h->stream, nb, 0, 0, 2, s.partials[0], s.d_out);
+    if ((rc = fetch(h, 2)) != TLPK_OK) return rc;
+    const double dzs = 1.0 + std::fmax(0.0, std::fmax(-1.5 * s.h_out[0], -1.5 * s.h_out[1]));
+    nb = mpc_launch_start(h->stream, v, 3, dzs, 0.0, s.partials[0]);
+    ipm_launch_finalize(h->stream, nb, 3, 0, 0, s.partials[0], s.d_out);
+    if ((rc = fetch(h, 3)) != TLPK_OK) return rc;
+    const double mu = s.h_out[0], ddx = mu / (2.0 * s.h_out[1]), ddz = mu / (2.0 * s.h_out[2]);
+    nb = mpc_launch_start(h->stream, v, 4, ddx, ddz, s.partials[0]);
+    ipm_launch_finalize(h->stream, nb, 1, 0, 0, s.partials[0], s.d_out);
+    if ((rc = fetch(h, 1)) != TLPK_OK) return rc;
+    out[0] = s.h_out[0];
+    s.cur = 0;
+    return TLPK_OK;
+}
+
+/* MPC/step.jl:164-217 (solve_newton_system + max_step_length_pd) for one right-hand side:
+ *   mode 0 predictor (xi = residuals, complementarity -x z), mode 1 corrector (same residuals, sigma mu - x z - dx dz
+ *   with the predictor direction, which it overwrites; gmu = sigma mu), mode 2 centrality corrector (zero residuals,
+ *   the targets of tlpk_mpc_targets; writes the candidate = solution + accepted direction).
+ * out[2] = largest primal step (over xl, xu) and largest dual step (over zl, zu) to the boundary, inf if none. */
+int tlpk_mpc_newton(tlpk_handle *h, int mode, double gmu, double *out) {
+    if (int rc = ipm_ready(h)) return rc;
+    if (!out || mode < 0 || mode > 2) return TLPK_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    IpmState &s = *h->ipm;
+    const IpmDir &acc = s.D[s.cur];
+    const IpmDir &dst = (mode == 2) ? s.D[1 - s.cur] : s.D[s.cur];
+    ipm_launch_newton_pre(h->stream, s.v, acc, mode, 1.0, gmu, 0.0, s.partials[0]);
+    int rc = tlpk_solve_device(h, dst.x, dst.y, s.v.xip, s.v.xid);
+    if (rc != TLPK_OK) return rc;
+    const int nb = ipm_launch_newton_post(h->stream, s.v, dst, acc, mode == 2 ? 1 : 0, 0.0, s.partials[1]);   // dtau = 0: hx, hy (zeros) unused
+    ipm_launch_finalize(h->stream, nb, 0, 0, 2, s.partials[1], s.d_out);
+    if ((rc = fetch(h, 2)) != TLPK_OK) return rc;
+    if ((rc = tlpk_sync(h)) != TLPK_OK) return rc;
+    out[0] = s.h_out[0]; out[1] = s.h_out[1];
+    return TLPK_OK;
+}
+
+/* MPC/step.jl:246-258, 290-296: out[0] = complementarity of the point moved by (ap, ad) along the accepted direction,
+ * out[1] = xl'zl + xu'zu of the point itself */
+int tlpk_mpc_gap(tlpk_handle *h, double ap, double ad, double *out) {
+    if (int rc = ipm_ready(h)) return rc;
+    if (!out) return TLPK_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    IpmState &s = *h->ipm;
+    const int nb = mpc_launch_gap(h->stream, s.v, s.D[s.cur], ap, ad, s.partials[0]);
+    ipm_launch_finalize(h->stream, nb, 2, 0, 0, s.partials[0], s.d_out);
+    if (int rc = fetch(h, 2)) return rc;
+    out[0] = s.h_out[0]; out[1] = s.h_out[1];
+    return TLPK_OK;
+}
+
+/* MPC/step.jl:329-358 (compute_target!): targets of the centrality corrector from the accepted direction at the trial
+ * step lengths (ap_, ad_), box [tmin, tmax]; they stay on the device for tlpk_mpc_newton(mode 2) */
+int tlpk_mpc_targets(tlpk_handle *h, double ap_, double ad_, double tmin, double tmax) {
+    if (int rc = ipm_ready(h)) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    IpmState &s = *h->ipm;
+    ipm_launch_targets(h->stream, s.v, s.D[s.cur], ap_, ad_, tmin, tmax, s.partials[0]);
+    return TLPK_OK;
+}
+
+/* MPC/step.jl:112-123: primal side += ap * D, dual side += ad * D; out[0] = xl'zl + xu'zu of the new point */
+int tlpk_mpc_advance(tlpk_handle *h, double ap, double ad, double *out) {
+    if (int rc = ipm_ready(h)) return rc;
+    if (!out) return TLPK_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    IpmState &s = *h->ipm;
+    const int nb = ipm_launch_advance(h->stream, s.v, s.D[s.cur], ap, ad, s.partials[0]);
+    ipm_launch_finalize(h->stream, nb, 1, 0, 0, s.partials[0], s.d_out);
+    if (int rc = fetch(h, 1)) return rc;
+    out[0] = s.h_out[0];
     return TLPK_OK;
 }
 

@@ -35,10 +35,13 @@ int ipm_launch_res_rows(hipStream_t st, const IpmVecs &v, double tau, double *pa
 void ipm_launch_theta(hipStream_t st, const IpmVecs &v, double *theta, double *regP, double *regD, double rP, double rD);
 void ipm_launch_hrhs(hipStream_t st, const IpmVecs &v);
 int ipm_launch_hdots(hipStream_t st, const IpmVecs &v, double *partials);
-int ipm_launch_targets(hipStream_t st, const IpmVecs &v, const IpmDir &D, double a_, double mu_l, double mu_u, double *partials);
+int ipm_launch_targets(hipStream_t st, const IpmVecs &v, const IpmDir &D, double a_p, double a_d, double mu_l, double mu_u, double *partials);
 int ipm_launch_newton_pre(hipStream_t st, const IpmVecs &v, const IpmDir &D, int mode, double eta, double gmu, double delta, double *partials);
 void ipm_launch_newton_dots(hipStream_t st, const IpmVecs &v, const IpmDir &D, int nblocks, double *partials);
 int ipm_launch_newton_post(hipStream_t st, const IpmVecs &v, const IpmDir &D, const IpmDir &Add, int add, double dtau, double *partials);
-int ipm_launch_advance(hipStream_t st, const IpmVecs &v, const IpmDir &D, double alpha, double *partials);
+int ipm_launch_advance(hipStream_t st, const IpmVecs &v, const IpmDir &D, double alpha_p, double alpha_d, double *partials);
+void mpc_launch_fill(hipStream_t st, const IpmVecs &v, double *theta, double *regP, double *regD);
+int mpc_launch_start(hipStream_t st, const IpmVecs &v, int stage, double a, double b, double *partials);
+int mpc_launch_gap(hipStream_t st, const IpmVecs &v, const IpmDir &D, double ap, double ad, double *partials);
 
 }  // namespace tlpk

@@ -5,8 +5,8 @@ postsolve (the flow of /root/reference/src/model.jl:
     m.optimize()                             # model.jl:67-166: presolve -> standard form -> IPM -> postsolve
     m.status, m.objective_value(), m.dual_objective_value(), m.solution.x, m.solution.y_lower ...
 
-The interior-point method is `DeviceHSD` (hsd_device.py): Tulip's homogeneous self-dual loop with the iterate in
-HBM and every Newton step through libtlpk.so.  `optimize(ipm=...)` accepts any callable `LP -> InnerResult`
+The interior-point method is `DeviceHSD` (hsd_device.py, Tulip's default homogeneous self-dual loop) or `DeviceMPC`
+(mpc_device.py, `algorithm="mpc"`), both with the iterate in HBM and every Newton step through libtlpk.so.  `optimize(ipm=...)` accepts any callable `LP -> InnerResult`
 instead (the parity tests run the same front end over the CPU oracle backend that way); the product default
 needs the GPU and fails loudly without it.
 """
@@ -37,11 +37,15 @@ class InnerResult:
     niter: int = 0
 
 
-def device_hsd(lp, **backend_kw):
-    """Default interior-point run: DeviceHSD on the standard form of `lp`."""
-    from .hsd_device import DeviceHSD
+def device_ipm(lp, algorithm="hsd", **backend_kw):
+    """Default interior-point run on the standard form of `lp`: DeviceHSD (Tulip's default, model.jl IPM.Factory)
+    or DeviceMPC, iterate in HBM."""
+    if algorithm == "mpc":
+        from .mpc_device import DeviceMPC as Opt
+    else:
+        from .hsd_device import DeviceHSD as Opt
     d = standard_form(lp)
-    opt = DeviceHSD(d.A, d.b, d.c, d.l, d.u, c0=d.c0, objsense_min=d.objsense, **backend_kw)
+    opt = Opt(d.A, d.b, d.c, d.l, d.u, c0=d.c0, objsense_min=d.objsense, **backend_kw)
     opt.optimize()
     return InnerResult(opt.status, opt.primal_status, opt.dual_status, opt._get(0, opt.n), opt._get(5, opt.m),
                        opt._get(3, opt.n), opt._get(4, opt.n), opt.tau, opt.primal_objective, opt.dual_objective,
@@ -79,8 +83,9 @@ def extract_solution(lp, res):
 
 
 class Model:
-    def __init__(self, lp=None, presolve_level=1, **backend_kw):
+    def __init__(self, lp=None, presolve_level=1, algorithm="hsd", **backend_kw):
         self.lp = lp
+        self.algorithm = algorithm
         self.presolve_options = PresolveOptions(Level=presolve_level)
         self.backend_kw = backend_kw
         self.presolve = None
@@ -95,7 +100,7 @@ class Model:
     def optimize(self, ipm=None):
         """model.jl:67-166."""
         lp = self.lp
-        ipm = ipm or (lambda p: device_hsd(p, **self.backend_kw))
+        ipm = ipm or (lambda p: device_ipm(p, self.algorithm, **self.backend_kw))
         lp_inner = lp
         if self.presolve_options.Level > 0:
             ps = self.presolve = Presolve(lp, self.presolve_options)
