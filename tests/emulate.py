@@ -29,13 +29,14 @@ class Emulator:
         self.root_front = int(g("root_front")[0])
         self.rank = kkt.backend_options.rank
         self.rowidx = g("rowidx"); self.rel = g("rel"); self.children = g("children")
+        self.ea_tab = g("ea_tab"); self.eatab = g("front_eatab")
         self.ucoff = g("front_ucoff"); self.gth_ptr = g("gth_ptr"); self.gth_src = g("gth_src")
         self.s_target = g("s_target"); self.s_diag_row = g("s_diag_row")
         self.pair_ptr = g("pair_ptr"); self.pair_j = g("pair_j")
         from tulip_jl_amd import _lib
         self.pair_w = _lib.symbolic_array_f64(kkt._h, "pair_w")
         self.tasks = {
-            LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 3),
+            LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 4),
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
             LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),
             LK["UPDATE"]: g("update_tasks").reshape(-1, 8),
@@ -159,7 +160,7 @@ class Emulator:
 
     def _k0(self, T):      # extend-add
         # group tasks by front: emulation processes whole columns ranges, children in order
-        for front, j0, j1 in T:
+        for front, j0, j1, bidx in T:
             f, ns = int(self.f[front]), int(self.ns[front])
             rs = f - ns
             if front not in self.U:
@@ -170,7 +171,10 @@ class Emulator:
                 relc = self.relidx(c)
                 rsc = len(relc)
                 Uc = self.U[c]
-                q0, q1 = np.searchsorted(relc, j0), np.searchsorted(relc, j1)
+                # the device finds the child's columns of the range in the analyse phase's lookup table
+                q0, q1 = (int(v) for v in self.ea_tab[self.eatab[c] + bidx: self.eatab[c] + bidx + 2])
+                assert (q0, q1) == (np.searchsorted(relc, j0), np.searchsorted(relc, j1)), "extend-add lookup table"
+                assert q1 - q0 <= 16
                 for q in range(q0, q1):
                     tc = relc[q]
                     src = Uc[q:, q]

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
     __shared__ i32 s_q0[CB], s_q1[CB], s_rsc[CB];
     __shared__ i64 s_uoff[CB], s_reloff[CB];
     __shared__ int s_ubuf[CB];
+    __shared__ unsigned char s_tc[CB][EA_COLS];     // parent column - j0 of the child's columns [q0, q1)
     const EaTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
@@ -135,14 +136,14 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
             const FrontDesc cd = c.fronts[c.children[fd.child_ptr + cb + tid]];
             const i32 rsc = cd.f - cd.ns;
             const i32 *relc = c.rel + cd.reloff;
-            // child columns whose parent column lies in [j0, j1): rel is increasing -> binary search
-            i32 lo = 0, hi = rsc;
-            while (lo < hi) { const i32 mid = (lo + hi) >> 1; if (relc[mid] < t.j0) lo = mid + 1; else hi = mid; }
-            const i32 q0 = lo;
-            hi = rsc;
-            while (lo < hi) { const i32 mid = (lo + hi) >> 1; if (relc[mid] < t.j1) lo = mid + 1; else hi = mid; }
-            s_q0[tid] = q0; s_q1[tid] = lo; s_rsc[tid] = rsc;
+            // child columns whose parent column lies in [j0, j1): two entries of the lookup table built by the analyse
+            // phase (two binary searches in the child's list here cost ~20 dependent loads per workgroup), then the
+            // <= EA_COLS parent columns themselves, loaded side by side
+            const i32 q0 = c.ea_tab[cd.eatab + t.bidx], q1 = c.ea_tab[cd.eatab + t.bidx + 1];
+            s_q0[tid] = q0; s_q1[tid] = q1; s_rsc[tid] = rsc;
             s_uoff[tid] = cd.uoff; s_reloff[tid] = cd.reloff; s_ubuf[tid] = cd.ubuf;
+#pragma unroll
+            for (int u = 0; u < EA_COLS; ++u) if (q0 + u < q1) s_tc[tid][u] = (unsigned char)(relc[q0 + u] - t.j0);
         }
         __syncthreads();
         for (i32 ci = 0; ci < nb; ++ci) {
@@ -151,19 +152,17 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
             const i32 rsc = s_rsc[ci];
             const double *Uc = (s_ubuf[ci] ? c.U1 : c.U0) + s_uoff[ci];
             const i32 *relc = c.rel + s_reloff[ci];
-            // the parent columns of this child's columns [q0, q1) (at most EA_COLS of them): ONE load per wave,
-            // handed out by readlane (a load per column made every wave wait q1 - q0 round trips per child)
-            static_assert(EA_COLS <= 64, "one lane per column of the range");
-            const i32 tcv = relc[min(q0 + lane, q1 - 1)];
             for (i32 q = q0; q < q1; ++q) {
-                const i32 tc = __builtin_amdgcn_readlane(tcv, q - q0);
+                const i32 tc = t.j0 + s_tc[ci][q - q0];
                 if (((tc - t.j0) & 3) != wave) continue;
                 const double *__restrict__ src = Uc + (i64)q * rsc;
                 double *__restrict__ dst = (tc < ns) ? (P + (i64)tc * lda) : (Up + (i64)(tc - ns) * rs - ns);
                 // targets of one column are distinct rows: batches of 4 x 64 independent read-modify-writes, short
-                // columns included (guards instead of a one-by-one tail: every trip is two dependent round trips)
-                // (fire-and-forget L2 adds were tried here: 8.9 vs 7.1 ms, the scattered targets cost the L2 more
-                // than the old-value round trip costs the waves)
+                // columns included (guards instead of a one-by-one tail: every trip is two dependent round trips).
+                // Tried and measured slower: fire-and-forget L2 adds (8.9 vs 7.1 ms: the scattered targets cost the L2
+                // more than the old-value round trip costs the waves); a flattened trip iterator with the loads of
+                // trip n + 1 issued before the read-modify-write of trip n (6.3 vs 5.5 ms: the per-trip bookkeeping
+                // costs more than the hidden round trip).
                 for (i32 r = q + lane; r < rsc; r += 256) {
                     i32 tg[4]; double v[4], d[4];
 #pragma unroll

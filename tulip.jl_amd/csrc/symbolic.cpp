@@ -21,6 +21,18 @@
 
 namespace tlpk {
 
+// Extend-add ranges of a parent front (one workgroup each): ea_cols(p) columns wide, counted from 0 inside the pivot
+// columns [0, ns) and from ns inside the update-matrix columns [ns, f).  Boundary k of ea_nbounds(p):
+//   k < npan: k * cols ; k == npan: ns ; k > npan: ns + (k - npan) * cols, the last one being f.
+static inline i32 ea_cols(const FrontDesc &p) { return (p.f >= 2048) ? EA_COLS : 4; }     // small fronts: more, narrower workgroups
+static inline i32 ea_npan(const FrontDesc &p) { const i32 c = ea_cols(p); return (p.ns + c - 1) / c; }
+static inline i32 ea_nbounds(const FrontDesc &p) { const i32 c = ea_cols(p); return ea_npan(p) + (p.f - p.ns + c - 1) / c + 1; }
+static inline i32 ea_bound(const FrontDesc &p, i32 k) {
+    const i32 c = ea_cols(p), npan = ea_npan(p);
+    return (k < npan) ? k * c : std::min(p.f, p.ns + (k - npan) * c);
+}
+
+
 namespace {
 
 // Liu's elimination-tree algorithm with path compression on a graph given in ORIGINAL labels
@@ -792,6 +804,36 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         }, 64);
         if (bad) return fail(S, TLPK_INTERNAL, "child row missing from parent front");
     }
+    // ---- 13a. extend-add lookup: the parent's columns are cut into the ranges of its extend-add workgroups
+    // (ea_cols wide from 0 inside the pivot columns, and from ns inside the update-matrix columns); for every
+    // range boundary the child stores the first of its columns that lands at or after it, so that a workgroup
+    // finds "the child's columns in my range" with two loads instead of two binary searches in HBM.
+    {
+        i64 acc = 0;
+        for (i32 s = 0; s < ns_total; ++s) {
+            FrontDesc &w = S.fronts[s];
+            w.eatab = -1;
+            if (w.parent == -1) continue;
+            const FrontDesc &p = S.fronts[w.parent];
+            if (acc > (i64)INT32_MAX - (ea_nbounds(p) + 1)) return fail(S, TLPK_TOO_LARGE, "extend-add lookup table exceeds 2^31 entries");
+            w.eatab = (i32)acc;
+            acc += ea_nbounds(p);
+        }
+        S.ea_tab.assign((size_t)acc, 0);
+        parallel_for_throw(ns_total, host_threads(ns_total), [&](unsigned, i64 s) {
+            const FrontDesc &w = S.fronts[s];
+            if (w.parent == -1) return;
+            const FrontDesc &p = S.fronts[w.parent];
+            const i32 rsc = w.f - w.ns, nb = ea_nbounds(p);
+            const i32 *rel = S.rel.data() + w.reloff;
+            i32 q = 0;
+            for (i32 k = 0; k < nb; ++k) {
+                const i32 bound = ea_bound(p, k);
+                while (q < rsc && rel[q] < bound) ++q;
+                S.ea_tab[(size_t)w.eatab + k] = q;
+            }
+        }, 64);
+    }
 
     pt.mark("gather lists");
     // ---- 13b. forward-solve gather lists: for every row t of a front, the entries of its
@@ -996,8 +1038,9 @@ static void build_schedule(Symbolic &S) {
                 const FrontDesc &w = S.fronts[s];
                 if (w.nchild == 0) continue;
                 const i32 jbeg = u_part ? w.ns : 0, jend = u_part ? w.f : w.ns;
-                const i32 cols = (w.f >= 2048) ? EA_COLS : 4;     // small fronts: more, narrower workgroups
-                for (i32 j = jbeg; j < jend; j += cols) S.ea_tasks.push_back(EaTask{s, j, std::min(j + cols, jend), 0});
+                const i32 cols = ea_cols(w);
+                i32 k = u_part ? ea_npan(w) : 0;                  // boundary index of j (section 13a)
+                for (i32 j = jbeg; j < jend; j += cols, ++k) S.ea_tasks.push_back(EaTask{s, j, std::min(j + cols, jend), k});
             }
             push_launch(S.factor_launches, LK_EXTEND_ADD, first, (i64)S.ea_tasks.size() - first);
         };

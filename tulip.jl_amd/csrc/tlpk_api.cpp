@@ -187,6 +187,7 @@ int upload_all(tlpk_handle *h) {
     { FrontDesc *p; UP(p, S.fronts); fr = p; }
     { i32 *p; UP(p, S.rowidx); ri = p; }
     { i32 *p; UP(p, S.rel); re = p; }
+    { i32 *p; UP(p, S.ea_tab); d.ctx.ea_tab = p; }
     { i32 *p; UP(p, S.children); ch = p; }
     d.ctx.fronts = fr; d.ctx.rowidx = ri; d.ctx.rel = re; d.ctx.children = ch;
     { i64 *p; UP(p, S.gth_ptr); d.ctx.gth_ptr = p; }
@@ -867,6 +868,8 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "pair_j") from32(S.pair_j);
     else if (w == "rowidx") from32(S.rowidx);
     else if (w == "rel") from32(S.rel);
+    else if (w == "ea_tab") from32(S.ea_tab);
+    else if (w == "front_eatab") field([](const FrontDesc &f) { return f.eatab; });
     else if (w == "children") from32(S.children);
     else if (w == "depth") from32(S.depth);
     else if (w == "front_block") from32(S.front_block);
@@ -891,7 +894,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "front_single") tmp.assign(S.front_single.begin(), S.front_single.end());
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
-    else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); } }
+    else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); tmp.push_back(t.bidx); } }
     else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks" || w == "fwd_small_tasks" || w == "bwd_small_tasks" ||
              w == "fwd_sweep_tasks" || w == "bwd_sweep_tasks") {
         const std::vector<SolveTask> &v = (w == "fwd_gather_tasks") ? S.fwd_gather_tasks : (w == "fwd_diag_tasks") ? S.fwd_diag_tasks :

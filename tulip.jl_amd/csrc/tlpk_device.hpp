@@ -11,6 +11,7 @@ struct DevCtx {
     const FrontDesc *fronts;
     const i32 *rowidx;
     const i32 *rel;
+    const i32 *ea_tab;  // extend-add lookup (FrontDesc.eatab)
     const i32 *children;
     const i64 *gth_ptr, *gth_src;   // forward gather lists (per front row: the children's uc entries)
     double *Lval;       // supernodal panels of L

@@ -45,7 +45,8 @@ struct FrontDesc {
     i32 flagoff;   // >= 0: the front's triangular solves run in the persistent sweep kernels; -1: small / single / not local
     i32 lda;       // leading dimension of the panel: f rounded up to 16 doubles (one 128-byte line) for fronts of >= LDA_PAD_MIN_F
                    // rows, so that every panel column starts on a cache-line boundary (loff is then a multiple of 16 too)
-    i32 pad2;
+    i32 eatab;     // offset into ea_tab: for every parent-column boundary of the parent's extend-add tasks, the first of this
+                   // front's update-matrix columns that lands at or after it (-1: no parent)
 };
 static_assert(sizeof(FrontDesc) == 88, "FrontDesc layout");
 
@@ -54,7 +55,7 @@ struct TrsmTask  { i32 front, k0, nb, row0, kprev, fuse_nb, pad1, pad2; };   // 
 struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; }; // pad1 = slot + 1: split-K part, the raw tile goes to scratch slot `slot`;
 // in reduce_tasks: k0 = first slot, kw = number of parts
 //  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
-struct EaTask    { i32 front, j0, j1, pad; };                        // parent columns [j0, j1)
+struct EaTask    { i32 front, j0, j1, bidx; };                       // parent columns [j0, j1) = boundaries bidx, bidx + 1 of the front's extend-add ranges
 struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };
 // sweep items (LK_FWD_SWEEP): k0/nb = first row / rows of the chunk (<= SWEEP_NB pivot rows or <= SOLVE_NB rows below),
 //   slot = 1 pivot block (solve + publish) | 0 rows below, nslot = SWEEP_NB-wide solved blocks to consume (0 .. nslot-1);
@@ -106,6 +107,7 @@ struct Symbolic {
     std::vector<i32> sn_of_col;
     std::vector<i32> rowidx;               // concatenated front row lists (permuted indices)
     std::vector<i32> rel;                  // concatenated relative indices
+    std::vector<i32> ea_tab;               // per child front: lower bounds of its rel list at the parent's extend-add range boundaries
     std::vector<i64> gth_ptr, gth_src;     // forward gather lists: front row (rowoff + t) -> children's uc entries, in child order
     std::vector<i32> children;             // concatenated child lists
     std::vector<i32> depth;                // depth of each front (roots = 0)
