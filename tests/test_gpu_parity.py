@@ -325,6 +325,35 @@ def test_c4_full_scale_identities_and_stream_groups():
     assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
 
 
+def test_headline_instance_identities_and_linearity():
+    """The north-star headline instance at FULL size (100 blocks x (20 000 inequality rows x 10 000 vars) + 1000 linking
+    rows: m = 2 001 000, n = 3 000 000 with slacks, 270 000 isolated 1 x 1 fronts): the residual identities of
+    src/KKT/Test/test.jl:39-43, and linearity of solve! in the right-hand side (size-independent): the solution for
+    xi_1 + 2 xi_2 equals sol_1 + 2 sol_2 to rounding."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from workloads import block_angular_lp, kernel_inputs
+    A, row_block = block_angular_lp(100, 20000, 10000, 1000, 4, 0.5, ineq=True)
+    m, n = A.shape
+    assert (m, n) == (2001000, 3000000)
+    th, rp, rd, xp, xd = kernel_inputs(m, n, 7, "mid")
+    kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=row_block))
+    tk.update(kkt, th, rp, rd)
+    dx = np.zeros(n); dy = np.zeros(m)
+    tk.solve(dx, dy, kkt, xp, xd)
+    r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+    scale = 1 + max(np.abs(xp).max(), np.abs(xd).max())
+    assert r1 <= 1e-8 * scale * max(1.0, np.abs(dy).max()) and r2 <= 1e-8 * scale * max(1.0, np.abs(dx).max())
+    rng = np.random.default_rng(3)
+    xp2, xd2 = rng.standard_normal(m), rng.standard_normal(n)
+    dx2 = np.zeros(n); dy2 = np.zeros(m); dx3 = np.zeros(n); dy3 = np.zeros(m)
+    tk.solve(dx2, dy2, kkt, xp2, xd2)
+    tk.solve(dx3, dy3, kkt, xp + 2 * xp2, xd + 2 * xd2)
+    assert np.abs(dy3 - (dy + 2 * dy2)).max() <= 1e-9 * max(1.0, np.abs(dy3).max())
+    assert np.abs(dx3 - (dx + 2 * dx2)).max() <= 1e-9 * max(1.0, np.abs(dx3).max())
+    kkt.close()
+
+
 def test_mpc_starting_point_pattern():
     """MPC's starting point calls update!(zeros(n), ones(n), 1e-6*ones(m)) and two solves with one
     zero right-hand-side half each (/root/reference/src/IPM/MPC/MPC.jl:359-363): D = 1,
