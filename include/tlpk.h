@@ -41,7 +41,7 @@ typedef struct tlpk_handle tlpk_handle;
 #define TLPK_SYSTEM_K1 0     /* normal equations  A D A' + Rd, Cholesky            (Cholmod/spd.jl) */
 #define TLPK_SYSTEM_K2 1     /* augmented system [-(Theta^-1+Rp) A'; A Rd], signed Cholesky L S L' = the LDL' of a
                                 quasi-definite matrix without pivoting (Cholmod/sqd.jl, LDLFactorizations/ldlfact.jl);
-                                single GPU, no row_block */
+                                single GPU (nranks = 1); row_block gives per-block ordering, stream groups and a root front */
 
 /* ordering selector */
 #define TLPK_ORDER_AMD 0

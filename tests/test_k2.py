@@ -30,8 +30,35 @@ def test_k2_analyse_structure():
     # nnz(L) of our ordering vs the K2 oracle's own symbolic factorisation with the same permutation
     orc = OracleK2(A, p)
     assert st["nnzL"] >= orc.nnzL                              # relaxed supernodes may add explicit zeros, never lose entries
-    with pytest.raises(tk.DimensionMismatch):
-        tk.setup(A, tk.K2(), tk.Backend(device=-1, row_block=np.zeros(40, dtype=np.int64)))
+
+
+def test_k2_block_angular_structure_and_emulated_schedule():
+    """K2 with a block-angular row partition: the nodes of the augmented system inherit the blocks of the rows, the
+    linking constraints and the variables that only touch them form the root front; the signed schedule through the numpy
+    emulator against the K2 oracle with the same permutation."""
+    from helpers import block_angular
+    A, row_block = block_angular(nblocks=5, mk=60, nk=130, m0=12, nnz_in=3, link_prob=0.5, seed=11)
+    A = sp.hstack([A, sp.csc_matrix((np.ones(12), (np.arange(A.shape[0] - 12, A.shape[0]), np.arange(12))), shape=(A.shape[0], 12))]).tocsc()
+    m, n = A.shape                                          # + 12 columns that touch linking rows only (their slacks)
+    kkt = k2_setup(A, row_block=row_block)
+    st = kkt.stats()
+    assert st["n_blocks"] == 5 and tk.linear_system(kkt) == "Augmented system (K2)"
+    p = kkt.perm()
+    assert sorted(p.tolist()) == list(range(m + n))
+    link_nodes = set((n + np.flatnonzero(row_block < 0)).tolist()) | set(range(n - 12, n))
+    assert set(p[-len(link_nodes):].tolist()) == link_nodes    # ordered last: the root front
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 5)
+    em = Emulator(kkt)
+    em.update(th, rp, rd)
+    assert em.fail_col is None
+    dx, dy = em.solve(xp, xd, A)
+    orc = OracleK2(A, p); orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    assert np.abs(dy - dyo).max() <= 1e-9 * max(1.0, np.abs(dyo).max())
+    assert np.abs(dx - dxo).max() <= 1e-9 * max(1.0, np.abs(dxo).max())
+    bad = row_block.copy(); bad[0] = 1 - bad[0] if bad[0] in (0, 1) else 0
+    with pytest.raises(Exception):                          # a column then couples two diagonal blocks
+        k2_setup(A, row_block=bad)
 
 
 @pytest.mark.parametrize("g", load_golden(), ids=lambda g: g["name"])
@@ -119,6 +146,23 @@ def test_k2_golden_vectors_on_device(g):
 def test_k2_random_sparse_vs_k2_oracle(seed):
     A = random_lp_matrix(300 + 170 * seed, 800 + 300 * seed, 3, 200 + seed, slack=(seed == 1))
     gpu_compare(A, seed, relax=(seed != 2))
+
+
+@pytest.mark.gpu
+def test_k2_block_angular_on_device():
+    """K2 on a block-angular LP (two stream groups, root front with both signs) against the K2 oracle and the K1 path."""
+    from helpers import block_angular
+    A, row_block = block_angular(nblocks=8, mk=300, nk=600, m0=60, nnz_in=3, link_prob=0.5, seed=5)
+    kkt, _, _ = gpu_compare(A, 3, row_block=row_block)
+    assert kkt.stats()["n_blocks"] == 8
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 3)
+    k1 = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=row_block))
+    tk.update(k1, th, rp, rd); tk.update(kkt, th, rp, rd)
+    d1 = (np.zeros(n), np.zeros(m)); d2 = (np.zeros(n), np.zeros(m))
+    tk.solve(d1[0], d1[1], k1, xp, xd); tk.solve(d2[0], d2[1], kkt, xp, xd)
+    assert np.abs(d1[1] - d2[1]).max() <= 1e-8 * max(1.0, np.abs(d1[1]).max())
+    assert np.abs(d1[0] - d2[0]).max() <= 1e-8 * max(1.0, np.abs(d1[0]).max())
 
 
 @pytest.mark.gpu

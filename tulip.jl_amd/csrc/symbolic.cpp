@@ -970,7 +970,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
 int analyse_k2(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
                int base, const Options &opt_in) {
     if (m < 0 || n < 0 || (base != 0 && base != 1) || !colptr) return fail(S, TLPK_BADARG, "bad dimensions or index base");
-    if (opt_in.row_block || opt_in.nranks > 1) return fail(S, TLPK_BADARG, "the augmented system (K2) is single-GPU and takes no row_block");
+    if (opt_in.nranks > 1) return fail(S, TLPK_BADARG, "the augmented system (K2) is single-GPU");
     if (opt_in.ordering == TLPK_ORDER_USER) return fail(S, TLPK_BADARG, "user_perm is not supported for K2");
     const i64 nnz = colptr[n] - base;
     if (nnz < 0 || m + n >= ((i64)1 << 31) || nnz >= ((i64)1 << 30)) return fail(S, TLPK_TOO_LARGE, "augmented system exceeds int32");
@@ -990,6 +990,26 @@ int analyse_k2(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, 
     bp[(size_t)nnz] = 2 * nnz;
     Options opt = opt_in;
     opt.system = 1; opt.k2_n = n;
+    // Block-angular LPs: the nodes of the augmented system inherit the blocks of the rows -- constraint node n + i that of
+    // row i, variable node j that of the diagonal-block rows its column touches (a column with entries in linking rows
+    // only, e.g. a linking row's slack, joins the linking nodes: -1 = root front).  Ordering per block, stream groups and
+    // the root front then work as for K1; the root mixes both signs, which the signed Cholesky does not mind.
+    std::vector<i64> node_block;
+    if (opt_in.row_block) {
+        node_block.assign((size_t)(m + n), -1);
+        for (i64 i = 0; i < m; ++i) node_block[(size_t)(n + i)] = opt_in.row_block[i];
+        for (i64 j = 0; j < n; ++j) {
+            i64 b = -1;
+            for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; ++p) {
+                const i64 rb = opt_in.row_block[rowval[p] - base];
+                if (rb < 0) continue;
+                if (b >= 0 && rb != b) return fail(S, TLPK_BADARG, "row_block is not a block-angular partition: a column couples two diagonal blocks");
+                b = rb;
+            }
+            node_block[(size_t)j] = b;
+        }
+        opt.row_block = node_block.data();
+    }
     const int rc = analyse(S, m + n, nnz, bp.data(), bi.data(), bx.data(), 0, opt);
     if (rc != TLPK_OK) return rc;
     S.system = 1; S.k2_n = n; S.k2_m = m;
