@@ -211,7 +211,6 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
     double (*colbuf)[NB_IN] = reinterpret_cast<double (*)[NB_IN]>(scratch + NB_IN * (NB_IN + 1));
     double (*rowbuf)[NB_IN] = colbuf + 2;
     double *dg = scratch + NB_IN * (NB_IN + 1) + 4 * NB_IN;
-    const i32 f = fd.f;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     double *P = c.Lval + fd.loff + (i64)bk0 + (i64)bk0 * lda;
     const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
@@ -371,7 +370,7 @@ __global__ __launch_bounds__(256) void k_potrf_small(const PotrfTask *__restrict
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
     const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
-    const i32 f = fd.f, ns = fd.ns;
+    const i32 ns = fd.ns;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     double *P = c.Lval + fd.loff;
     const i32 ic = min(lane, ns - 1);
@@ -437,7 +436,6 @@ template <bool SIGNED = false>
 __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, const i32 k0, const i32 nb,
                                           const i32 row0, const i32 rowlim, const i32 kprev, double *Ws) {
     const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
-    const i32 f = fd.f;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     double *P = c.Lval + fd.loff;
     const double *W = front_dinv(c, fd, k0);
@@ -578,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     __shared__ double Ws[NB_IN * LDW];              // staged operand: Ws[k*LDW + c]
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, k0 = t.k0, w = t.nb;
+    const i32 k0 = t.k0, w = t.nb;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     double *P = c.Lval + fd.loff;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -700,7 +698,7 @@ __global__ __launch_bounds__(256) void k_trsm_thin(const TrsmTask *__restrict__ 
     __shared__ double Wl[TRSM_THIN_W * TRSM_THIN_W];
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, w = t.nb;
+    const i32 w = t.nb;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *W = front_dinv(c, fd, t.k0);          // w x w, column-major, ld = w, upper part zero
     for (int idx = threadIdx.x; idx < w * w; idx += 256) Wl[idx] = W[idx];
@@ -1041,15 +1039,20 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
 // cut into parts computed by different workgroups (k_update with pad1 != 0 writes the raw
 // 128 x 128 partial products to scratch); this kernel adds the parts of one tile in fixed order
 // and applies the sum to the tile's targets with the masks of the ordinary epilogue.
+// RED_SPLIT workgroups per tile (TILE / RED_SPLIT columns each): a launch that needed split-K has few tiles by
+// definition, one workgroup per tile pulled parts x 128 KB through ONE CU (105 us per launch on a 7 900-row front).
+constexpr int RED_SPLIT = 8;
 __global__ __launch_bounds__(256) void k_update_reduce(const UpdateTask *__restrict__ tasks, DevCtx c) {
-    const UpdateTask t = tasks[blockIdx.x];
+    const UpdateTask t = tasks[blockIdx.x / RED_SPLIT];
+    const int part = blockIdx.x % RED_SPLIT;
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *Sp = c.spart + (i64)t.k0 * (TILE * TILE);
     double *Pw = c.Lval + fd.loff;
     double *Uw = front_u(c, fd);
-    for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+    constexpr int PER = TILE * TILE / RED_SPLIT;
+    for (int e = part * PER + threadIdx.x; e < (part + 1) * PER; e += 256) {
         const i32 row = t.i0 + (e & (TILE - 1)), col = t.j0 + (e >> 7);
         if (row >= f || col >= t.jlim || row < col) continue;
         double sum = Sp[e];
@@ -1163,7 +1166,7 @@ constexpr int FWD_DIAG_SCRATCH = 2 * SOLVE_NB + 4 * NB_IN;     // doubles of LDS
 // for the previous one -- that was 22 us of a 37 us diagonal workgroup).
 template <bool BACKWARD, int WHICH>
 __device__ __forceinline__ void load_frag(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb, double (&w)[16]) {
-    const i32 f = fd.f, na = min(nb, NB_IN), nb2 = nb - na;
+    const i32 na = min(nb, NB_IN), nb2 = nb - na;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const int i = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const double *M; i64 ld; i32 nr, nc;                   // matrix, leading dimension, rows, columns
@@ -1356,7 +1359,7 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
     __shared__ double tacc[SOLVE_NB];       // running sums per column (a column belongs to one wave)
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    const i32 f = fd.f, ns = fd.ns, nb = t.nb, nrows = t.slot;
+    const i32 ns = fd.ns, nb = t.nb, nrows = t.slot;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const bool fused = t.nslot != 0;                     // workgroup-uniform
     const i32 *rows = c.rowidx + fd.rowoff;
@@ -1922,7 +1925,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
     case LK_TRSM: TLPK_LAUNCH_S(k_trsm, a.trsm_tasks); break;
     case LK_TRSM_THIN: TLPK_LAUNCH_S(k_trsm_thin, a.trsm_tasks); break;
     case LK_UPDATE: TLPK_LAUNCH_S(k_update, a.update_tasks); break;
-    case LK_UPDATE_REDUCE: hipLaunchKernelGGL(k_update_reduce, g, dim3(256), 0, st, a.reduce_tasks + L.first, a.ctx); break;
+    case LK_UPDATE_REDUCE: hipLaunchKernelGGL(k_update_reduce, dim3((unsigned)L.count * RED_SPLIT), dim3(256), 0, st, a.reduce_tasks + L.first, a.ctx); break;
     case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;
     case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(256), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
     case LK_FWD_UPDATE: hipLaunchKernelGGL(k_fwd_update, g, dim3(256), 0, st, a.fwd_update_tasks + L.first, a.ctx); break;
