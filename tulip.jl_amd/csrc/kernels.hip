@@ -287,7 +287,15 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
                 for (int q = 0; q <= jq; ++q) rowbuf[pb][cg + 4 * q] = wv[q];   // W[j][0 .. j]
             }
             __syncthreads();
+            // every LDS read of the step is issued here, before the pivot arithmetic: the serial chain of a column is one
+            // LDS round trip + the reciprocal square root, not three round trips
             double d = colbuf[pb][j];
+            const double crj = colbuf[pb][r];                                   // A[r][j] of this thread's row
+            double cv[16], rv[16];
+#pragma unroll
+            for (int q = jq; q < 16; ++q) cv[q] = colbuf[pb][cg + 4 * q];
+#pragma unroll
+            for (int q = 0; q <= jq; ++q) rv[q] = rowbuf[pb][cg + 4 * q];
             const double sj = SIGNED ? sg[bk0 + j] : 1.0;
             if (!(sj * d > 0.0)) {
                 if (tid == 0) atomicMin(c.info, fd.col0 + bk0 + j);
@@ -303,24 +311,17 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
             sq = fma(0.5 * isq, fma(-sq, sq, d), sq);
             const double inv2 = SIGNED ? isq * isq * sj : isq * isq;            // 1 / (signed pivot)
             if (SIGNED) isq *= sj;                                              // column scale s_j / sqrt|d|
-            const double arj = (rok && r > j) ? colbuf[pb][r] * inv2 : 0.0;    // multiplier L~[r][j]
-            // all LDS reads first (independent), then branch-free predicated updates
-            double cv[16], rv[16];
+            const double arj = (rok && r > j) ? crj * inv2 : 0.0;              // multiplier L~[r][j] (0 for the rows above)
+            // Branch-free updates without per-entry masks:
+            //  * A[r][col] -= arj * A[col][j] for the columns after j.  Registers q > jq hold only such columns; in
+            //    register jq only the threads with cg > jj do.  Entries above the diagonal (col > r) are never read
+            //    (they start at 0, stay finite, and are neither broadcast for a row <= their column nor stored);
+            //  * W[r][c] -= arj * W[j][c]: row j of the inverse is zero beyond column j, no mask needed.
 #pragma unroll
-            for (int q = jq; q < 16; ++q) cv[q] = colbuf[pb][cg + 4 * q];
+            for (int q = jq + 1; q < 16; ++q) av[q] = fma(-arj, cv[q], av[q]);
+            av[jq] = fma(-((cg > jj) ? arj : 0.0), cv[jq], av[jq]);
 #pragma unroll
-            for (int q = 0; q <= jq; ++q) rv[q] = rowbuf[pb][cg + 4 * q];
-#pragma unroll
-            for (int q = jq; q < 16; ++q) {
-                const i32 col = cg + 4 * q;
-                const double m1 = (col > j && col <= r) ? arj : 0.0;
-                av[q] = fma(-m1, cv[q], av[q]);
-            }
-#pragma unroll
-            for (int q = 0; q <= jq; ++q) {
-                const double m2 = (cg + 4 * q <= j) ? arj : 0.0;
-                wv[q] = fma(-m2, rv[q], wv[q]);
-            }
+            for (int q = 0; q <= jq; ++q) wv[q] = fma(-arj, rv[q], wv[q]);
             if (cg == jj) av[jq] = (r == j) ? sq : ((r > j) ? av[jq] * isq : av[jq]);   // finish column j: L[r][j]
         }
     }
