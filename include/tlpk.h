@@ -62,7 +62,8 @@ typedef struct tlpk_options {
                                   linking rows last as one dense root supernode. */
     int64_t mem_budget_bytes;  /* 0 = 90 % of the device's free memory (or unlimited if device=-1) */
     int32_t system;            /* TLPK_SYSTEM_K1 (default) | TLPK_SYSTEM_K2 */
-    int32_t reserved;
+    int32_t refine_steps;      /* iterative-refinement steps per solve on the residuals of the augmented system (each step = one more
+                                  pair of sweeps); 0 = none = the reference's behaviour (spd.jl:68 leaves it as a TODO).  K1, nranks = 1 */
 } tlpk_options;
 
 typedef struct tlpk_stats {

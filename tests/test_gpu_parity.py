@@ -163,6 +163,37 @@ def test_late_ipm_regime_at_c4_block_scale():
     late_regime_check(A, gpu_setup(A), 7, "5000x10000")
 
 
+def test_iterative_refinement_option():
+    """tlpk_options.refine_steps (off by default = spd.jl:68): one step on late-IPM data must not increase either residual
+    of the augmented system and must reduce the larger one; on well-conditioned data it changes the solution at rounding
+    level only; K2 / sharded handles refuse it."""
+    A = random_lp_matrix(1500, 3200, 4, 77)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 3, "late")
+    res = {}
+    for steps in (0, 1, 2):
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, refine=steps))
+        tk.update(kkt, th, rp, rd)
+        dx = np.zeros(n); dy = np.zeros(m)
+        tk.solve(dx, dy, kkt, xp, xd)
+        res[steps] = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+        kkt.close()
+    print("refinement late regime (r1, r2):", res)
+    assert max(res[1]) <= max(res[0]) and max(res[2]) <= 1.05 * max(res[1])
+    assert max(res[1]) <= 0.5 * max(res[0]) or max(res[0]) <= 1e-12 * (1 + np.abs(xp).max())
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 3, "mid")
+    sols = []
+    for steps in (0, 1):
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, refine=steps))
+        tk.update(kkt, th, rp, rd)
+        dx = np.zeros(n); dy = np.zeros(m)
+        tk.solve(dx, dy, kkt, xp, xd)
+        sols.append((dx, dy)); kkt.close()
+    assert np.abs(sols[0][1] - sols[1][1]).max() <= 1e-9 * max(1.0, np.abs(sols[0][1]).max())
+    with pytest.raises(Exception):
+        tk.setup(A, tk.K2(), tk.Backend(device=0, refine=1))
+
+
 def test_late_ipm_regime_block_angular_with_root_front():
     A, row_block = block_angular(nblocks=6, mk=700, nk=1400, m0=120, nnz_in=4, link_prob=0.5, seed=21)
     late_regime_check(A, gpu_setup(A, row_block=row_block), 5, "block-angular")

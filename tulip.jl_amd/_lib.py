@@ -26,7 +26,7 @@ class Options(C.Structure):
                 ("relax", C.c_int32), ("profile", C.c_int32), ("rank", C.c_int32),
                 ("nranks", C.c_int32), ("streams", C.c_int32),
                 ("user_perm", p64), ("row_block", p64), ("mem_budget_bytes", C.c_int64),
-                ("system", C.c_int32), ("reserved", C.c_int32)]
+                ("system", C.c_int32), ("refine_steps", C.c_int32)]
 
 
 class Stats(C.Structure):

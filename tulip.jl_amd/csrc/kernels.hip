@@ -1846,6 +1846,34 @@ __global__ void k_dx(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ 
     dx[j] = D[j] * (s - xi_d[j]);
 }
 
+// Optional iterative refinement (tlpk_options.refine_steps; the reference leaves it as a TODO, spd.jl:68): residuals of the
+// augmented system for the solution just computed,
+//   r1 = xi_p - A dx - Rd dy   (rows, CSR)        r2 = xi_d + (theta + Rp) dx - A' dy   (columns, CSC)
+// a second solve with (r1, r2) gives the correction that k_axpy2 adds.
+__global__ void k_resid_rows(i64 m, const i64 *__restrict__ Tp, const i32 *__restrict__ Tj, const double *__restrict__ Tx,
+                             const double *__restrict__ xi_p, const double *__restrict__ regD, const double *__restrict__ dx,
+                             const double *__restrict__ dy, double *__restrict__ r1) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double s = 0.0;
+    for (i64 q = Tp[i]; q < Tp[i + 1]; ++q) s += Tx[q] * dx[Tj[q]];
+    r1[i] = (xi_p[i] - regD[i] * dy[i]) - s;
+}
+__global__ void k_resid_cols(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ Ai, const double *__restrict__ Ax,
+                             const double *__restrict__ xi_d, const double *__restrict__ theta, const double *__restrict__ regP,
+                             const double *__restrict__ dx, const double *__restrict__ dy, double *__restrict__ r2) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) s += Ax[p] * dy[Ai[p]];
+    r2[j] = (xi_d[j] + (theta[j] + regP[j]) * dx[j]) - s;
+}
+__global__ void k_axpy2(i64 n, double *__restrict__ x, const double *__restrict__ dxc, i64 m, double *__restrict__ y, const double *__restrict__ dyc) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] += dxc[i];
+    if (i < m) y[i] += dyc[i];
+}
+
 // out = own + src[0] + src[1] + ... (fixed order): the root-panel / root-rhs reduction of the multi-device mode.
 // NOT in place: the ranks copy the result out of `out` at their own pace while the lead already factorises / solves
 // its own copy.
@@ -1961,6 +1989,15 @@ void launch_sum_to(hipStream_t st, i64 len, double *out, const double *own, cons
 }
 void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy_shared, int rank) {
     if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw, dy, dy_shared, rank);
+}
+void launch_residuals(hipStream_t st, const DevArrays &a, const double *xi_p, const double *xi_d, const double *theta, const double *regP,
+                      const double *regD, const double *dx, const double *dy, double *r1, double *r2) {
+    if (a.m > 0) hipLaunchKernelGGL(k_resid_rows, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.Tp, a.Tj, a.Tx, xi_p, regD, dx, dy, r1);
+    if (a.n > 0) hipLaunchKernelGGL(k_resid_cols, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, xi_d, theta, regP, dx, dy, r2);
+}
+void launch_axpy2(hipStream_t st, i64 n, double *x, const double *dxc, i64 m, double *y, const double *dyc) {
+    const i64 len = std::max(n, m);
+    if (len > 0) hipLaunchKernelGGL(k_axpy2, dim3(nblk(len, 256)), dim3(256), 0, st, n, x, dxc, m, y, dyc);
 }
 void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx, int local_only) {
     if (a.n > 0) hipLaunchKernelGGL(k_dx, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, D, dy, xi_d, a.col_local, dx, local_only);

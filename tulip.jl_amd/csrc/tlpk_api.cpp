@@ -207,6 +207,7 @@ int upload_all(tlpk_handle *h) {
     const i64 nn = std::max<i64>(S.n, S.k2_n + 1);             // K2: user vectors have k2_n entries, D2 one more
     AL(h->d_theta, nn); AL(h->d_regP, nn); AL(h->d_regD, S.m); AL(h->d_D, nn);
     AL(h->d_xip, S.m); AL(h->d_xid, nn); AL(h->d_dx, nn); AL(h->d_dy, S.m);
+    if (h->refine_steps > 0) { AL(h->d_r1, S.m); AL(h->d_r2, nn); AL(h->d_cx, nn); AL(h->d_cy, S.m); }
     d.ctx.csign = nullptr;
     d.ctx.upd_remap = 2;
     if (const char *e = std::getenv("TLPK_UPD_REMAP")) d.ctx.upd_remap = std::atoi(e);      // tuning knob
@@ -282,6 +283,11 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
         h->opt.rank = def.rank; h->opt.nranks = def.nranks < 1 ? 1 : def.nranks;
         h->opt.streams = def.streams;
         h->opt.system = (def.system == TLPK_SYSTEM_K2) ? 1 : 0;
+        h->refine_steps = def.refine_steps;
+        if (def.refine_steps < 0 || (def.refine_steps > 0 && (h->opt.system == 1 || h->opt.nranks > 1))) {
+            h->last_error = "refine_steps: K1 on one rank only, >= 0";
+            rc = TLPK_BADARG;
+        }
         if (def.row_block && m > 0) {
             h->row_block_copy.assign(def.row_block, def.row_block + m);
             h->opt.row_block = h->row_block_copy.data();
@@ -295,8 +301,9 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
         if (const char *e = std::getenv("TLPK_SERIAL")) h->serial = std::atoi(e) != 0;
         if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
         const auto t0 = std::chrono::steady_clock::now();
-        rc = (h->opt.system == 1) ? analyse_k2(h->S, m, n, colptr, rowval, nzval, index_base, h->opt)
-                                  : analyse(h->S, m, n, colptr, rowval, nzval, index_base, h->opt);
+        if (rc == TLPK_OK)
+            rc = (h->opt.system == 1) ? analyse_k2(h->S, m, n, colptr, rowval, nzval, index_base, h->opt)
+                                      : analyse(h->S, m, n, colptr, rowval, nzval, index_base, h->opt);
         h->ms_analyse = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         h->last_error = h->S.error;
         if (rc == TLPK_OK) {
@@ -585,7 +592,17 @@ int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     if (int g = sharded_needs_split(h, "tlpk_solve_device")) return g;
     int rc = tlpk_solve_local(h, d_xip, d_xid);
     if (rc != TLPK_OK) return rc;
-    return tlpk_solve_finish(h, d_dx, d_dy, d_xid);
+    rc = tlpk_solve_finish(h, d_dx, d_dy, d_xid);
+    // optional iterative refinement on the residuals of the augmented system (KKT.jl:70-75): each step is one more solve with
+    // (r1, r2) as right-hand side, its result added to (dx, dy).  Off by default = the reference (spd.jl:68).
+    for (int it = 0; it < h->refine_steps && rc == TLPK_OK; ++it) {
+        launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, d_dx, d_dy, h->d_r1, h->d_r2);
+        rc = tlpk_solve_local(h, h->d_r1, h->d_r2);
+        if (rc == TLPK_OK) rc = tlpk_solve_finish(h, h->d_cx, h->d_cy, h->d_r2);
+        if (rc == TLPK_OK) launch_axpy2(h->stream, h->S.n, d_dx, h->d_cx, h->S.m, d_dy, h->d_cy);
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    }
+    return rc;
 }
 
 int tlpk_sync(tlpk_handle *h) {

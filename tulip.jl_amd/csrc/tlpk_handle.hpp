@@ -37,6 +37,8 @@ struct tlpk_handle {
     i64 device_bytes = 0;
     double *d_theta = nullptr, *d_regP = nullptr, *d_regD = nullptr, *d_D = nullptr;
     double *d_xip = nullptr, *d_xid = nullptr, *d_dx = nullptr, *d_dy = nullptr;
+    int refine_steps = 0;                         // tlpk_options.refine_steps
+    double *d_r1 = nullptr, *d_r2 = nullptr, *d_cx = nullptr, *d_cy = nullptr;   // refinement: residuals and correction
     int *h_info = nullptr;
     double *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-pointer entry points (lazily allocated)
     bool factored = false, local_done = false, solve_local_done = false, solve_timed = false;

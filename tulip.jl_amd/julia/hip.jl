@@ -22,12 +22,13 @@ import ..KKT: setup, update!, solve!, backend, linear_system
 using ...TLPLinearAlgebra.LibTLPK
 
 """
-    Backend(; device=0, row_block=nothing, streams=0, ngpus=1, devices=nothing)
+    Backend(; device=0, row_block=nothing, streams=0, ngpus=1, devices=nothing, refine=0)
 
 HIP (gfx950) backend.  `row_block` is the optional block-angular structure hook (length m; block id ≥ 0, or
 -1 for a linking row).  `ngpus > 1` (block-angular LPs, system `K1`): this ONE Julia process shards the
 diagonal blocks over `ngpus` devices of the node (`devices`: HIP ordinals, default `0:ngpus-1`); the
 linking-block reductions happen inside the library.  `streams`: concurrent stream groups (0 = auto).
+`refine`: iterative-refinement steps per `solve!` (0 = none, as `spd.jl:68`; `K1` on one GPU).
 """
 struct Backend <: AbstractKKTBackend
     device::Int
@@ -35,9 +36,10 @@ struct Backend <: AbstractKKTBackend
     streams::Int
     ngpus::Int
     devices::Union{Nothing,Vector{Int32}}
+    refine::Int
 end
-Backend(; device::Int=0, row_block=nothing, streams::Int=0, ngpus::Int=1, devices=nothing) =
-    Backend(device, row_block, streams, ngpus, devices === nothing ? nothing : Vector{Int32}(devices))
+Backend(; device::Int=0, row_block=nothing, streams::Int=0, ngpus::Int=1, devices=nothing, refine::Int=0) =
+    Backend(device, row_block, streams, ngpus, devices === nothing ? nothing : Vector{Int32}(devices), refine)
 
 """
     HIPNormalEquations
@@ -81,7 +83,7 @@ _system_code(::K2) = LibTLPK.TLPK_SYSTEM_K2
 function setup(A::SparseMatrixCSC{Float64,Int}, system::Union{K1,K2}, b::Backend)
     m, n = size(A)
     rc, h = LibTLPK.create(m, n, A.colptr, A.rowval, A.nzval; device=b.device, row_block=b.row_block,
-                           system=_system_code(system), streams=b.streams, ngpus=b.ngpus, devices=b.devices)
+                           system=_system_code(system), streams=b.streams, ngpus=b.ngpus, devices=b.devices, refine=b.refine)
     rc == LibTLPK.TLPK_OK || (h == C_NULL || LibTLPK.destroy(h); _check(rc, C_NULL, "KKT.setup"))
     return HIPNormalEquations(m, n, A, h)
 end

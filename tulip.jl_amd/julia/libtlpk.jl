@@ -49,7 +49,7 @@ Base.@kwdef mutable struct Options
     row_block::Ptr{Int64} = C_NULL
     mem_budget_bytes::Int64 = 0
     system::Int32 = 0            # TLPK_SYSTEM_K1 | TLPK_SYSTEM_K2
-    reserved::Int32 = 0
+    refine_steps::Int32 = 0
 end
 
 strerror(code::Integer) = unsafe_string(ccall((:tlpk_strerror, libtlpk[]), Cstring, (Cint,), code))
@@ -66,12 +66,13 @@ with its 1-based `colptr`/`rowval` (index_base = 1); the library copies everythi
 """
 function create(m::Int, n::Int, colptr::Vector{Int}, rowval::Vector{Int}, nzval::Vector{Float64};
                 device::Integer=0, row_block::Union{Nothing,Vector{Int}}=nothing, system::Int32=TLPK_SYSTEM_K1,
-                streams::Integer=0, ngpus::Integer=1, devices::Union{Nothing,Vector{Int32}}=nothing)
+                streams::Integer=0, ngpus::Integer=1, devices::Union{Nothing,Vector{Int32}}=nothing, refine::Integer=0)
     opt = Options()
     opt.struct_size = Int32(sizeof(Options))
     opt.device = Int32(device)
     opt.system = system
     opt.streams = Int32(streams)
+    opt.refine_steps = Int32(refine)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rb = row_block === nothing ? Int[] : row_block
     dv = devices === nothing ? Int32[] : devices

@@ -51,7 +51,7 @@ class Backend:
     """
 
     def __init__(self, device=0, ordering="amd", relax=True, row_block=None, user_perm=None,
-                 profile=False, rank=0, nranks=1, mem_budget_bytes=0, streams=0, ngpus=1, devices=None):
+                 profile=False, rank=0, nranks=1, mem_budget_bytes=0, streams=0, ngpus=1, devices=None, refine=0):
         self.device = device
         self.ordering = {"amd": _lib.ORDER_AMD, "natural": _lib.ORDER_NATURAL, "user": _lib.ORDER_USER}[ordering]
         self.relax = bool(relax)
@@ -61,6 +61,7 @@ class Backend:
         self.rank, self.nranks = int(rank), int(nranks)
         self.mem_budget_bytes = int(mem_budget_bytes)
         self.streams = int(streams)            # 0 = auto (2 concurrent block groups), 1 = single group
+        self.refine = int(refine)              # iterative-refinement steps per solve (0 = the reference's behaviour; K1, one rank)
         # single-process multi-GPU (block-angular LPs): one handle shards the diagonal blocks over `ngpus` devices
         self.ngpus = int(ngpus)
         self.devices = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
@@ -105,6 +106,7 @@ class HIPNormalEquations:
         opt.rank, opt.nranks = backend_.rank, backend_.nranks
         opt.mem_budget_bytes = backend_.mem_budget_bytes
         opt.streams = backend_.streams
+        opt.refine_steps = backend_.refine
         opt.system = system
         self.system = system
         self._keep = []
