@@ -101,7 +101,11 @@ static void build_schedule(Symbolic &S);
 // threads (every item writes its own outputs).  Returns false if a worker threw (out of memory).
 static unsigned host_threads(i64 n) {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return (unsigned)std::max<i64>(1, std::min<i64>({(i64)hw, 16, n}));
+    // up to a quarter of the hardware threads, at most 64 (env TLPK_HOST_THREADS overrides): the per-front / per-block phases
+    // of a block-angular LP with 64 diagonal blocks were 3-4 rounds deep with the old cap of 16 on a 256-thread host
+    static const i64 cap = [] { const char *e = std::getenv("TLPK_HOST_THREADS"); return e ? std::max<i64>(1, std::atoll(e)) : (i64)64; }();
+    const i64 mine = std::getenv("TLPK_HOST_THREADS") ? cap : std::min<i64>(cap, std::max<i64>(16, hw / 4));
+    return (unsigned)std::max<i64>(1, std::min<i64>({(i64)hw, mine, n}));
 }
 // `chunk` consecutive items go to the same thread (neighbouring items usually write neighbouring memory:
 // item-by-item hand-out made the threads fight over cache lines on instances with 400 000 small fronts).
