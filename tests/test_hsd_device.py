@@ -117,3 +117,24 @@ def test_device_hsd_retry_loop():
     dev, sd = device_hsd(lp)
     assert dev.timers["n_bump"] > 0 and sd["status"] == "Trm_Optimal"
     assert abs(sd["z_primal"] - BUMP_OPT) <= 1e-6 * (1 + abs(BUMP_OPT))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["lpex_opt.mps", "lpex_freevars.mps", "lpex_inf.mps", "stair25.mps"])
+def test_device_loops_on_the_augmented_system(name):
+    """DeviceHSD / DeviceMPC over a K2 handle (signed Cholesky of the augmented system, the reference's default linear
+    system): same status and objective as over K1."""
+    from tulip_jl_amd.hsd_device import DeviceHSD
+    from tulip_jl_amd.mpc_device import DeviceMPC
+    lp = read_free_mps(os.path.join(GOLDEN, name))
+    d = standard_form(lp)
+    for cls in (DeviceHSD, DeviceMPC):
+        r = {}
+        for sysm in ("K1", "K2"):
+            opt = cls(d.A, d.b, d.c, d.l, d.u, c0=d.c0, objsense_min=d.objsense, device=0, system=sysm).optimize()
+            r[sysm] = opt
+        assert tk.linear_system(r["K2"].kkt) == "Augmented system (K2)"
+        assert r["K1"].status == r["K2"].status
+        assert abs(r["K1"].niter - r["K2"].niter) <= 2
+        if r["K1"].status == "Trm_Optimal":
+            assert abs(r["K1"].primal_objective - r["K2"].primal_objective) <= 1e-7 * (1 + abs(r["K1"].primal_objective))

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <vector>
 
 #include "tlpk_handle.hpp"
 #include "tlpk_ipm.hpp"
@@ -62,15 +63,47 @@ int tlpk_ipm_load(tlpk_handle *h, const double *b, const double *c, const double
     if (h->opt.nranks > 1) { h->last_error = "the device-resident IPM vectors are single-rank"; return TLPK_BADARG; }
     if (h->ipm) { h->last_error = "tlpk_ipm_load called twice on one handle"; return TLPK_BADARG; }
     HIPCHK(h, hipSetDevice(h->device));
-    const i64 m = h->S.m, n = h->S.n;
+    const bool k2 = h->S.system == 1;
+    const i64 m = k2 ? h->S.k2_m : h->S.m, n = k2 ? h->S.k2_n : h->S.n;
     IpmState *sp = new (std::nothrow) IpmState();
     if (!sp) return TLPK_OOM;
     h->ipm = sp;
     IpmState &s = *sp;
     IpmVecs &v = s.v;
     v.m = m; v.n = n;
-    v.Ap = h->d.Ap; v.Ai = h->d.Ai; v.Ax = h->d.Ax; v.Tp = h->d.Tp; v.Tj = h->d.Tj; v.Tx = h->d.Tx;
     int rc;
+    if (!k2) { v.Ap = h->d.Ap; v.Ai = h->d.Ai; v.Ax = h->d.Ax; v.Tp = h->d.Tp; v.Tj = h->d.Tj; v.Tx = h->d.Tx; }
+    else {
+        // K2 handle: the analyse phase holds the incidence matrix of the augmented system (column p = entry p of A: 1 on
+        // variable node j, A[i,j] on constraint node n + i, in A's column-major entry order) -- rebuild A (CSC + CSR) from
+        // it for the residual / right-hand-side kernels
+        const Symbolic &S = h->S;
+        const i64 nnz = S.n;
+        std::vector<i64> ap((size_t)n + 1, 0), tp((size_t)m + 1, 0);
+        std::vector<i32> ai((size_t)nnz), tj((size_t)nnz);
+        std::vector<double> ax((size_t)nnz), tx((size_t)nnz);
+        for (i64 p = 0; p < nnz; ++p) {
+            if (S.Ap[(size_t)p + 1] - S.Ap[(size_t)p] != 2) { h->last_error = "K2 incidence matrix: unexpected column"; return TLPK_INTERNAL; }
+            const i64 q = S.Ap[(size_t)p];
+            const i32 a = S.Ai[(size_t)q], b = S.Ai[(size_t)q + 1];
+            const bool afirst = a < (i32)n;                       // the variable node is the smaller index
+            const i32 j = afirst ? a : b, i = (afirst ? b : a) - (i32)n;
+            ai[(size_t)p] = i; ax[(size_t)p] = S.Ax[(size_t)q + (afirst ? 1 : 0)];
+            ++ap[(size_t)j + 1]; ++tp[(size_t)i + 1];
+        }
+        for (i64 j = 0; j < n; ++j) ap[(size_t)j + 1] += ap[(size_t)j];
+        for (i64 i = 0; i < m; ++i) tp[(size_t)i + 1] += tp[(size_t)i];
+        // entries of A come column by column (p ascending = j non-decreasing): ap is consistent with ai / ax as stored
+        { std::vector<i64> cur(tp.begin(), tp.end() - 1); i64 p = 0;
+          for (i64 j = 0; j < n; ++j) for (; p < ap[(size_t)j + 1]; ++p) { const i64 c = cur[(size_t)ai[(size_t)p]]++; tj[(size_t)c] = (i32)j; tx[(size_t)c] = ax[(size_t)p]; } }
+        i64 *dp; i32 *di; double *dxv;
+        if ((rc = dev_upload(h, &dp, ap)) != TLPK_OK) return rc; v.Ap = dp;
+        if ((rc = dev_upload(h, &di, ai)) != TLPK_OK) return rc; v.Ai = di;
+        if ((rc = dev_upload(h, &dxv, ax)) != TLPK_OK) return rc; v.Ax = dxv;
+        if ((rc = dev_upload(h, &dp, tp)) != TLPK_OK) return rc; v.Tp = dp;
+        if ((rc = dev_upload(h, &di, tj)) != TLPK_OK) return rc; v.Tj = di;
+        if ((rc = dev_upload(h, &dxv, tx)) != TLPK_OK) return rc; v.Tx = dxv;
+    }
     // problem data: b, c, l .* lflag, u .* uflag, flags (ipmdata.jl:46-47)
     std::vector<double> lz((size_t)n), uz((size_t)n), lf((size_t)n), uf((size_t)n);
     for (i64 j = 0; j < n; ++j) {

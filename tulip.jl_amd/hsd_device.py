@@ -17,7 +17,7 @@ import time
 import numpy as np
 
 from . import _lib
-from .kkt import K1, Backend, DimensionMismatch, OutOfMemoryError, PosDefException, _raise_for, setup
+from .kkt import K1, K2, Backend, DimensionMismatch, OutOfMemoryError, PosDefException, _raise_for, setup
 
 SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))
 INF = float("inf")
@@ -36,8 +36,9 @@ class Options:
 
 
 class DeviceHSD:
-    def __init__(self, A, b, c, l, u, c0=0.0, objsense_min=True, options=None, **backend_kw):
-        self.kkt = setup(A, K1(), Backend(**backend_kw))
+    def __init__(self, A, b, c, l, u, c0=0.0, objsense_min=True, options=None, system="K1", **backend_kw):
+        # system: "K1" normal equations | "K2" augmented system (the reference's default for Float64, KKT.jl:134-141)
+        self.kkt = setup(A, K2() if str(system).upper() == "K2" else K1(), Backend(**backend_kw))
         self.m, self.n = self.kkt.m, self.kkt.n
         self.opt = options or Options()
         self._b = np.ascontiguousarray(b, dtype=np.float64); self._c = np.ascontiguousarray(c, dtype=np.float64)
