@@ -195,6 +195,23 @@ def test_free_column_singleton():
     solve_and_check(lp, (FreeColumnSingleton,))
 
 
+def test_free_column_singleton_with_a_multiplier_of_the_wrong_sign_is_unbounded():
+    """x2 is free, appears only in the one-sided row  x0 + 2 x2 >= 1  and has cost -1: its dual constraint 2 y = -1 needs
+    y < 0 on a row that has no upper bound -> dual infeasible.  free_column_singleton.jl:79 adds y * Inf to the objective
+    constant instead (the reference option reproduces that: the interior-point run then cannot terminate properly)."""
+    from tulip_jl_amd.presolve import Presolve, PresolveOptions
+    A = sp.csc_matrix(np.array([[1.0, 0.0, 2.0], [1.0, 1.0, 0.0]]))
+    lp = LP(A, [1.0, 1.0, -1.0], 0.0, [1.0, 0.5], [INF, 2.0], [0.0, 0.0, -INF], [3.0, 3.0, INF])
+    assert highs(lp).status == 3                          # HiGHS: unbounded
+    m = Model(lp).optimize(ipm=cpu_ipm())
+    assert m.status == "Trm_DualInfeasible" and m.inner is None
+    d = m.solution.x
+    assert m.solution.primal_status == "Sln_InfeasibilityCertificate" and d[2] > 0
+    assert float(lp.obj @ d) < 0 and ((lp.A @ d)[0] >= 0) and abs((lp.A @ d)[1]) <= 1e-12 and d[0] == 0 and d[1] == 0
+    ps = Presolve(lp, PresolveOptions(ReferenceUnboundedSingleton=True))
+    assert ps.run() == "Trm_Unknown" and ps.obj0 == -INF  # as the reference: objective constant -Inf, no verdict
+
+
 def test_dominated_column():
     # x2 >= 0 has cost +5 and only helps "<=" rows' slack the wrong way: reduced cost always positive -> lower bound
     A = sp.csc_matrix(np.array([[1.0, 1.0, 1.0], [1.0, -1.0, 2.0]]))
@@ -315,7 +332,7 @@ def test_generated_netlib_class_lps_with_presolve(name, algorithm):
     assert m.presolve.nrow <= lp.A.shape[0] and m.presolve.ncol <= lp.A.shape[1]
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(16))
 def test_random_lps_with_reducible_structure(seed):
     """Random feasible LPs salted with fixed variables, singleton rows, empty rows / columns, free singleton columns
     and redundant rows: presolve + postsolve must return an optimal primal-dual pair of the original problem."""
@@ -341,10 +358,13 @@ def test_random_lps_with_reducible_structure(seed):
     lcon[9], ucon[9] = -1e6, 1e6                           # redundant row
     obj = rng.normal(size=n_)
     obj[11] = abs(obj[11])
-    lp = LP(A, obj, 1.25, lcon, ucon, lvar, uvar)
+    lp = LP(A, obj if seed % 3 else -obj, 1.25, lcon, ucon, lvar, uvar, objsense_min=bool(seed % 3))   # every third one maximises
     r = highs(lp)
-    if r.status != 0:
-        pytest.skip("generated LP not solvable to optimality")
+    if r.status != 0:                                      # HiGHS: 2 infeasible, 3 unbounded -- the front end must agree
+        mod = Model(lp).optimize(ipm=cpu_ipm())
+        assert r.status in (2, 3), r.message
+        assert mod.status == {2: "Trm_PrimalInfeasible", 3: "Trm_DualInfeasible"}[r.status]
+        return
     mod = solve_and_check(lp, (FixedVariable, EmptyRow, EmptyColumn))
     assert mod.presolve.nrow < m_ and mod.presolve.ncol < n_
 

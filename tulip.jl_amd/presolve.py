@@ -80,6 +80,7 @@ class PresolveOptions:                      # Presolve.jl:1-6
     TolerancePFeas: float = SQRT_EPS
     ToleranceDFeas: float = SQRT_EPS
     ReferenceForcingRowDual: bool = False   # see _undo_forcing_row
+    ReferenceUnboundedSingleton: bool = False   # see _free_column_singleton
 
 
 # recorded transformations (reversed in postsolve, last first)
@@ -436,7 +437,17 @@ class Presolve:
             if not (l <= lo <= up <= u):
                 return
         y = self.obj[j] / aij
-        self.obj0 += y * lr if y >= 0.0 else y * ur
+        bound = lr if y >= 0.0 else ur                        # the row bound its multiplier prices
+        if not math.isfinite(bound) and y != 0.0 and not self.opt.ReferenceUnboundedSingleton:
+            # deviation: the multiplier has the sign of a bound the row does not have -- the dual constraint of column j
+            # cannot hold, the LP is dual infeasible (unbounded along x_j if it is feasible at all).
+            # free_column_singleton.jl:79 adds y * (+-Inf) to the objective constant here and carries on; the
+            # interior-point method then runs into its iteration limit on an objective of -Inf.
+            step = math.copysign(1.0, aij) * (1.0 if y < 0.0 else -1.0)
+            def pray(sol):
+                sol.x[self.new_var_idx[j]] = step
+            return self._decided(TRM_DUAL_INFEASIBLE, primal_ray=pray)
+        self.obj0 += y * bound
         rc, rv = [], []
         for j_, a_ in zip(cols, rvals):
             if not self.colflag[j_] or j_ == j:
