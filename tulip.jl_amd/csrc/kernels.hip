@@ -574,7 +574,10 @@ __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restri
 // the stored factor block X gets its column signs only at the final store.
 template <bool SIGNED>
 __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
-    __shared__ double Ws[NB_IN * LDW];              // staged operand: Ws[k*LDW + c]
+    // two operand buffers: the block staged for step n + 1 never overwrites what slower waves still read for step n, so a
+    // step needs ONE barrier (after its stores) instead of two
+    __shared__ double Wb[2][NB_IN * LDW];           // staged operand: Wb[.][k*LDW + c]
+    int wsel = 0;
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb;
@@ -624,7 +627,9 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
             }
         }
     };
+    double *Ws = Wb[0];
     auto stage = [&]() {
+        Ws = Wb[wsel]; wsel ^= 1;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int idx = tid + 256 * u, cc = idx & (NB_IN - 1), k = idx >> 6;
@@ -640,7 +645,6 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
             for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < i; ++j) {            // solved steps: acc += X_j * L[k0+64i.., k0+64j..]'
-                __syncthreads();
                 stage();
                 __syncthreads();
                 fetch(i, j + 1);
@@ -658,7 +662,6 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bf[i][4 * a + q] -= acc[a][q];
             }
-            __syncthreads();
             stage();
             __syncthreads();
             if (i < 3 && 64 * (i + 1) < w) fetch(i + 1, 0);
