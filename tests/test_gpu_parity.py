@@ -262,7 +262,8 @@ def test_bitwise_deterministic():
         tk.solve(dx, dy, kkt, xp, xd)
         outs.append((dx.copy(), dy.copy(), kkt.factor_panels().copy()))
     for o in outs[1:]:
-        assert (o[0] == outs[0][0]).all() and (o[1] == outs[0][1]).all() and (o[2] == outs[0][2]).all()
+        # (the blocks above the diagonal blocks of a panel are never written nor read: equal_nan covers TLPK_POISON=1 runs)
+        assert (o[0] == outs[0][0]).all() and (o[1] == outs[0][1]).all() and np.array_equal(o[2], outs[0][2], equal_nan=True)
 
 
 def test_degenerate_shapes():

@@ -104,6 +104,28 @@ __global__ void k_single_solve(i64 n, const i64 *__restrict__ dinvoff, const i32
     xw[col[i]] = (xw[col[i]] * w) * w;                            // forward (x L^-1) then backward (x L^-1)
 }
 
+// Zero-fill of the factor storage before the assembly.  One workgroup per 64-column slice of a panel: rows from the slice's
+// first row down to lda.  The blocks ABOVE the 64 x 64 diagonal blocks (39 % of a square pivot block) are never read by any
+// kernel -- updates, trsm, extend-add, assembly and the sweeps address rows >= the block's first row only -- and stay
+// whatever the allocation held (a plain memset of Lval wrote 8.4 GB per factorisation on config C4, this writes 5.3).
+__global__ __launch_bounds__(256) void k_zero_panels(const i32 *__restrict__ tasks, DevCtx c) {
+    const i32 s = tasks[2 * blockIdx.x], c0 = tasks[2 * blockIdx.x + 1];
+    const FrontDesc fd = c.fronts[s];
+    const i32 lda = fd.lda, nc = min(NB_IN, fd.ns - c0);
+    double *P = c.Lval + fd.loff + (i64)c0 * lda;
+    for (i32 col = 0; col < nc; ++col)
+        for (i32 r = c0 + (i32)threadIdx.x; r < lda; r += 256) P[(i64)col * lda + r] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_zero_small(const i32 *__restrict__ fronts, i64 n, DevCtx c) {      // one wave per small front
+    const i64 idx = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= n) return;
+    const FrontDesc fd = c.fronts[fronts[idx]];
+    const i64 len = (i64)fd.lda * fd.ns;
+    double *P = c.Lval + fd.loff;
+    for (i64 e = threadIdx.x & 63; e < len; e += 64) P[e] = 0.0;
+}
+
 // ------------------------------------------------------------------------------------------
 // extend-add: one workgroup owns parent columns [j0, j1) and adds, child after child, the child
 // update-matrix columns that land in its range (panel columns before the front is factorised, U
@@ -1946,6 +1968,10 @@ static inline unsigned nblk(i64 n, int b) { return (unsigned)((n + b - 1) / b); 
 
 void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D) {
     if (n > 0) hipLaunchKernelGGL(k_compute_d, dim3(nblk(n, 256)), dim3(256), 0, st, n, theta, regP, D);
+}
+void launch_zero_panels(hipStream_t st, const DevArrays &a) {
+    if (a.n_zero_tasks > 0) hipLaunchKernelGGL(k_zero_panels, dim3((unsigned)a.n_zero_tasks), dim3(256), 0, st, a.zero_tasks, a.ctx);
+    if (a.n_zero_small > 0) hipLaunchKernelGGL(k_zero_small, dim3((unsigned)((a.n_zero_small + 3) / 4)), dim3(256), 0, st, a.zero_small, a.n_zero_small, a.ctx);
 }
 void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD) {
     if (a.n_asm > 0)

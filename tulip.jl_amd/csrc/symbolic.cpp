@@ -1043,6 +1043,15 @@ static void build_schedule(Symbolic &S) {
             if (S.front_local[s]) { S.single_loff.push_back(w.loff); S.single_dinvoff.push_back(w.dinvoff); S.single_col.push_back(w.col0); }
         }
     }
+    // zero-fill of the panels before the assembly: per 64-column slice only the rows from the slice's first row down (the
+    // blocks above the diagonal blocks are never read)
+    S.zero_tasks.clear(); S.zero_small.clear();
+    for (size_t s = 0; s < S.fronts.size(); ++s) {
+        if (!S.front_local[s]) continue;
+        const FrontDesc &w = S.fronts[s];
+        if ((i64)w.lda * w.ns <= 4096) { S.zero_small.push_back((i32)s); continue; }      // whole panel by one wave
+        for (i32 c0 = 0; c0 < w.ns; c0 += NB_IN) { S.zero_tasks.push_back((i32)s); S.zero_tasks.push_back(c0); }
+    }
     auto in_scope = [&](i32 s) { return S.front_local[s] && !S.front_single[s] && (cur_g < 0 || S.front_group[s] == cur_g); };
     auto push_launch = [&](std::vector<Launch> &L, i32 kind, i64 first, i64 count) {
         if (count > 0) L.push_back(Launch{kind, cur_g, first, count, cur_side, 0});

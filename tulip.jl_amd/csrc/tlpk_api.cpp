@@ -196,6 +196,8 @@ int upload_all(tlpk_handle *h) {
     UP(d.update_tasks, S.update_tasks); UP(d.reduce_tasks, S.reduce_tasks);
     d.n_single = (i64)S.single_col.size();
     UP(d.single_loff, S.single_loff); UP(d.single_dinvoff, S.single_dinvoff); UP(d.single_col, S.single_col);
+    UP(d.zero_tasks, S.zero_tasks); d.n_zero_tasks = (i64)S.zero_tasks.size() / 2;
+    UP(d.zero_small, S.zero_small); d.n_zero_small = (i64)S.zero_small.size();
     UP(d.fwd_gather_tasks, S.fwd_gather_tasks); UP(d.fwd_diag_tasks, S.fwd_diag_tasks);
     UP(d.fwd_update_tasks, S.fwd_update_tasks); UP(d.bwd_update_tasks, S.bwd_update_tasks);
     UP(d.fwd_small_tasks, S.fwd_small_tasks); UP(d.bwd_small_tasks, S.bwd_small_tasks);
@@ -203,6 +205,8 @@ int upload_all(tlpk_handle *h) {
 #undef UP
 #define AL(dst, cnt) if ((rc = dev_alloc(h, &(dst), (cnt))) != TLPK_OK) return rc
     AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
+    // debugging aid: start from NaNs everywhere, so that a read of storage the factorisation never writes would show
+    if (std::getenv("TLPK_POISON") && S.lval_len > 0) { HIPCHK(h, hipMemset(d.ctx.Lval, 0xFF, (size_t)S.lval_len * 8)); HIPCHK(h, hipDeviceSynchronize()); }
     AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4); AL(d.ctx.dinv, S.dinv_len); AL(d.ctx.spart, S.spart_len);
     const i64 nn = std::max<i64>(S.n, S.k2_n + 1);             // K2: user vectors have k2_n entries, D2 one more
     AL(h->d_theta, nn); AL(h->d_regP, nn); AL(h->d_regD, S.m); AL(h->d_D, nn);
@@ -426,7 +430,7 @@ int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_reg
     }
     {
         ProfScope ps(h, TLPK_KC_ASSEMBLE);
-        if (S.lval_len > 0) HIPCHK(h, hipMemsetAsync(h->d.ctx.Lval, 0, (size_t)S.lval_len * 8, h->stream));
+        launch_zero_panels(h->stream, h->d);
         launch_assemble(h->stream, h->d, h->d_D, h->d_regD);
         launch_single_factor(h->stream, h->d);
     }

@@ -40,6 +40,8 @@ struct DevArrays {
     i64 *Ap = nullptr; i32 *Ai = nullptr; double *Ax = nullptr;
     i64 *Tp = nullptr; i32 *Tj = nullptr; double *Tx = nullptr;
     i32 *perm = nullptr;
+    i32 *zero_tasks = nullptr; i64 n_zero_tasks = 0;   // (front, c0) pairs of k_zero_panels
+    i32 *zero_small = nullptr; i64 n_zero_small = 0;   // fronts zeroed whole, one wave each
     char *row_local = nullptr, *col_local = nullptr;
     // assembly lists (local entries only)
     i64 n_asm = 0;
@@ -58,6 +60,7 @@ struct DevArrays {
 
 void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D);
 void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD);
+void launch_zero_panels(hipStream_t st, const DevArrays &a);
 void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const SweepArgs *sw = nullptr);
 void launch_single_factor(hipStream_t st, const DevArrays &a);
 void launch_single_solve(hipStream_t st, const DevArrays &a);

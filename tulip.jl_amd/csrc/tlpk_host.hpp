@@ -119,6 +119,8 @@ struct Symbolic {
     std::vector<char> front_local;         // processed by this rank
     std::vector<char> front_single;        // isolated 1 x 1 front (f = ns = 1, no children): handled by k_single_*, not by the schedules
     std::vector<i64> single_loff, single_dinvoff; std::vector<i32> single_col;   // the local ones, for the device
+    std::vector<i32> zero_tasks;           // (front, first column) of every 64-column slice of a local panel: k_zero_panels
+    std::vector<i32> zero_small;           // local fronts whose whole panel (<= 4096 entries) one wave zeroes
     std::vector<char> col_local;           // column of A handled by this rank
     std::vector<char> row_local;           // 0 = other rank's block row, 1 = local block row, 2 = linking row
     i32 root_front = -1;                   // the replicated linking front (or -1)
