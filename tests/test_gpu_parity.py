@@ -81,6 +81,31 @@ def test_large_fronts_blocked_path():
     compare_with_oracle(A, kkt, 2, ltol=1e-10, xtol=1e-8)
 
 
+def test_unzeroed_storage_is_never_read(monkeypatch):
+    """The zero-fill before the assembly skips the blocks above the 64 x 64 diagonal blocks of every panel (they are never
+    read).  With TLPK_POISON=1 the factor storage starts as NaNs: factor entries and solutions must still match the oracle
+    on a multi-panel front, a block-angular LP with a root front, K2, and across a failed factorisation."""
+    monkeypatch.setenv("TLPK_POISON", "1")
+    A = random_lp_matrix(1500, 2500, 6, 11)
+    compare_with_oracle(A, gpu_setup(A), 2, ltol=1e-10, xtol=1e-8)
+    A, row_block = block_angular(nblocks=8, mk=300, nk=600, m0=60, nnz_in=3, link_prob=0.5, seed=5)
+    compare_with_oracle(A, gpu_setup(A, row_block=row_block), 3)
+    A = random_lp_matrix(700, 1500, 4, 5)
+    kkt = gpu_setup(A)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 0)
+    bad = rd.copy(); bad[7] = -1e6
+    with pytest.raises(tk.PosDefException):
+        tk.update(kkt, th, rp, bad)
+    compare_with_oracle(A, kkt, 0)
+    k2 = tk.setup(A, tk.K2(), tk.Backend(device=0))
+    tk.update(k2, th, rp, rd)
+    dx = np.zeros(n); dy = np.zeros(m)
+    tk.solve(dx, dy, k2, xp, xd)
+    r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+    assert np.isfinite(dx).all() and np.isfinite(dy).all() and max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp).max(), np.abs(xd).max())) * max(1.0, np.abs(dx).max(), np.abs(dy).max())
+
+
 def test_general_sparse_c3_shape_macro_columns():
     """BASELINE configs[2] shape at test scale: A = [A0 I], 25 nnz per structural column => one dense
     front of ~2400 columns.  A single front has few tiles per block column, so the schedule groups
