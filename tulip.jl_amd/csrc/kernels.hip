@@ -1096,6 +1096,12 @@ __global__ __launch_bounds__(256) void k_update_reduce(const UpdateTask *__restr
 // ------------------------------------------------------------------------------------------
 // xw[ii] = xi_p[i] + sum_j A[i,j] D_j xi_d[j],  i = perm[ii].  Sharded runs: a rank sums only its
 // own columns and only rank 0 adds xi_p on linking rows (the all-reduce completes the sum).
+// w = D .* xi_d on this rank's columns (0 elsewhere), once per solve: the row kernel below then gathers ONE vector per
+// entry of A instead of three (column mask, D, xi_d); the products are formed in the same order as before
+__global__ void k_rhs_scale(i64 n, const double *__restrict__ D, const double *__restrict__ xi_d, const char *__restrict__ col_local, double *__restrict__ w) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) w[j] = col_local[j] ? D[j] * xi_d[j] : 0.0;
+}
 __global__ __launch_bounds__(256) void k_rhs(i64 m, const i32 *__restrict__ perm, const i64 *__restrict__ Tp,
                       const i32 *__restrict__ Tj, const double *__restrict__ Tx,
                       const double *__restrict__ D, const double *__restrict__ xi_p,
@@ -1110,10 +1116,7 @@ __global__ __launch_bounds__(256) void k_rhs(i64 m, const i32 *__restrict__ perm
     const char rl = live ? row_local[i] : 0;
     double s = 0.0;
     if (rl != 0) {
-        for (i64 q = Tp[i] + lane; q < Tp[i + 1]; q += 8) {
-            const i32 j = Tj[q];
-            if (col_local[j]) s += Tx[q] * (D[j] * xi_d[j]);
-        }
+        for (i64 q = Tp[i] + lane; q < Tp[i + 1]; q += 8) s += Tx[q] * D[Tj[q]];      // D = the pre-scaled vector w (k_rhs_scale)
     }
 #pragma unroll
     for (int off = 4; off > 0; off >>= 1) s += __shfl_down(s, off, 8);
@@ -2029,8 +2032,11 @@ void launch_k2_out(hipStream_t st, const DevArrays &a, i64 n, double *dx, double
 }
 void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank) {
     if (a.m > 0)
-        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, D, xi_p, xi_d,
+    {
+        if (a.n > 0) hipLaunchKernelGGL(k_rhs_scale, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, D, xi_d, a.col_local, a.rhs_w);
+        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, a.rhs_w, xi_p, xi_d,
                            a.row_local, a.col_local, rank, a.ctx.xw);
+    }
 }
 void launch_sum_to(hipStream_t st, i64 len, double *out, const double *own, const double *src, int nsrc, i64 stride) {
     if (len > 0) hipLaunchKernelGGL(k_sum_to, dim3(nblk(len, 256)), dim3(256), 0, st, len, out, own, src, nsrc, stride);

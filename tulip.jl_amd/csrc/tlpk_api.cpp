@@ -211,6 +211,7 @@ int upload_all(tlpk_handle *h) {
     const i64 nn = std::max<i64>(S.n, S.k2_n + 1);             // K2: user vectors have k2_n entries, D2 one more
     AL(h->d_theta, nn); AL(h->d_regP, nn); AL(h->d_regD, S.m); AL(h->d_D, nn);
     AL(h->d_xip, S.m); AL(h->d_xid, nn); AL(h->d_dx, nn); AL(h->d_dy, S.m);
+    AL(d.rhs_w, std::max<i64>(S.n, 1));
     if (h->refine_steps > 0) { AL(h->d_r1, S.m); AL(h->d_r2, nn); AL(h->d_cx, nn); AL(h->d_cy, S.m); }
     d.ctx.csign = nullptr;
     d.ctx.upd_remap = 2;

@@ -40,6 +40,7 @@ struct DevArrays {
     i64 *Ap = nullptr; i32 *Ai = nullptr; double *Ax = nullptr;
     i64 *Tp = nullptr; i32 *Tj = nullptr; double *Tx = nullptr;
     i32 *perm = nullptr;
+    double *rhs_w = nullptr;                  // D .* xi_d of the current solve (k_rhs_scale)
     i32 *zero_tasks = nullptr; i64 n_zero_tasks = 0;   // (front, c0) pairs of k_zero_panels
     i32 *zero_small = nullptr; i64 n_zero_small = 0;   // fronts zeroed whole, one wave each
     char *row_local = nullptr, *col_local = nullptr;
