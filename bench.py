@@ -221,13 +221,16 @@ def main():
             root_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
             _, c = kkt.root_rhs()
             rhs_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
-        lib_stream = torch.cuda.ExternalStream(kkt.stream_ptr(), device=dev) if world > 1 else None
+        lib_streams = {}                      # handle -> torch view of the library's main stream of THAT handle
 
         def reduce_root(k, which, buf):
             # library stream -> (event) -> torch's current stream runs the RCCL all-reduce -> (event) ->
             # library stream: no host synchronisation between the two halves of update / solve
             if buf is None:
                 return
+            lib_stream = lib_streams.get(id(k))
+            if lib_stream is None:
+                lib_stream = lib_streams[id(k)] = torch.cuda.ExternalStream(k.stream_ptr(), device=dev)
             k.root_copy(which, "out", P(buf))
             ev = torch.cuda.Event(); ev.record(lib_stream)
             torch.cuda.current_stream().wait_event(ev)
@@ -288,55 +291,62 @@ def main():
                           "residual_inf": [r_p, r_d]},
                "frac_step": st["flops_chol"] / (ms_per_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
 
+        def roofline_leg():
+                # Per-kernel-class device time of one Newton step, HIP events around every launch on the
+                # stream it is launched on.  The timed region above runs the diagonal blocks on concurrent
+                # stream groups (plus side streams); under that overlap a kernel's [start, end] interval includes
+                # time it shares the chip with other groups' kernels, so the roofline leg replays the SAME
+                # LP and the SAME kernels serialised on one stream (profile mode does that), where every launch
+                # has the device to itself.  profiles/*kernel_stats.csv is taken the same way.
+                # (block-angular LPs: a second handle with ONE stream group, so that a launch holds the tiles of all
+                # diagonal blocks, as it does when the groups run concurrently)
+                kkt1 = kkt if st["n_blocks"] < 2 else tk.setup(
+                    A, tk.K1(), tk.Backend(device=local_rank, row_block=row_block, rank=rank, nranks=world, streams=1))
+                newton_step(kkt1)
+                kkt1.set_profile(True)
+                newton_step(kkt1)
+                kt = kkt1.kernel_times()
+                kkt1.set_profile(False)
+                if kkt1 is not kkt:
+                    kkt1.close()
+                upd = kt["update"]
+                fl_alg, fl_exec = st["flops_update_alg"], st["flops_update"]
+                sec = upd["ms"] * 1e-3
+                ach = fl_alg / sec / 1e12 if sec > 0 else 0.0
+                traffic, traffic_src = None, None
+                try:        # HBM bytes per launch from the committed PMC pass of this command (cannot be collected in-process)
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_update.json")))
+                    if pm.get("workload") == workload and world == 1:
+                        traffic = pm["traffic_bytes_per_launch"]
+                        traffic_src = pm.get("source", "profiles/pmc_k_update.json (rocprofv3 --pmc passes of this command, not collected in this run)")
+                except Exception:
+                    pass
+                nl = max(upd["launches"], 1)
+                out["roofline"] = {"bound": "mfma", "kernel": "k_update (v_mfma_f64_16x16x4_f64)", "achieved": ach,
+                                   "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                                   "traffic": traffic, "traffic_source": traffic_src, "launches": upd["launches"],
+                                   "avg_launch_ms": upd["ms"] / nl,
+                                   "flops_per_step": fl_alg, "flops_per_launch": fl_alg / nl,
+                                   "flops": "algorithmic: share of sum_j l_j^2 whose targets lie outside column j's own 256-wide block column (tlpk_stats.flops_update_alg)",
+                                   "frac_executed": (fl_exec / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS) if sec > 0 else 0.0,
+                                   "flops_executed_per_step": fl_exec,
+                                   "frac_if_all_of_flops_chol_were_credited": (st["flops_chol"] / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS) if sec > 0 else 0.0,
+                                   "frac_step": out["frac_step"], "peak_measured": 77.9, "measured_with_streams": 1}
+                solve_bytes = 2 * 8 * st["nnzL"] + 2 * 12 * A.nnz + 8 * (4 * n + 3 * m)
+                sol_ms = (kt["solve_fwd"]["ms"] + kt["solve_bwd"]["ms"] + kt["spmv"]["ms"]) / max(args.solves, 1)
+                out["kernel_ms"] = {k: round(v["ms"], 4) for k, v in kt.items()}
+                out["kernel_launches"] = {k: v["launches"] for k, v in kt.items()}
+                out["solve_roofline"] = {"bound": "hbm", "achieved": solve_bytes / (sol_ms * 1e-3) / 1e9 if sol_ms > 0 else 0.0,
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_solve": solve_bytes,
+                                         "ms_per_solve": sol_ms}
+                out["solve_roofline"]["frac"] = out["solve_roofline"]["achieved"] / HBM_PEAK_GBS
+
         if roofline:
-            # Per-kernel-class device time of one Newton step, HIP events around every launch on the
-            # stream it is launched on.  The timed region above runs the diagonal blocks on concurrent
-            # stream groups (plus side streams); under that overlap a kernel's [start, end] interval includes
-            # time it shares the chip with other groups' kernels, so the roofline leg replays the SAME
-            # LP and the SAME kernels serialised on one stream (profile mode does that), where every launch
-            # has the device to itself.  profiles/*kernel_stats.csv is taken the same way.
-            # (block-angular LPs: a second handle with ONE stream group, so that a launch holds the tiles of all
-            # diagonal blocks, as it does when the groups run concurrently)
-            kkt1 = kkt if st["n_blocks"] < 2 else tk.setup(
-                A, tk.K1(), tk.Backend(device=local_rank, row_block=row_block, rank=rank, nranks=world, streams=1))
-            newton_step(kkt1)
-            kkt1.set_profile(True)
-            newton_step(kkt1)
-            kt = kkt1.kernel_times()
-            kkt1.set_profile(False)
-            if kkt1 is not kkt:
-                kkt1.close()
-            upd = kt["update"]
-            fl_alg, fl_exec = st["flops_update_alg"], st["flops_update"]
-            sec = upd["ms"] * 1e-3
-            ach = fl_alg / sec / 1e12 if sec > 0 else 0.0
-            traffic, traffic_src = None, None
-            try:        # HBM bytes per launch from the committed PMC pass of this command (cannot be collected in-process)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_update.json")))
-                if pm.get("workload") == workload and world == 1:
-                    traffic = pm["traffic_bytes_per_launch"]
-                    traffic_src = pm.get("source", "profiles/pmc_k_update.json (rocprofv3 --pmc passes of this command, not collected in this run)")
-            except Exception:
-                pass
-            nl = max(upd["launches"], 1)
-            out["roofline"] = {"bound": "mfma", "kernel": "k_update (v_mfma_f64_16x16x4_f64)", "achieved": ach,
-                               "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                               "traffic": traffic, "traffic_source": traffic_src, "launches": upd["launches"],
-                               "avg_launch_ms": upd["ms"] / nl,
-                               "flops_per_step": fl_alg, "flops_per_launch": fl_alg / nl,
-                               "flops": "algorithmic: share of sum_j l_j^2 whose targets lie outside column j's own 256-wide block column (tlpk_stats.flops_update_alg)",
-                               "frac_executed": (fl_exec / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS) if sec > 0 else 0.0,
-                               "flops_executed_per_step": fl_exec,
-                               "frac_if_all_of_flops_chol_were_credited": (st["flops_chol"] / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS) if sec > 0 else 0.0,
-                               "frac_step": out["frac_step"], "peak_measured": 77.9, "measured_with_streams": 1}
-            solve_bytes = 2 * 8 * st["nnzL"] + 2 * 12 * A.nnz + 8 * (4 * n + 3 * m)
-            sol_ms = (kt["solve_fwd"]["ms"] + kt["solve_bwd"]["ms"] + kt["spmv"]["ms"]) / max(args.solves, 1)
-            out["kernel_ms"] = {k: round(v["ms"], 4) for k, v in kt.items()}
-            out["kernel_launches"] = {k: v["launches"] for k, v in kt.items()}
-            out["solve_roofline"] = {"bound": "hbm", "achieved": solve_bytes / (sol_ms * 1e-3) / 1e9 if sol_ms > 0 else 0.0,
-                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_solve": solve_bytes,
-                                     "ms_per_solve": sol_ms}
-            out["solve_roofline"]["frac"] = out["solve_roofline"]["achieved"] / HBM_PEAK_GBS
+            try:
+                roofline_leg()
+            except Exception as e:      # the headline number must survive a failing measurement leg (and say so)
+                out["roofline"] = None
+                out["roofline_error"] = repr(e)
 
         if world == 1 and not args.no_host_abi:
             # The drop-in path: what the Julia glue calls (host pointers in, host pointers out, blocking).
@@ -360,7 +370,9 @@ def main():
         torch.cuda.empty_cache()
         return out, A, row_block
 
-    res, A, row_block = run(args.workload, args.steps, args.warmup, not args.no_roofline)
+    # The roofline leg (a second, single-stream-group handle in profile mode) is measured at N = 1 only: with ranks it would run
+    # collectives on a handle the timed loop never used, and a rank failing there would leave the others waiting in an all-reduce.
+    res, A, row_block = run(args.workload, args.steps, args.warmup, (not args.no_roofline) and world == 1)
     out = {
         "metric": "IPM Newton-step rate: KKT.update! (A*D*A'+Rd, supernodal Cholesky) + %d KKT.solve!" % args.solves,
         "value": res["value"], "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -374,6 +386,11 @@ def main():
             out[k] = res[k]
     if "roofline" not in out:
         out["frac_step"] = res["frac_step"]
+        if world > 1:
+            out["roofline"] = None
+            out["roofline_note"] = "measured at n_gpus = 1 only (same kernels; the N = 1 line of this bench carries it)"
+    if "roofline_error" in res:
+        out["roofline_error"] = res["roofline_error"]
     if rank == 0 and world == 1 and args.workload == "c4" and not args.no_headline:
         try:
             hres, _, _ = run("headline", max(2, min(args.steps, 5)), 1, not args.no_roofline)
