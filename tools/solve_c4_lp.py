@@ -10,10 +10,11 @@ from tulip_jl_amd.hsd_device import DeviceHSD   # noqa: E402
 from tulip_jl_amd.mpc_device import DeviceMPC   # noqa: E402
 from workloads import block_angular_lp   # noqa: E402
 
-A, row_block = block_angular_lp()
+HEADLINE = os.environ.get("HEADLINE") == "1"       # the north-star instance: 100 blocks x (20 000 inequality rows x 10 000 vars) + 1000 linking rows
+A, row_block = block_angular_lp(100, 20000, 10000, 1000, 4, 0.5, ineq=True) if HEADLINE else block_angular_lp()
 m, n = A.shape
 rng = np.random.default_rng(20260927)
-xs = rng.uniform(0.0, 1.0, n) * (rng.random(n) < 0.6)          # a vertex-ish feasible point
+xs = rng.uniform(0.0, 1.0, n) * (rng.random(n) < 0.6)          # a vertex-ish feasible point (slack columns included)
 b = A @ xs
 ys = rng.standard_normal(m)
 zs = rng.uniform(0.0, 1.0, n) * (xs == 0.0)                    # complementary slack
