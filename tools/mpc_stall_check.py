@@ -17,7 +17,7 @@ d = IPMData(); d.A = A.tocsc(); d.b = b; d.c = c; d.c0 = 0.0; d.objsense = True
 d.l = np.zeros(n); d.u = np.full(n, np.inf); d.lflag = np.isfinite(d.l); d.uflag = np.isfinite(d.u)
 d.lz = np.where(d.lflag, d.l, 0.0); d.uz = np.where(d.uflag, d.u, 0.0); d.nrow, d.ncol, d.nvar = m, n, n
 print("LP", m, n, "known optimum", float(c @ xs))
-for alg in (MPC, HSD):
+for alg in ((MPC,) if os.environ.get("ONLY_MPC") else (MPC, HSD)):
     for name, be in (("HIP", lambda: HipBackend(d.A, device=0, row_block=row_block)), ("oracle", lambda: OracleBackend(d.A))):
         t0 = time.perf_counter()
         ipm = alg(d, be(), None).optimize()
