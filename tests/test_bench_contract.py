@@ -1,0 +1,48 @@
+"""bench.py prints ONE JSON line with the agreed keys (the driver parses it); the cpu_baseline leg runs the comparator in a
+child process on a bounded sample.  Small step counts: this checks the contract, not the numbers."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*flags, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line on stdout"
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_contract():
+    d = run_bench("--steps", "2", "--warmup", "1", "--no-headline", "--no-cpu-baseline")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "solve_roofline", "host_abi", "kernel_ms"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-9 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12
+    assert 0.2 < r["frac"] < 1.0 and r["traffic"] is None or r["traffic"] > 0
+    assert max(d["config"]["residual_inf"]) <= 1e-6                        # the timed step solved the system
+    s = d["solve_roofline"]
+    assert s["bound"] == "hbm" and s["unit"] == "GB/s" and 0.05 < s["frac"] < 1.0
+
+
+@pytest.mark.gpu
+def test_bench_cpu_baseline_leg():
+    d = run_bench("--steps", "2", "--warmup", "1", "--no-headline", "--no-host-abi", "--no-roofline")
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, (k, c)
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"] and c["value"] > 0
+    assert max(c["residual_inf"]) <= 1e-6                                  # the comparator solved the same system
