@@ -313,10 +313,10 @@ class Emulator:
         return self.solve_finish(xi_d, A)
 
     def _k4(self, T):      # fwd gather: one row chunk of a front, sources from the gather lists
-        for front, _, _, row0, *_ in T:
+        for front, _, nrows, row0, *_ in T:
             f, ns = int(self.f[front]), int(self.ns[front])
             c0 = int(self.col0[front]); ro = int(self.rowoff[front]); uo = int(self.ucoff[front])
-            for r in range(row0, min(row0 + 256, f)):
+            for r in range(row0, min(row0 + int(nrows), f)):
                 q0, q1 = self.gth_ptr[ro + r], self.gth_ptr[ro + r + 1]
                 v = self.xw[c0 + r] if r < ns else 0.0
                 for q in range(q0, q1):

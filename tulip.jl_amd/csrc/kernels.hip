@@ -1129,22 +1129,21 @@ __global__ __launch_bounds__(256) void k_rhs(i64 m, const i32 *__restrict__ perm
 __global__ __launch_bounds__(256) void k_fwd_gather(const SolveTask *__restrict__ tasks, DevCtx c) {
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    if (fd.nchild >= 24) {
-        // wide fan-in (the root front of a block-angular LP: every linking row collects one entry per diagonal block): 8 lanes
-        // per row, fixed shuffle tree -- one thread per row walked 64 dependent loads (53 us for 1000 rows, on every solve)
-        const int l8 = threadIdx.x & 7, sub = threadIdx.x >> 3;
-        for (int sb = 0; sb < 8; ++sb) {
-            const i32 rr = t.row0 + 32 * sb + sub;
-            const bool live = rr < fd.f;
-            const i64 a0 = live ? c.gth_ptr[fd.rowoff + rr] : 0, a1 = live ? c.gth_ptr[fd.rowoff + rr + 1] : 0;
-            double s = 0.0;
-            for (i64 q = a0 + l8; q < a1; q += 8) s += c.uc[c.gth_src[q]];
+    if (t.nb == SOLVE_ROWS / 8) {
+        // wide fan-in (the root front of a block-angular LP: every linking row collects one entry per diagonal block): the
+        // task holds 32 rows, 8 lanes per row, fixed shuffle tree -- one thread per row walked 64 dependent loads (53 us
+        // for the 1000 rows of the root in 4 workgroups, on every solve)
+        const int l8 = threadIdx.x & 7;
+        const i32 rr = t.row0 + (threadIdx.x >> 3);
+        const bool live = rr < fd.f;
+        const i64 a0 = live ? c.gth_ptr[fd.rowoff + rr] : 0, a1 = live ? c.gth_ptr[fd.rowoff + rr + 1] : 0;
+        double s = 0.0;
+        for (i64 q = a0 + l8; q < a1; q += 8) s += c.uc[c.gth_src[q]];
 #pragma unroll
-            for (int off = 4; off > 0; off >>= 1) s += __shfl_down(s, off, 8);
-            if (live && l8 == 0 && !(rr < fd.ns && a0 == a1)) {
-                double *d = (rr < fd.ns) ? (c.xw + fd.col0 + rr) : (c.uc + fd.ucoff + (rr - fd.ns));
-                *d = ((rr < fd.ns) ? *d : 0.0) + s;
-            }
+        for (int off = 4; off > 0; off >>= 1) s += __shfl_down(s, off, 8);
+        if (live && l8 == 0 && !(rr < fd.ns && a0 == a1)) {
+            double *d = (rr < fd.ns) ? (c.xw + fd.col0 + rr) : (c.uc + fd.ucoff + (rr - fd.ns));
+            *d = ((rr < fd.ns) ? *d : 0.0) + s;
         }
         return;
     }

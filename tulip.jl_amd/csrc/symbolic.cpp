@@ -1313,8 +1313,12 @@ static void build_schedule(Symbolic &S) {
                 const FrontDesc &w = S.fronts[s];
                 if (w.nchild == 0 && w.f == w.ns) continue;
                 // leaves only clear their contribution vector (rows >= ns)
-                for (i32 r0 = (w.nchild == 0) ? (w.ns / SOLVE_ROWS) * SOLVE_ROWS : 0; r0 < w.f; r0 += SOLVE_ROWS)
-                    S.fwd_gather_tasks.push_back(SolveTask{s, 0, 0, r0, 0, 0, 0, 0});
+                // nb = rows of the task: 256 (one thread per row), or 32 = 8 lanes per row for a front whose rows collect many
+                // entries each (the root front of a block-angular LP: one per diagonal block)
+                const double per_row = (double)(S.gth_ptr[(size_t)w.rowoff + w.f] - S.gth_ptr[(size_t)w.rowoff]) / std::max(1, w.f);
+                const i32 step = (per_row >= GATHER_WIDE_PER_ROW) ? SOLVE_ROWS / 8 : SOLVE_ROWS;
+                for (i32 r0 = (w.nchild == 0) ? (w.ns / SOLVE_ROWS) * SOLVE_ROWS : 0; r0 < w.f; r0 += step)
+                    S.fwd_gather_tasks.push_back(SolveTask{s, 0, step, r0, 0, 0, 0, 0});
             }
             push_launch(S.fwd_launches, LK_FWD_GATHER, first, (i64)S.fwd_gather_tasks.size() - first);
         }

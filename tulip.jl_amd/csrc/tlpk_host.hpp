@@ -27,6 +27,7 @@ constexpr int SWEEP_NB = NB_IN;  // width of a pivot block handed from workgroup
 constexpr int MAX_GROUPS = 8;    // concurrent streams for independent diagonal blocks
 constexpr int LDA_PAD_MIN_F = 64;   // fronts with at least this many rows get a line-aligned panel (lda multiple of 16)
 constexpr int SOLVE_ROWS = 256; // rows per forward-update workgroup
+constexpr int GATHER_WIDE_PER_ROW = 16;  // forward gather: fronts whose rows collect at least this many entries on average take 8 lanes per row (32-row tasks)
 constexpr int BWD_ROWS = 128;   // rows per backward-update workgroup (partial sums, reduced in fixed order)
 
 // ---- device-visible descriptors (plain structs, uploaded as arrays) ----
