@@ -333,3 +333,13 @@ int k1sn_get_factor(const k1sn *h, double *lval, i64 cap) {
     return 0;
 }
 const double *k1sn_factor_ptr(const k1sn *h) { return h ? h->Lval : NULL; }
+/* diagonal of L in permuted order (m entries), for pivot reports: L_jj^2 is the pivot of column j.  After a failed
+ * update the fronts factorised before the failure hold factor entries, the others their assembled values. */
+int k1sn_get_diag(const k1sn *h, double *diag, i64 cap) {
+    if (!h || !diag || cap < h->m) return 2;
+    for (i64 s = 0; s < h->nf; ++s) {
+        const double *P = h->Lval + h->loff[s];
+        for (i64 j = 0; j < h->ns[s]; ++j) diag[h->col0[s] + j] = P[j + j * h->lda[s]];
+    }
+    return 0;
+}

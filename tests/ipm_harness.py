@@ -77,6 +77,32 @@ class OracleBackend:
         dx[:] = ddx; dy[:] = ddy
 
 
+class SupernodalBackend:
+    """The CHOLMOD-class CPU comparator (oracle/k1_supernodal.c: supernodal multifrontal Cholesky on dpotrf / dtrsm /
+    dsyrk, OpenMP over the tree) behind the same three calls: the backend swap at BENCHMARK scale that the 1-core
+    simplicial oracle cannot do (SURVEY.md 8(d) parity protocol (ii); callers HSD/step.jl:28-51, MPC/step.jl:28-51).
+    Same ordering and supernodes as the HIP run (an analyse-only libtlpk handle supplies the symbolic structure)."""
+
+    def __init__(self, A, threads=0, **backend_kw):
+        import tulip_jl_amd as tk
+        from oracle_binding import SupernodalK1
+        backend_kw = dict(backend_kw); backend_kw["device"] = -1
+        self._sym = tk.setup(A, tk.K1(), tk.Backend(**backend_kw))
+        self.o = SupernodalK1(A, self._sym, threads=threads)
+        self.name = f"CPU supernodal (OpenBLAS, {self.o.threads} threads) / Normal equations (K1)"
+
+    def update(self, th, rp, rd):
+        from oracle_binding import OraclePosDefError
+        try:
+            self.o.update(th, rp, rd)
+        except OraclePosDefError as e:
+            raise PosDef(str(e))
+
+    def solve(self, dx, dy, xp, xd):
+        ddx, ddy = self.o.solve(xp, xd)
+        dx[:] = ddx; dy[:] = ddy
+
+
 # ------------------------------------------------------------------------------------------------
 # HSD
 # ------------------------------------------------------------------------------------------------

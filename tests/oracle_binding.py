@@ -263,6 +263,7 @@ def _lib3():
         lib.k1sn_threads.argtypes = [vp]; lib.k1sn_threads.restype = C.c_int
         lib.k1sn_times.argtypes = [vp, pd]; lib.k1sn_times.restype = None
         lib.k1sn_get_factor.argtypes = [vp, pd, i64]; lib.k1sn_get_factor.restype = C.c_int
+        lib.k1sn_get_diag.argtypes = [vp, pd, i64]; lib.k1sn_get_diag.restype = C.c_int
         _LIB3 = lib
     return _LIB3
 
@@ -325,6 +326,14 @@ class SupernodalK1:
         if rc != OK:
             raise RuntimeError(f"k1sn_get_factor rc={rc}")
         return buf[: self.lval_len]
+
+    def diag(self):
+        """diag(L) in permuted order; L_jj^2 is the pivot of column j."""
+        d = np.empty(max(self.m, 1))
+        rc = _lib3().k1sn_get_diag(self._h, _pd(d), d.size)
+        if rc != OK:
+            raise RuntimeError(f"k1sn_get_diag rc={rc}")
+        return d[: self.m]
 
     def close(self):
         if getattr(self, "_h", None):
