@@ -27,6 +27,32 @@ def test_ipm_entry_points_fail_loudly_without_device():
     assert L.tlpk_ipm_newton(None, 0, _lib.as_pd(out), _lib.as_pd(out)) == _lib.BADARG
 
 
+def test_device_loops_refuse_multi_gpu_backends_early():
+    """Round-2 advisor finding: Model(lp, row_block=..., ngpus=8) reached tlpk_ipm_* with a multi-device parent handle
+    (null device vectors -> GPU memory fault).  The host loops now refuse before any handle exists."""
+    from tulip_jl_amd.hsd_device import DeviceHSD
+    from tulip_jl_amd.mpc_device import DeviceMPC
+    A = sp.csc_matrix(np.array([[1.0, 0, 1, 0], [0, 1, 0, 1]]))
+    for cls in (DeviceHSD, DeviceMPC):
+        with pytest.raises(ValueError, match="single-device"):
+            cls(A, np.ones(2), np.ones(4), np.zeros(4), np.full(4, np.inf), device=0, row_block=np.array([0, 1]), ngpus=2)
+
+
+@pytest.mark.gpu
+def test_ipm_entry_points_refuse_a_multi_device_handle():
+    from helpers import block_angular
+    A, rb = block_angular(nblocks=4, mk=60, nk=120, m0=10, nnz_in=3, link_prob=0.5, seed=3)
+    m, n = A.shape
+    kkt = tk.setup(A, tk.K1(), tk.Backend(row_block=rb, ngpus=2, devices=[0, 0]))
+    L = _lib.lib()
+    v = np.ones(n)
+    assert L.tlpk_ipm_load(kkt._h, _lib.as_pd(np.ones(m)), _lib.as_pd(v), _lib.as_pd(v), _lib.as_pd(v)) == _lib.BADARG
+    assert b"single-device" in L.tlpk_last_error(kkt._h)
+    out = np.zeros(16)
+    assert L.tlpk_ipm_residuals(kkt._h, 1.0, _lib.as_pd(out)) == _lib.BADARG
+    assert L.tlpk_ipm_factor(kkt._h, 1e-4, 1e-4) == _lib.BADARG
+
+
 def device_hsd(lp, **kw):
     from tulip_jl_amd.hsd_device import DeviceHSD
     d = standard_form(lp)

@@ -212,6 +212,31 @@ def test_free_column_singleton_with_a_multiplier_of_the_wrong_sign_is_unbounded(
     assert ps.run() == "Trm_Unknown" and ps.obj0 == -INF  # as the reference: objective constant -Inf, no verdict
 
 
+def test_zero_cost_free_column_singleton_in_a_one_sided_row():
+    """min x0 + x1  s.t.  x0 + x1 + s <= 5 (s free, cost 0),  x0 - x1 >= 1: the singleton's multiplier is y = 0 and the row
+    bound it would price is -Inf; nothing may be added to the objective constant (0 * Inf = NaN) and postsolve must place
+    s on a FINITE row activity (round-2 advisor finding: x = [1, 0, -inf], objective NaN, status optimal)."""
+    A = sp.csc_matrix(np.array([[1.0, 1.0, 1.0], [1.0, -1.0, 0.0]]))
+    lp = LP(A, [1.0, 1.0, 0.0], 0.0, [-INF, 1.0], [5.0, INF], [0.0, 0.0, -INF], [INF, INF, INF])
+    m = solve_and_check(lp, (FreeColumnSingleton,))
+    assert np.isfinite(m.presolve.obj0) and np.all(np.isfinite(m.solution.x))
+    assert abs(m.objective_value() - 1.0) <= 1e-6
+    # a free row keeps the activity 0
+    lp2 = LP(A, [1.0, 1.0, 0.0], 0.0, [-INF, 1.0], [INF, INF], [0.0, 0.0, -INF], [INF, INF, INF])
+    m2 = Model(lp2).optimize(ipm=cpu_ipm())
+    assert m2.status == "Trm_Optimal" and np.all(np.isfinite(m2.solution.x)) and abs(m2.objective_value() - 1.0) <= 1e-6
+
+
+def test_forcing_row_ignores_explicit_zeros():
+    """An explicit zero in a forcing row whose column has an infinite bound: 0 * Inf must not poison the other rows' bounds
+    (round-2 advisor finding: standard_form raised 'Invalid bounds for row 0: [-inf, nan]')."""
+    # row 0: x0 + x1 + 0 * x2 <= 0 with x0, x1 >= 0 (forcing), x2 free with an explicit zero in row 0
+    A = sp.csc_matrix((np.array([1.0, 1.0, 1.0, 2.0, 1.0, 0.0, 1.0, 1.0]), np.array([0, 1, 0, 1, 2, 0, 1, 2]), np.array([0, 2, 5, 8])), shape=(3, 3))
+    lp = LP(A, [-1.0, -1.0, 1.0], 0.0, [-INF, 2.0, -INF], [0.0, INF, 5.0], [0.0, 0.0, -INF], [INF, INF, INF])
+    m = solve_and_check(lp, (ForcingRow,))
+    assert abs(m.solution.x[0]) <= 1e-9 and abs(m.solution.x[1]) <= 1e-9 and np.all(np.isfinite(m.solution.x))
+
+
 def test_dominated_column():
     # x2 >= 0 has cost +5 and only helps "<=" rows' slack the wrong way: reduced cost always positive -> lower bound
     A = sp.csc_matrix(np.array([[1.0, 1.0, 1.0], [1.0, -1.0, 2.0]]))

@@ -32,6 +32,7 @@ namespace {
 
 int ipm_ready(tlpk_handle *h) {
     if (!h) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "device-resident IPM is single-device (multi-device handles take tlpk_update / tlpk_solve)"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->ipm) { h->last_error = "tlpk_ipm_load has not been called"; return TLPK_BADARG; }
     if (h->opt.nranks > 1) { h->last_error = "the device-resident IPM vectors are single-rank"; return TLPK_BADARG; }
@@ -57,11 +58,21 @@ void ipm_free(tlpk_handle *h) {
 
 extern "C" {
 
+static int ipm_load_impl(tlpk_handle *h, const double *b, const double *c, const double *l, const double *u);
+
 int tlpk_ipm_load(tlpk_handle *h, const double *b, const double *c, const double *l, const double *u) {
+    // a failed load leaves no half-initialised state behind: later tlpk_ipm_* calls report "not loaded", a retry is possible
+    if (h && h->ipm) { h->last_error = "tlpk_ipm_load called twice on one handle"; return TLPK_BADARG; }
+    const int rc = ipm_load_impl(h, b, c, l, u);
+    if (rc != TLPK_OK && h) ipm_free(h);
+    return rc;
+}
+
+static int ipm_load_impl(tlpk_handle *h, const double *b, const double *c, const double *l, const double *u) {
     if (!h || !b || !c || !l || !u) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "device-resident IPM is single-device (multi-device handles take tlpk_update / tlpk_solve)"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (h->opt.nranks > 1) { h->last_error = "the device-resident IPM vectors are single-rank"; return TLPK_BADARG; }
-    if (h->ipm) { h->last_error = "tlpk_ipm_load called twice on one handle"; return TLPK_BADARG; }
     HIPCHK(h, hipSetDevice(h->device));
     const bool k2 = h->S.system == 1;
     const i64 m = k2 ? h->S.k2_m : h->S.m, n = k2 ? h->S.k2_n : h->S.n;

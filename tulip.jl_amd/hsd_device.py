@@ -38,6 +38,9 @@ class Options:
 class DeviceHSD:
     def __init__(self, A, b, c, l, u, c0=0.0, objsense_min=True, options=None, system="K1", **backend_kw):
         # system: "K1" normal equations | "K2" augmented system (the reference's default for Float64, KKT.jl:134-141)
+        if int(backend_kw.get("ngpus", 1)) > 1 or int(backend_kw.get("nranks", 1)) > 1:
+            raise ValueError("the device-resident interior-point loops are single-device: ngpus / nranks must be 1 "
+                             "(multi-GPU handles serve the drop-in interface KKT.update! / KKT.solve!)")
         self.kkt = setup(A, K2() if str(system).upper() == "K2" else K1(), Backend(**backend_kw))
         self.m, self.n = self.kkt.m, self.kkt.n
         self.opt = options or Options()

@@ -351,7 +351,7 @@ class Presolve:
         lo = up = 0.0
         with np.errstate(invalid="ignore"):
             for j, aij in zip(cols, vals):
-                if not self.colflag[j]:
+                if not self.colflag[j] or aij == 0.0:         # an explicit zero is not an entry of the row (0 * Inf = NaN otherwise)
                     continue
                 if aij < 0.0:
                     lo += aij * self.ucol[j]; up += aij * self.lcol[j]
@@ -375,10 +375,10 @@ class Presolve:
             at_lower = False
         else:
             return
-        live = self.colflag[cols]
+        live = self.colflag[cols] & (vals != 0.0)             # explicit zeros neither fix their column nor enter the record
         op = ForcingRow(i, at_lower, [int(j) for j in cols[live]], [float(a) for a in vals[live]], literal=self.opt.ReferenceForcingRowDual)
         for j, aij in zip(cols, vals):
-            if not self.colflag[j]:
+            if not self.colflag[j] or aij == 0.0:
                 continue
             if at_lower:
                 xj = self.lcol[j] if aij > 0 else self.ucol[j]
@@ -447,7 +447,12 @@ class Presolve:
             def pray(sol):
                 sol.x[self.new_var_idx[j]] = step
             return self._decided(TRM_DUAL_INFEASIBLE, primal_ray=pray)
-        self.obj0 += y * bound
+        if y != 0.0:
+            self.obj0 += y * bound
+        else:
+            # zero-cost free singleton: nothing is priced (0 * Inf would be NaN when the row is one-sided) and postsolve
+            # needs a FINITE row activity to place x_j on: a finite row bound, or 0 for a free row
+            lr = ur = lr if math.isfinite(lr) else (ur if math.isfinite(ur) else 0.0)
         rc, rv = [], []
         for j_, a_ in zip(cols, rvals):
             if not self.colflag[j_] or j_ == j:
