@@ -55,16 +55,19 @@ def parse():
     ap.add_argument("--m0", type=int, default=1000)
     ap.add_argument("--nnz-col", type=int, default=4)
     ap.add_argument("--regime", default="mid", choices=["mid", "late"])
-    ap.add_argument("--workload", default="c4", choices=["c4", "headline", "c3"],
+    ap.add_argument("--workload", default="c4", choices=["c4", "headline", "c3", "stair25", "pds"],
                     help="c4: BASELINE configs[3] (default). headline: the north-star instance, 100 blocks x "
                          "(2e4 inequality rows x 1e4 vars) + 1e3 linking rows = 1e6 vars / 2e6 constraints. "
                          "c3: BASELINE configs[2] (general sparse, A = [A0 I], 25 nnz/col) at --c3-rows rows "
-                         "(the 5e5-row original has a ~0.86 TB factor); single GPU only")
+                         "(the 5e5-row original has a ~0.86 TB factor); single GPU only. "
+                         "stair25 / pds: the generated stand-ins of BASELINE configs[1] (Netlib 25fv47 class, tests/golden/stair25.mps) "
+                         "and configs[4] (pds-20 class, tests/lp_generators.multicommodity_lp) in standard form -- latency-bound sizes")
     ap.add_argument("--c3-rows", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-headline", action="store_true", help="skip the extra north-star headline run (N=1, workload c4 only)")
     ap.add_argument("--no-host-abi", action="store_true")
+    ap.add_argument("--no-small-lp", action="store_true", help="skip the latency-bound legs (25fv47-class and pds-20-class LPs)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child-process mode of the cpu_baseline leg
     return ap.parse_args()
@@ -134,6 +137,21 @@ def cpu_baseline(args, A, row_block, nblocks_total):
 
 def build_workload(args, workload):
     from workloads import block_angular_lp, general_sparse_lp
+    if workload in ("stair25", "pds"):
+        # BASELINE configs[1] / configs[4]: the Netlib files are not in the image (no network); seeded generators of the
+        # same classes, read / built as LPs and converted to Tulip's standard form (ipmdata.jl:64-173), no presolve
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from tulip_jl_amd.problem import read_free_mps, standard_form
+        if workload == "stair25":
+            lp = read_free_mps(os.path.join(ROOT, "tests", "golden", "stair25.mps"))
+            name = "BASELINE configs[1] class (Netlib 25fv47 stand-in tests/golden/stair25.mps)"
+        else:
+            from lp_generators import multicommodity_lp
+            lp = multicommodity_lp()
+            name = "BASELINE configs[4] class (pds-20 stand-in: generated multicommodity flow LP)"
+        A = standard_form(lp).A.tocsc(); A.sort_indices()
+        m, n = A.shape
+        return A, None, "%s, standard form: general sparse LP, m=%d n=%d nnz(A)=%d" % (name, m, n, A.nnz)
     if workload == "c3":
         A, row_block = general_sparse_lp(args.c3_rows), None
         desc = None
@@ -153,11 +171,11 @@ def build_workload(args, workload):
     return A, row_block, text
 
 
-def cpu_baseline_subprocess(args):
+def cpu_baseline_subprocess(args, workload=None):
     """The CPU comparator runs in a child process: its OpenMP / OpenBLAS thread pools stay out of the
     process that owns the HIP runtime, and a crash of the CPU leg can never cost the GPU line."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload or args.workload,
            "--solves", str(args.solves), "--blocks", str(args.blocks), "--mk", str(args.mk), "--nk", str(args.nk),
            "--m0", str(args.m0), "--nnz-col", str(args.nnz_col), "--regime", args.regime, "--cpu-seconds", str(args.cpu_seconds)]
     try:
@@ -174,7 +192,7 @@ def main():
     args = parse()
     if args.cpu_baseline_only:
         A, row_block, _ = build_workload(args, args.workload)
-        print(json.dumps(cpu_baseline(args, A, row_block, args.blocks if args.workload == "c4" else 100)))
+        print(json.dumps(cpu_baseline(args, A, row_block, args.blocks if args.workload == "c4" else (100 if args.workload == "headline" else 1))))
         return
     import torch
     import tulip_jl_amd as tk
@@ -285,6 +303,7 @@ def main():
                "config": {"workload": text, "solves_per_step": args.solves, "regime": args.regime,
                           "parallelism": "blocks/%d" % world, "stream_groups": int(kkt.symbolic("ngroups")[0]),
                           "nnzS": st["nnzS"], "nnzL": st["nnzL"], "nnzL_stored": st["nnzL_stored"],
+                          "stored_over_nnzL": st["nnzL_stored"] / max(st["nnzL"], 1), "device_bytes": st["device_bytes"],
                           "flops_chol": st["flops_chol"], "n_supernodes": st["n_supernodes"], "n_levels": st["n_levels"],
                           "max_front": st["max_front"], "launches_update": st["launches_update"],
                           "launches_solve": st["launches_solve"], "ms_analyse": st["ms_analyse"],
@@ -401,8 +420,42 @@ def main():
             for k in ("roofline", "solve_roofline", "kernel_ms", "host_abi"):
                 if k in hres:
                     out["headline"][k] = hres[k]
+            out["headline"]["stored_over_nnzL"] = hres["config"]["stored_over_nnzL"]
+            if not args.no_cpu_baseline:
+                # north_star: ">= 10x the CPU CHOLMOD KKT path on a 1e6-var / 2e6-constraint LP": the CPU comparator on THIS instance
+                hc = cpu_baseline_subprocess(args, "headline")
+                if "value" in hc:
+                    hc["gpu_over_cpu"] = out["headline"]["value"] / hc["value"]
+                out["headline"]["cpu_baseline"] = hc
         except Exception as e:          # the headline leg must never cost the main line
             out["headline"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and args.workload == "c4" and not args.no_small_lp:
+        # The small configs (BASELINE configs[1], configs[4] classes): a Newton step here is bound by launch latency and the
+        # serial chain of diagonal blocks, not by the matrix cores -- reported as measured, next to the CPU comparator.
+        out["small_lp"] = {}
+        for wl in ("stair25", "pds"):
+            try:
+                sres, _, _ = run(wl, 20, 3, False)
+                leg = {"workload": sres["config"]["workload"], "ms_per_step": sres["ms_per_step"],
+                       "host_abi_ms_per_step": sres.get("host_abi", {}).get("ms_per_step"),
+                       "launches_update": sres["config"]["launches_update"], "launches_solve": sres["config"]["launches_solve"],
+                       "nnzL": sres["config"]["nnzL"], "flops_chol": sres["config"]["flops_chol"], "max_front": sres["config"]["max_front"],
+                       "frac_step": sres["frac_step"], "residual_inf": sres["config"]["residual_inf"]}
+                if not args.no_cpu_baseline:
+                    sc = cpu_baseline_subprocess(args, wl)
+                    if "value" in sc:
+                        leg["cpu_ms_per_step"] = sc["ms_per_step"]; leg["cpu_threads"] = sc["cores"]
+                        leg["gpu_over_cpu"] = sc["ms_per_step"] / sres["ms_per_step"]
+                    else:
+                        leg["cpu_error"] = sc.get("error")
+                cpu_txt = ("CPU comparator %.2f ms" % leg["cpu_ms_per_step"]) if "cpu_ms_per_step" in leg else "CPU comparator not run"
+                leg["statement"] = ("latency-bound: %.2f ms per Newton step on the GPU (%d + %d x %d launches, %.1e factor flops = %.4f of "
+                                    "the fp64 matrix peak over the step), %s" % (
+                                        leg["ms_per_step"], leg["launches_update"], args.solves, leg["launches_solve"], leg["flops_chol"],
+                                        leg["frac_step"], cpu_txt))
+                out["small_lp"][wl] = leg
+            except Exception as e:
+                out["small_lp"][wl] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c3":
         out["cpu_baseline"] = cpu_baseline_subprocess(args)
         if "value" in out["cpu_baseline"]:

@@ -182,6 +182,15 @@ int k1sn_create(k1sn **out, const char *blas_path, i64 m, i64 n, const i64 *Ap, 
         for (i64 t = a; t < b; ++t) h->level_fronts[t] = wk[t - a].s;
     }
     free(wk);
+    {
+        /* Small problems (a Netlib-size LP: ~1e7 factor flops) run on ONE thread: forking an OpenMP team and re-sizing the
+         * BLAS thread pool per tree level costs milliseconds per call, 100x the arithmetic (CHOLMOD itself stays serial
+         * below its own thresholds).  nthreads_arg < 0 keeps the requested team whatever the size. */
+        double work = 0.0;
+        for (i64 s = 0; s < nf; ++s) work += (double)f[s] * (double)f[s] * (double)ns[s];
+        if (nthreads >= 0 && work < 2.0e8) h->nthreads = 1;
+        h->setnt(h->nthreads);
+    }
     h->fail_col = -1;
     *out = h;
     return 0;
@@ -227,7 +236,9 @@ static void factor_front(k1sn *h, i64 s, i64 *fail) {
 #define FOR_LEVEL_FRONTS(h, d, BODY)                                                              \
     do {                                                                                          \
         const i64 a_ = (h)->level_ptr[d], b_ = (h)->level_ptr[(d) + 1];                          \
-        if (2 * (b_ - a_) >= (i64)(h)->nthreads && (h)->nthreads > 1) {                                 \
+        if ((h)->nthreads <= 1) {                                                                 \
+            for (i64 t_ = a_; t_ < b_; ++t_) { const i64 s = (h)->level_fronts[t_]; BODY; }       \
+        } else if (2 * (b_ - a_) >= (i64)(h)->nthreads) {                                         \
             (h)->setnt(1);                                                                        \
             _Pragma("omp parallel for schedule(dynamic, 1) num_threads((h)->nthreads)")           \
             for (i64 t_ = a_; t_ < b_; ++t_) { const i64 s = (h)->level_fronts[t_]; BODY; }       \
@@ -257,7 +268,7 @@ int k1sn_update(k1sn *h, const double *theta, const double *regP, const double *
     i64 fail = -1;
     for (i64 d = h->nlevels - 1; d >= 0 && fail == -1; --d) FOR_LEVEL_FRONTS(h, d, factor_front(h, s, &fail));
     for (i64 s = 0; s < h->nf; ++s) { free(h->U[s]); h->U[s] = NULL; }
-    h->setnt(h->nthreads);
+    if (h->nthreads > 1) h->setnt(h->nthreads);
     h->t_assemble = t1 - t0; h->t_factor = now_s() - t1;
     if (fail == -2) return 3;
     if (fail >= 0) { h->fail_col = fail; return 1; }
@@ -310,7 +321,7 @@ int k1sn_solve(k1sn *h, double *dx, double *dy, const double *xi_p, const double
     for (i64 ii = 0; ii < m; ++ii) h->xw[ii] = xi[h->perm[ii]];
     for (i64 d = h->nlevels - 1; d >= 0; --d) FOR_LEVEL_FRONTS(h, d, fwd_front(h, s));          /* spd.jl:61 */
     for (i64 d = 0; d < h->nlevels; ++d) FOR_LEVEL_FRONTS(h, d, bwd_front(h, s));
-    h->setnt(h->nthreads);
+    if (h->nthreads > 1) h->setnt(h->nthreads);
     for (i64 ii = 0; ii < m; ++ii) dy[h->perm[ii]] = h->xw[ii];
 #pragma omp parallel for schedule(static, 1024) num_threads(h->nthreads)
     for (i64 j = 0; j < n; ++j) {                                                                /* spd.jl:64-66 */
