@@ -64,6 +64,11 @@ typedef struct tlpk_options {
     int32_t system;            /* TLPK_SYSTEM_K1 (default) | TLPK_SYSTEM_K2 */
     int32_t refine_steps;      /* iterative-refinement steps per solve on the residuals of the augmented system (each step = one more
                                   pair of sweeps); 0 = none = the reference's behaviour (spd.jl:68 leaves it as a TODO).  K1, nranks = 1 */
+    int32_t detect_blocks;     /* 1 (and row_block == NULL): find the block-angular structure of THIS matrix with tlpk_detect_blocks --
+                                  the hook that survives Tulip's presolve, which renumbers the rows before KKT.setup sees them
+                                  (model.jl:88-131).  No structure found: general sparse path (tlpk_create) / TLPK_BADARG (tlpk_create_multi) */
+    int32_t reserved0;
+    int64_t max_link_rows;     /* detect_blocks: most linking rows to accept; 0 = max(16, m / 50) */
 } tlpk_options;
 
 typedef struct tlpk_stats {
@@ -161,6 +166,15 @@ int tlpk_root_copy(tlpk_handle *h, int which, int dir, double *d_buf);
  * gathered on devices[0].  The handle accepts tlpk_update / tlpk_solve / tlpk_info / tlpk_get_perm / tlpk_destroy. */
 int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
                       const double *nzval, int index_base, const tlpk_options *opt, int ngpus, const int32_t *devices);
+
+/* Block-angular structure of an m x n CSC matrix (int64 indices, index_base in {0,1}): row_block[i] = block id >= 0 of row i,
+ * or -1 for a linking row -- the vector tlpk_options.row_block takes.  Rows are adjacent when they share a column; the densest
+ * rows are removed (at most max_link_rows, 0 = max(16, m / 50)) until no connected component of the rest holds more than half of
+ * the remaining rows; the smallest such set of linking rows is found by bisection; small components (isolated rows) are packed into
+ * the blocks.  *n_blocks = number of diagonal blocks, 1 = no block structure (then every row_block[i] = 0 and the caller should
+ * pass row_block = NULL).  Host only, deterministic, O(nnz log max_link_rows).  n_blocks / n_link may be NULL. */
+int tlpk_detect_blocks(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int index_base,
+                       int64_t max_link_rows, int64_t *row_block /*m*/, int64_t *n_blocks, int64_t *n_link);
 
 /* Introspection */
 int tlpk_info(const tlpk_handle *h, tlpk_stats *out);

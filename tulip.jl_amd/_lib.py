@@ -26,7 +26,8 @@ class Options(C.Structure):
                 ("relax", C.c_int32), ("profile", C.c_int32), ("rank", C.c_int32),
                 ("nranks", C.c_int32), ("streams", C.c_int32),
                 ("user_perm", p64), ("row_block", p64), ("mem_budget_bytes", C.c_int64),
-                ("system", C.c_int32), ("refine_steps", C.c_int32)]
+                ("system", C.c_int32), ("refine_steps", C.c_int32),
+                ("detect_blocks", C.c_int32), ("reserved0", C.c_int32), ("max_link_rows", C.c_int64)]
 
 
 class Stats(C.Structure):
@@ -63,6 +64,7 @@ EXPORTS = [
     "tlpk_create_multi", "tlpk_ipm_load", "tlpk_ipm_reset", "tlpk_ipm_residuals", "tlpk_ipm_factor", "tlpk_ipm_hsolve", "tlpk_ipm_targets",
     "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get",
     "tlpk_mpc_start", "tlpk_mpc_newton", "tlpk_mpc_gap", "tlpk_mpc_targets", "tlpk_mpc_advance",
+    "tlpk_detect_blocks",
 ]
 
 
@@ -118,6 +120,8 @@ def lib():
     L.tlpk_linear_system.argtypes = [vp]
     L.tlpk_linear_system.restype = C.c_char_p
     L.tlpk_device_count.restype = C.c_int
+    L.tlpk_detect_blocks.argtypes = [C.c_int64, C.c_int64, p64, p64, C.c_int, C.c_int64, p64, p64, p64]
+    L.tlpk_detect_blocks.restype = C.c_int
     L.tlpk_ipm_load.argtypes = [vp, pd, pd, pd, pd]
     L.tlpk_ipm_reset.argtypes = [vp]
     L.tlpk_ipm_residuals.argtypes = [vp, C.c_double, pd]

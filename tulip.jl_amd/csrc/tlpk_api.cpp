@@ -296,6 +296,14 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
         if (def.row_block && m > 0) {
             h->row_block_copy.assign(def.row_block, def.row_block + m);
             h->opt.row_block = h->row_block_copy.data();
+        } else if (def.detect_blocks && m > 1 && colptr) {
+            // the hook that survives Tulip's presolve: find the block structure of the matrix KKT.setup actually received
+            h->row_block_copy.assign((size_t)m, 0);
+            int64_t nb = 1, nl = 0;
+            const int drc = tlpk_detect_blocks(m, n, colptr, rowval, index_base, def.max_link_rows, h->row_block_copy.data(), &nb, &nl);
+            if (drc != TLPK_OK && drc != TLPK_BADARG) { rc = drc; h->last_error = "tlpk_detect_blocks failed"; }
+            if (drc == TLPK_OK && nb >= 2) h->opt.row_block = h->row_block_copy.data();
+            else h->row_block_copy.clear();          // no structure (or malformed input: analyse reports it): general sparse path
         }
         if (def.ordering == TLPK_ORDER_USER && def.user_perm && m > 0) {
             h->user_perm_copy.resize((size_t)m);
@@ -775,15 +783,23 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
                       int index_base, const tlpk_options *uopt, int ngpus, const int32_t *devices) {
     if (!out) return TLPK_BADARG;
     *out = nullptr;
-    if (!uopt || uopt->struct_size != (int32_t)sizeof(tlpk_options) || ngpus < 1 || ngpus > MAX_DEVICES || !uopt->row_block ||
-        uopt->system == TLPK_SYSTEM_K2)
+    if (!uopt || uopt->struct_size != (int32_t)sizeof(tlpk_options) || ngpus < 1 || ngpus > MAX_DEVICES ||
+        (!uopt->row_block && !uopt->detect_blocks) || uopt->system == TLPK_SYSTEM_K2)
         return TLPK_BADARG;                              // block-angular K1 only (general sparse LPs stay single-GPU)
     tlpk_handle *h = new (std::nothrow) tlpk_handle();
     if (!h) return TLPK_OOM;
     int rc = TLPK_OK;
     try {
+        tlpk_options base = *uopt;
+        if (!base.row_block) {                           // detect once, every shard gets the same explicit map
+            h->row_block_copy.assign((size_t)std::max<int64_t>(m, 1), 0);
+            int64_t nb = 1;
+            rc = tlpk_detect_blocks(m, n, colptr, rowval, index_base, base.max_link_rows, h->row_block_copy.data(), &nb, nullptr);
+            if (rc == TLPK_OK && nb < 2) { rc = TLPK_BADARG; }
+            base.row_block = h->row_block_copy.data(); base.detect_blocks = 0;
+        }
         for (int r = 0; r < ngpus && rc == TLPK_OK; ++r) {
-            tlpk_options o = *uopt;
+            tlpk_options o = base;
             o.device = devices ? devices[r] : r;
             o.rank = r; o.nranks = ngpus;
             tlpk_handle *c = nullptr;
@@ -895,6 +911,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "children") from32(S.children);
     else if (w == "depth") from32(S.depth);
     else if (w == "front_block") from32(S.front_block);
+    else if (w == "row_block") tmp = h->row_block_copy;             // the block map in use (given or detected); empty = general sparse
     else if (w == "front_group") from32(S.front_group);
     else if (w == "ngroups") tmp.assign(1, S.ngroups);
     else if (w == "front_local") tmp.assign(S.front_local.begin(), S.front_local.end());

@@ -50,6 +50,9 @@ Base.@kwdef mutable struct Options
     mem_budget_bytes::Int64 = 0
     system::Int32 = 0            # TLPK_SYSTEM_K1 | TLPK_SYSTEM_K2
     refine_steps::Int32 = 0
+    detect_blocks::Int32 = 0     # 1: the library finds the block-angular structure of the matrix it is given
+    reserved0::Int32 = 0
+    max_link_rows::Int64 = 0
 end
 
 strerror(code::Integer) = unsafe_string(ccall((:tlpk_strerror, libtlpk[]), Cstring, (Cint,), code))
@@ -66,13 +69,16 @@ with its 1-based `colptr`/`rowval` (index_base = 1); the library copies everythi
 """
 function create(m::Int, n::Int, colptr::Vector{Int}, rowval::Vector{Int}, nzval::Vector{Float64};
                 device::Integer=0, row_block::Union{Nothing,Vector{Int}}=nothing, system::Int32=TLPK_SYSTEM_K1,
-                streams::Integer=0, ngpus::Integer=1, devices::Union{Nothing,Vector{Int32}}=nothing, refine::Integer=0)
+                streams::Integer=0, ngpus::Integer=1, devices::Union{Nothing,Vector{Int32}}=nothing, refine::Integer=0,
+                detect_blocks::Bool=false, max_link_rows::Integer=0)
     opt = Options()
     opt.struct_size = Int32(sizeof(Options))
     opt.device = Int32(device)
     opt.system = system
     opt.streams = Int32(streams)
     opt.refine_steps = Int32(refine)
+    opt.detect_blocks = Int32(detect_blocks && row_block === nothing)
+    opt.max_link_rows = Int64(max_link_rows)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rb = row_block === nothing ? Int[] : row_block
     dv = devices === nothing ? Int32[] : devices
@@ -93,6 +99,21 @@ function create(m::Int, n::Int, colptr::Vector{Int}, rowval::Vector{Int}, nzval:
 end
 
 destroy(h::Ptr{Cvoid}) = ccall((:tlpk_destroy, libtlpk[]), Cvoid, (Ptr{Cvoid},), h)
+
+"""
+    detect_blocks(m, n, colptr, rowval; max_link_rows=0) -> (row_block::Vector{Int}, n_blocks, n_link)
+
+`tlpk_detect_blocks`: block id (0-based, -1 = linking row) of every row of a 1-based CSC matrix; `n_blocks == 1` means
+no block-angular structure was found.
+"""
+function detect_blocks(m::Int, n::Int, colptr::Vector{Int}, rowval::Vector{Int}; max_link_rows::Integer=0)
+    rb = zeros(Int, max(m, 1)); nb = Ref{Int64}(1); nl = Ref{Int64}(0)
+    rc = GC.@preserve colptr rowval rb ccall((:tlpk_detect_blocks, libtlpk[]), Cint,
+        (Int64, Int64, Ptr{Int64}, Ptr{Int64}, Cint, Int64, Ptr{Int64}, Ref{Int64}, Ref{Int64}),
+        m, n, colptr, rowval, 1, max_link_rows, rb, nb, nl)
+    rc == TLPK_OK || error("tlpk_detect_blocks: " * strerror(rc))
+    return resize!(rb, m), Int(nb[]), Int(nl[])
+end
 
 update(h::Ptr{Cvoid}, θinv::Vector{Float64}, regP::Vector{Float64}, regD::Vector{Float64}) =
     GC.@preserve θinv regP regD ccall((:tlpk_update, libtlpk[]), Cint,

@@ -47,14 +47,24 @@ class Backend:
     (/root/reference/src/KKT/Cholmod/cholmod.jl:18).
 
     row_block: optional block-angular structure (length m; block id >= 0 or -1 for a linking
-    row) -- Tulip's structured-matrix hook (parameters.jl:11 MatrixFactory -> KKT.setup dispatch).
+    row) -- Tulip's structured-matrix hook (parameters.jl:11 MatrixFactory -> KKT.setup dispatch) --
+    or "auto": the library finds the structure of the matrix it is given (tlpk_detect_blocks).  An explicit
+    map indexes the rows of the matrix KKT.setup receives, i.e. it is only meaningful without presolve
+    (Tulip's presolve removes and renumbers rows, model.jl:88-131); "auto" works on the presolved matrix.
     """
 
     def __init__(self, device=0, ordering="amd", relax=True, row_block=None, user_perm=None,
-                 profile=False, rank=0, nranks=1, mem_budget_bytes=0, streams=0, ngpus=1, devices=None, refine=0):
+                 profile=False, rank=0, nranks=1, mem_budget_bytes=0, streams=0, ngpus=1, devices=None, refine=0,
+                 max_link_rows=0):
         self.device = device
         self.ordering = {"amd": _lib.ORDER_AMD, "natural": _lib.ORDER_NATURAL, "user": _lib.ORDER_USER}[ordering]
         self.relax = bool(relax)
+        self.detect_blocks = isinstance(row_block, str)
+        if self.detect_blocks:
+            if row_block != "auto":
+                raise ValueError("row_block: a vector of block ids, None, or 'auto'")
+            row_block = None
+        self.max_link_rows = int(max_link_rows)
         self.row_block = None if row_block is None else np.ascontiguousarray(row_block, dtype=np.int64)
         self.user_perm = None if user_perm is None else np.ascontiguousarray(user_perm, dtype=np.int64)
         self.profile = bool(profile)
@@ -65,6 +75,20 @@ class Backend:
         # single-process multi-GPU (block-angular LPs): one handle shards the diagonal blocks over `ngpus` devices
         self.ngpus = int(ngpus)
         self.devices = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+
+
+def detect_blocks(A, max_link_rows=0):
+    """tlpk_detect_blocks on a scipy sparse matrix: (row_block, n_blocks, n_link); n_blocks == 1: no block structure."""
+    import scipy.sparse as sp
+    A = sp.csc_matrix(A)
+    m, n = A.shape
+    colptr = np.ascontiguousarray(A.indptr, dtype=np.int64); rowval = np.ascontiguousarray(A.indices, dtype=np.int64)
+    rb = np.zeros(max(m, 1), dtype=np.int64)
+    nb, nl = C.c_int64(1), C.c_int64(0)
+    rc = _lib.lib().tlpk_detect_blocks(m, n, _lib.as_p64(colptr), _lib.as_p64(rowval), 0, int(max_link_rows), _lib.as_p64(rb),
+                                       C.byref(nb), C.byref(nl))
+    _raise_for(rc, None, "tlpk_detect_blocks: ")
+    return rb[:m], int(nb.value), int(nl.value)
 
 
 def _raise_for(code, handle=None, what=""):
@@ -107,6 +131,8 @@ class HIPNormalEquations:
         opt.mem_budget_bytes = backend_.mem_budget_bytes
         opt.streams = backend_.streams
         opt.refine_steps = backend_.refine
+        opt.detect_blocks = int(getattr(backend_, "detect_blocks", False))
+        opt.max_link_rows = int(getattr(backend_, "max_link_rows", 0))
         opt.system = system
         self.system = system
         self._keep = []
