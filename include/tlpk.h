@@ -68,7 +68,7 @@ typedef struct tlpk_options {
                                   the hook that survives Tulip's presolve, which renumbers the rows before KKT.setup sees them
                                   (model.jl:88-131).  No structure found: general sparse path (tlpk_create) / TLPK_BADARG (tlpk_create_multi) */
     int32_t reserved0;
-    int64_t max_link_rows;     /* detect_blocks: most linking rows to accept; 0 = max(16, m / 50) */
+    int64_t max_link_rows;     /* detect_blocks: most linking rows to accept; 0 = max(64, m / 20) */
 } tlpk_options;
 
 typedef struct tlpk_stats {
@@ -169,7 +169,7 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
 
 /* Block-angular structure of an m x n CSC matrix (int64 indices, index_base in {0,1}): row_block[i] = block id >= 0 of row i,
  * or -1 for a linking row -- the vector tlpk_options.row_block takes.  Rows are adjacent when they share a column; the densest
- * rows are removed (at most max_link_rows, 0 = max(16, m / 50)) until no connected component of the rest holds more than half of
+ * rows are removed (at most max_link_rows, 0 = max(64, m / 20)) until no connected component of the rest holds more than half of
  * the remaining rows; the smallest such set of linking rows is found by bisection; small components (isolated rows) are packed into
  * the blocks.  *n_blocks = number of diagonal blocks, 1 = no block structure (then every row_block[i] = 0 and the caller should
  * pass row_block = NULL).  Host only, deterministic, O(nnz log max_link_rows).  n_blocks / n_link may be NULL. */

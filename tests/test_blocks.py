@@ -1,0 +1,171 @@
+"""tlpk_detect_blocks and Backend(row_block="auto"): the block-angular hook on the matrix KKT.setup actually receives
+(round-2 verdict, missing item 3: an explicit row_block does not survive Tulip's presolve, /root/reference/src/model.jl:88-131)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import tulip_jl_amd as tk
+from tulip_jl_amd.kkt import detect_blocks
+from tulip_jl_amd.presolve import Presolve
+from tulip_jl_amd.problem import LP, standard_form
+from helpers import block_angular, ipm_like_data, kkt_residuals, random_lp_matrix
+
+INF = float("inf")
+
+
+def is_valid_partition(A, rb):
+    """The definition: no column may touch two different diagonal blocks."""
+    A = sp.csc_matrix(A)
+    for j in range(A.shape[1]):
+        b = rb[A.indices[A.indptr[j]:A.indptr[j + 1]]]
+        if len(set(b[b >= 0].tolist())) > 1:
+            return False
+    return True
+
+
+def test_detects_the_generated_partition_exactly():
+    A, rb = block_angular(nblocks=8, mk=150, nk=600, m0=40, nnz_in=3, link_prob=0.5, seed=11)     # no empty rows at this density
+    d, nb, nl = detect_blocks(A)
+    assert nb == 8 and nl == 40
+    np.testing.assert_array_equal(d, rb)            # blocks are numbered by their first row: the same numbering
+
+
+def test_rows_shuffled_and_isolated_rows_are_packed():
+    A, rb = block_angular(nblocks=5, mk=200, nk=300, m0=25, nnz_in=3, link_prob=0.6, seed=5)
+    A = sp.hstack([A, sp.identity(A.shape[0], format="csc")], format="csc")     # inequality rows: one slack each
+    iso = sp.csc_matrix((np.ones(30), (np.arange(30), np.arange(30))), shape=(30, 30))    # 30 rows that only hold their slack
+    A = sp.block_diag([A, iso], format="csc")
+    rng = np.random.default_rng(0)
+    p = rng.permutation(A.shape[0])
+    Ap = sp.csr_matrix(A)[p].tocsc()
+    d, nb, nl = detect_blocks(Ap)
+    assert nb == 5 and nl == 25 and is_valid_partition(Ap, d)
+    assert set(np.flatnonzero(d < 0).tolist()) == set(np.flatnonzero(np.concatenate([rb, np.zeros(30, int)])[p] < 0).tolist())
+    sizes = np.bincount(d[d >= 0])
+    assert sizes.min() >= 200 and sizes.sum() == A.shape[0] - 25
+
+
+def test_general_sparse_has_no_structure():
+    A = random_lp_matrix(400, 900, 5, 3)
+    d, nb, nl = detect_blocks(A)
+    assert nb == 1 and nl == 0 and not d.any()
+    kkt = tk.setup(A, tk.K1(), tk.Backend(device=-1, row_block="auto"))
+    assert kkt.stats()["n_blocks"] == 0 and kkt.symbolic("row_block").size == 0
+
+
+def test_linking_row_budget():
+    A, rb = block_angular(nblocks=4, mk=150, nk=300, m0=30, nnz_in=3, link_prob=0.8, seed=2)
+    _, nb, _ = detect_blocks(A, max_link_rows=10)          # fewer than the 30 linking rows: nothing found
+    assert nb == 1
+    _, nb, nl = detect_blocks(A, max_link_rows=30)
+    assert nb == 4 and nl == 30
+
+
+def test_auto_gives_the_same_analysis_as_the_explicit_map():
+    A, rb = block_angular(nblocks=6, mk=120, nk=480, m0=30, nnz_in=3, link_prob=0.5, seed=21)
+    a = tk.setup(A, tk.K1(), tk.Backend(device=-1, row_block="auto"))
+    b = tk.setup(A, tk.K1(), tk.Backend(device=-1, row_block=rb))
+    np.testing.assert_array_equal(a.symbolic("row_block"), rb)
+    for what in ("perm", "front_f", "front_ns", "front_block", "front_group", "rowidx"):
+        np.testing.assert_array_equal(a.symbolic(what), b.symbolic(what))
+    assert a.stats()["n_blocks"] == 6
+    # the augmented system takes the same hook
+    a2 = tk.setup(A, tk.K2(), tk.Backend(device=-1, row_block="auto"))
+    b2 = tk.setup(A, tk.K2(), tk.Backend(device=-1, row_block=rb))
+    np.testing.assert_array_equal(a2.symbolic("perm"), b2.symbolic("perm"))
+
+
+def block_lp_with_reducible_structure(seed=4):
+    """A block-angular LP that Tulip's presolve changes: singleton rows (-> bounds, fixed variables), an empty column,
+    a dominated row.  Returns (LP, row_block of the ORIGINAL rows)."""
+    A, rb = block_angular(nblocks=4, mk=100, nk=400, m0=16, nnz_in=3, link_prob=0.5, seed=seed)
+    m, n = A.shape
+    rng = np.random.default_rng(seed)
+    x0 = rng.uniform(0.5, 1.5, n)
+    # extra rows: 6 singleton rows fixing / bounding variables of blocks 0..2, placed in FRONT (renumbers every row)
+    sing_cols = rng.choice(n, size=6, replace=False)
+    S = sp.csc_matrix((np.ones(6), (np.arange(6), sing_cols)), shape=(6, n))
+    A2 = sp.vstack([S, A], format="csc")
+    A2 = sp.hstack([A2, sp.csc_matrix((m + 6, 1))], format="csc")                  # an empty column
+    x0 = np.concatenate([x0, [0.0]])
+    act = A2 @ x0
+    lcon = act.copy(); ucon = act.copy()
+    ucon[6 + 5] = INF; lcon[6 + 7] = -INF                                            # a few inequality rows
+    y = rng.standard_normal(m + 6); y[6 + 5] = abs(y[6 + 5]); y[6 + 7] = -abs(y[6 + 7])
+    z = rng.uniform(0.1, 1.0, n + 1)
+    obj = A2.T @ y + z
+    lvar = np.zeros(n + 1); uvar = np.full(n + 1, INF)
+    x0 = np.maximum(x0, 0)
+    lp = LP(A2, obj, 0.0, lcon, ucon, lvar, uvar)
+    return lp, np.concatenate([np.full(6, -2), rb])       # -2: rows presolve removes (singletons)
+
+
+def test_detection_on_the_presolved_matrix():
+    lp, rb0 = block_lp_with_reducible_structure()
+    ps = Presolve(lp)
+    assert ps.run() == "Trm_Unknown"
+    red = ps.reduced_problem()
+    assert red.A.shape[0] < lp.A.shape[0]                # presolve removed rows: an explicit map of the original rows is useless
+    d = standard_form(red)
+    rb_explicit = rb0[ps.old_con_idx]                    # what the user would have to compute -- needs presolve's internals
+    assert (rb_explicit >= -1).all()
+    det, nb, nl = detect_blocks(d.A)
+    assert nb == 4 and is_valid_partition(d.A, det)
+    np.testing.assert_array_equal(det, rb_explicit)
+    kkt = tk.setup(d.A, tk.K1(), tk.Backend(device=-1, row_block="auto"))
+    assert kkt.stats()["n_blocks"] == 4
+
+
+@pytest.mark.gpu
+def test_auto_blocks_equal_the_explicit_map_bitwise_on_device():
+    A, rb = block_angular(nblocks=6, mk=200, nk=800, m0=40, nnz_in=3, link_prob=0.5, seed=8)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 3)
+    out = []
+    for r in ("auto", rb):
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=r))
+        tk.update(kkt, th, rp, rd)
+        dx, dy = np.zeros(n), np.zeros(m)
+        tk.solve(dx, dy, kkt, xp, xd)
+        out.append((dx, dy))
+        r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+        assert max(r1, r2) <= 1e-8
+        kkt.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.gpu
+def test_model_with_presolve_and_auto_detected_blocks():
+    """The whole pipeline Tulip runs: presolve (rows renumbered) -> standard form -> KKT.setup with row_block = 'auto';
+    equal, bit for bit, to the run with the explicit map of the presolved rows (which only presolve's internals can provide),
+    and to HiGHS in value."""
+    from scipy.optimize import linprog
+    from tulip_jl_amd.model import Model
+    lp, rb0 = block_lp_with_reducible_structure()
+    ps = Presolve(lp); ps.run(); ps.reduced_problem()
+    rb_explicit = rb0[ps.old_con_idx]
+    ma = Model(lp, device=0, row_block="auto").optimize()
+    me = Model(lp, device=0, row_block=rb_explicit).optimize()
+    assert ma.status == me.status == "Trm_Optimal"
+    assert np.array_equal(ma.solution.x, me.solution.x) and ma.inner.niter == me.inner.niter
+    eq = lp.lcon == lp.ucon
+    A = sp.csr_matrix(lp.A)
+    ub = np.isfinite(lp.ucon) & ~eq; lb = np.isfinite(lp.lcon) & ~eq
+    r = linprog(lp.obj, A_ub=sp.vstack([A[ub], -A[lb]]), b_ub=np.concatenate([lp.ucon[ub], -lp.lcon[lb]]), A_eq=A[eq], b_eq=lp.lcon[eq],
+                bounds=[(0, None)] * lp.A.shape[1], method="highs")
+    assert r.status == 0 and abs(ma.objective_value() - r.fun) <= 1e-6 * (1 + abs(r.fun))
+
+
+@pytest.mark.gpu
+def test_multi_device_handle_with_detected_blocks():
+    A, rb = block_angular(nblocks=6, mk=120, nk=480, m0=30, nnz_in=3, link_prob=0.5, seed=9)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 5)
+    res = []
+    for r in ("auto", rb):
+        kkt = tk.setup(A, tk.K1(), tk.Backend(row_block=r, ngpus=2, devices=[0, 0]))
+        tk.update(kkt, th, rp, rd)
+        dx, dy = np.zeros(n), np.zeros(m)
+        tk.solve(dx, dy, kkt, xp, xd)
+        res.append((dx, dy)); kkt.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])

@@ -75,7 +75,7 @@ extern "C" int tlpk_detect_blocks(int64_t m64, int64_t n64, const int64_t *colpt
         std::vector<i32> order((size_t)m);
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](i32 a, i32 b) { return cnt[a] > cnt[b]; });
-        i64 kmax = max_link_rows > 0 ? max_link_rows : std::max<i64>(16, m / 50);
+        i64 kmax = max_link_rows > 0 ? max_link_rows : std::max<i64>(64, m / 20);
         kmax = std::min<i64>(kmax, m - 2);
         std::vector<char> link((size_t)m, 0);
         std::vector<i32> comp((size_t)m), csize;
