@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--no-small-lp", action="store_true", help="skip the latency-bound legs (25fv47-class and pds-20-class LPs)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child-process mode of the cpu_baseline leg
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: run the multi-GPU code path (process group on backend nccl = RCCL, split-phase calls, all-reduce of "
+                         "the root panel / root rhs ordered with the library stream by events) with a world of one rank -- the branch the "
+                         "8-GPU scaling run takes, exercised on a single-GPU box")
     return ap.parse_args()
 
 
@@ -209,10 +213,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    split = world > 1 or args.force_collectives          # split-phase calls + collectives (always at N > 1)
+    if split:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
         if args.workload == "c3":
             raise SystemExit("general sparse LPs run on one GPU (replicas only, SURVEY.md 8e)")
@@ -234,7 +240,7 @@ def main():
         d_dx = torch.empty(n, dtype=torch.float64, device=dev)
         d_dy = torch.empty(m, dtype=torch.float64, device=dev)
         root_t = rhs_t = None
-        if world > 1:                         # torch-owned buffers for the two collectives
+        if split:                             # torch-owned buffers for the two collectives
             _, c = kkt.root_panel()
             root_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
             _, c = kkt.root_rhs()
@@ -258,7 +264,7 @@ def main():
             k.root_copy(which, "in", P(buf))
 
         def newton_step(k):
-            if world == 1:
+            if not split:
                 k.update_device(P(d_th), P(d_rp), P(d_rd))
                 for _ in range(args.solves):
                     k.solve_device(P(d_dx), P(d_dy), P(d_xp), P(d_xd), sync=False)
@@ -367,7 +373,7 @@ def main():
                 out["roofline"] = None
                 out["roofline_error"] = repr(e)
 
-        if world == 1 and not args.no_host_abi:
+        if world == 1 and not split and not args.no_host_abi:
             # The drop-in path: what the Julia glue calls (host pointers in, host pointers out, blocking).
             dxh, dyh = np.empty(n), np.empty(m)
             def host_step():
@@ -391,7 +397,7 @@ def main():
 
     # The roofline leg (a second, single-stream-group handle in profile mode) is measured at N = 1 only: with ranks it would run
     # collectives on a handle the timed loop never used, and a rank failing there would leave the others waiting in an all-reduce.
-    res, A, row_block = run(args.workload, args.steps, args.warmup, (not args.no_roofline) and world == 1)
+    res, A, row_block = run(args.workload, args.steps, args.warmup, (not args.no_roofline) and not split)
     out = {
         "metric": "IPM Newton-step rate: KKT.update! (A*D*A'+Rd, supernodal Cholesky) + %d KKT.solve!" % args.solves,
         "value": res["value"], "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -410,7 +416,9 @@ def main():
             out["roofline_note"] = "measured at n_gpus = 1 only (same kernels; the N = 1 line of this bench carries it)"
     if "roofline_error" in res:
         out["roofline_error"] = res["roofline_error"]
-    if rank == 0 and world == 1 and args.workload == "c4" and not args.no_headline:
+    if split and world == 1:
+        out["collectives"] = "forced at N = 1: process group on backend nccl (RCCL), split-phase update / solve with all-reduce of the root panel and the root rhs"
+    if rank == 0 and world == 1 and not split and args.workload == "c4" and not args.no_headline:
         try:
             hres, _, _ = run("headline", max(2, min(args.steps, 5)), 1, not args.no_roofline)
             out["headline"] = {"ms_per_step": hres["ms_per_step"], "value": hres["value"], "unit": "iter/s",
@@ -429,7 +437,7 @@ def main():
                 out["headline"]["cpu_baseline"] = hc
         except Exception as e:          # the headline leg must never cost the main line
             out["headline"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and args.workload == "c4" and not args.no_small_lp:
+    if rank == 0 and world == 1 and not split and args.workload == "c4" and not args.no_small_lp:
         # The small configs (BASELINE configs[1], configs[4] classes): a Newton step here is bound by launch latency and the
         # serial chain of diagonal blocks, not by the matrix cores -- reported as measured, next to the CPU comparator.
         out["small_lp"] = {}
@@ -456,7 +464,7 @@ def main():
                 out["small_lp"][wl] = leg
             except Exception as e:
                 out["small_lp"][wl] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c3":
+    if rank == 0 and world == 1 and not split and not args.no_cpu_baseline and args.workload not in ("c3", "stair25", "pds"):
         out["cpu_baseline"] = cpu_baseline_subprocess(args)
         if "value" in out["cpu_baseline"]:
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -95,6 +95,8 @@ typedef struct tlpk_stats {
     double  flops_update_alg;  /* ALGORITHMIC flops of that kernel: the share of flops_chol = sum_j l_j^2 whose target
                                   column lies outside column j's own 256-wide block column, sum_j (l_j - r_j)^2 with the
                                   true column counts l_j (no amalgamation zeros); <= flops_chol, <= flops_update */
+    double  ms_enqueue_update; /* multi-device handles: host time from the entry of the last tlpk_update until the work of EVERY shard
+                                  (root fronts included) was enqueued; ms_last_update is then the wall time of the whole call */
 } tlpk_stats;
 
 /* per-kernel-class timing, filled when options.profile = 1 */

@@ -20,7 +20,7 @@ def run_bench(*flags, timeout=900):
 
 @pytest.mark.gpu
 def test_bench_line_contract():
-    d = run_bench("--steps", "2", "--warmup", "1", "--no-headline", "--no-cpu-baseline")
+    d = run_bench("--steps", "2", "--warmup", "1", "--no-headline", "--no-cpu-baseline", "--no-small-lp")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "solve_roofline", "host_abi", "kernel_ms"):
         assert k in d, k
@@ -40,9 +40,32 @@ def test_bench_line_contract():
 
 @pytest.mark.gpu
 def test_bench_cpu_baseline_leg():
-    d = run_bench("--steps", "2", "--warmup", "1", "--no-headline", "--no-host-abi", "--no-roofline")
+    d = run_bench("--steps", "2", "--warmup", "1", "--no-headline", "--no-host-abi", "--no-roofline", "--no-small-lp")
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, (k, c)
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"] and c["value"] > 0
     assert max(c["residual_inf"]) <= 1e-6                                  # the comparator solved the same system
+
+
+@pytest.mark.gpu
+def test_bench_small_lp_legs():
+    """The latency-bound configs (25fv47 class, pds-20 class): GPU step, host-ABI step and the CPU comparator, with the statement."""
+    d = run_bench("--steps", "2", "--warmup", "1", "--no-headline", "--no-roofline", "--no-host-abi", "--blocks", "4")
+    for wl in ("stair25", "pds"):
+        leg = d["small_lp"][wl]
+        assert "error" not in leg, leg
+        assert leg["ms_per_step"] > 0 and leg["cpu_ms_per_step"] > 0 and leg["statement"].startswith("latency-bound")
+        assert max(leg["residual_inf"]) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_branch_with_a_world_of_one():
+    """The branch the 8-GPU scaling run takes -- process group on backend nccl (= RCCL), split-phase update / solve, all-reduce of
+    the root panel and the root right-hand side on torch's stream ordered with the library stream by events -- executed with one
+    rank on this box's single GPU: same step, same residuals as the plain N = 1 path."""
+    a = run_bench("--steps", "2", "--warmup", "1", "--no-headline", "--no-cpu-baseline", "--no-small-lp", "--no-roofline", "--no-host-abi", "--blocks", "8")
+    b = run_bench("--steps", "2", "--warmup", "1", "--blocks", "8", "--force-collectives")
+    assert "collectives" in b and b["n_gpus"] == 1
+    assert max(b["config"]["residual_inf"]) <= 1e-6 and max(a["config"]["residual_inf"]) <= 1e-6
+    assert b["ms_per_step"] < 3 * a["ms_per_step"] + 5.0                     # no host round trips hidden in the collective path

@@ -164,3 +164,19 @@ def test_c5_equivalent_full_scale_hip_vs_highs(tmp_path):
     ref = highs(lp)
     assert abs(sg["z_primal"] - ref) <= 1e-6 * (1 + abs(ref))
     assert abs(sg["z_dual"] - ref) <= 1e-6 * (1 + abs(ref))
+
+
+@pytest.mark.gpu
+def test_ipm_parity_at_benchmark_scale_hip_vs_cpu_supernodal_backend():
+    """SURVEY.md 8(d) parity protocol (ii) on the bench workload's family (BASELINE configs[3] shape, 16 of the 64 diagonal
+    blocks: m = 81 000, n = 160 000): HSD and MPC host-vector loops with the KKT backend swapped between the HIP library and
+    the CHOLMOD-class CPU comparator (same ordering) -- same status, |d niter| <= 1, objectives to 1e-8, rho <= sqrt(eps).
+    The 64-block and north-star runs of the same tool are in profiles/r03_ipm_parity_*.txt."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    from ipm_parity_at_scale import run
+    lines = []
+    ok, results = run(16, False, ["hip", "supernodal"], out=lines.append)
+    assert ok, "\n".join(lines)
+    for alg, (res, checks) in results.items():
+        assert res[0].status == "Trm_Optimal" and all(checks.values()), (alg, checks)

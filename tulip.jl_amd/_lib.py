@@ -39,7 +39,7 @@ class Stats(C.Structure):
                 ("fail_col", C.c_int64), ("ms_analyse", C.c_double), ("ms_last_update", C.c_double),
                 ("ms_last_solve", C.c_double), ("n_local_blocks", C.c_int32), ("n_blocks", C.c_int32),
                 ("root_panel_len", C.c_int64), ("flops_update", C.c_double),
-                ("flops_update_alg", C.c_double)]
+                ("flops_update_alg", C.c_double), ("ms_enqueue_update", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -151,8 +151,12 @@ struct PhaseTimer {
     }
 };
 
-int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval, const double *nzval,
-            int base, const Options &opt) {
+// The analyse phase in two parts.  analyse_common: everything that does not depend on the rank of a sharded run -- copy of
+// A, the graph of A*A', the ordering, the elimination tree, column counts, supernodes, amalgamation, front structures (87 % of
+// the time on config C4).  analyse_rank: ownership, storage offsets, relative indices, gather / assembly lists and the launch
+// schedules of ONE rank.  tlpk_create runs both; tlpk_create_multi runs the common part once and the rank part per device.
+int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval, const double *nzval,
+                   int base, const Options &opt) {
     PhaseTimer pt;
     if (m64 < 0 || n64 < 0 || (base != 0 && base != 1) || !colptr) return fail(S, TLPK_BADARG, "bad dimensions or index base");
     if (m64 >= (i64)1 << 31 || n64 >= (i64)1 << 31) return fail(S, TLPK_TOO_LARGE, "m or n exceeds int32");
@@ -192,7 +196,8 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
 
     pt.mark("block structure");
     // ---- 2. block-angular structure (optional) ----
-    std::vector<i32> row_block, col_block;
+    std::vector<i32> &row_block = S.row_block_v, &col_block = S.col_block_v;
+    row_block.clear(); col_block.clear();
     i32 nblocks = 0, nlink = 0;
     if (opt.row_block) {
         row_block.resize(m);
@@ -431,7 +436,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     }
     sn_start.push_back(m);
     i32 ns_total = 0;
-    std::vector<i32> sparent;
+    std::vector<i32> &sparent = S.sparent_v;
 
     pt.mark("fronts");
     // ---- 9. supernodal tree and front row structures (for a given column partition) ----
@@ -625,6 +630,19 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         if (rc != TLPK_OK) return rc;
     }
     { std::vector<i32>().swap(adj); std::vector<i64>().swap(xadj); }
+    S.nlink_v = nlink;
+    pt.mark(nullptr);
+    return TLPK_OK;
+}
+
+int analyse_rank(Symbolic &S, const Options &opt) {
+    PhaseTimer pt;
+    const i32 m = (i32)S.m, n = (i32)S.n;
+    const std::vector<i32> &row_block = S.row_block_v, &col_block = S.col_block_v, &sparent = S.sparent_v;
+    const i32 nblocks = S.nblocks, nlink = S.nlink_v, ns_total = S.nsuper;
+    if (opt.nranks < 1 || opt.rank < 0 || opt.rank >= opt.nranks) return fail(S, TLPK_BADARG, "bad rank/nranks");
+    if (opt.nranks > 1 && row_block.empty()) return fail(S, TLPK_BADARG, "sharding needs row_block (general sparse LPs are single-GPU)");
+    const bool have_blocks = !row_block.empty();
 
     pt.mark("levels");
     // ---- 10. depths, levels ----
@@ -647,7 +665,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     S.front_local.assign(ns_total, 1);
     S.root_front = (nlink > 0) ? ns_total - 1 : -1;
     std::vector<i32> block_owner(std::max(nblocks, 1), 0);
-    if (opt.row_block) {
+    if (have_blocks) {
         std::vector<double> bflops(nblocks, 0.0);
         for (i32 s = 0; s < ns_total; ++s) {
             const i32 b = row_block[S.perm[S.fronts[s].col0]];
@@ -681,7 +699,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     // on stream b % ngroups so that one group's latency-bound steps (potrf/trsm chains, diagonal
     // solves) overlap the other groups' MFMA updates.  General sparse LPs: one group.
     S.ngroups = 1;
-    if (opt.row_block && nblocks >= 2) {
+    if (have_blocks && nblocks >= 2) {
         // 2 groups x (stream + side stream) = 4 streams = the runtime's default number of hardware
         // queues; more streams share queues and serialise (measured: 2 -> 69.5, 3 -> 75.5, 4 -> 74.3 ms/step on C4)
         S.ngroups = std::min(2, nblocks);
@@ -705,7 +723,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         }
     S.col_local.assign(n, 1);
     S.row_local.assign(m, 1);
-    if (opt.row_block && opt.nranks > 1) {
+    if (have_blocks && opt.nranks > 1) {
         for (i32 j = 0; j < n; ++j) {
             const i32 b = col_block[j];
             S.col_local[j] = (b < 0) ? (opt.rank == 0) : (block_owner[b] == opt.rank);
@@ -714,7 +732,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
             const i32 b = row_block[i];
             S.row_local[i] = (b < 0) ? 2 : (block_owner[b] == opt.rank);   // 2 = linking (replicated)
         }
-    } else if (opt.row_block) {
+    } else if (have_blocks) {
         for (i32 i = 0; i < m; ++i) if (row_block[i] < 0) S.row_local[i] = 2;
     }
 
@@ -878,7 +896,7 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
         S.s_local.assign((size_t)S.nnzS, 0);
         S.pair_ptr.assign((size_t)S.nnzS + 1, 0);
         auto col_is_mine = [&](i32 j) -> bool {
-            if (opt.nranks == 1 || !opt.row_block) return true;
+            if (opt.nranks == 1 || !have_blocks) return true;
             const i32 b = col_block[j];
             return (b < 0) ? (opt.rank == 0) : (block_owner[b] == opt.rank);
         };
@@ -959,6 +977,11 @@ int analyse(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval,
     build_schedule(S);
     pt.mark(nullptr);
     return TLPK_OK;
+}
+
+int analyse(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval, int base, const Options &opt) {
+    const int rc = analyse_common(S, m, n, colptr, rowval, nzval, base, opt);
+    return rc != TLPK_OK ? rc : analyse_rank(S, opt);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -6,6 +6,8 @@
 // device-resident state: A (CSC+CSR), stored copies of theta/regP/regD, the supernodal factor.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -14,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tlpk.h"
@@ -212,6 +215,10 @@ int upload_all(tlpk_handle *h) {
     AL(h->d_theta, nn); AL(h->d_regP, nn); AL(h->d_regD, S.m); AL(h->d_D, nn);
     AL(h->d_xip, S.m); AL(h->d_xid, nn); AL(h->d_dx, nn); AL(h->d_dy, S.m);
     AL(d.rhs_w, std::max<i64>(S.n, 1));
+    // a shard of a multi-device handle receives only its slices of the input vectors: the rest stays zero (never used in arithmetic
+    // that reaches a result, but never uninitialised either)
+    HIPCHK(h, hipMemset(h->d_theta, 0, (size_t)nn * 8)); HIPCHK(h, hipMemset(h->d_regP, 0, (size_t)nn * 8)); HIPCHK(h, hipMemset(h->d_xid, 0, (size_t)nn * 8));
+    HIPCHK(h, hipMemset(h->d_regD, 0, (size_t)std::max<i64>(S.m, 1) * 8)); HIPCHK(h, hipMemset(h->d_xip, 0, (size_t)std::max<i64>(S.m, 1) * 8));
     if (h->refine_steps > 0) { AL(h->d_r1, S.m); AL(h->d_r2, nn); AL(h->d_cx, nn); AL(h->d_cy, S.m); }
     d.ctx.csign = nullptr;
     d.ctx.upd_remap = 2;
@@ -270,6 +277,106 @@ int tlpk_device_count(void) {
     return n;
 }
 
+// tlpk_create in two steps (tlpk_create_multi runs the first one once for all shards and the second per device):
+//   create_host   : options -> handle, block detection, host analyse (or: copy of an analysed Symbolic + this rank's part)
+//   create_device : streams / events, memory gate, upload
+static int create_host(tlpk_handle *h, const tlpk_options &def, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                       const double *nzval, int index_base, const Symbolic *common) {
+    int rc = TLPK_OK;
+    h->opt.ordering = def.ordering; h->opt.relax = def.relax;
+    h->opt.rank = def.rank; h->opt.nranks = def.nranks < 1 ? 1 : def.nranks;
+    h->opt.streams = def.streams;
+    h->opt.system = (def.system == TLPK_SYSTEM_K2) ? 1 : 0;
+    h->refine_steps = def.refine_steps;
+    if (def.refine_steps < 0 || (def.refine_steps > 0 && (h->opt.system == 1 || h->opt.nranks > 1))) {
+        h->last_error = "refine_steps: K1 on one rank only, >= 0";
+        rc = TLPK_BADARG;
+    }
+    if (def.row_block && m > 0) {
+        h->row_block_copy.assign(def.row_block, def.row_block + m);
+        h->opt.row_block = h->row_block_copy.data();
+    } else if (def.detect_blocks && m > 1 && colptr && !common) {
+        // the hook that survives Tulip's presolve: find the block structure of the matrix KKT.setup actually received
+        h->row_block_copy.assign((size_t)m, 0);
+        int64_t nb = 1, nl = 0;
+        const int drc = tlpk_detect_blocks(m, n, colptr, rowval, index_base, def.max_link_rows, h->row_block_copy.data(), &nb, &nl);
+        if (drc != TLPK_OK && drc != TLPK_BADARG) { rc = drc; h->last_error = "tlpk_detect_blocks failed"; }
+        if (drc == TLPK_OK && nb >= 2) h->opt.row_block = h->row_block_copy.data();
+        else h->row_block_copy.clear();          // no structure (or malformed input: analyse reports it): general sparse path
+    }
+    if (def.ordering == TLPK_ORDER_USER && def.user_perm && m > 0) {
+        h->user_perm_copy.resize((size_t)m);
+        for (i64 i = 0; i < m; ++i) h->user_perm_copy[(size_t)i] = def.user_perm[i] - index_base;
+        h->opt.user_perm = h->user_perm_copy.data();
+    }
+    h->profile = def.profile != 0;
+    if (const char *e = std::getenv("TLPK_SERIAL")) h->serial = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (rc == TLPK_OK) {
+        if (common) { h->S = *common; rc = analyse_rank(h->S, h->opt); }
+        else rc = (h->opt.system == 1) ? analyse_k2(h->S, m, n, colptr, rowval, nzval, index_base, h->opt)
+                                       : analyse(h->S, m, n, colptr, rowval, nzval, index_base, h->opt);
+    }
+    h->ms_analyse = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->last_error = h->S.error.empty() ? h->last_error : h->S.error;
+    if (rc == TLPK_OK) {
+        find_markers(h);
+        h->nlink = (h->S.root_front >= 0) ? h->S.fronts[h->S.root_front].ns : 0;
+        h->first_link = h->S.m - h->nlink;
+    }
+    return rc;
+}
+
+static int create_device(tlpk_handle *h, const tlpk_options &def) {
+    int rc = TLPK_OK;
+    if (def.device >= 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || def.device >= ndev) {
+            h->last_error = "no HIP device " + std::to_string(def.device) + " visible";
+            return TLPK_NO_DEVICE;
+        }
+        h->device = def.device;
+        hipError_t e = hipSetDevice(h->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        h->gstream[0] = h->stream;
+        // Only the streams the schedule uses, created back to back: the runtime multiplexes
+        // streams onto a few hardware queues (4 by default) in creation order, and two of OUR
+        // streams on one queue serialise (measured: 70 vs 80 ms/step on C4 depending on what
+        // else the process had created before).
+        const int ng = std::max(1, h->S.ngroups);
+        for (int g = 1; g < ng && e == hipSuccess; ++g) e = hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking);
+        for (int g = 0; g < ng && e == hipSuccess; ++g) e = hipStreamCreateWithFlags(&h->sstream[g], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+        for (int g = 1; g < ng && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming);
+        for (int g = 0; g < ng && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_side[g], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+        if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+        if (e != hipSuccess) rc = hip_fail(h, e, "device init");
+        if (rc == TLPK_OK) {
+            // memory gate: refuse before allocating
+            size_t free_b = 0, total_b = 0;
+            hipMemGetInfo(&free_b, &total_b);
+            const double budget = def.mem_budget_bytes > 0 ? (double)def.mem_budget_bytes : 0.9 * (double)free_b;
+            const double need = 8.0 * ((double)h->S.lval_len + (double)h->S.ubuf_len[0] + (double)h->S.ubuf_len[1] +
+                                       (double)h->S.spart_len + (double)h->S.dinv_len + (double)h->S.uc_len +
+                                       (double)h->S.gth_ptr.size() + (double)h->S.gth_src.size()) +
+                                12.0 * (double)h->S.pair_w.size() + 20.0 * (double)h->S.nnzS + 40.0 * (double)h->S.nnzA +
+                                8.0 * (double)h->S.rowidx.size();
+            if (need > budget) {
+                h->last_error = "factor needs " + std::to_string(need / 1e9) + " GB, budget " + std::to_string(budget / 1e9) + " GB";
+                rc = TLPK_TOO_LARGE;
+            }
+        }
+        if (rc == TLPK_OK) rc = upload_all(h);
+        if (rc == TLPK_OK) h->has_device = true;
+    } else if (def.mem_budget_bytes > 0) {
+        const double need = 8.0 * ((double)h->S.lval_len + (double)h->S.ubuf_len[0] + (double)h->S.ubuf_len[1]);
+        if (need > (double)def.mem_budget_bytes) { h->last_error = "factor exceeds mem_budget_bytes"; rc = TLPK_TOO_LARGE; }
+    }
+    return rc;
+}
+
 int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
                 const double *nzval, int index_base, const tlpk_options *uopt) {
     if (!out) return TLPK_BADARG;
@@ -284,91 +391,8 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
     if (!h) return TLPK_OOM;
     int rc = TLPK_OK;
     try {
-        h->opt.ordering = def.ordering; h->opt.relax = def.relax;
-        h->opt.rank = def.rank; h->opt.nranks = def.nranks < 1 ? 1 : def.nranks;
-        h->opt.streams = def.streams;
-        h->opt.system = (def.system == TLPK_SYSTEM_K2) ? 1 : 0;
-        h->refine_steps = def.refine_steps;
-        if (def.refine_steps < 0 || (def.refine_steps > 0 && (h->opt.system == 1 || h->opt.nranks > 1))) {
-            h->last_error = "refine_steps: K1 on one rank only, >= 0";
-            rc = TLPK_BADARG;
-        }
-        if (def.row_block && m > 0) {
-            h->row_block_copy.assign(def.row_block, def.row_block + m);
-            h->opt.row_block = h->row_block_copy.data();
-        } else if (def.detect_blocks && m > 1 && colptr) {
-            // the hook that survives Tulip's presolve: find the block structure of the matrix KKT.setup actually received
-            h->row_block_copy.assign((size_t)m, 0);
-            int64_t nb = 1, nl = 0;
-            const int drc = tlpk_detect_blocks(m, n, colptr, rowval, index_base, def.max_link_rows, h->row_block_copy.data(), &nb, &nl);
-            if (drc != TLPK_OK && drc != TLPK_BADARG) { rc = drc; h->last_error = "tlpk_detect_blocks failed"; }
-            if (drc == TLPK_OK && nb >= 2) h->opt.row_block = h->row_block_copy.data();
-            else h->row_block_copy.clear();          // no structure (or malformed input: analyse reports it): general sparse path
-        }
-        if (def.ordering == TLPK_ORDER_USER && def.user_perm && m > 0) {
-            h->user_perm_copy.resize((size_t)m);
-            for (i64 i = 0; i < m; ++i) h->user_perm_copy[(size_t)i] = def.user_perm[i] - index_base;
-            h->opt.user_perm = h->user_perm_copy.data();
-        }
-        h->profile = def.profile != 0;
-        if (const char *e = std::getenv("TLPK_SERIAL")) h->serial = std::atoi(e) != 0;
-        if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
-        const auto t0 = std::chrono::steady_clock::now();
-        if (rc == TLPK_OK)
-            rc = (h->opt.system == 1) ? analyse_k2(h->S, m, n, colptr, rowval, nzval, index_base, h->opt)
-                                      : analyse(h->S, m, n, colptr, rowval, nzval, index_base, h->opt);
-        h->ms_analyse = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        h->last_error = h->S.error;
-        if (rc == TLPK_OK) {
-            find_markers(h);
-            h->nlink = (h->S.root_front >= 0) ? h->S.fronts[h->S.root_front].ns : 0;
-            h->first_link = h->S.m - h->nlink;
-        }
-        if (rc == TLPK_OK && def.device >= 0) {
-            int ndev = 0;
-            if (hipGetDeviceCount(&ndev) != hipSuccess || def.device >= ndev) {
-                h->last_error = "no HIP device " + std::to_string(def.device) + " visible";
-                rc = TLPK_NO_DEVICE;
-            } else {
-                h->device = def.device;
-                hipError_t e = hipSetDevice(h->device);
-                if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-                h->gstream[0] = h->stream;
-                // Only the streams the schedule uses, created back to back: the runtime multiplexes
-                // streams onto a few hardware queues (4 by default) in creation order, and two of OUR
-                // streams on one queue serialise (measured: 70 vs 80 ms/step on C4 depending on what
-                // else the process had created before).
-                const int ng = std::max(1, h->S.ngroups);
-                for (int g = 1; g < ng && e == hipSuccess; ++g) e = hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking);
-                for (int g = 0; g < ng && e == hipSuccess; ++g) e = hipStreamCreateWithFlags(&h->sstream[g], hipStreamNonBlocking);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
-                for (int g = 1; g < ng && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming);
-                for (int g = 0; g < ng && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_side[g], hipEventDisableTiming);
-                if (e == hipSuccess) e = hipEventCreate(&h->ev0);
-                if (e == hipSuccess) e = hipEventCreate(&h->ev1);
-                if (e != hipSuccess) rc = hip_fail(h, e, "device init");
-                if (rc == TLPK_OK) {
-                    // memory gate: refuse before allocating
-                    size_t free_b = 0, total_b = 0;
-                    hipMemGetInfo(&free_b, &total_b);
-                    const double budget = def.mem_budget_bytes > 0 ? (double)def.mem_budget_bytes : 0.9 * (double)free_b;
-                    const double need = 8.0 * ((double)h->S.lval_len + (double)h->S.ubuf_len[0] + (double)h->S.ubuf_len[1] +
-                                               (double)h->S.spart_len + (double)h->S.dinv_len + (double)h->S.uc_len +
-                                               (double)h->S.gth_ptr.size() + (double)h->S.gth_src.size()) +
-                                        12.0 * (double)h->S.pair_w.size() + 20.0 * (double)h->S.nnzS + 40.0 * (double)h->S.nnzA +
-                                        8.0 * (double)h->S.rowidx.size();
-                    if (need > budget) {
-                        h->last_error = "factor needs " + std::to_string(need / 1e9) + " GB, budget " + std::to_string(budget / 1e9) + " GB";
-                        rc = TLPK_TOO_LARGE;
-                    }
-                }
-                if (rc == TLPK_OK) rc = upload_all(h);
-                if (rc == TLPK_OK) h->has_device = true;
-            }
-        } else if (rc == TLPK_OK && def.mem_budget_bytes > 0) {
-            const double need = 8.0 * ((double)h->S.lval_len + (double)h->S.ubuf_len[0] + (double)h->S.ubuf_len[1]);
-            if (need > (double)def.mem_budget_bytes) { h->last_error = "factor exceeds mem_budget_bytes"; rc = TLPK_TOO_LARGE; }
-        }
+        rc = create_host(h, def, m, n, colptr, rowval, nzval, index_base, nullptr);
+        if (rc == TLPK_OK) rc = create_device(h, def);
     } catch (const std::bad_alloc &) {
         rc = TLPK_OOM; h->last_error = "host out of memory during analyse";
     } catch (...) {
@@ -380,9 +404,12 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
     return rc;
 }
 
+namespace { void multi_comm_destroy(void *comm); }
+
 void tlpk_destroy(tlpk_handle *h) {
     if (!h) return;
     if (!h->sub.empty() || h->multi_tmp) {                // multi-device parent: owns its per-device handles, nothing else
+        if (h->multi_rccl) for (size_t r = 0; r < h->sub.size(); ++r) if (h->multi_comm[r]) multi_comm_destroy(h->multi_comm[r]);
         for (tlpk_handle *c : h->sub) tlpk_destroy(c);
         if (h->multi_tmp) { hipSetDevice(h->device); hipFree(h->multi_tmp); }
         if (h->multi_done) hipEventDestroy(h->multi_done);
@@ -471,9 +498,10 @@ int tlpk_root_copy(tlpk_handle *h, int which, int dir, double *d_buf) {
     return TLPK_OK;
 }
 
-int tlpk_update_finish(tlpk_handle *h) {
-    if (!h) return TLPK_BADARG;
-    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
+// tlpk_update_finish = enqueue (root front + status read-back) + wait.  The multi-device mode enqueues the finish of EVERY shard
+// before it waits for any of them: with the synchronisation inside, shard r's root factorisation was not even enqueued before
+// shard r - 1's had completed (N - 1 serialised root fronts per update).
+static int update_finish_enqueue(tlpk_handle *h) {
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->local_done) return TLPK_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -481,6 +509,10 @@ int tlpk_update_finish(tlpk_handle *h) {
     run_launches(h, S.factor_launches, h->factor_marker, S.factor_launches.size());
     HIPCHK(h, hipMemcpyAsync(h->h_info, h->d.ctx.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    return TLPK_OK;
+}
+static int update_finish_wait(tlpk_handle *h) {
+    HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->ms_update = ms;
@@ -489,6 +521,13 @@ int tlpk_update_finish(tlpk_handle *h) {
     if (h->h_info[0] != INT_MAX) { h->fail_col = h->h_info[0]; return TLPK_NOT_POSDEF; }
     h->factored = true;
     return TLPK_OK;
+}
+
+int tlpk_update_finish(tlpk_handle *h) {
+    if (!h) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
+    if (int rc = update_finish_enqueue(h)) return rc;
+    return update_finish_wait(h);
 }
 
 // The composed entry points run both halves back to back WITHOUT the all-reduce of the root panel /
@@ -671,13 +710,61 @@ int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const
 // One handle drives `ngpus` devices from one host thread (what a Julia process needs): internally one sharded
 // handle per device (rank r of ngpus, same split-phase schedule as the one-process-per-GPU mode).  The two
 // reductions of a Newton step -- the root (linking) panel after the local factorisations, the root right-hand
-// side inside every solve -- are done by the library over peer-to-peer copies: gather on the lead device, add in
-// rank order (deterministic), copy back; stream-ordered through events, no host synchronisation between the
-// halves.  Results are written by every rank straight into the lead device's dx / dy (P2P stores of the entries
-// it owns) and leave through one pinned copy.
+// side inside every solve -- are done by the library, stream-ordered through events, no host synchronisation
+// between the halves:
+//   * default: peer-to-peer copies -- gather on the lead device, add in rank order (deterministic, bit-identical to the
+//     one-process-per-GPU mode with an ordered reduction), copy back;
+//   * TLPK_MULTI_REDUCE=rccl: ncclAllReduce over xGMI on every shard's stream (librccl.so is dlopen'ed, one communicator per
+//     device from ncclCommInitAll); needs distinct devices; the sum order is RCCL's.
+// Results are written by every rank straight into the lead device's dx / dy (P2P stores of the entries it owns) and leave
+// through one pinned copy.  Host -> device: every shard receives only the slices of theta / regP / regD / xi it reads.
 namespace {
 
+// --- RCCL through dlopen: the library does not link against it (single-GPU users never load it) ---
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load(std::string &err) {
+        if (lib) return true;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) { err = std::string("dlopen(librccl.so): ") + dlerror(); return false; }
+        *(void **)&CommInitAll = dlsym(lib, "ncclCommInitAll"); *(void **)&CommDestroy = dlsym(lib, "ncclCommDestroy");
+        *(void **)&AllReduce = dlsym(lib, "ncclAllReduce"); *(void **)&GroupStart = dlsym(lib, "ncclGroupStart");
+        *(void **)&GroupEnd = dlsym(lib, "ncclGroupEnd"); *(void **)&GetErrorString = dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd) { err = "librccl.so lacks the expected symbols"; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0;          // rccl.h: ncclFloat64 = 8, ncclSum = 0
+
+int multi_allreduce_rccl(tlpk_handle *h, bool panel) {
+    const int N = (int)h->sub.size();
+    int rc = g_rccl.GroupStart();
+    for (int r = 0; r < N && rc == 0; ++r) {
+        tlpk_handle *c = h->sub[r];
+        double *p = nullptr; int64_t cnt = 0;
+        const int q = panel ? tlpk_root_panel(c, &p, &cnt) : tlpk_root_rhs(c, &p, &cnt);
+        if (q != TLPK_OK) { g_rccl.GroupEnd(); return q; }
+        if (cnt == 0) { g_rccl.GroupEnd(); return TLPK_OK; }
+        HIPCHK(h, hipSetDevice(c->device));
+        rc = g_rccl.AllReduce(p, p, (size_t)cnt, NCCL_DOUBLE, NCCL_SUM, h->multi_comm[r], c->stream);      // in place, on the shard's stream
+    }
+    const int rc2 = g_rccl.GroupEnd();
+    if (rc != 0 || rc2 != 0) {
+        h->last_error = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error");
+        return TLPK_HIPERR;
+    }
+    return TLPK_OK;
+}
+
 int multi_allreduce(tlpk_handle *h, bool panel) {
+    if (h->multi_rccl) return multi_allreduce_rccl(h, panel);
     tlpk_handle *lead = h->sub[0];
     double *p0 = nullptr; int64_t cnt = 0;
     int rc = panel ? tlpk_root_panel(lead, &p0, &cnt) : tlpk_root_rhs(lead, &p0, &cnt);
@@ -712,9 +799,19 @@ int multi_allreduce(tlpk_handle *h, bool panel) {
     return TLPK_OK;
 }
 
+// host -> device copy of the entries [lo, hi) of a pinned full-length vector (device arrays are full length too)
+inline hipError_t upload_range(double *dst, const double *src, i64 lo, i64 hi, hipStream_t st) {
+    return hi > lo ? hipMemcpyAsync(dst + lo, src + lo, (size_t)(hi - lo) * 8, hipMemcpyHostToDevice, st) : hipSuccess;
+}
+
+void multi_comm_destroy(void *comm) { if (g_rccl.CommDestroy) g_rccl.CommDestroy(comm); }
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int multi_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
     tlpk_handle *lead = h->sub[0];
     const i64 n = h->S.n, m = h->S.m;
+    const double t_in = now_ms();
     HIPCHK(h, hipSetDevice(lead->device));
     if (int rc = ensure_pinned(lead)) { h->last_error = lead->last_error; return rc; }
     for (tlpk_handle *c : h->sub) { HIPCHK(h, hipSetDevice(c->device)); HIPCHK(h, hipStreamSynchronize(c->stream)); }   // staging area free again
@@ -722,19 +819,27 @@ int multi_update(tlpk_handle *h, const double *theta, const double *regP, const 
     std::memcpy(p0, theta, (size_t)n * 8); std::memcpy(p1, regP, (size_t)n * 8); std::memcpy(p2, regD, (size_t)m * 8);
     for (tlpk_handle *c : h->sub) {
         HIPCHK(h, hipSetDevice(c->device));
-        HIPCHK(h, hipMemcpyAsync(c->d_theta, p0, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(h, hipMemcpyAsync(c->d_regP, p1, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(h, hipMemcpyAsync(c->d_regD, p2, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        // only what this shard reads: its columns of theta / regP, its block rows and the linking rows of regD
+        HIPCHK(h, upload_range(c->d_theta, p0, c->col_lo, c->col_hi, c->stream));
+        HIPCHK(h, upload_range(c->d_regP, p1, c->col_lo, c->col_hi, c->stream));
+        HIPCHK(h, upload_range(c->d_regD, p2, c->row_lo, c->row_hi, c->stream));
+        HIPCHK(h, upload_range(c->d_regD, p2, c->link_lo, c->link_hi, c->stream));
         const int rc = tlpk_update_local(c, c->d_theta, c->d_regP, c->d_regD);
         if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
     }
     if (int rc = multi_allreduce(h, true)) return rc;
+    for (tlpk_handle *c : h->sub) {                      // every root front is enqueued before anybody waits
+        const int rc = update_finish_enqueue(c);
+        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    }
+    h->ms_enqueue_update = now_ms() - t_in;
     int worst = TLPK_OK; h->fail_col = -1;
     for (tlpk_handle *c : h->sub) {
-        const int rc = tlpk_update_finish(c);
+        const int rc = update_finish_wait(c);
         if (rc == TLPK_NOT_POSDEF) { if (h->fail_col < 0 || c->fail_col < h->fail_col) h->fail_col = c->fail_col; if (worst == TLPK_OK) worst = rc; }
         else if (rc != TLPK_OK) { h->last_error = c->last_error; worst = rc; }
     }
+    h->ms_update = now_ms() - t_in;
     h->factored = (worst == TLPK_OK);
     return worst;
 }
@@ -750,8 +855,9 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
     std::memcpy(pi0, xi_p, (size_t)m * 8); std::memcpy(pi1, xi_d, (size_t)n * 8);
     for (tlpk_handle *c : h->sub) {
         HIPCHK(h, hipSetDevice(c->device));
-        HIPCHK(h, hipMemcpyAsync(c->d_xip, pi0, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(h, hipMemcpyAsync(c->d_xid, pi1, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(h, upload_range(c->d_xip, pi0, c->row_lo, c->row_hi, c->stream));
+        HIPCHK(h, upload_range(c->d_xip, pi0, c->link_lo, c->link_hi, c->stream));
+        HIPCHK(h, upload_range(c->d_xid, pi1, c->col_lo, c->col_hi, c->stream));
         const int rc = tlpk_solve_local(c, c->d_xip, c->d_xid);
         if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
     }
@@ -777,6 +883,18 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
     return TLPK_OK;
 }
 
+// index ranges a shard reads from the job-wide input vectors
+void shard_ranges(tlpk_handle *c) {
+    const Symbolic &S = c->S;
+    auto range = [](const std::vector<char> &v, char what, i64 &lo, i64 &hi) {
+        lo = hi = 0; bool any = false;
+        for (size_t i = 0; i < v.size(); ++i) if (v[i] == what) { if (!any) { lo = (i64)i; any = true; } hi = (i64)i + 1; }
+    };
+    range(S.col_local, 1, c->col_lo, c->col_hi);
+    range(S.row_local, 1, c->row_lo, c->row_hi);
+    range(S.row_local, 2, c->link_lo, c->link_hi);
+}
+
 }  // namespace
 
 int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, const double *nzval,
@@ -795,17 +913,46 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
             h->row_block_copy.assign((size_t)std::max<int64_t>(m, 1), 0);
             int64_t nb = 1;
             rc = tlpk_detect_blocks(m, n, colptr, rowval, index_base, base.max_link_rows, h->row_block_copy.data(), &nb, nullptr);
-            if (rc == TLPK_OK && nb < 2) { rc = TLPK_BADARG; }
+            if (rc == TLPK_OK && nb < 2) { rc = TLPK_BADARG; h->last_error = "no block-angular structure found"; }
             base.row_block = h->row_block_copy.data(); base.detect_blocks = 0;
         }
+        // ONE host analyse for the job: ordering, elimination tree, supernodes and front structures do not depend on the rank;
+        // each shard then adds its ownership, storage offsets, lists and schedules (in parallel on the host), and uploads
+        Symbolic common;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (rc == TLPK_OK) {
+            Options o; o.ordering = base.ordering; o.relax = base.relax; o.nranks = ngpus; o.row_block = base.row_block;
+            rc = analyse_common(common, m, n, colptr, rowval, nzval, index_base, o);
+            if (rc != TLPK_OK) h->last_error = common.error;
+        }
+        std::vector<int> rcs((size_t)ngpus, TLPK_OK);
+        std::vector<tlpk_options> opts((size_t)ngpus, base);
+        if (rc == TLPK_OK) {
+            for (int r = 0; r < ngpus; ++r) {
+                tlpk_handle *c = new (std::nothrow) tlpk_handle();
+                if (!c) { rc = TLPK_OOM; break; }
+                h->sub.push_back(c);
+                opts[(size_t)r].device = devices ? devices[r] : r;
+                opts[(size_t)r].rank = r; opts[(size_t)r].nranks = ngpus;
+            }
+        }
+        if (rc == TLPK_OK) {
+            std::vector<std::thread> pool;
+            auto work = [&](int r) {
+                try { rcs[(size_t)r] = create_host(h->sub[(size_t)r], opts[(size_t)r], m, n, colptr, rowval, nzval, index_base, &common); }
+                catch (...) { rcs[(size_t)r] = TLPK_OOM; }
+            };
+            try { for (int r = 1; r < ngpus; ++r) pool.emplace_back(work, r); } catch (...) { /* fewer threads: the rest runs below */ }
+            work(0);
+            for (auto &t : pool) t.join();
+            for (int r = (int)pool.size() + 1; r < ngpus; ++r) work(r);
+            for (int r = 0; r < ngpus && rc == TLPK_OK; ++r) if (rcs[(size_t)r] != TLPK_OK) { rc = rcs[(size_t)r]; h->last_error = h->sub[(size_t)r]->last_error; }
+        }
+        h->ms_analyse = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         for (int r = 0; r < ngpus && rc == TLPK_OK; ++r) {
-            tlpk_options o = base;
-            o.device = devices ? devices[r] : r;
-            o.rank = r; o.nranks = ngpus;
-            tlpk_handle *c = nullptr;
-            rc = tlpk_create(&c, m, n, colptr, rowval, nzval, index_base, &o);
-            if (rc != TLPK_OK) { if (c) { h->last_error = c->last_error; tlpk_destroy(c); } break; }
-            h->sub.push_back(c);
+            rc = create_device(h->sub[(size_t)r], opts[(size_t)r]);
+            if (rc != TLPK_OK) h->last_error = h->sub[(size_t)r]->last_error;
+            else shard_ranges(h->sub[(size_t)r]);
         }
     } catch (...) { rc = TLPK_OOM; }
     if (rc == TLPK_OK) {
@@ -830,7 +977,26 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
         }
         if (e != hipSuccess) rc = hip_fail(h, e, "multi-device init");
     }
-    if (rc != TLPK_OK) { tlpk_destroy(h); return rc; }
+    if (rc == TLPK_OK) {
+        // library-owned reductions over RCCL (north_star: "RCCL-reducing the linking-block Schur complement over xGMI"): opt-in,
+        // needs one DISTINCT device per shard (RCCL refuses two ranks on one device)
+        const char *e = std::getenv("TLPK_MULTI_REDUCE");
+        if (e && std::string(e) == "rccl" && ngpus > 1) {
+            bool distinct = true;
+            for (int a = 0; a < ngpus; ++a) for (int b = a + 1; b < ngpus; ++b) if (h->sub[a]->device == h->sub[b]->device) distinct = false;
+            std::string err;
+            if (!distinct) { h->last_error = "TLPK_MULTI_REDUCE=rccl needs one distinct device per shard"; rc = TLPK_BADARG; }
+            else if (!g_rccl.load(err)) { h->last_error = err; rc = TLPK_HIPERR; }
+            else {
+                int devs[MAX_DEVICES];
+                for (int r = 0; r < ngpus; ++r) devs[r] = h->sub[r]->device;
+                const int q = g_rccl.CommInitAll(h->multi_comm, ngpus, devs);
+                if (q != 0) { h->last_error = std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(q) : "error"); rc = TLPK_HIPERR; }
+                else h->multi_rccl = true;
+            }
+        }
+    }
+    if (rc != TLPK_OK) { std::string msg = h->last_error; tlpk_destroy(h); (void)msg; return rc; }
     *out = h;
     return TLPK_OK;
 }
@@ -844,6 +1010,7 @@ int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
         i64 bytes = 0; i32 nloc = 0;
         for (const tlpk_handle *c : h->sub) { bytes += c->device_bytes; nloc += c->S.n_local_blocks; }
         out->device_bytes = bytes; out->n_local_blocks = nloc;
+        out->ms_analyse = h->ms_analyse; out->ms_last_update = h->ms_update; out->ms_enqueue_update = h->ms_enqueue_update;
         return rc;
     }
     const Symbolic &S = h->S;

@@ -57,6 +57,9 @@ struct tlpk_handle {
     double *multi_tmp = nullptr;        // device 0: staging of the peers' root panels / root rhs for the reduction
     i64 multi_red_off = 0, multi_dy0_off = 0;   // ... followed by the reduced buffer and the lead's rank-local dy
     hipEvent_t multi_ev[MAX_DEVICES] = {}; hipEvent_t multi_done = nullptr;
+    void *multi_comm[MAX_DEVICES] = {}; bool multi_rccl = false;   // TLPK_MULTI_REDUCE=rccl: one ncclComm_t per shard
+    double ms_enqueue_update = 0;       // parent: host time from the entry of tlpk_update until every shard's work is enqueued
+    i64 col_lo = 0, col_hi = 0, row_lo = 0, row_hi = 0, link_lo = 0, link_hi = 0;   // child: slices of the job-wide input vectors it reads
     double *shared_dy = nullptr;        // child: job-wide dy on the lead device (P2P), filled with the rows this rank owns
     bool dx_local_only = false;         // child: dx is the job-wide vector, leave the other ranks' columns alone
     IpmState *ipm = nullptr;            // device-resident interior-point vectors (tlpk_ipm_load), freed by tlpk_destroy

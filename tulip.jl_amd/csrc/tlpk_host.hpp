@@ -147,6 +147,10 @@ struct Symbolic {
     i64 n_sweep_flags = 0;                 // number of fronts handled by the sweep kernels
     bool sweep = true;                     // persistent sweep kernels (TLPK_SWEEP=0: one launch per 128-column block step)
     std::vector<Launch> factor_launches, fwd_launches, bwd_launches;
+    // state handed from analyse_common to analyse_rank (rank-independent)
+    std::vector<i32> row_block_v, col_block_v;   // block of each row / column of A (-1: linking), empty = general sparse
+    std::vector<i32> sparent_v;                  // parent of each front
+    i32 nlink_v = 0;                             // number of linking rows
     std::string error;
 };
 
@@ -157,6 +161,11 @@ void amd_order(i32 n, const std::vector<i64> &xadj, const std::vector<i32> &adj,
 // [-(Theta^-1 + Rp) A'; A Rd] (order n + m) from the same machinery.
 int analyse(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
             int index_base, const Options &opt);
+// the two halves of analyse(): the rank-independent part (ordering ... front structures) and one rank's ownership, storage
+// offsets, lists and schedules; a copy of a Symbolic after analyse_common can be finished for any (rank, nranks)
+int analyse_common(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
+                   int index_base, const Options &opt);
+int analyse_rank(Symbolic &S, const Options &opt);
 int analyse_k2(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
                int index_base, const Options &opt);
 
