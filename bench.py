@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-headline", action="store_true", help="skip the extra north-star headline run (N=1, workload c4 only)")
     ap.add_argument("--no-host-abi", action="store_true")
+    ap.add_argument("--unpaired", action="store_true",
+                    help="solve the right-hand sides of a step one by one (default: the first two as a pair, one pass over the factor "
+                         "-- Tulip's HSD step solves the h-system and the predictor, independent right-hand sides, in every iteration)")
     ap.add_argument("--no-small-lp", action="store_true", help="skip the latency-bound legs (25fv47-class and pds-20-class LPs)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child-process mode of the cpu_baseline leg
@@ -198,6 +201,17 @@ def main():
         A, row_block, _ = build_workload(args, args.workload)
         print(json.dumps(cpu_baseline(args, A, row_block, args.blocks if args.workload == "c4" else (100 if args.workload == "headline" else 1))))
         return
+    # The contract is ONE JSON line on stdout.  RCCL prints a banner ("Hostname ...", "Librccl path ...") on stdout when a
+    # communicator is created, and any library may: everything written to file descriptor 1 while the bench runs goes to
+    # stderr, the JSON line is written to the real stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.write(real_stdout, (line + "\n").encode())
+
     import torch
     import tulip_jl_amd as tk
     from workloads import kernel_inputs
@@ -239,6 +253,9 @@ def main():
         d_th, d_rp, d_rd, d_xp, d_xd = (torch.from_numpy(v).to(dev) for v in (th, rp, rd, xp, xd))
         d_dx = torch.empty(n, dtype=torch.float64, device=dev)
         d_dy = torch.empty(m, dtype=torch.float64, device=dev)
+        d_dx2 = torch.empty(n, dtype=torch.float64, device=dev)
+        d_dy2 = torch.empty(m, dtype=torch.float64, device=dev)
+        pair = (not args.unpaired) and args.solves >= 2 and not split
         root_t = rhs_t = None
         if split:                             # torch-owned buffers for the two collectives
             _, c = kkt.root_panel()
@@ -266,7 +283,9 @@ def main():
         def newton_step(k):
             if not split:
                 k.update_device(P(d_th), P(d_rp), P(d_rd))
-                for _ in range(args.solves):
+                if pair:      # the h-system + predictor pair of an HSD step (HSD/step.jl:63,79): two right-hand sides, one pass over L
+                    k.solve2_device(P(d_dx2), P(d_dy2), P(d_xp), P(d_xd), P(d_dx), P(d_dy), P(d_xp), P(d_xd), sync=False)
+                for _ in range(args.solves - (2 if pair else 0)):
                     k.solve_device(P(d_dx), P(d_dy), P(d_xp), P(d_xd), sync=False)
                 k.sync()
             else:
@@ -307,6 +326,8 @@ def main():
 
         out = {"ms_per_step": ms_per_step, "value": 1e3 / ms_per_step,
                "config": {"workload": text, "solves_per_step": args.solves, "regime": args.regime,
+                          "solve_schedule": ("1 pair (two right-hand sides in one pass over the factor: HSD's h-system + predictor) + %d single" % (args.solves - 2))
+                                            if pair else "%d single" % args.solves,
                           "parallelism": "blocks/%d" % world, "stream_groups": int(kkt.symbolic("ngroups")[0]),
                           "nnzS": st["nnzS"], "nnzL": st["nnzL"], "nnzL_stored": st["nnzL_stored"],
                           "stored_over_nnzL": st["nnzL_stored"] / max(st["nnzL"], 1), "device_bytes": st["device_bytes"],
@@ -390,8 +411,22 @@ def main():
                                "pcie_bytes_per_step": 8 * (2 * n + m) + args.solves * 16 * (m + n),
                                "note": "tlpk_update + %d x tlpk_solve with pageable host vectors through pinned staging; "
                                        "PCIe-inclusive, never reported as `value`" % args.solves}
+        if pair and world == 1:
+            # the same step with every right-hand side solved on its own (the round-2 definition of the step), for comparison
+            def unpaired_step():
+                kkt.update_device(P(d_th), P(d_rp), P(d_rd))
+                for _ in range(args.solves):
+                    kkt.solve_device(P(d_dx), P(d_dy), P(d_xp), P(d_xd), sync=False)
+                kkt.sync()
+            unpaired_step()
+            us = max(2, min(steps, 10))
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(us):
+                unpaired_step()
+            torch.cuda.synchronize()
+            out["unpaired_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / us
         kkt.close()
-        del d_th, d_rp, d_rd, d_xp, d_xd, d_dx, d_dy
+        del d_th, d_rp, d_rd, d_xp, d_xd, d_dx, d_dy, d_dx2, d_dy2
         torch.cuda.empty_cache()
         return out, A, row_block
 
@@ -406,7 +441,7 @@ def main():
     }
     out["config"]["configs_untested_by_name"] = ("Netlib 25fv47 / pds-20 .mps are not in the image; generated equivalents of both classes "
                                                  "run end-to-end (HSD + MPC, HIP vs oracle vs HiGHS) in tests/test_lp_configs.py")
-    for k in ("roofline", "kernel_ms", "kernel_launches", "solve_roofline", "host_abi"):
+    for k in ("roofline", "kernel_ms", "kernel_launches", "solve_roofline", "host_abi", "unpaired_ms_per_step"):
         if k in res:
             out[k] = res[k]
     if "roofline" not in out:
@@ -469,7 +504,7 @@ def main():
         if "value" in out["cpu_baseline"]:
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
-        print(json.dumps(out))
+        emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -140,6 +140,11 @@ int tlpk_update_device(tlpk_handle *h, const double *d_theta_inv, const double *
                        const double *d_regD);
 int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xi_p,
                       const double *d_xi_d);
+/* Two right-hand sides in one pass over the factor (the solve sweeps are HBM-bound on the bytes of L: the pair costs little more than
+ * one solve).  Same semantics and bit-identical results as two tlpk_solve_device calls.  Single-rank handles.  Tulip's HSD iteration
+ * has such a pair: the h-system and the predictor (HSD/step.jl:63,79); tlpk_ipm_hsolve_newton uses it. */
+int tlpk_solve2_device(tlpk_handle *h, double *d_dx0, double *d_dy0, const double *d_xi_p0, const double *d_xi_d0,
+                       double *d_dx1, double *d_dy1, const double *d_xi_p1, const double *d_xi_d1);
 int tlpk_sync(tlpk_handle *h);
 void *tlpk_stream(tlpk_handle *h);           /* hipStream_t the kernels are launched on */
 
@@ -216,6 +221,9 @@ int tlpk_ipm_targets(tlpk_handle *h, double a_, double mu_l, double mu_u, double
 /* step.jl:198-266 + 294-306: one Newton system.  mode 0 predictor | 1 corrector | 2 centrality corrector;
  * sc[8] = { tau, kappa, h0, xi_g, xi_tk, eta, gamma*mu, delta }; out[3] = { dtau, dkappa, max step to the boundary } */
 int tlpk_ipm_newton(tlpk_handle *h, int mode, const double *sc, double *out);
+/* step.jl:56-94: tlpk_ipm_hsolve + tlpk_ipm_newton(mode 0) with the two independent solves sharing one pass over the factor
+ * (tlpk_solve2_device).  sc[8] as above except sc[2] = kappa / tau + regG (the host part of h0); out[4] = { dtau, dkappa, max step, h0 } */
+int tlpk_ipm_hsolve_newton(tlpk_handle *h, const double *sc, double *out);
 int tlpk_ipm_accept(tlpk_handle *h);                         /* step.jl:112-118: candidate -> accepted direction */
 int tlpk_ipm_advance(tlpk_handle *h, double alpha, double *out);   /* step.jl:139-148; out[0] = xl'zl + xu'zu */
 /* what = 0 x, 1 xl, 2 xu, 3 zl, 4 zu (n), 5 y (m) */

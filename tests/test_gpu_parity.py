@@ -604,3 +604,42 @@ def test_multi_device_rccl_option_needs_distinct_devices(monkeypatch):
     A, rb = block_angular(nblocks=4, mk=60, nk=240, m0=10, nnz_in=3, link_prob=0.5, seed=3)
     with pytest.raises(tk.DimensionMismatch):
         tk.setup(A, tk.K1(), tk.Backend(row_block=rb, ngpus=2, devices=[0, 0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["block_angular", "general", "k2", "small_fronts_only"])
+def test_two_right_hand_sides_in_one_pass_equal_two_solves_bitwise(kind):
+    """tlpk_solve2_device: both right-hand sides ride one pass over L in the persistent sweeps (the hand-over carries two words per
+    column); every other solve kernel runs once per right-hand side.  Same summation order per right-hand side => the pair must
+    equal two single solves bit for bit, in either slot, and leave the handle usable for single solves."""
+    import torch
+    if kind == "block_angular":
+        A, rb = block_angular(nblocks=5, mk=400, nk=900, m0=90, nnz_in=3, link_prob=0.5, seed=31)
+    elif kind == "small_fronts_only":
+        A, rb = random_lp_matrix(300, 900, 2, 5), None
+    else:
+        A, rb = random_lp_matrix(900, 2000, 4, 17, slack=True), None
+    m, n = A.shape
+    kkt = tk.setup(A, tk.K2() if kind == "k2" else tk.K1(), tk.Backend(device=0, row_block=rb))
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 3)
+    tk.update(kkt, th, rp, rd)
+    rng = np.random.default_rng(1)
+    xp1, xd1 = rng.standard_normal(m), rng.standard_normal(n)
+    dev = torch.device("cuda", 0)
+    T = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)      # noqa: E731
+    P = lambda t: t.data_ptr()                                           # noqa: E731
+    d_xp, d_xd, d_xp1, d_xd1 = T(xp), T(xd), T(xp1), T(xd1)
+    out = [torch.full((sz,), float("nan"), dtype=torch.float64, device=dev) for sz in (n, m, n, m, n, m, n, m)]
+    kkt.solve_device(P(out[0]), P(out[1]), P(d_xp), P(d_xd))
+    kkt.solve_device(P(out[2]), P(out[3]), P(d_xp1), P(d_xd1))
+    kkt.solve2_device(P(out[4]), P(out[5]), P(d_xp), P(d_xd), P(out[6]), P(out[7]), P(d_xp1), P(d_xd1))
+    for a, b in ((0, 4), (1, 5), (2, 6), (3, 7)):
+        assert torch.equal(out[a], out[b]), (kind, a)
+    kkt.solve2_device(P(out[4]), P(out[5]), P(d_xp1), P(d_xd1), P(out[6]), P(out[7]), P(d_xp), P(d_xd))       # slots swapped
+    assert torch.equal(out[2], out[4]) and torch.equal(out[3], out[5]) and torch.equal(out[0], out[6]) and torch.equal(out[1], out[7])
+    kkt.solve_device(P(out[4]), P(out[5]), P(d_xp), P(d_xd))                                                   # and a single solve again
+    assert torch.equal(out[0], out[4]) and torch.equal(out[1], out[5])
+    dx, dy = out[2].cpu().numpy(), out[3].cpu().numpy()
+    r1, r2 = kkt_residuals(A, th, rp, rd, xp1, xd1, dx, dy)
+    assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp1).max(), np.abs(xd1).max()))
+    kkt.close()

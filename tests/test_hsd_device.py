@@ -164,3 +164,23 @@ def test_device_loops_on_the_augmented_system(name):
         if r["K1"].status == "Trm_Optimal":                      # (on the infeasible LP the diverging iterates take 8 vs 13 steps to certify)
             assert abs(r["K1"].niter - r["K2"].niter) <= 2
             assert abs(r["K1"].primal_objective - r["K2"].primal_objective) <= 1e-7 * (1 + abs(r["K1"].primal_objective))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("system", ["K1", "K2"])
+def test_paired_h_system_and_predictor_solves_change_nothing(system):
+    """tlpk_ipm_hsolve_newton: the h-system and the predictor ride one pass over the factor (tlpk_solve2_device).  Same
+    arithmetic in the same order: the whole HSD run -- iteration count, every objective, the final point -- must be
+    bit-identical to the run with separate solves."""
+    from tulip_jl_amd.hsd_device import DeviceHSD
+    lp = read_free_mps(os.path.join(GOLDEN, "stair25.mps"))
+    d = standard_form(lp)
+    runs = []
+    for pair in (True, False):
+        opt = DeviceHSD(d.A, d.b, d.c, d.l, d.u, c0=d.c0, objsense_min=d.objsense, system=system, pair_solves=pair, device=0).optimize()
+        runs.append((opt.status, opt.niter, opt.primal_objective, opt.dual_objective, opt.timers["n_solve"], opt._get(0, opt.n), opt._get(5, opt.m)))
+        opt.kkt.close()
+    a, b = runs
+    assert a[0] == b[0] == "Trm_Optimal" and a[1] == b[1] and a[4] == b[4]
+    assert a[2] == b[2] and a[3] == b[3]
+    assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])

@@ -132,7 +132,7 @@ __global__ void k_ipm_theta(IpmVecs v, double *__restrict__ theta, double *__res
 }
 __global__ void k_ipm_hrhs(IpmVecs v) {                                     // step.jl:61: xi_ = c - th_l lz - th_u uz
     const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) v.xid[j] = v.c[j] - v.thl[j] * v.lz[j] - v.thu[j] * v.uz[j];
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < v.n; j += stride) v.hxid[j] = v.c[j] - v.thl[j] * v.lz[j] - v.thu[j] * v.uz[j];
 }
 // h0 pieces (step.jl:69-76): sum_j lz^2 th_l + uz^2 th_u - (c + th_l lz + th_u uz) hx ; sum_i b hy
 __global__ __launch_bounds__(IPM_T) void k_ipm_hdots(IpmVecs v, double *__restrict__ partials) {

@@ -1540,6 +1540,27 @@ __device__ __forceinline__ double poll_block(const double *xh, const int cnt, co
     asm volatile("" ::: "memory");        // nothing that follows may be scheduled above the poll
     return __longlong_as_double((long long)v);
 }
+// two right-hand sides: the words of both must have arrived (the producer publishes them back to back)
+__device__ __forceinline__ void poll_block2(const double *xh0, const double *xh1, const int cnt, const int lane, int *info, bool &dead,
+                                            const SweepArgs &a, double &o0, double &o1) {
+    const unsigned long long *p0 = reinterpret_cast<const unsigned long long *>(xh0) + min(lane, cnt - 1);
+    const unsigned long long *p1 = reinterpret_cast<const unsigned long long *>(xh1) + min(lane, cnt - 1);
+    unsigned long long v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (!dead && !__all(v0 != SW_SENTINEL && v1 != SW_SENTINEL)) {
+        const int naps = (spins < (unsigned)a.poll_nfast) ? a.poll_fast : a.poll_slow;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 127u) == 0u) {
+            if (__hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
+            else if (spins > (1u << 21)) { __hip_atomic_store(info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
+        }
+        v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("" ::: "memory");
+    o0 = __longlong_as_double((long long)v0); o1 = __longlong_as_double((long long)v1);
+}
 __device__ __forceinline__ double readlane_f64(const double v, const int l) {      // l wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
@@ -1548,7 +1569,10 @@ __device__ __forceinline__ double readlane_f64(const double v, const int l) {   
 // PIVOT item: rows [k0, k0 + nb) (nb <= 64) are a pivot block; lane = row, wave = quarter of the 64 columns of a
 // consumed block.  BELOW item: <= 128 rows below the pivot block; waves 0/1 = rows 0..63 / 64..127 of the chunk
 // for columns 0..31 of a block, waves 2/3 the same rows for columns 32..63.
-template <bool PIVOT>
+// NR = 2: two right-hand sides share one pass over L (HSD's h-system and predictor are independent: HSD/step.jl:63,79): every
+// panel entry loaded once feeds two accumulators; the second right-hand side lives at xw + c.xw2, uc + c.uc2, xh + a.xh2; each is
+// summed in the order of the single-rhs kernel (bit-identical results).
+template <bool PIVOT, int NR>
 __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDesc &fd, const DevCtx &c, const SweepArgs &a, double *scratch) {
     const double *xh = a.xh;
     constexpr int NBATCH = PIVOT ? 1 : 2;                      // batches of 16 columns per wave and block
@@ -1565,7 +1589,9 @@ __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDe
     const i32 nin = t.nslot;
     double w[16];
     if (PIVOT) load_frag<false, 0>(c, fd, t.k0, t.nb, w);      // inverted diagonal block, held from the start
-    double acc = 0.0;
+    double acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
     double b0[16], b1[16];
     bool dead = false;
     auto issue = [&](double (&b)[16], const i32 j, const int q) {          // block j (clamped), batch q
@@ -1574,32 +1600,39 @@ __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDe
         for (int u = 0; u < 16; ++u)                             // clamped column: x is zero beyond the block
             b[u] = *reinterpret_cast<const double *>(Lb + (size_t)min(c0 + u, ns - 1) * (size_t)lda * 8u + roff);
     };
-    auto consume = [&](const double (&b)[16], const double xv, const int q) {
+    auto consume = [&](const double (&b)[16], const double (&xv)[NR], const int q) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc += b[u] * readlane_f64(xv, 16 * q + u);
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] += b[u] * readlane_f64(xv[r], 16 * q + u);
     };
-    auto wait_block = [&](const i32 j) -> double {             // this wave's columns of block j (zero beyond its width)
+    auto wait_block = [&](const i32 j, double (&xv)[NR]) {      // this wave's columns of block j (zero beyond its width)
         const i32 cnt = min(WCOLS, min(SWEEP_NB, ns - j * SWEEP_NB) - cp0);
-        if (cnt <= 0) return 0.0;
-        const double v = poll_block(xhf + j * SWEEP_NB + cp0, cnt, lane, c.info, dead, a);
-        return (lane < cnt) ? v : 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) xv[r] = 0.0;
+        if (cnt <= 0) return;
+        if (NR == 1) xv[0] = poll_block(xhf + j * SWEEP_NB + cp0, cnt, lane, c.info, dead, a);
+        else poll_block2(xhf + j * SWEEP_NB + cp0, xhf + a.xh2 + j * SWEEP_NB + cp0, cnt, lane, c.info, dead, a, xv[0], xv[NR - 1]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) xv[r] = (lane < cnt) ? xv[r] : 0.0;
     };
     if (nin > 0) {
         if (PIVOT) { issue(b0, 0, 0); issue(b1, 1, 0); }
         else { issue(b0, 0, 0); issue(b1, 0, 1); }
     }
+    double xv[NR];
     if (PIVOT) {
         for (i32 j = 0; j < nin; j += 2) {
-            double xv = wait_block(j);
+            wait_block(j, xv);
             consume(b0, xv, 0); issue(b0, j + 2, 0);
             if (j + 1 < nin) {                                  // wave-uniform
-                xv = wait_block(j + 1);
+                wait_block(j + 1, xv);
                 consume(b1, xv, 0); issue(b1, j + 3, 0);
             }
         }
     } else {
         for (i32 j = 0; j < nin; ++j) {
-            const double xv = wait_block(j);
+            wait_block(j, xv);
             consume(b0, xv, 0); issue(b0, j + 1, 0);
             consume(b1, xv, 1); issue(b1, j + 1, 1);
         }
@@ -1607,38 +1640,48 @@ __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDe
     double (*ps)[NB_IN] = reinterpret_cast<double (*)[NB_IN]>(scratch + 2 * SOLVE_NB);      // 4 x 64 doubles
     if (PIVOT) {
         double *bs = scratch;
-        ps[wave][lane] = acc;
-        __syncthreads();
-        if (wave == 0) {
-            const double total = ((ps[0][lane] + ps[1][lane]) + ps[2][lane]) + ps[3][lane];
-            bs[lane] = (lane < t.nb) ? c.xw[fd.col0 + t.k0 + min(lane, t.nb - 1)] - total : 0.0;
-        }
-        __syncthreads();
-        const double y = dot4(w, bs, lane, wave, ps);           // y = W (b - sum); valid in wave 0
-        if (wave == 0 && lane < t.nb) {
-            c.xw[fd.col0 + t.k0 + lane] = y;
-            st_agent(const_cast<double *>(xhf) + t.k0 + lane, y);     // hand-over: the data is its own flag
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            double *xwr = c.xw + (r ? c.xw2 : 0);
+            if (r) __syncthreads();
+            ps[wave][lane] = acc[r];
+            __syncthreads();
+            if (wave == 0) {
+                const double total = ((ps[0][lane] + ps[1][lane]) + ps[2][lane]) + ps[3][lane];
+                bs[lane] = (lane < t.nb) ? xwr[fd.col0 + t.k0 + min(lane, t.nb - 1)] - total : 0.0;
+            }
+            __syncthreads();
+            const double y = dot4(w, bs, lane, wave, ps);           // y = W (b - sum); valid in wave 0
+            if (wave == 0 && lane < t.nb) {
+                xwr[fd.col0 + t.k0 + lane] = y;
+                st_agent(const_cast<double *>(xhf) + (r ? a.xh2 : 0) + t.k0 + lane, y);     // hand-over: the data is its own flag
+            }
         }
     } else {
         double *red = &ps[0][0];                                // 256 doubles: [column half][row]
-        if (wave >= 2) red[rloc] = acc;
-        __syncthreads();
-        if (wave < 2 && rloc < t.nb) {
-            double *dst = c.uc + fd.ucoff + (t.k0 + rloc - ns);
-            *dst = *dst - (acc + red[rloc]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r) __syncthreads();
+            if (wave >= 2) red[rloc] = acc[r];
+            __syncthreads();
+            if (wave < 2 && rloc < t.nb) {
+                double *dst = c.uc + (r ? c.uc2 : 0) + fd.ucoff + (t.k0 + rloc - ns);
+                *dst = *dst - (acc[r] + red[rloc]);
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256, 4) void k_fwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
+template <int NR>
+__global__ __launch_bounds__(256, NR == 1 ? 4 : 3) void k_fwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
     __shared__ double scratch[FWD_DIAG_SCRATCH];
     __shared__ unsigned s_item;
-    if (threadIdx.x == 0) s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) - a.base);
+    if (threadIdx.x == 0) s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) + 1ULL);      // the counter starts at all ones (see SweepArgs): first ticket = 0
     __syncthreads();
     const SolveTask t = tasks[s_item];
     const FrontDesc fd = c.fronts[t.front];
-    if (t.slot) fwd_sweep_item<true>(t, fd, c, a, scratch);             // workgroup-uniform
-    else fwd_sweep_item<false>(t, fd, c, a, scratch);
+    if (t.slot) fwd_sweep_item<true, NR>(t, fd, c, a, scratch);         // workgroup-uniform
+    else fwd_sweep_item<false, NR>(t, fd, c, a, scratch);
 }
 
 // Backward: item = column block [k0, k0 + nb) (nb <= 64) of a front.  t[k0 + j] = b - sum_r L[r, k0 + j] x[r] over the
@@ -1646,14 +1689,15 @@ __global__ __launch_bounds__(256, 4) void k_fwd_sweep(const SolveTask *__restric
 // front, consumed as they are published (last block first); then x = W' t and the publish.  Lanes run along the 64
 // contiguous rows of a tile, a wave owns 16 of the columns and keeps per-lane partial sums over ALL tiles (one
 // shuffle reduction at the end).
-__global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
+template <int NR>
+__global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_bwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
     __shared__ double red[NB_IN][NB_IN + 1];        // per-lane partial sums of the 64 columns, transposed reduction
-    __shared__ double ts[NB_IN], bsh[NB_IN];
+    __shared__ double ts[NB_IN], bsh[NR][NB_IN];
     __shared__ double ps[4][NB_IN];
     __shared__ unsigned s_item;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) - a.base);
+    if (tid == 0) s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) + 1ULL);
     __syncthreads();
     const SolveTask t = tasks[s_item];
     const FrontDesc fd = c.fronts[t.front];
@@ -1666,12 +1710,13 @@ __global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restric
     const i32 ntiles = nbelow + t.nslot;
     // this wave's columns: wave-uniform bases (scalar registers) + 32-bit lane offsets
     const char *Pb = reinterpret_cast<const char *>(c.Lval + fd.loff + (i64)t.k0 * lda);
-    size_t coloff[1];
-    (void)coloff;
     // Held from the start, off the chain: this block's right-hand side and the fragment of the inverted diagonal
     // block for x[ci] = sum_k W[k][ci] t[k]: thread (ci = lane, part = wave) keeps W[16 part + kk][ci] (W is stored
     // column-major: 16 consecutive doubles per lane)
-    if (tid < NB_IN) bsh[tid] = (tid < nb) ? c.xw[fd.col0 + t.k0 + min(tid, nb - 1)] : 0.0;
+    if (tid < NB_IN) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) bsh[r][tid] = (tid < nb) ? c.xw[(r ? c.xw2 : 0) + fd.col0 + t.k0 + min(tid, nb - 1)] : 0.0;
+    }
     double w[16];
     {
         const double *W = front_dinv(c, fd, t.k0);              // nb x nb, column-major, ld = nb, upper part zero
@@ -1683,9 +1728,11 @@ __global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restric
             w[kk] = (lane < nb && k < nb && k >= lane) ? v : 0.0;
         }
     }
-    double acc[16];
+    double acc[NR][16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[r][u] = 0.0;
     bool dead = false;
     auto tile_r0 = [&](const i32 q) { const i32 qc = min(q, ntiles - 1); return qc < nbelow ? (qc == 0 ? ns : (ns / 64 + qc) * 64) : (nblk - 1 - (qc - nbelow)) * SWEEP_NB; };
     auto tile_nr = [&](const i32 q) { const i32 qc = min(q, ntiles - 1); const i32 r0 = tile_r0(qc); return qc < nbelow ? min(f, (ns / 64 + qc + 1) * 64) - r0 : min(SWEEP_NB, ns - r0); };
@@ -1701,33 +1748,39 @@ __global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restric
         const i32 r0 = (qc == 0) ? ns : (ns / 64 + qc) * 64, nr = min(f, (ns / 64 + qc + 1) * 64) - r0;
         return (nbelow > 0) ? rows[r0 + min(lane, max(nr - 1, 0))] : 0;
     };
-    auto consume = [&](const double (&b)[16], const double xr) {
+    auto consume = [&](const double (&b)[16], const double (&xr)[NR]) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc[u] += b[u] * xr;
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r][u] += b[u] * xr[r];
     };
     double b0[16], b1[16];
     if (ntiles > 0) { issue(b0, 0); issue(b1, 1); }
     // rows below the pivot block: x of the ancestors through the row indices -- indices two tiles ahead, values one
     i32 gi0 = row_index(0), gi1 = row_index(1);
-    double xn = (nbelow > 0) ? c.xw[gi0] : 0.0;                 // x of tile 0
-    auto tile_x = [&](const i32 q) -> double {                  // x[row of this lane] for tile q
+    double xn[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) xn[r] = (nbelow > 0) ? c.xw[(r ? c.xw2 : 0) + gi0] : 0.0;       // x of tile 0
+    auto tile_x = [&](const i32 q, double (&xv)[NR]) {          // x[row of this lane] for tile q
         const i32 nr = tile_nr(q);
-        double xv;
         if (q < nbelow) {
-            xv = xn;                                            // requested one tile ago
-            xn = c.xw[gi1];                                     // tile q + 1 (index loaded two tiles ago)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { xv[r] = xn[r]; xn[r] = c.xw[(r ? c.xw2 : 0) + gi1]; }   // requested one tile ago; next: tile q + 1
             gi1 = row_index(q + 2);
         } else {
             const i32 jb = nblk - 1 - (q - nbelow);
-            xv = poll_block(xhf + jb * SWEEP_NB, nr, lane, c.info, dead, a);
+            if (NR == 1) xv[0] = poll_block(xhf + jb * SWEEP_NB, nr, lane, c.info, dead, a);
+            else poll_block2(xhf + jb * SWEEP_NB, xhf + a.xh2 + jb * SWEEP_NB, nr, lane, c.info, dead, a, xv[0], xv[NR - 1]);
         }
-        return (lane < nr) ? xv : 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) xv[r] = (lane < nr) ? xv[r] : 0.0;
     };
+    double xr[NR];
     for (i32 q = 0; q < ntiles; q += 2) {
-        double xr = tile_x(q);
+        tile_x(q, xr);
         consume(b0, xr); issue(b0, q + 2);
         if (q + 1 < ntiles) {                                   // workgroup-uniform
-            xr = tile_x(q + 1);
+            tile_x(q + 1, xr);
             consume(b1, xr); issue(b1, q + 3);
         }
     }
@@ -1736,27 +1789,31 @@ __global__ __launch_bounds__(256, 3) void k_bwd_sweep(const SolveTask *__restric
     // sums, the four subs are combined by two quad shuffles -- fixed order, ~40 LDS accesses on the chain instead of
     // two 96-shuffle trees
 #pragma unroll
-    for (int u = 0; u < 16; ++u) red[16 * wave + u][lane] = acc[u];
-    __syncthreads();
-    {
-        const int col = tid >> 2, sub = tid & 3;
-        double s_ = 0.0;
+    for (int r = 0; r < NR; ++r) {
+        if (r) __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s_ += red[col][16 * sub + i];
-        s_ += __shfl_xor(s_, 1);
-        s_ += __shfl_xor(s_, 2);
-        if (sub == 0) ts[col] = bsh[col] - s_;                  // zero beyond nb (clamped duplicate columns are dropped by w)
-    }
-    __syncthreads();
-    double xs_ = 0.0;
+        for (int u = 0; u < 16; ++u) red[16 * wave + u][lane] = acc[r][u];
+        __syncthreads();
+        {
+            const int col = tid >> 2, sub = tid & 3;
+            double s_ = 0.0;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) xs_ += w[kk] * ts[16 * wave + kk];
-    ps[wave][lane] = xs_;
-    __syncthreads();
-    if (wave == 0 && lane < nb) {
-        const double x = ((ps[0][lane] + ps[1][lane]) + ps[2][lane]) + ps[3][lane];
-        c.xw[fd.col0 + t.k0 + lane] = x;
-        st_agent(const_cast<double *>(xhf) + t.k0 + lane, x);   // hand-over: the data is its own flag
+            for (int i = 0; i < 16; ++i) s_ += red[col][16 * sub + i];
+            s_ += __shfl_xor(s_, 1);
+            s_ += __shfl_xor(s_, 2);
+            if (sub == 0) ts[col] = bsh[r][col] - s_;               // zero beyond nb (clamped duplicate columns are dropped by w)
+        }
+        __syncthreads();
+        double xs_ = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) xs_ += w[kk] * ts[16 * wave + kk];
+        ps[wave][lane] = xs_;
+        __syncthreads();
+        if (wave == 0 && lane < nb) {
+            const double x = ((ps[0][lane] + ps[1][lane]) + ps[2][lane]) + ps[3][lane];
+            c.xw[(r ? c.xw2 : 0) + fd.col0 + t.k0 + lane] = x;
+            st_agent(const_cast<double *>(xhf) + (r ? a.xh2 : 0) + t.k0 + lane, x);   // hand-over: the data is its own flag
+        }
     }
 }
 
@@ -1985,15 +2042,26 @@ void launch_single_factor(hipStream_t st, const DevArrays &a) {
         hipLaunchKernelGGL(k_single_factor, dim3(nblk(a.n_single, 256)), dim3(256), 0, st, a.n_single, a.single_loff, a.single_dinvoff,
                            a.single_col, a.ctx.Lval, a.ctx.dinv, a.ctx.info, a.ctx.csign);
 }
-void launch_single_solve(hipStream_t st, const DevArrays &a) {
+void launch_single_solve(hipStream_t st, const DevArrays &a, int rhs) {
     if (a.n_single > 0)
         hipLaunchKernelGGL(k_single_solve, dim3(nblk(a.n_single, 256)), dim3(256), 0, st, a.n_single, a.single_dinvoff, a.single_col,
-                           a.ctx.dinv, a.ctx.xw);
+                           a.ctx.dinv, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
 }
-void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const SweepArgs *sw) {
+// nrhs = 2 (solve schedules only): the two persistent sweep kernels run their two-right-hand-side instances (one pass over L for
+// both), every other solve kernel is launched once per right-hand side (the second on a context whose xw / uc point at the copies)
+void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const SweepArgs *sw, int nrhs) {
     if (L.count <= 0) return;
     const dim3 g((unsigned)L.count);
     const bool sgn = a.ctx.csign != nullptr;                  // K2: signed Cholesky
+    if (nrhs == 2) {
+        if (L.kind == LK_FWD_SWEEP) { if (sw) hipLaunchKernelGGL(k_fwd_sweep<2>, g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw); return; }
+        if (L.kind == LK_BWD_SWEEP) { if (sw) hipLaunchKernelGGL(k_bwd_sweep<2>, g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw); return; }
+        launch_tasks(st, a, L, sw, 1);
+        DevArrays b = a;
+        b.ctx.xw += a.ctx.xw2; b.ctx.uc += a.ctx.uc2;
+        launch_tasks(st, b, L, sw, 1);
+        return;
+    }
 #define TLPK_LAUNCH_S(KERNEL, TASKS) do { if (sgn) hipLaunchKernelGGL(KERNEL<true>, g, dim3(256), 0, st, TASKS + L.first, a.ctx); \
                                           else hipLaunchKernelGGL(KERNEL<false>, g, dim3(256), 0, st, TASKS + L.first, a.ctx); } while (0)
     switch (L.kind) {
@@ -2011,8 +2079,8 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
     case LK_BWD_UPDATE: hipLaunchKernelGGL(k_bwd_update, g, dim3(256), 0, st, a.bwd_update_tasks + L.first, a.ctx); break;
     case LK_FWD_SMALL: hipLaunchKernelGGL(k_fwd_small, g, dim3(256), 0, st, a.fwd_small_tasks + L.first, a.ctx); break;
     case LK_BWD_SMALL: hipLaunchKernelGGL(k_bwd_small, g, dim3(256), 0, st, a.bwd_small_tasks + L.first, a.ctx); break;
-    case LK_FWD_SWEEP: if (sw) hipLaunchKernelGGL(k_fwd_sweep, g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw); break;
-    case LK_BWD_SWEEP: if (sw) hipLaunchKernelGGL(k_bwd_sweep, g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw); break;
+    case LK_FWD_SWEEP: if (sw) hipLaunchKernelGGL(k_fwd_sweep<1>, g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw); break;
+    case LK_BWD_SWEEP: if (sw) hipLaunchKernelGGL(k_bwd_sweep<1>, g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw); break;
     default: break;
     }
 #undef TLPK_LAUNCH_S
@@ -2020,28 +2088,29 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
 void launch_k2_diag(hipStream_t st, i64 n, const double *theta, const double *regP, double *D2) {
     hipLaunchKernelGGL(k_k2_diag, dim3(nblk(n + 1, 256)), dim3(256), 0, st, n, theta, regP, D2);
 }
-void launch_k2_rhs(hipStream_t st, const DevArrays &a, i64 n, const double *xi_p, const double *xi_d) {
-    if (a.m > 0) hipLaunchKernelGGL(k_k2_rhs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, n, a.perm, xi_p, xi_d, a.ctx.xw);
+void launch_k2_rhs(hipStream_t st, const DevArrays &a, i64 n, const double *xi_p, const double *xi_d, int rhs) {
+    if (a.m > 0) hipLaunchKernelGGL(k_k2_rhs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, n, a.perm, xi_p, xi_d, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
 }
-void launch_apply_signs(hipStream_t st, const DevArrays &a) {
-    if (a.m > 0) hipLaunchKernelGGL(k_apply_signs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.ctx.csign, a.ctx.xw);
+void launch_apply_signs(hipStream_t st, const DevArrays &a, int rhs) {
+    if (a.m > 0) hipLaunchKernelGGL(k_apply_signs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.ctx.csign, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
 }
-void launch_k2_out(hipStream_t st, const DevArrays &a, i64 n, double *dx, double *dy) {
-    if (a.m > 0) hipLaunchKernelGGL(k_k2_out, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, n, a.perm, a.ctx.xw, dx, dy);
+void launch_k2_out(hipStream_t st, const DevArrays &a, i64 n, double *dx, double *dy, int rhs) {
+    if (a.m > 0) hipLaunchKernelGGL(k_k2_out, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, n, a.perm, a.ctx.xw + (rhs ? a.ctx.xw2 : 0), dx, dy);
 }
-void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank) {
+void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank, int rhs) {
     if (a.m > 0)
     {
-        if (a.n > 0) hipLaunchKernelGGL(k_rhs_scale, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, D, xi_d, a.col_local, a.rhs_w);
-        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, a.rhs_w, xi_p, xi_d,
-                           a.row_local, a.col_local, rank, a.ctx.xw);
+        double *w = a.rhs_w + (rhs ? a.n : 0);
+        if (a.n > 0) hipLaunchKernelGGL(k_rhs_scale, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, D, xi_d, a.col_local, w);
+        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, w, xi_p, xi_d,
+                           a.row_local, a.col_local, rank, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
     }
 }
 void launch_sum_to(hipStream_t st, i64 len, double *out, const double *own, const double *src, int nsrc, i64 stride) {
     if (len > 0) hipLaunchKernelGGL(k_sum_to, dim3(nblk(len, 256)), dim3(256), 0, st, len, out, own, src, nsrc, stride);
 }
-void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy_shared, int rank) {
-    if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw, dy, dy_shared, rank);
+void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy_shared, int rank, int rhs) {
+    if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw + (rhs ? a.ctx.xw2 : 0), dy, dy_shared, rank);
 }
 void launch_residuals(hipStream_t st, const DevArrays &a, const double *xi_p, const double *xi_d, const double *theta, const double *regP,
                       const double *regD, const double *dx, const double *dy, double *r1, double *r2) {

@@ -95,7 +95,7 @@ void join_groups(tlpk_handle *h) {
 }
 
 // dir: 0 = forward-solve schedule, 1 = backward-solve schedule, -1 = factorisation (no sweeps)
-void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, size_t to, int dir = -1) {
+void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, size_t to, int dir = -1, int nrhs = 1) {
     size_t skip_update = (size_t)-1;
     for (size_t i = from; i < to; ++i) {
         if (L[i].group < 0) join_groups(h);
@@ -137,14 +137,11 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
         }
         ProfScope ps(h, kind_class(cur.kind), st);
         if (cur.kind == LK_FWD_SWEEP || cur.kind == LK_BWD_SWEEP) {
-            std::vector<unsigned long long> &runs = dir == 0 ? h->sweep_runs_fwd : h->sweep_runs_bwd;
             const i32 slot = (dir == 0 ? h->sweep_slot_fwd : h->sweep_slot_bwd)[i];
-            SweepArgs sw{h->d.sweep_tickets + slot, runs[i] * (unsigned long long)cur.count,
-                         h->d.sweep_xh + (dir == 0 ? 0 : h->S.m), h->poll[0], h->poll[1], h->poll[2]};
-            runs[i] += 1;
-            launch_tasks(st, h->d, cur, &sw);
+            SweepArgs sw{h->d.sweep_tickets + slot, h->d.sweep_xh + (dir == 0 ? 0 : h->S.m), 2 * h->S.m, h->poll[0], h->poll[1], h->poll[2]};
+            launch_tasks(st, h->d, cur, &sw, nrhs);
         } else
-            launch_tasks(st, h->d, cur);
+            launch_tasks(st, h->d, cur, nullptr, nrhs);
     }
     join_groups(h);
 }
@@ -210,11 +207,12 @@ int upload_all(tlpk_handle *h) {
     AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
     // debugging aid: start from NaNs everywhere, so that a read of storage the factorisation never writes would show
     if (std::getenv("TLPK_POISON") && S.lval_len > 0) { HIPCHK(h, hipMemset(d.ctx.Lval, 0xFF, (size_t)S.lval_len * 8)); HIPCHK(h, hipDeviceSynchronize()); }
-    AL(d.ctx.uc, S.uc_len); AL(d.ctx.xw, S.m); AL(d.ctx.info, 4); AL(d.ctx.dinv, S.dinv_len); AL(d.ctx.spart, S.spart_len);
+    AL(d.ctx.uc, 2 * S.uc_len); AL(d.ctx.xw, 2 * S.m); AL(d.ctx.info, 4);      // two copies: the second right-hand side of tlpk_solve2_device
+    d.ctx.xw2 = S.m; d.ctx.uc2 = S.uc_len; AL(d.ctx.dinv, S.dinv_len); AL(d.ctx.spart, S.spart_len);
     const i64 nn = std::max<i64>(S.n, S.k2_n + 1);             // K2: user vectors have k2_n entries, D2 one more
     AL(h->d_theta, nn); AL(h->d_regP, nn); AL(h->d_regD, S.m); AL(h->d_D, nn);
     AL(h->d_xip, S.m); AL(h->d_xid, nn); AL(h->d_dx, nn); AL(h->d_dy, S.m);
-    AL(d.rhs_w, std::max<i64>(S.n, 1));
+    AL(d.rhs_w, std::max<i64>(2 * S.n, 1));
     // a shard of a multi-device handle receives only its slices of the input vectors: the rest stays zero (never used in arithmetic
     // that reaches a result, but never uninitialised either)
     HIPCHK(h, hipMemset(h->d_theta, 0, (size_t)nn * 8)); HIPCHK(h, hipMemset(h->d_regP, 0, (size_t)nn * 8)); HIPCHK(h, hipMemset(h->d_xid, 0, (size_t)nn * 8));
@@ -231,10 +229,12 @@ int upload_all(tlpk_handle *h) {
         h->sweep_slot_fwd.assign(S.fwd_launches.size(), -1); h->sweep_slot_bwd.assign(S.bwd_launches.size(), -1);
         for (size_t i = 0; i < S.fwd_launches.size(); ++i) if (S.fwd_launches[i].kind == LK_FWD_SWEEP) h->sweep_slot_fwd[i] = nslots++;
         for (size_t i = 0; i < S.bwd_launches.size(); ++i) if (S.bwd_launches[i].kind == LK_BWD_SWEEP) h->sweep_slot_bwd[i] = nslots++;
-        h->sweep_runs_fwd.assign(S.fwd_launches.size(), 0); h->sweep_runs_bwd.assign(S.bwd_launches.size(), 0);
-        if ((rc = dev_alloc(h, &d.sweep_tickets, (i64)nslots)) != TLPK_OK) return rc;
-        if ((rc = dev_alloc(h, &d.sweep_xh, 2 * S.m)) != TLPK_OK) return rc;
-        HIPCHK(h, hipMemset(d.sweep_tickets, 0, (size_t)std::max<i64>(nslots, 1) * sizeof(unsigned long long)));
+        // tickets and hand-over words in ONE allocation (tickets first, padded to 16 words): one memset per solve resets both
+        const i64 nt = ((i64)nslots + 15) / 16 * 16;
+        unsigned long long *blk = nullptr;
+        if ((rc = dev_alloc(h, &blk, nt + 4 * S.m)) != TLPK_OK) return rc;       // [forward | backward] x two right-hand sides
+        d.sweep_tickets = blk; d.sweep_xh = reinterpret_cast<double *>(blk + nt);
+        d.sweep_reset_bytes = (nt + 2 * S.m) * 8; d.sweep_reset_bytes2 = (nt + 4 * S.m) * 8;
         HIPCHK(h, hipMemset(d.ctx.info, 0, 4 * sizeof(int)));
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_info, 4 * sizeof(int), hipHostMallocDefault));
@@ -596,7 +596,8 @@ int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
     {
         ProfScope ps(h, TLPK_KC_SPMV);
         // hand-over words of both sweeps back to the sentinel (all ones): the data is its own flag
-        if (h->S.sweep && h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_xh, 0xFF, (size_t)(2 * h->S.m) * 8, h->stream));
+        // tickets + hand-over words of both sweeps back to all ones: the data is its own flag, ticket + 1 = 0 is the first item
+        if (h->S.sweep && h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes, h->stream));
         if (h->S.system == 1) launch_k2_rhs(h->stream, h->d, h->S.k2_n, d_xip, d_xid);        // [xi_d ; xi_p] permuted (sqd.jl:62-66)
         else launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank);
         launch_single_solve(h->stream, h->d);
@@ -655,6 +656,56 @@ int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *
         HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     }
     return rc;
+}
+
+// Two right-hand sides against the same factor in ONE pass over L (the persistent sweeps are bound by the bytes of L: the
+// pair costs little more than one solve).  Tulip's HSD step has such a pair in every iteration: the h-system and the predictor
+// (/root/reference/src/IPM/HSD/step.jl:63 and :79 -- neither right-hand side depends on the other solve).  Results are bit-identical
+// to two tlpk_solve_device calls.  Single-rank handles; with refine_steps > 0 the pair falls back to two refined solves.
+int tlpk_solve2_device(tlpk_handle *h, double *d_dx0, double *d_dy0, const double *d_xip0, const double *d_xid0,
+                       double *d_dx1, double *d_dy1, const double *d_xip1, const double *d_xid1) {
+    if (!h || !d_dx0 || !d_dy0 || !d_xip0 || !d_xid0 || !d_dx1 || !d_dy1 || !d_xip1 || !d_xid1) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
+    if (int g = sharded_needs_split(h, "tlpk_solve2_device")) return g;
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (!h->factored) return TLPK_NOT_FACTORED;
+    if (h->refine_steps > 0 || !h->S.sweep) {            // refinement / launch-per-block schedule: two ordinary solves
+        const int rc = tlpk_solve_device(h, d_dx0, d_dy0, d_xip0, d_xid0);
+        return rc != TLPK_OK ? rc : tlpk_solve_device(h, d_dx1, d_dy1, d_xip1, d_xid1);
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    prof_begin(h, false);
+    h->solve_timed = false;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    const bool k2 = h->S.system == 1;
+    const double *xip[2] = {d_xip0, d_xip1}, *xid[2] = {d_xid0, d_xid1};
+    double *dx[2] = {d_dx0, d_dx1}, *dy[2] = {d_dy0, d_dy1};
+    {
+        ProfScope ps(h, TLPK_KC_SPMV);
+        if (h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes2, h->stream));
+        for (int r = 0; r < 2; ++r) {
+            if (k2) launch_k2_rhs(h->stream, h->d, h->S.k2_n, xip[r], xid[r], r);
+            else launch_rhs(h->stream, h->d, h->d_D, xip[r], xid[r], h->opt.rank, r);
+            launch_single_solve(h->stream, h->d, r);
+        }
+    }
+    h->solve_epoch += 1;
+    run_launches(h, h->S.fwd_launches, 0, h->S.fwd_launches.size(), 0, 2);
+    if (k2) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d, 0); launch_apply_signs(h->stream, h->d, 1); }
+    run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1, 2);
+    for (int r = 0; r < 2; ++r) {
+        ProfScope ps(h, TLPK_KC_SPMV);
+        if (k2) launch_k2_out(h->stream, h->d, h->S.k2_n, dx[r], dy[r], r);
+        else {
+            launch_unpermute(h->stream, h->d, dy[r], nullptr, h->opt.rank, r);
+            launch_dx(h->stream, h->d, h->d_D, dy[r], xid[r], dx[r], 0);
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_info + 1, h->d.ctx.info + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->solve_timed = true;
+    return TLPK_OK;
 }
 
 int tlpk_sync(tlpk_handle *h) {

@@ -23,13 +23,16 @@ struct DevCtx {
     int *info;          // info[0] = smallest failing pivot column (INT_MAX = none); info[1] != 0: a sweep gave up waiting
     int upd_remap;         // k_update blockIdx -> task mapping (0 identity, 1 XCD-contiguous, 2 runs of 64 tasks per XCD)
     const double *csign;   // K2 (augmented system): +1 / -1 per permuted column, the S of P K P' = L S L'; nullptr for K1
+    i64 xw2, uc2;          // two-right-hand-side solves: the second rhs / solution at xw + xw2, its contribution vectors at uc + uc2
 };
 
 // per-launch arguments of the persistent sweep kernels
 struct SweepArgs {
-    unsigned long long *ticket;   // hand-out counter of this launch (monotonic over the life of the handle)
-    unsigned long long base;      // its value before this launch: item = ticket - base
+    unsigned long long *ticket;   // hand-out counter of this launch: reset to all ones with the hand-over words (ONE memset per solve covers
+                                  // both), so that atomicAdd(ticket, 1) + 1 hands out 0, 1, 2, ... -- no per-launch host state in the kernel
+                                  // arguments: the solve schedule can be replayed from a captured graph
     double *xh;                   // hand-over words of this direction, one per permuted column, sentinel-filled before the solve
+    i64 xh2;                      // ... of the second right-hand side at xh + xh2 (two-rhs sweeps)
     int poll_fast, poll_nfast, poll_slow;   // polling back-off (units of s_sleep 1 = 64 clocks): first poll_nfast polls every poll_fast, then every poll_slow
 };
 
@@ -55,26 +58,27 @@ struct DevArrays {
     SolveTask *fwd_gather_tasks = nullptr, *fwd_diag_tasks = nullptr, *fwd_update_tasks = nullptr,
               *bwd_update_tasks = nullptr, *fwd_small_tasks = nullptr, *bwd_small_tasks = nullptr,
               *fwd_sweep_tasks = nullptr, *bwd_sweep_tasks = nullptr;
-    unsigned long long *sweep_tickets = nullptr;      // one counter per sweep launch of the schedules
-    double *sweep_xh = nullptr;                       // hand-over words: [0, m) forward sweep, [m, 2m) backward sweep
+    unsigned long long *sweep_tickets = nullptr;      // one counter per sweep launch of the schedules, stored right in front of ...
+    double *sweep_xh = nullptr;                       // ... the hand-over words: [0, m) forward sweep, [m, 2m) backward sweep
+    i64 sweep_reset_bytes = 0, sweep_reset_bytes2 = 0;   // tickets + hand-over words (of one / two right-hand sides): one hipMemsetAsync(0xFF) per solve
 };
 
 void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D);
 void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD);
 void launch_zero_panels(hipStream_t st, const DevArrays &a);
-void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const SweepArgs *sw = nullptr);
+void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const SweepArgs *sw = nullptr, int nrhs = 1);
 void launch_single_factor(hipStream_t st, const DevArrays &a);
-void launch_single_solve(hipStream_t st, const DevArrays &a);
-void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank);
-void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy_shared = nullptr, int rank = 0);
+void launch_single_solve(hipStream_t st, const DevArrays &a, int rhs = 0);
+void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank, int rhs = 0);
+void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy_shared = nullptr, int rank = 0, int rhs = 0);
 void launch_residuals(hipStream_t st, const DevArrays &a, const double *xi_p, const double *xi_d, const double *theta, const double *regP,
                       const double *regD, const double *dx, const double *dy, double *r1, double *r2);
 void launch_axpy2(hipStream_t st, i64 n, double *x, const double *dxc, i64 m, double *y, const double *dyc);
 void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx, int local_only = 0);
 void launch_sum_to(hipStream_t st, i64 len, double *out, const double *own, const double *src, int nsrc, i64 stride);
 void launch_k2_diag(hipStream_t st, i64 n, const double *theta, const double *regP, double *D2);
-void launch_k2_rhs(hipStream_t st, const DevArrays &a, i64 n, const double *xi_p, const double *xi_d);
-void launch_apply_signs(hipStream_t st, const DevArrays &a);
-void launch_k2_out(hipStream_t st, const DevArrays &a, i64 n, double *dx, double *dy);
+void launch_k2_rhs(hipStream_t st, const DevArrays &a, i64 n, const double *xi_p, const double *xi_d, int rhs = 0);
+void launch_apply_signs(hipStream_t st, const DevArrays &a, int rhs = 0);
+void launch_k2_out(hipStream_t st, const DevArrays &a, i64 n, double *dx, double *dy, int rhs = 0);
 
 }  // namespace tlpk

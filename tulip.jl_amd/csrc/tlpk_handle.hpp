@@ -47,9 +47,8 @@ struct tlpk_handle {
     tlpk_kernel_times kt{};
     size_t factor_marker = 0, fwd_marker = 0;   // index of the LK_ALLREDUCE_ROOT launch (or size)
     i64 first_link = 0, nlink = 0;
-    // persistent sweeps: ticket-counter slot and number of runs of every sweep launch, flag epoch
+    // persistent sweeps: ticket-counter slot of every sweep launch
     std::vector<i32> sweep_slot_fwd, sweep_slot_bwd;
-    std::vector<unsigned long long> sweep_runs_fwd, sweep_runs_bwd;
     unsigned long long solve_epoch = 0;
     int poll[3] = {8, 16, 32};          // TLPK_POLL=fast,nfast,slow (tuning knob of the sweep kernels' polling back-off)
     // single-process multi-device mode (tlpk_create_multi): the parent owns one sharded handle per device

@@ -128,7 +128,7 @@ static int ipm_load_impl(tlpk_handle *h, const double *b, const double *c, const
 #undef UPV
 #define ALV(dst, len) do { if ((rc = dev_alloc(h, &p, (len))) != TLPK_OK) return rc; HIPCHK(h, hipMemset(p, 0, (size_t)std::max<i64>((len), 1) * 8)); dst = p; } while (0)
     ALV(v.x, n); ALV(v.xl, n); ALV(v.xu, n); ALV(v.zl, n); ALV(v.zu, n); ALV(v.y, m);
-    ALV(v.rp, m); ALV(v.rl, n); ALV(v.ru, n); ALV(v.rd, n); ALV(v.thl, n); ALV(v.thu, n); ALV(v.hx, n); ALV(v.hy, m);
+    ALV(v.rp, m); ALV(v.rl, n); ALV(v.ru, n); ALV(v.rd, n); ALV(v.thl, n); ALV(v.thu, n); ALV(v.hx, n); ALV(v.hy, m); ALV(v.hxid, n);
     ALV(v.xil, n); ALV(v.xiu, n); ALV(v.xzl, n); ALV(v.xzu, n); ALV(v.xid, n); ALV(v.xip, m);
     for (int k = 0; k < 2; ++k) { ALV(s.D[k].x, n); ALV(s.D[k].xl, n); ALV(s.D[k].xu, n); ALV(s.D[k].zl, n); ALV(s.D[k].zu, n); ALV(s.D[k].y, m); }
     ALV(s.partials[0], (i64)IPM_BLOCKS * IPM_SLOTS); ALV(s.partials[1], (i64)IPM_BLOCKS * IPM_SLOTS);
@@ -184,7 +184,7 @@ int tlpk_ipm_hsolve(tlpk_handle *h, double *out) {
     HIPCHK(h, hipSetDevice(h->device));
     IpmState &s = *h->ipm;
     ipm_launch_hrhs(h->stream, s.v);
-    int rc = tlpk_solve_device(h, s.v.hx, s.v.hy, s.v.b, s.v.xid);
+    int rc = tlpk_solve_device(h, s.v.hx, s.v.hy, s.v.b, s.v.hxid);
     if (rc != TLPK_OK) return rc;
     const int nb = ipm_launch_hdots(h->stream, s.v, s.partials[0]);
     ipm_launch_finalize(h->stream, nb, 2, 0, 0, s.partials[0], s.d_out);
@@ -239,6 +239,40 @@ int tlpk_ipm_newton(tlpk_handle *h, int mode, const double *sc, double *out) {
     ipm_launch_finalize(h->stream, nb2, 0, 0, 2, s.partials[1], s.d_out);
     if ((rc = fetch(h, 2)) != TLPK_OK) return rc;
     out[0] = dtau; out[1] = dkappa; out[2] = std::fmin(s.h_out[0], s.h_out[1]);    // one step length for both sides
+    return TLPK_OK;
+}
+
+/* step.jl:56-94 in ONE call: the h-system (step.jl:56-76) and the predictor's Newton system (mode 0 of tlpk_ipm_newton) are
+ * independent right-hand sides against the same factor -- they share one pass over L (tlpk_solve2_device: the sweeps are bound by
+ * the bytes of L).  sc[8] as for tlpk_ipm_newton, except sc[2] = kappa / tau + regG, the host-side part of h0 (the device supplies
+ * the dot products).  out[4] = { dtau, dkappa, largest step to the boundary, h0 }.  Same arithmetic as tlpk_ipm_hsolve followed by
+ * tlpk_ipm_newton(mode 0): bit-identical vectors and scalars. */
+int tlpk_ipm_hsolve_newton(tlpk_handle *h, const double *sc, double *out) {
+    if (int rc = ipm_ready(h)) return rc;
+    if (!sc || !out) return TLPK_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    IpmState &s = *h->ipm;
+    const double tau = sc[0], kappa = sc[1], h0_host = sc[2], xi_g = sc[3], xi_tk = sc[4], eta = sc[5], gmu = sc[6], delta = sc[7];
+    const IpmDir &dst = s.D[s.cur];
+    ipm_launch_hrhs(h->stream, s.v);
+    const int nb = ipm_launch_newton_pre(h->stream, s.v, dst, 0, eta, gmu, delta, s.partials[0]);
+    int rc = tlpk_solve2_device(h, s.v.hx, s.v.hy, s.v.b, s.v.hxid, dst.x, dst.y, s.v.xip, s.v.xid);
+    if (rc != TLPK_OK) return rc;
+    const int nbh = ipm_launch_hdots(h->stream, s.v, s.partials[1]);
+    ipm_launch_finalize(h->stream, nbh, 2, 0, 0, s.partials[1], s.d_out + IPM_SLOTS);
+    ipm_launch_newton_dots(h->stream, s.v, dst, nb, s.partials[0]);
+    ipm_launch_finalize(h->stream, nb, 6, 0, 0, s.partials[0], s.d_out);
+    if ((rc = fetch(h, IPM_SLOTS + 2)) != TLPK_OK) return rc;
+    if ((rc = tlpk_sync(h)) != TLPK_OK) return rc;
+    const double *q = s.h_out;
+    const double h0 = (q[IPM_SLOTS] + q[IPM_SLOTS + 1]) + h0_host;
+    const double xi_g_ = xi_g + xi_tk / tau - q[0] + q[1] - q[2] - q[3];
+    const double dtau = (xi_g_ + q[4] - q[5]) / h0;
+    const double dkappa = (xi_tk - kappa * dtau) / tau;
+    const int nb2 = ipm_launch_newton_post(h->stream, s.v, dst, dst, 0, dtau, s.partials[1]);
+    ipm_launch_finalize(h->stream, nb2, 0, 0, 2, s.partials[1], s.d_out);
+    if ((rc = fetch(h, 2)) != TLPK_OK) return rc;
+    out[0] = dtau; out[1] = dkappa; out[2] = std::fmin(s.h_out[0], s.h_out[1]); out[3] = h0;
     return TLPK_OK;
 }
 

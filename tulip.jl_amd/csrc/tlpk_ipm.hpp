@@ -25,6 +25,8 @@ struct IpmVecs {
     double *rp, *rl, *ru, *rd;                            // residuals (HSD.jl:83-110)
     double *thl, *thu;                                    // zl ./ xl, zu ./ xu on bounded entries
     double *hx, *hy;                                      // solution of the h-system (step.jl:56-66)
+    double *hxid;                                         // its right-hand side c - th_l lz - th_u uz (own vector: the h-system and the
+                                                          // predictor are solved as a pair, tlpk_ipm_hsolve_newton)
     double *xil, *xiu, *xzl, *xzu, *xid, *xip;            // right-hand sides of the current Newton system
 };
 

@@ -36,7 +36,9 @@ class Options:
 
 
 class DeviceHSD:
-    def __init__(self, A, b, c, l, u, c0=0.0, objsense_min=True, options=None, system="K1", **backend_kw):
+    def __init__(self, A, b, c, l, u, c0=0.0, objsense_min=True, options=None, system="K1", pair_solves=True, **backend_kw):
+        # pair_solves: the h-system and the predictor share one pass over the factor (tlpk_ipm_hsolve_newton; same arithmetic)
+        self.pair_solves = bool(pair_solves)
         # system: "K1" normal equations | "K2" augmented system (the reference's default for Float64, KKT.jl:134-141)
         if int(backend_kw.get("ngpus", 1)) > 1 or int(backend_kw.get("nranks", 1)) > 1:
             raise ValueError("the device-resident interior-point loops are single-device: ngpus / nranks must be 1 "
@@ -134,11 +136,18 @@ class DeviceHSD:
                 self.timers["n_bump"] += 1
         if not nbump < 3:                                                    # step.jl:51 (the reference's off-by-one is kept)
             raise PosDefException(0)
-        self._call(self.L.tlpk_ipm_hsolve(self.kkt._h, _lib.as_pd(self._out)))
-        self.timers["n_solve"] += 1
-        self.h0 = float(self._out[0]) + self.kappa / self.tau + self.regG
-        # predictor
-        dtau, dkappa, av = self._newton(0, self.rg, -self.tau * self.kappa)
+        if self.pair_solves:
+            # h-system (step.jl:56-76) and predictor: independent right-hand sides, one pass over the factor
+            self._sc[:] = (self.tau, self.kappa, self.kappa / self.tau + self.regG, self.rg, -self.tau * self.kappa, 0.0, 0.0, 0.0)
+            self._call(self.L.tlpk_ipm_hsolve_newton(self.kkt._h, _lib.as_pd(self._sc), _lib.as_pd(self._out)))
+            self.timers["n_solve"] += 2; self.timers["n_paired"] = self.timers.get("n_paired", 0) + 1
+            dtau, dkappa, av, self.h0 = (float(v) for v in self._out[:4])
+        else:
+            self._call(self.L.tlpk_ipm_hsolve(self.kkt._h, _lib.as_pd(self._out)))
+            self.timers["n_solve"] += 1
+            self.h0 = float(self._out[0]) + self.kappa / self.tau + self.regG
+            # predictor
+            dtau, dkappa, av = self._newton(0, self.rg, -self.tau * self.kappa)
         alpha = self._max_step(av, dtau, dkappa)
         gamma = (1 - alpha) ** 2 * min(1 - alpha, o.GammaMin)
         eta = 1 - gamma

@@ -235,6 +235,12 @@ class HIPNormalEquations:
         if sync:
             _raise_for(_lib.lib().tlpk_sync(self._h), self._h)
 
+    def solve2_device(self, d_dx0, d_dy0, d_xip0, d_xid0, d_dx1, d_dy1, d_xip1, d_xid1, sync=True):
+        """Two right-hand sides in one pass over the factor (tlpk_solve2_device); bit-identical to two solve_device calls."""
+        _raise_for(_lib.lib().tlpk_solve2_device(self._h, d_dx0, d_dy0, d_xip0, d_xid0, d_dx1, d_dy1, d_xip1, d_xid1), self._h)
+        if sync:
+            _raise_for(_lib.lib().tlpk_sync(self._h), self._h)
+
     def sync(self):
         _raise_for(_lib.lib().tlpk_sync(self._h), self._h)
 
