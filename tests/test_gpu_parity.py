@@ -643,3 +643,47 @@ def test_two_right_hand_sides_in_one_pass_equal_two_solves_bitwise(kind):
     r1, r2 = kkt_residuals(A, th, rp, rd, xp1, xd1, dx, dy)
     assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp1).max(), np.abs(xd1).max()))
     kkt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["block_angular", "general", "k2"])
+def test_graph_replay_equals_direct_enqueue_bitwise(kind, monkeypatch):
+    """hipGraph replay of the static schedules (default) against direct enqueueing (TLPK_GRAPH=0): factor and solutions bit for
+    bit, over several update / solve rounds with changing data, different right-hand-side pointers (graph cache), a failed
+    factorisation in between (the handle must stay usable) and the paired solve."""
+    import torch
+    if kind == "block_angular":
+        A, rb = block_angular(nblocks=5, mk=300, nk=700, m0=60, nnz_in=3, link_prob=0.5, seed=41)
+    else:
+        A, rb = random_lp_matrix(700, 1500, 4, 23, slack=True), None
+    m, n = A.shape
+    system = tk.K2() if kind == "k2" else tk.K1()
+    dev = torch.device("cuda", 0)
+    T = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)      # noqa: E731
+    P = lambda t: t.data_ptr()                                           # noqa: E731
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TLPK_GRAPH", mode)
+        kkt = tk.setup(A, system, tk.Backend(device=0, row_block=rb))
+        outs = []
+        for rnd in range(3):
+            th, rp, rd, xp, xd = ipm_like_data(m, n, 50 + rnd)
+            d = [T(v) for v in (th, rp, rd, xp, xd)]
+            kkt.update_device(P(d[0]), P(d[1]), P(d[2]))
+            if rnd == 1:                                                 # a failing factorisation, then the good data again
+                bad = rd.copy(); bad[3] = -1e9
+                with pytest.raises(tk.PosDefException):
+                    kkt.update_device(P(d[0]), P(d[1]), P(T(bad)))
+                kkt.update_device(P(d[0]), P(d[1]), P(d[2]))
+            o = [torch.zeros(sz, dtype=torch.float64, device=dev) for sz in (n, m, n, m)]
+            for rep in range(2):                                         # second repetition replays the cached graph
+                kkt.solve_device(P(o[0]), P(o[1]), P(d[3]), P(d[4]))
+            kkt.solve2_device(P(o[2]), P(o[3]), P(d[3]), P(d[4]), P(o[0]), P(o[1]), P(d[3]), P(d[4]))
+            assert torch.equal(o[0], o[2]) and torch.equal(o[1], o[3])
+            outs.append((o[0].cpu().numpy().copy(), o[1].cpu().numpy().copy()))
+            r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, outs[-1][0], outs[-1][1])
+            assert max(r1, r2) <= 1e-7 * (1 + max(np.abs(xp).max(), np.abs(xd).max()))
+        results[mode] = outs
+        kkt.close()
+    for a, b in zip(results["1"], results["0"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -253,6 +253,48 @@ void find_markers(tlpk_handle *h) {
         if (h->S.fwd_launches[i].kind == LK_ALLREDUCE_ROOT) h->fwd_marker = i;
 }
 
+// ---- hipGraph replay of the static schedules -------------------------------------------------------------------------
+// The launch schedules never change over the life of a handle: `update!` is ~220 launches on up to four streams, a `solve!`
+// ~40.  The first call with a given set of argument pointers records the enqueue sequence with stream capture (cross-stream
+// fork / join events become graph edges), later calls replay the instantiated graph with one hipGraphLaunch.  What it buys is
+// host launch time and inter-kernel gaps, i.e. the small, latency-bound LPs (profiles/r03_small_lp_graph.txt); TLPK_GRAPH=0
+// turns it off, profile mode and the split-phase (sharded) calls never use it.  The sweep kernels need no per-launch host
+// state (their tickets are reset by the solve's own memset), every pointer in a captured node is either handle-owned or part
+// of the cache key.
+struct GraphKey { int kind; const void *p[8]; bool operator==(const GraphKey &o) const { return kind == o.kind && std::memcmp(p, o.p, sizeof(p)) == 0; } };
+
+template <class F>
+int graph_or_direct(tlpk_handle *h, const GraphKey &key, F &&body) {
+    if (!h->use_graph || h->profile || h->serial) return body();
+    for (size_t i = 0; i < h->graph_keys.size(); ++i)
+        if (*reinterpret_cast<const GraphKey *>(h->graph_keys[i].data()) == key) {
+            HIPCHK(h, hipGraphLaunch(h->graph_execs[i], h->stream));
+            return TLPK_OK;
+        }
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); h->use_graph = false; return body(); }
+    const int rc = body();
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (e == hipSuccess && rc == TLPK_OK) e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    if (g) hipGraphDestroy(g);
+    if (e != hipSuccess || rc != TLPK_OK || !exec) {
+        // capture is not available here (or the body failed): nothing has run yet -- enqueue directly from now on
+        (void)hipGetLastError();
+        h->use_graph = false;
+        if (exec) hipGraphExecDestroy(exec);
+        return rc != TLPK_OK ? rc : body();
+    }
+    if (h->graph_execs.size() >= 24) {                  // bounded cache (the interior-point loops use a handful of pointer sets)
+        hipGraphExecDestroy(h->graph_execs.front());
+        h->graph_execs.erase(h->graph_execs.begin()); h->graph_keys.erase(h->graph_keys.begin());
+    }
+    h->graph_execs.push_back(exec);
+    h->graph_keys.emplace_back(reinterpret_cast<const char *>(&key), reinterpret_cast<const char *>(&key) + sizeof(key));
+    HIPCHK(h, hipGraphLaunch(exec, h->stream));
+    return TLPK_OK;
+}
+
 // user-visible dimensions: for K2 the Symbolic describes the augmented matrix (order n + m)
 inline i64 user_n(const tlpk_handle *h) { return h->S.system == 1 ? h->S.k2_n : h->S.n; }
 inline i64 user_m(const tlpk_handle *h) { return h->S.system == 1 ? h->S.k2_m : h->S.m; }
@@ -311,6 +353,7 @@ static int create_host(tlpk_handle *h, const tlpk_options &def, int64_t m, int64
     }
     h->profile = def.profile != 0;
     if (const char *e = std::getenv("TLPK_SERIAL")) h->serial = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TLPK_GRAPH")) h->use_graph = std::atoi(e) != 0;
     if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
     const auto t0 = std::chrono::steady_clock::now();
     if (rc == TLPK_OK) {
@@ -421,6 +464,7 @@ void tlpk_destroy(tlpk_handle *h) {
         hipSetDevice(h->device);
         if (h->stream) hipStreamSynchronize(h->stream);
         ipm_free(h);
+        for (hipGraphExec_t g : h->graph_execs) hipGraphExecDestroy(g);
         for (void *p : h->allocs) hipFree(p);
         if (h->h_info) hipHostFree(h->h_info);
         if (h->pin_in) hipHostFree(h->pin_in);
@@ -443,6 +487,33 @@ void tlpk_destroy(tlpk_handle *h) {
 }
 
 // ---- update ----
+// everything of an update up to the reduction of the root panel, on the handle-owned copies of theta / regP / regD
+static int enq_update_local(tlpk_handle *h) {
+    const Symbolic &S = h->S;
+    HIPCHK(h, hipMemcpyAsync(h->d.ctx.info, h->h_info, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    {
+        ProfScope ps(h, TLPK_KC_ASSEMBLE);
+        if (S.system == 1) launch_k2_diag(h->stream, user_n(h), h->d_theta, h->d_regP, h->d_D);      // D2 = [theta + regP ; 1]  (sqd.jl:44-50)
+        else launch_compute_d(h->stream, S.n, h->d_theta, h->d_regP, h->d_D);
+    }
+    {
+        ProfScope ps(h, TLPK_KC_ASSEMBLE);
+        launch_zero_panels(h->stream, h->d);
+        launch_assemble(h->stream, h->d, h->d_D, h->d_regD);
+        launch_single_factor(h->stream, h->d);
+    }
+    run_launches(h, S.factor_launches, 0, h->factor_marker);
+    HIPCHK(h, hipGetLastError());
+    return TLPK_OK;
+}
+// the root front and the read-back of the status word
+static int enq_update_finish(tlpk_handle *h) {
+    const Symbolic &S = h->S;
+    run_launches(h, S.factor_launches, h->factor_marker, S.factor_launches.size());
+    HIPCHK(h, hipMemcpyAsync(h->h_info, h->d.ctx.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    return TLPK_OK;
+}
+
 int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_regP, const double *d_regD) {
     if (!h || !d_theta || !d_regP || !d_regD) return TLPK_BADARG;
     if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
@@ -458,20 +529,8 @@ int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_reg
     if (d_regP != h->d_regP) HIPCHK(h, hipMemcpyAsync(h->d_regP, d_regP, (size_t)un * 8, hipMemcpyDeviceToDevice, h->stream));
     if (d_regD != h->d_regD) HIPCHK(h, hipMemcpyAsync(h->d_regD, d_regD, (size_t)um * 8, hipMemcpyDeviceToDevice, h->stream));
     h->h_info[0] = INT_MAX;
-    HIPCHK(h, hipMemcpyAsync(h->d.ctx.info, h->h_info, sizeof(int), hipMemcpyHostToDevice, h->stream));
-    {
-        ProfScope ps(h, TLPK_KC_ASSEMBLE);
-        if (S.system == 1) launch_k2_diag(h->stream, un, h->d_theta, h->d_regP, h->d_D);      // D2 = [theta + regP ; 1]  (sqd.jl:44-50)
-        else launch_compute_d(h->stream, S.n, h->d_theta, h->d_regP, h->d_D);
-    }
-    {
-        ProfScope ps(h, TLPK_KC_ASSEMBLE);
-        launch_zero_panels(h->stream, h->d);
-        launch_assemble(h->stream, h->d, h->d_D, h->d_regD);
-        launch_single_factor(h->stream, h->d);
-    }
-    run_launches(h, S.factor_launches, 0, h->factor_marker);
-    HIPCHK(h, hipGetLastError());
+    if (h->update_whole) return TLPK_OK;                 // tlpk_update_device on an unsharded handle: the caller enqueues both halves (graph)
+    if (int rc = enq_update_local(h)) return rc;
     h->local_done = true;
     return TLPK_OK;
 }
@@ -505,9 +564,7 @@ static int update_finish_enqueue(tlpk_handle *h) {
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->local_done) return TLPK_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
-    const Symbolic &S = h->S;
-    run_launches(h, S.factor_launches, h->factor_marker, S.factor_launches.size());
-    HIPCHK(h, hipMemcpyAsync(h->h_info, h->d.ctx.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (int rc = enq_update_finish(h)) return rc;
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     return TLPK_OK;
 }
@@ -547,9 +604,22 @@ static int sharded_needs_split(tlpk_handle *h, const char *what) {
 
 int tlpk_update_device(tlpk_handle *h, const double *d_theta, const double *d_regP, const double *d_regD) {
     if (int g = sharded_needs_split(h, "tlpk_update_device")) return g;
+    if (!h || !h->sub.empty() || !h->has_device || !h->use_graph || h->profile || h->serial) {
+        int rc = tlpk_update_local(h, d_theta, d_regP, d_regD);
+        if (rc != TLPK_OK) return rc;
+        return tlpk_update_finish(h);
+    }
+    // unsharded handle: prologue (stored copies of the caller's vectors), then the WHOLE factorisation as one replayed graph
+    h->update_whole = true;
     int rc = tlpk_update_local(h, d_theta, d_regP, d_regD);
+    h->update_whole = false;
     if (rc != TLPK_OK) return rc;
-    return tlpk_update_finish(h);
+    const GraphKey key{1, {}};
+    rc = graph_or_direct(h, key, [&]() { const int q = enq_update_local(h); return q != TLPK_OK ? q : enq_update_finish(h); });
+    if (rc != TLPK_OK) return rc;
+    h->local_done = true;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    return update_finish_wait(h);
 }
 
 // Host-pointer entry points: the caller's vectors are ordinary pageable memory (Julia arrays).  They go
@@ -584,6 +654,32 @@ int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const d
 }
 
 // ---- solve ----
+static int enq_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
+    {
+        ProfScope ps(h, TLPK_KC_SPMV);
+        // tickets + hand-over words of both sweeps back to all ones: the data is its own flag, ticket + 1 = 0 is the first item
+        if (h->S.sweep && h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes, h->stream));
+        if (h->S.system == 1) launch_k2_rhs(h->stream, h->d, h->S.k2_n, d_xip, d_xid);        // [xi_d ; xi_p] permuted (sqd.jl:62-66)
+        else launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank);
+        launch_single_solve(h->stream, h->d);
+    }
+    run_launches(h, h->S.fwd_launches, 0, h->fwd_marker, 0);
+    HIPCHK(h, hipGetLastError());
+    return TLPK_OK;
+}
+static int enq_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xid) {
+    run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size(), 0);
+    if (h->S.system == 1) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d); }     // L S L' x = b: z = S y between the sweeps
+    run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1);
+    if (h->S.system == 1) { ProfScope ps(h, TLPK_KC_SPMV); launch_k2_out(h->stream, h->d, h->S.k2_n, d_dx, d_dy); }
+    else {
+        { ProfScope ps(h, TLPK_KC_SPMV); launch_unpermute(h->stream, h->d, d_dy, h->shared_dy, h->opt.rank); }
+        { ProfScope ps(h, TLPK_KC_SPMV); launch_dx(h->stream, h->d, h->d_D, d_dy, d_xid, d_dx, h->dx_local_only ? 1 : 0); }
+    }
+    if (h->S.sweep) HIPCHK(h, hipMemcpyAsync(h->h_info + 1, h->d.ctx.info + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    return TLPK_OK;
+}
+
 int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
     if (!h || !d_xip || !d_xid) return TLPK_BADARG;
     if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
@@ -593,18 +689,9 @@ int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
     prof_begin(h, false);
     h->solve_timed = false;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    {
-        ProfScope ps(h, TLPK_KC_SPMV);
-        // hand-over words of both sweeps back to the sentinel (all ones): the data is its own flag
-        // tickets + hand-over words of both sweeps back to all ones: the data is its own flag, ticket + 1 = 0 is the first item
-        if (h->S.sweep && h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes, h->stream));
-        if (h->S.system == 1) launch_k2_rhs(h->stream, h->d, h->S.k2_n, d_xip, d_xid);        // [xi_d ; xi_p] permuted (sqd.jl:62-66)
-        else launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank);
-        launch_single_solve(h->stream, h->d);
-    }
     h->solve_epoch += 1;
-    run_launches(h, h->S.fwd_launches, 0, h->fwd_marker, 0);
-    HIPCHK(h, hipGetLastError());
+    if (h->solve_whole) return TLPK_OK;                  // tlpk_solve_device: the caller enqueues both halves (graph)
+    if (int rc = enq_solve_local(h, d_xip, d_xid)) return rc;
     h->solve_local_done = true;
     return TLPK_OK;
 }
@@ -626,15 +713,23 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     if (!h->solve_local_done) { h->last_error = "tlpk_solve_finish without a preceding tlpk_solve_local"; return TLPK_BADARG; }
     h->solve_local_done = false;
     HIPCHK(h, hipSetDevice(h->device));
-    run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size(), 0);
-    if (h->S.system == 1) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d); }     // L S L' x = b: z = S y between the sweeps
-    run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1);
-    if (h->S.system == 1) { ProfScope ps(h, TLPK_KC_SPMV); launch_k2_out(h->stream, h->d, h->S.k2_n, d_dx, d_dy); }
-    else {
-        { ProfScope ps(h, TLPK_KC_SPMV); launch_unpermute(h->stream, h->d, d_dy, h->shared_dy, h->opt.rank); }
-        { ProfScope ps(h, TLPK_KC_SPMV); launch_dx(h->stream, h->d, h->d_D, d_dy, d_xid, d_dx, h->dx_local_only ? 1 : 0); }
-    }
-    if (h->S.sweep) HIPCHK(h, hipMemcpyAsync(h->h_info + 1, h->d.ctx.info + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (int rc = enq_solve_finish(h, d_dx, d_dy, d_xid)) return rc;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->solve_timed = true;
+    return TLPK_OK;
+}
+
+// one whole solve (both halves) from the graph cache, keyed by its four pointers
+static int solve_whole(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xip, const double *d_xid) {
+    if (!d_dx || !d_dy) return TLPK_BADARG;
+    h->solve_whole = true;
+    int rc = tlpk_solve_local(h, d_xip, d_xid);          // argument / state checks, ev0
+    h->solve_whole = false;
+    if (rc != TLPK_OK) return rc;
+    const GraphKey key{2, {d_dx, d_dy, d_xip, d_xid}};
+    rc = graph_or_direct(h, key, [&]() { const int q = enq_solve_local(h, d_xip, d_xid); return q != TLPK_OK ? q : enq_solve_finish(h, d_dx, d_dy, d_xid); });
+    if (rc != TLPK_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
     h->solve_timed = true;
@@ -643,15 +738,16 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
 
 int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xip, const double *d_xid) {
     if (int g = sharded_needs_split(h, "tlpk_solve_device")) return g;
-    int rc = tlpk_solve_local(h, d_xip, d_xid);
+    const bool whole = h && h->sub.empty() && h->has_device && h->use_graph && !h->profile && !h->serial;
+    int rc = whole ? solve_whole(h, d_dx, d_dy, d_xip, d_xid) : tlpk_solve_local(h, d_xip, d_xid);
     if (rc != TLPK_OK) return rc;
-    rc = tlpk_solve_finish(h, d_dx, d_dy, d_xid);
+    if (!whole) rc = tlpk_solve_finish(h, d_dx, d_dy, d_xid);
     // optional iterative refinement on the residuals of the augmented system (KKT.jl:70-75): each step is one more solve with
     // (r1, r2) as right-hand side, its result added to (dx, dy).  Off by default = the reference (spd.jl:68).
     for (int it = 0; it < h->refine_steps && rc == TLPK_OK; ++it) {
         launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, d_dx, d_dy, h->d_r1, h->d_r2);
-        rc = tlpk_solve_local(h, h->d_r1, h->d_r2);
-        if (rc == TLPK_OK) rc = tlpk_solve_finish(h, h->d_cx, h->d_cy, h->d_r2);
+        rc = whole ? solve_whole(h, h->d_cx, h->d_cy, h->d_r1, h->d_r2) : tlpk_solve_local(h, h->d_r1, h->d_r2);
+        if (rc == TLPK_OK && !whole) rc = tlpk_solve_finish(h, h->d_cx, h->d_cy, h->d_r2);
         if (rc == TLPK_OK) launch_axpy2(h->stream, h->S.n, d_dx, h->d_cx, h->S.m, d_dy, h->d_cy);
         HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     }
@@ -680,6 +776,9 @@ int tlpk_solve2_device(tlpk_handle *h, double *d_dx0, double *d_dy0, const doubl
     const bool k2 = h->S.system == 1;
     const double *xip[2] = {d_xip0, d_xip1}, *xid[2] = {d_xid0, d_xid1};
     double *dx[2] = {d_dx0, d_dx1}, *dy[2] = {d_dy0, d_dy1};
+    h->solve_epoch += 1;
+    const GraphKey key{3, {d_dx0, d_dy0, d_xip0, d_xid0, d_dx1, d_dy1, d_xip1, d_xid1}};
+    const int grc = graph_or_direct(h, key, [&]() -> int {
     {
         ProfScope ps(h, TLPK_KC_SPMV);
         if (h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes2, h->stream));
@@ -689,7 +788,6 @@ int tlpk_solve2_device(tlpk_handle *h, double *d_dx0, double *d_dy0, const doubl
             launch_single_solve(h->stream, h->d, r);
         }
     }
-    h->solve_epoch += 1;
     run_launches(h, h->S.fwd_launches, 0, h->S.fwd_launches.size(), 0, 2);
     if (k2) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d, 0); launch_apply_signs(h->stream, h->d, 1); }
     run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1, 2);
@@ -702,6 +800,9 @@ int tlpk_solve2_device(tlpk_handle *h, double *d_dx0, double *d_dy0, const doubl
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->h_info + 1, h->d.ctx.info + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    return TLPK_OK;
+    });
+    if (grc != TLPK_OK) return grc;
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
     h->solve_timed = true;

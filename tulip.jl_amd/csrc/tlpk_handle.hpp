@@ -61,6 +61,11 @@ struct tlpk_handle {
     i64 col_lo = 0, col_hi = 0, row_lo = 0, row_hi = 0, link_lo = 0, link_hi = 0;   // child: slices of the job-wide input vectors it reads
     double *shared_dy = nullptr;        // child: job-wide dy on the lead device (P2P), filled with the rows this rank owns
     bool dx_local_only = false;         // child: dx is the job-wide vector, leave the other ranks' columns alone
+    // hipGraph replay of the static schedules (tlpk_api.cpp: graph_or_direct): instantiated graphs and their keys
+    bool use_graph = true;              // TLPK_GRAPH=0 turns it off; switched off for good if capture fails on this system
+    bool update_whole = false, solve_whole = false;   // internal: the composed entry point enqueues both halves itself
+    std::vector<hipGraphExec_t> graph_execs;
+    std::vector<std::vector<char>> graph_keys;
     IpmState *ipm = nullptr;            // device-resident interior-point vectors (tlpk_ipm_load), freed by tlpk_destroy
     std::string last_error;
 };
