@@ -222,7 +222,7 @@ int tlpk_ipm_targets(tlpk_handle *h, double a_, double mu_l, double mu_u, double
  * sc[8] = { tau, kappa, h0, xi_g, xi_tk, eta, gamma*mu, delta }; out[3] = { dtau, dkappa, max step to the boundary } */
 int tlpk_ipm_newton(tlpk_handle *h, int mode, const double *sc, double *out);
 /* step.jl:56-94: tlpk_ipm_hsolve + tlpk_ipm_newton(mode 0) with the two independent solves sharing one pass over the factor
- * (tlpk_solve2_device).  sc[8] as above except sc[2] = kappa / tau + regG (the host part of h0); out[4] = { dtau, dkappa, max step, h0 } */
+ * (tlpk_solve2_device).  sc[8] as above except sc[2] = regG (h0 is formed inside); out[4] = { dtau, dkappa, max step, h0 } */
 int tlpk_ipm_hsolve_newton(tlpk_handle *h, const double *sc, double *out);
 int tlpk_ipm_accept(tlpk_handle *h);                         /* step.jl:112-118: candidate -> accepted direction */
 int tlpk_ipm_advance(tlpk_handle *h, double alpha, double *out);   /* step.jl:139-148; out[0] = xl'zl + xu'zu */

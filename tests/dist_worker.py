@@ -12,6 +12,7 @@ PROBLEM = dict(nblocks=5, mk=40, nk=90, m0=14, nnz_in=3, link_prob=0.6)
 
 def main():
     rank, world, port, seed, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
+    system = sys.argv[6] if len(sys.argv) > 6 else "K1"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # the container hostname may not resolve
@@ -26,7 +27,7 @@ def main():
         A, row_block = block_angular(seed=seed, **PROBLEM)
         m, n = A.shape
         th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
-        kkt = tk.setup(A, tk.K1(), tk.Backend(device=-1, row_block=row_block, rank=rank, nranks=world))
+        kkt = tk.setup(A, tk.K2() if system == "K2" else tk.K1(), tk.Backend(device=-1, row_block=row_block, rank=rank, nranks=world))
         em = Emulator(kkt)
         # --- update: local subtrees + partial root panel, all-reduce, root factorisation ---
         em.update(th, rp, rd, stop_at_marker=True)
@@ -44,8 +45,11 @@ def main():
         link = row_block < 0
         dy_sh = dy.copy(); dy_sh[link] /= world
         tdy = torch.from_numpy(dy_sh); dist.all_reduce(tdy)
-        own = torch.from_numpy(np.concatenate([(kkt.symbolic("col_local") != 0).astype(np.int64),
-                                               (kkt.symbolic("row_local") == 1).astype(np.int64)]))
+        if system == "K2":       # node ownership: variable and constraint nodes outside the replicated root
+            own = torch.from_numpy((kkt.symbolic("row_local") == 1).astype(np.int64))
+        else:
+            own = torch.from_numpy(np.concatenate([(kkt.symbolic("col_local") != 0).astype(np.int64),
+                                                   (kkt.symbolic("row_local") == 1).astype(np.int64)]))
         dist.all_reduce(own)
         st = kkt.stats()
         np.savez(out, dx=tdx.numpy(), dy=tdy.numpy(), own=own.numpy(), nloc=st["n_local_blocks"],

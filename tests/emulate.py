@@ -271,8 +271,9 @@ class Emulator:
 
     # ---- solve! ----
     def solve_local(self, xi_p, xi_d, A):
-        if self.k2:                                                     # k_k2_rhs: [xi_d ; xi_p] permuted
-            self.xw = np.concatenate([xi_d, xi_p])[self.perm].copy()
+        if self.k2:                                                     # k_k2_rhs: [xi_d ; xi_p] permuted; sharded: own nodes, root nodes on rank 0
+            nl = self.row_local[self.perm]
+            self.xw = np.where((nl == 0) | ((nl == 2) & (self.rank != 0)), 0.0, np.concatenate([xi_d, xi_p])[self.perm])
         else:
             # k_rhs: a rank sums only its own columns; only rank 0 adds xi_p on linking rows
             Aloc = A @ __import__("scipy.sparse").sparse.diags(self.col_local.astype(float))
@@ -300,7 +301,7 @@ class Emulator:
         self._run(self.bwd_launches)
         if self.k2:                                                     # k_k2_out
             sol = np.zeros(self.m + self.n)
-            sol[self.perm] = self.xw
+            sol[self.perm] = np.where(self.row_local[self.perm] != 0, self.xw, 0.0)
             return sol[: self.n], sol[self.n:]
         dy = np.zeros(self.m)
         dy[self.perm] = self.xw

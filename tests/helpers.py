@@ -81,3 +81,49 @@ def block_angular(nblocks, mk, nk, m0, nnz_in, link_prob, seed):
     A.sort_indices()
     row_block = np.concatenate([np.repeat(np.arange(nblocks), mk), np.full(m0, -1)]).astype(np.int64)
     return A, row_block
+
+
+class DevBuf:
+    """A device buffer of doubles for the device-pointer entry points, through the HIP runtime libtlpk.so itself is linked
+    against (ctypes on libamdhip64.so: the already-loaded instance).  torch is NOT used inside the pytest process: its wheel
+    bundles its own HIP runtime, and the second runtime of a process sees no GPU ("No HIP GPUs are available") once libtlpk has
+    initialised the first."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import ctypes
+            import tulip_jl_amd._lib as L
+            L.lib()                                             # libtlpk.so first: pulls in its libamdhip64.so
+            h = ctypes.CDLL("libamdhip64.so")
+            h.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+            h.hipFree.argtypes = [ctypes.c_void_p]
+            h.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            h.hipDeviceSynchronize.argtypes = []
+            cls._hip = h
+        return cls._hip
+
+    def __init__(self, data_or_len, fill=np.nan):
+        import ctypes
+        a = np.full(int(data_or_len), fill) if np.isscalar(data_or_len) else np.ascontiguousarray(data_or_len, dtype=np.float64)
+        self.n = a.size
+        p = ctypes.c_void_p()
+        assert self.hip().hipMalloc(ctypes.byref(p), max(8 * self.n, 8)) == 0
+        self.ptr = p.value
+        if self.n:
+            assert self.hip().hipMemcpy(self.ptr, a.ctypes.data, 8 * self.n, 1) == 0          # hipMemcpyHostToDevice
+
+    def get(self):
+        out = np.empty(self.n)
+        self.hip().hipDeviceSynchronize()
+        if self.n:
+            assert self.hip().hipMemcpy(out.ctypes.data, self.ptr, 8 * self.n, 2) == 0        # hipMemcpyDeviceToHost
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self.hip().hipFree(self.ptr); self.ptr = None
+        except Exception:
+            pass

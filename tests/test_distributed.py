@@ -63,3 +63,45 @@ def test_sharded_newton_step_matches_oracle(world, tmp_path):
         assert np.abs(z["dy_link"] - dyo[row_block < 0]).max() <= 1e-9 * max(1, np.abs(dyo).max())  # replicated
         nloc.append(int(z["nloc"]))
     assert sum(nloc) == PROBLEM["nblocks"] and all(v >= 1 for v in nloc)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_augmented_system_matches_k2_oracle(world, tmp_path):
+    """K2 (the reference's default linear system, KKT.jl:134-141) on sharded handles: every rank owns the variable and constraint
+    nodes of its diagonal blocks, the root front (linking constraint nodes + the variable nodes of columns that touch linking rows
+    only, pivots of both signs) is replicated, its assembled entries and its right-hand side come from rank 0, the ranks'
+    contributions arrive through the two all-reduces.  Every rank must end with the K2 oracle's solution."""
+    from dist_worker import PROBLEM
+    from helpers import block_angular, ipm_like_data
+    from oracle_binding import OracleK2
+    seed = 17
+    port = str(_free_port())
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, str(seed), outs[r], "K2"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("distributed worker timed out")
+        logs.append(out.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    A, row_block = block_angular(seed=seed, **PROBLEM)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
+    orc = OracleK2(A)
+    orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    for r in range(world):
+        z = np.load(outs[r])
+        # dx: every column's variable node is owned by one rank, or sits in the replicated root (then every rank returns it)
+        own = z["own"]
+        nrep_x = np.where(own[:n] == 0, world, 1)              # a root variable node is reported by every rank
+        assert np.abs(z["dx"] / nrep_x - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max())
+        assert np.abs(z["dy"] - dyo).max() <= 1e-9 * max(1, np.abs(dyo).max())
+        assert np.abs(z["dy_link"] - dyo[row_block < 0]).max() <= 1e-9 * max(1, np.abs(dyo).max())

@@ -612,7 +612,7 @@ def test_two_right_hand_sides_in_one_pass_equal_two_solves_bitwise(kind):
     """tlpk_solve2_device: both right-hand sides ride one pass over L in the persistent sweeps (the hand-over carries two words per
     column); every other solve kernel runs once per right-hand side.  Same summation order per right-hand side => the pair must
     equal two single solves bit for bit, in either slot, and leave the handle usable for single solves."""
-    import torch
+    from helpers import DevBuf
     if kind == "block_angular":
         A, rb = block_angular(nblocks=5, mk=400, nk=900, m0=90, nnz_in=3, link_prob=0.5, seed=31)
     elif kind == "small_fronts_only":
@@ -625,21 +625,20 @@ def test_two_right_hand_sides_in_one_pass_equal_two_solves_bitwise(kind):
     tk.update(kkt, th, rp, rd)
     rng = np.random.default_rng(1)
     xp1, xd1 = rng.standard_normal(m), rng.standard_normal(n)
-    dev = torch.device("cuda", 0)
-    T = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)      # noqa: E731
-    P = lambda t: t.data_ptr()                                           # noqa: E731
-    d_xp, d_xd, d_xp1, d_xd1 = T(xp), T(xd), T(xp1), T(xd1)
-    out = [torch.full((sz,), float("nan"), dtype=torch.float64, device=dev) for sz in (n, m, n, m, n, m, n, m)]
+    P = lambda t: t.ptr                                                  # noqa: E731
+    eq = lambda a, b: np.array_equal(a.get(), b.get())                   # noqa: E731
+    d_xp, d_xd, d_xp1, d_xd1 = DevBuf(xp), DevBuf(xd), DevBuf(xp1), DevBuf(xd1)
+    out = [DevBuf(sz) for sz in (n, m, n, m, n, m, n, m)]
     kkt.solve_device(P(out[0]), P(out[1]), P(d_xp), P(d_xd))
     kkt.solve_device(P(out[2]), P(out[3]), P(d_xp1), P(d_xd1))
     kkt.solve2_device(P(out[4]), P(out[5]), P(d_xp), P(d_xd), P(out[6]), P(out[7]), P(d_xp1), P(d_xd1))
     for a, b in ((0, 4), (1, 5), (2, 6), (3, 7)):
-        assert torch.equal(out[a], out[b]), (kind, a)
+        assert eq(out[a], out[b]), (kind, a)
     kkt.solve2_device(P(out[4]), P(out[5]), P(d_xp1), P(d_xd1), P(out[6]), P(out[7]), P(d_xp), P(d_xd))       # slots swapped
-    assert torch.equal(out[2], out[4]) and torch.equal(out[3], out[5]) and torch.equal(out[0], out[6]) and torch.equal(out[1], out[7])
+    assert eq(out[2], out[4]) and eq(out[3], out[5]) and eq(out[0], out[6]) and eq(out[1], out[7])
     kkt.solve_device(P(out[4]), P(out[5]), P(d_xp), P(d_xd))                                                   # and a single solve again
-    assert torch.equal(out[0], out[4]) and torch.equal(out[1], out[5])
-    dx, dy = out[2].cpu().numpy(), out[3].cpu().numpy()
+    assert eq(out[0], out[4]) and eq(out[1], out[5])
+    dx, dy = out[2].get(), out[3].get()
     r1, r2 = kkt_residuals(A, th, rp, rd, xp1, xd1, dx, dy)
     assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp1).max(), np.abs(xd1).max()))
     kkt.close()
@@ -651,16 +650,15 @@ def test_graph_replay_equals_direct_enqueue_bitwise(kind, monkeypatch):
     """hipGraph replay of the static schedules (default) against direct enqueueing (TLPK_GRAPH=0): factor and solutions bit for
     bit, over several update / solve rounds with changing data, different right-hand-side pointers (graph cache), a failed
     factorisation in between (the handle must stay usable) and the paired solve."""
-    import torch
+    from helpers import DevBuf
     if kind == "block_angular":
         A, rb = block_angular(nblocks=5, mk=300, nk=700, m0=60, nnz_in=3, link_prob=0.5, seed=41)
     else:
         A, rb = random_lp_matrix(700, 1500, 4, 23, slack=True), None
     m, n = A.shape
     system = tk.K2() if kind == "k2" else tk.K1()
-    dev = torch.device("cuda", 0)
-    T = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)      # noqa: E731
-    P = lambda t: t.data_ptr()                                           # noqa: E731
+    T = DevBuf
+    P = lambda t: t.ptr                                                  # noqa: E731
     results = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("TLPK_GRAPH", mode)
@@ -675,12 +673,12 @@ def test_graph_replay_equals_direct_enqueue_bitwise(kind, monkeypatch):
                 with pytest.raises(tk.PosDefException):
                     kkt.update_device(P(d[0]), P(d[1]), P(T(bad)))
                 kkt.update_device(P(d[0]), P(d[1]), P(d[2]))
-            o = [torch.zeros(sz, dtype=torch.float64, device=dev) for sz in (n, m, n, m)]
+            o = [DevBuf(sz, 0.0) for sz in (n, m, n, m)]
             for rep in range(2):                                         # second repetition replays the cached graph
                 kkt.solve_device(P(o[0]), P(o[1]), P(d[3]), P(d[4]))
             kkt.solve2_device(P(o[2]), P(o[3]), P(d[3]), P(d[4]), P(o[0]), P(o[1]), P(d[3]), P(d[4]))
-            assert torch.equal(o[0], o[2]) and torch.equal(o[1], o[3])
-            outs.append((o[0].cpu().numpy().copy(), o[1].cpu().numpy().copy()))
+            assert np.array_equal(o[0].get(), o[2].get()) and np.array_equal(o[1].get(), o[3].get())
+            outs.append((o[0].get(), o[1].get()))
             r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, outs[-1][0], outs[-1][1])
             assert max(r1, r2) <= 1e-7 * (1 + max(np.abs(xp).max(), np.abs(xd).max()))
         results[mode] = outs

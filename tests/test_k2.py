@@ -234,3 +234,39 @@ def test_k2_in_the_ipm_loop():
     assert abs(h2.niter - h1.niter) <= 2
     assert abs(s2["z_primal"] - STAIR25_OPT) <= 1e-6 * (1 + abs(STAIR25_OPT))
     assert max(s2["rho"]) <= SQRT_EPS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ngpus", [2, 3])
+def test_k2_single_process_multi_device_mode(ngpus):
+    """The reference's default linear system (K2, KKT.jl:134-141) on a multi-device handle (tlpk_create_multi; the shards share this
+    box's single GPU): per-rank ownership of the variable / constraint nodes, replicated root front of both signs, library-owned
+    reductions of the root panel and the root right-hand side, results gathered by P2P stores -- against the K2 oracle and against
+    the single-device K2 handle."""
+    from helpers import block_angular, kkt_residuals
+    A, row_block = block_angular(nblocks=7, mk=200, nk=500, m0=50, nnz_in=3, link_prob=0.5, seed=19)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 19)
+    kkt = tk.setup(A, tk.K2(), tk.Backend(device=0, row_block=row_block, ngpus=ngpus, devices=[0] * ngpus))
+    assert tk.linear_system(kkt) == "Augmented system (K2)"
+    one = tk.setup(A, tk.K2(), tk.Backend(device=0, row_block=row_block))
+    orc = OracleK2(A)
+    orc.update(th, rp, rd)
+    for it in range(2):
+        tk.update(kkt, th, rp, rd); tk.update(one, th, rp, rd)
+        dx, dy = np.full(n, np.nan), np.full(m, np.nan)
+        tk.solve(dx, dy, kkt, xp, xd)
+        dx1, dy1 = np.zeros(n), np.zeros(m)
+        tk.solve(dx1, dy1, one, xp, xd)
+        dxo, dyo = orc.solve(xp, xd)
+        sc = max(1.0, np.abs(dxo).max(), np.abs(dyo).max())
+        assert np.abs(dx - dxo).max() <= 1e-9 * sc and np.abs(dy - dyo).max() <= 1e-9 * sc
+        assert np.abs(dx - dx1).max() <= 1e-10 * sc and np.abs(dy - dy1).max() <= 1e-10 * sc
+        r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+        assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp).max(), np.abs(xd).max()))
+        xp = xp[::-1].copy()
+    bad = rd.copy(); bad[2] = -1e6                      # a constraint node of the wrong sign in the first shard
+    with pytest.raises(tk.PosDefException):
+        tk.update(kkt, th, rp, bad)
+    tk.update(kkt, th, rp, rd)
+    tk.run_ls_tests(A, kkt)

@@ -2000,12 +2000,15 @@ __global__ void k_k2_diag(i64 n, const double *__restrict__ theta, const double 
     else if (j == n) D2[j] = 1.0;
 }
 // permuted right-hand side [xi_d ; xi_p]                                                          sqd.jl:62-66
-__global__ void k_k2_rhs(i64 N, i64 n, const i32 *__restrict__ perm, const double *__restrict__ xi_p, const double *__restrict__ xi_d,
-                         double *__restrict__ xw) {
+// Sharded runs (node_local: 0 = another rank's node, 1 = local, 2 = node of the replicated root front): a rank loads the right-hand
+// side of its own nodes, rank 0 that of the root nodes; the all-reduce of the root rhs completes them with the ranks' contributions.
+__global__ void k_k2_rhs(i64 N, i64 n, const i32 *__restrict__ perm, const char *__restrict__ node_local, int rank,
+                         const double *__restrict__ xi_p, const double *__restrict__ xi_d, double *__restrict__ xw) {
     const i64 kk = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (kk >= N) return;
     const i32 v = perm[kk];
-    xw[kk] = (v < n) ? xi_d[v] : xi_p[v - n];
+    const char nl = node_local[v];
+    xw[kk] = (nl == 0 || (nl == 2 && rank != 0)) ? 0.0 : ((v < n) ? xi_d[v] : xi_p[v - n]);
 }
 // between the sweeps of L S L' x = b:  z = S y
 __global__ void k_apply_signs(i64 N, const double *__restrict__ csign, double *__restrict__ xw) {
@@ -2013,11 +2016,17 @@ __global__ void k_apply_signs(i64 N, const double *__restrict__ csign, double *_
     if (kk < N) xw[kk] *= csign[kk];
 }
 // [dx ; dy] = P' x                                                                                 sqd.jl:69-72
-__global__ void k_k2_out(i64 N, i64 n, const i32 *__restrict__ perm, const double *__restrict__ xw, double *__restrict__ dx, double *__restrict__ dy) {
+// owned_only (single-process multi-device mode: dx / dy are the job-wide vectors on the lead device): a rank stores the nodes it owns
+// (its own; the root nodes on rank 0) and leaves the others alone; otherwise the entries of other ranks' nodes are written as 0.
+__global__ void k_k2_out(i64 N, i64 n, const i32 *__restrict__ perm, const char *__restrict__ node_local, int rank, int owned_only,
+                         const double *__restrict__ xw, double *__restrict__ dx, double *__restrict__ dy) {
     const i64 kk = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (kk >= N) return;
     const i32 v = perm[kk];
-    if (v < n) dx[v] = xw[kk]; else dy[v - n] = xw[kk];
+    const char nl = node_local[v];
+    if (owned_only && !(nl == 1 || (nl == 2 && rank == 0))) return;
+    const double val = nl ? xw[kk] : 0.0;
+    if (v < n) dx[v] = val; else dy[v - n] = val;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2088,14 +2097,14 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
 void launch_k2_diag(hipStream_t st, i64 n, const double *theta, const double *regP, double *D2) {
     hipLaunchKernelGGL(k_k2_diag, dim3(nblk(n + 1, 256)), dim3(256), 0, st, n, theta, regP, D2);
 }
-void launch_k2_rhs(hipStream_t st, const DevArrays &a, i64 n, const double *xi_p, const double *xi_d, int rhs) {
-    if (a.m > 0) hipLaunchKernelGGL(k_k2_rhs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, n, a.perm, xi_p, xi_d, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
+void launch_k2_rhs(hipStream_t st, const DevArrays &a, i64 n, const double *xi_p, const double *xi_d, int rhs, int rank) {
+    if (a.m > 0) hipLaunchKernelGGL(k_k2_rhs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, n, a.perm, a.row_local, rank, xi_p, xi_d, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
 }
 void launch_apply_signs(hipStream_t st, const DevArrays &a, int rhs) {
     if (a.m > 0) hipLaunchKernelGGL(k_apply_signs, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.ctx.csign, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
 }
-void launch_k2_out(hipStream_t st, const DevArrays &a, i64 n, double *dx, double *dy, int rhs) {
-    if (a.m > 0) hipLaunchKernelGGL(k_k2_out, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, n, a.perm, a.ctx.xw + (rhs ? a.ctx.xw2 : 0), dx, dy);
+void launch_k2_out(hipStream_t st, const DevArrays &a, i64 n, double *dx, double *dy, int rhs, int rank, int owned_only) {
+    if (a.m > 0) hipLaunchKernelGGL(k_k2_out, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, n, a.perm, a.row_local, rank, owned_only, a.ctx.xw + (rhs ? a.ctx.xw2 : 0), dx, dy);
 }
 void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank, int rhs) {
     if (a.m > 0)

@@ -931,13 +931,17 @@ int analyse_rank(Symbolic &S, const Options &opt) {
                             S.s_target[e] = w.loff + pos_in_front[ii] + (i64)(kk - w.col0) * w.lda;
                             S.s_local[e] = 1;
                         }
-                        if (opt.system == 1) { if (k >= opt.k2_n) S.s_diag_row[S.Sp[kk]] = k - (i32)opt.k2_n; }   // constraint node: regD
+                        if (opt.system == 1) { if (k >= opt.k2_n && (!is_root || opt.rank == 0)) S.s_diag_row[S.Sp[kk]] = k - (i32)opt.k2_n; }   // constraint node: regD
                         else if (!is_root || opt.rank == 0) S.s_diag_row[S.Sp[kk]] = k;
                     }
                     if (opt.system == 1) {
                         // Augmented system: the diagonal of a variable node is -(theta + regP) = -1 * D2[k]; an
                         // off-diagonal entry is the constant A[i,j] = A[i,j] * D2[k2_n] with D2[k2_n] = 1 (the columns
                         // of the incidence matrix carry (1, A[i,j]) on the variable / constraint node).
+                        // Sharded runs: the assembled entries of the replicated root front (linking constraint nodes and the
+                        // variable nodes of columns that touch linking rows only) belong to rank 0; the all-reduce of the root
+                        // panel adds the ranks' extend-add contributions to them.
+                        if (is_root && opt.rank != 0) continue;
                         if (k < opt.k2_n) {
                             const i64 e = S.Sp[kk];
                             if (!pass) S.pair_ptr[e + 1]++;
@@ -994,10 +998,10 @@ int analyse(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, con
 // variable node and A[i,j] on the constraint node of the p-th nonzero of A: the whole analyse phase is
 // reused on B, only the assembly lists differ (see step 14).
 // ---------------------------------------------------------------------------------------------
-int analyse_k2(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
-               int base, const Options &opt_in) {
+// rank-independent part: incidence matrix, analyse_common on it, signs
+int analyse_k2_common(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
+                      int base, const Options &opt_in, Options *opt_out) {
     if (m < 0 || n < 0 || (base != 0 && base != 1) || !colptr) return fail(S, TLPK_BADARG, "bad dimensions or index base");
-    if (opt_in.nranks > 1) return fail(S, TLPK_BADARG, "the augmented system (K2) is single-GPU");
     if (opt_in.ordering == TLPK_ORDER_USER) return fail(S, TLPK_BADARG, "user_perm is not supported for K2");
     const i64 nnz = colptr[n] - base;
     if (nnz < 0 || m + n >= ((i64)1 << 31) || nnz >= ((i64)1 << 30)) return fail(S, TLPK_TOO_LARGE, "augmented system exceeds int32");
@@ -1037,12 +1041,21 @@ int analyse_k2(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, 
         }
         opt.row_block = node_block.data();
     }
-    const int rc = analyse(S, m + n, nnz, bp.data(), bi.data(), bx.data(), 0, opt);
+    const int rc = analyse_common(S, m + n, nnz, bp.data(), bi.data(), bx.data(), 0, opt);
     if (rc != TLPK_OK) return rc;
     S.system = 1; S.k2_n = n; S.k2_m = m;
     S.csign.resize((size_t)(m + n));
     for (i64 kk = 0; kk < m + n; ++kk) S.csign[(size_t)kk] = (S.perm[(size_t)kk] < n) ? -1.0 : 1.0;
+    opt.row_block = nullptr;                    // (points into a local; analyse_rank reads the copy inside S)
+    if (opt_out) *opt_out = opt;
     return TLPK_OK;
+}
+
+int analyse_k2(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
+               int base, const Options &opt_in) {
+    Options opt;
+    const int rc = analyse_k2_common(S, m, n, colptr, rowval, nzval, base, opt_in, &opt);
+    return rc != TLPK_OK ? rc : analyse_rank(S, opt);
 }
 
 // ---------------------------------------------------------------------------------------------

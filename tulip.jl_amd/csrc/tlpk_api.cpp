@@ -357,7 +357,7 @@ static int create_host(tlpk_handle *h, const tlpk_options &def, int64_t m, int64
     if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
     const auto t0 = std::chrono::steady_clock::now();
     if (rc == TLPK_OK) {
-        if (common) { h->S = *common; rc = analyse_rank(h->S, h->opt); }
+        if (common) { h->S = *common; h->opt.k2_n = common->k2_n; rc = analyse_rank(h->S, h->opt); }
         else rc = (h->opt.system == 1) ? analyse_k2(h->S, m, n, colptr, rowval, nzval, index_base, h->opt)
                                        : analyse(h->S, m, n, colptr, rowval, nzval, index_base, h->opt);
     }
@@ -659,7 +659,7 @@ static int enq_solve_local(tlpk_handle *h, const double *d_xip, const double *d_
         ProfScope ps(h, TLPK_KC_SPMV);
         // tickets + hand-over words of both sweeps back to all ones: the data is its own flag, ticket + 1 = 0 is the first item
         if (h->S.sweep && h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes, h->stream));
-        if (h->S.system == 1) launch_k2_rhs(h->stream, h->d, h->S.k2_n, d_xip, d_xid);        // [xi_d ; xi_p] permuted (sqd.jl:62-66)
+        if (h->S.system == 1) launch_k2_rhs(h->stream, h->d, h->S.k2_n, d_xip, d_xid, 0, h->opt.rank);        // [xi_d ; xi_p] permuted (sqd.jl:62-66)
         else launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank);
         launch_single_solve(h->stream, h->d);
     }
@@ -671,8 +671,11 @@ static int enq_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const do
     run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size(), 0);
     if (h->S.system == 1) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d); }     // L S L' x = b: z = S y between the sweeps
     run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1);
-    if (h->S.system == 1) { ProfScope ps(h, TLPK_KC_SPMV); launch_k2_out(h->stream, h->d, h->S.k2_n, d_dx, d_dy); }
-    else {
+    if (h->S.system == 1) {
+        // multi-device mode: every shard stores the nodes it owns straight into the lead device's job-wide dx / dy
+        ProfScope ps(h, TLPK_KC_SPMV);
+        launch_k2_out(h->stream, h->d, h->S.k2_n, d_dx, h->shared_dy ? h->shared_dy : d_dy, 0, h->opt.rank, h->dx_local_only ? 1 : 0);
+    } else {
         { ProfScope ps(h, TLPK_KC_SPMV); launch_unpermute(h->stream, h->d, d_dy, h->shared_dy, h->opt.rank); }
         { ProfScope ps(h, TLPK_KC_SPMV); launch_dx(h->stream, h->d, h->d_D, d_dy, d_xid, d_dx, h->dx_local_only ? 1 : 0); }
     }
@@ -1018,7 +1021,7 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
         tlpk_handle *c = h->sub[r];
         // every rank fills its own entries of the lead device's dx / dy (P2P stores); its local dy feeds its k_dx
         c->shared_dy = lead->d_dy; c->dx_local_only = true;
-        const int rc = tlpk_solve_finish(c, lead->d_dx, r == 0 ? h->multi_tmp + h->multi_dy0_off : c->d_dy, c->d_xid);
+        const int rc = tlpk_solve_finish(c, lead->d_dx, (c->S.system == 1) ? lead->d_dy : (r == 0 ? h->multi_tmp + h->multi_dy0_off : c->d_dy), c->d_xid);
         if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
         HIPCHK(h, hipSetDevice(c->device));
         if (r > 0) HIPCHK(h, hipEventRecord(h->multi_ev[r], c->stream));
@@ -1038,6 +1041,10 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
 // index ranges a shard reads from the job-wide input vectors
 void shard_ranges(tlpk_handle *c) {
     const Symbolic &S = c->S;
+    if (S.system == 1) {             // K2: the Symbolic describes the incidence matrix of the augmented system; every shard takes the
+        c->col_lo = 0; c->col_hi = S.k2_n; c->row_lo = 0; c->row_hi = S.k2_m; c->link_lo = c->link_hi = 0;     // user vectors whole
+        return;
+    }
     auto range = [](const std::vector<char> &v, char what, i64 &lo, i64 &hi) {
         lo = hi = 0; bool any = false;
         for (size_t i = 0; i < v.size(); ++i) if (v[i] == what) { if (!any) { lo = (i64)i; any = true; } hi = (i64)i + 1; }
@@ -1054,8 +1061,8 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
     if (!out) return TLPK_BADARG;
     *out = nullptr;
     if (!uopt || uopt->struct_size != (int32_t)sizeof(tlpk_options) || ngpus < 1 || ngpus > MAX_DEVICES ||
-        (!uopt->row_block && !uopt->detect_blocks) || uopt->system == TLPK_SYSTEM_K2)
-        return TLPK_BADARG;                              // block-angular K1 only (general sparse LPs stay single-GPU)
+        (!uopt->row_block && !uopt->detect_blocks))
+        return TLPK_BADARG;                              // block-angular LPs only (general sparse LPs stay single-GPU)
     tlpk_handle *h = new (std::nothrow) tlpk_handle();
     if (!h) return TLPK_OOM;
     int rc = TLPK_OK;
@@ -1074,7 +1081,8 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
         const auto t0 = std::chrono::steady_clock::now();
         if (rc == TLPK_OK) {
             Options o; o.ordering = base.ordering; o.relax = base.relax; o.nranks = ngpus; o.row_block = base.row_block;
-            rc = analyse_common(common, m, n, colptr, rowval, nzval, index_base, o);
+            rc = (base.system == TLPK_SYSTEM_K2) ? analyse_k2_common(common, m, n, colptr, rowval, nzval, index_base, o, nullptr)
+                                                 : analyse_common(common, m, n, colptr, rowval, nzval, index_base, o);
             if (rc != TLPK_OK) h->last_error = common.error;
         }
         std::vector<int> rcs((size_t)ngpus, TLPK_OK);

@@ -166,6 +166,10 @@ int analyse(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, con
 int analyse_common(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
                    int index_base, const Options &opt);
 int analyse_rank(Symbolic &S, const Options &opt);
+// K2: analyse_k2 = analyse_k2_common (incidence matrix of the augmented system, rank-independent analysis, signs; *opt_out = the
+// options analyse_rank needs: system, k2_n) + analyse_rank
+int analyse_k2_common(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
+                      int index_base, const Options &opt, Options *opt_out);
 int analyse_k2(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, const double *nzval,
                int index_base, const Options &opt);
 

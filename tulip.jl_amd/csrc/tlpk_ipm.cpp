@@ -244,15 +244,14 @@ int tlpk_ipm_newton(tlpk_handle *h, int mode, const double *sc, double *out) {
 
 /* step.jl:56-94 in ONE call: the h-system (step.jl:56-76) and the predictor's Newton system (mode 0 of tlpk_ipm_newton) are
  * independent right-hand sides against the same factor -- they share one pass over L (tlpk_solve2_device: the sweeps are bound by
- * the bytes of L).  sc[8] as for tlpk_ipm_newton, except sc[2] = kappa / tau + regG, the host-side part of h0 (the device supplies
- * the dot products).  out[4] = { dtau, dkappa, largest step to the boundary, h0 }.  Same arithmetic as tlpk_ipm_hsolve followed by
+ * the bytes of L).  sc[8] as for tlpk_ipm_newton, except sc[2] = regG (h0 = dot products + kappa / tau + regG is formed here).  out[4] = { dtau, dkappa, largest step to the boundary, h0 }.  Same arithmetic as tlpk_ipm_hsolve followed by
  * tlpk_ipm_newton(mode 0): bit-identical vectors and scalars. */
 int tlpk_ipm_hsolve_newton(tlpk_handle *h, const double *sc, double *out) {
     if (int rc = ipm_ready(h)) return rc;
     if (!sc || !out) return TLPK_BADARG;
     HIPCHK(h, hipSetDevice(h->device));
     IpmState &s = *h->ipm;
-    const double tau = sc[0], kappa = sc[1], h0_host = sc[2], xi_g = sc[3], xi_tk = sc[4], eta = sc[5], gmu = sc[6], delta = sc[7];
+    const double tau = sc[0], kappa = sc[1], regG = sc[2], xi_g = sc[3], xi_tk = sc[4], eta = sc[5], gmu = sc[6], delta = sc[7];
     const IpmDir &dst = s.D[s.cur];
     ipm_launch_hrhs(h->stream, s.v);
     const int nb = ipm_launch_newton_pre(h->stream, s.v, dst, 0, eta, gmu, delta, s.partials[0]);
@@ -265,7 +264,7 @@ int tlpk_ipm_hsolve_newton(tlpk_handle *h, const double *sc, double *out) {
     if ((rc = fetch(h, IPM_SLOTS + 2)) != TLPK_OK) return rc;
     if ((rc = tlpk_sync(h)) != TLPK_OK) return rc;
     const double *q = s.h_out;
-    const double h0 = (q[IPM_SLOTS] + q[IPM_SLOTS + 1]) + h0_host;
+    const double h0 = ((q[IPM_SLOTS] + q[IPM_SLOTS + 1]) + kappa / tau) + regG;      // the association of hsd_device.py / HSD/step.jl:69-76
     const double xi_g_ = xi_g + xi_tk / tau - q[0] + q[1] - q[2] - q[3];
     const double dtau = (xi_g_ + q[4] - q[5]) / h0;
     const double dkappa = (xi_tk - kappa * dtau) / tau;

@@ -138,7 +138,7 @@ class DeviceHSD:
             raise PosDefException(0)
         if self.pair_solves:
             # h-system (step.jl:56-76) and predictor: independent right-hand sides, one pass over the factor
-            self._sc[:] = (self.tau, self.kappa, self.kappa / self.tau + self.regG, self.rg, -self.tau * self.kappa, 0.0, 0.0, 0.0)
+            self._sc[:] = (self.tau, self.kappa, self.regG, self.rg, -self.tau * self.kappa, 0.0, 0.0, 0.0)
             self._call(self.L.tlpk_ipm_hsolve_newton(self.kkt._h, _lib.as_pd(self._sc), _lib.as_pd(self._out)))
             self.timers["n_solve"] += 2; self.timers["n_paired"] = self.timers.get("n_paired", 0) + 1
             dtau, dkappa, av, self.h0 = (float(v) for v in self._out[:4])
