@@ -661,7 +661,8 @@ def test_graph_replay_equals_direct_enqueue_bitwise(kind, monkeypatch):
     P = lambda t: t.ptr                                                  # noqa: E731
     results = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("TLPK_GRAPH", mode)
+        # "2" forces graphs for the two-stream-group schedule of the block-angular LP too (off by default there, see graph_usable)
+        monkeypatch.setenv("TLPK_GRAPH", "2" if (mode == "1" and kind == "block_angular") else mode)
         kkt = tk.setup(A, system, tk.Backend(device=0, row_block=rb))
         outs = []
         for rnd in range(3):

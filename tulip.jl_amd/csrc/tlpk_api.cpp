@@ -263,9 +263,18 @@ void find_markers(tlpk_handle *h) {
 // of the cache key.
 struct GraphKey { int kind; const void *p[8]; bool operator==(const GraphKey &o) const { return kind == o.kind && std::memcmp(p, o.p, sizeof(p)) == 0; } };
 
+// Graphs are used for schedules with ONE stream group (general sparse LPs -- the small, launch-bound ones are of this kind; their
+// side-stream fork / join is captured).  Block-angular LPs run two concurrent stream groups + side streams: capturing those four
+// streams crashed (SIGSEGV inside the HIP runtime) in processes that had loaded PyTorch's bundled runtime first, while the same
+// capture passes on the system runtime; the launches of these large LPs are hidden behind the kernels anyway
+// (profiles/r03_small_lp_graph.txt).  TLPK_GRAPH=2 forces graphs for every schedule, TLPK_GRAPH=0 turns them off.
+inline bool graph_usable(const tlpk_handle *h) {
+    return h->use_graph && !h->profile && !h->serial && (h->S.ngroups <= 1 || h->force_graph);
+}
+
 template <class F>
 int graph_or_direct(tlpk_handle *h, const GraphKey &key, F &&body) {
-    if (!h->use_graph || h->profile || h->serial) return body();
+    if (!graph_usable(h)) return body();
     for (size_t i = 0; i < h->graph_keys.size(); ++i)
         if (*reinterpret_cast<const GraphKey *>(h->graph_keys[i].data()) == key) {
             HIPCHK(h, hipGraphLaunch(h->graph_execs[i], h->stream));
@@ -353,7 +362,7 @@ static int create_host(tlpk_handle *h, const tlpk_options &def, int64_t m, int64
     }
     h->profile = def.profile != 0;
     if (const char *e = std::getenv("TLPK_SERIAL")) h->serial = std::atoi(e) != 0;
-    if (const char *e = std::getenv("TLPK_GRAPH")) h->use_graph = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TLPK_GRAPH")) { h->use_graph = std::atoi(e) != 0; h->force_graph = std::atoi(e) >= 2; }
     if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
     const auto t0 = std::chrono::steady_clock::now();
     if (rc == TLPK_OK) {
@@ -604,7 +613,7 @@ static int sharded_needs_split(tlpk_handle *h, const char *what) {
 
 int tlpk_update_device(tlpk_handle *h, const double *d_theta, const double *d_regP, const double *d_regD) {
     if (int g = sharded_needs_split(h, "tlpk_update_device")) return g;
-    if (!h || !h->sub.empty() || !h->has_device || !h->use_graph || h->profile || h->serial) {
+    if (!h || !h->sub.empty() || !h->has_device || !graph_usable(h)) {
         int rc = tlpk_update_local(h, d_theta, d_regP, d_regD);
         if (rc != TLPK_OK) return rc;
         return tlpk_update_finish(h);
@@ -741,7 +750,7 @@ static int solve_whole(tlpk_handle *h, double *d_dx, double *d_dy, const double 
 
 int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xip, const double *d_xid) {
     if (int g = sharded_needs_split(h, "tlpk_solve_device")) return g;
-    const bool whole = h && h->sub.empty() && h->has_device && h->use_graph && !h->profile && !h->serial;
+    const bool whole = h && h->sub.empty() && h->has_device && graph_usable(h);
     int rc = whole ? solve_whole(h, d_dx, d_dy, d_xip, d_xid) : tlpk_solve_local(h, d_xip, d_xid);
     if (rc != TLPK_OK) return rc;
     if (!whole) rc = tlpk_solve_finish(h, d_dx, d_dy, d_xid);
@@ -1118,6 +1127,7 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
     if (rc == TLPK_OK) {
         tlpk_handle *lead = h->sub[0];
         h->S.m = m; h->S.n = n; h->has_device = true; h->device = lead->device; h->opt.nranks = 1;
+        if (lead->S.system == 1) { h->S.system = 1; h->S.k2_n = n; h->S.k2_m = m; }     // user dimensions / KKT.linear_system of the job
         double *p = nullptr; int64_t cnt = 0;
         tlpk_root_panel(lead, &p, &cnt);
         const i64 tmp_len = (i64)ngpus * cnt + m;                            // staging of the peers' root buffers, the reduced buffer, the lead's rank-local dy

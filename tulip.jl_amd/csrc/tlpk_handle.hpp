@@ -63,6 +63,7 @@ struct tlpk_handle {
     bool dx_local_only = false;         // child: dx is the job-wide vector, leave the other ranks' columns alone
     // hipGraph replay of the static schedules (tlpk_api.cpp: graph_or_direct): instantiated graphs and their keys
     bool use_graph = true;              // TLPK_GRAPH=0 turns it off; switched off for good if capture fails on this system
+    bool force_graph = false;           // TLPK_GRAPH=2: also for schedules with concurrent stream groups
     bool update_whole = false, solve_whole = false;   // internal: the composed entry point enqueues both halves itself
     std::vector<hipGraphExec_t> graph_execs;
     std::vector<std::vector<char>> graph_keys;
