@@ -1130,6 +1130,10 @@ static void build_schedule(Symbolic &S) {
         i64 *dry = nullptr;
         i32 upd_super = 4;
         if (const char *e = std::getenv("TLPK_UPD_SUPER")) upd_super = std::max(1, std::atoi(e));   // tuning knob
+        // Canonical index of a tile inside its launch: position in the list that ALL of this rank's fronts of the level would
+        // produce (level order), whatever the stream group the front runs in -- what the tail split below is decided on.
+        std::vector<i64> canon_count(S.fronts.size(), 0), canon_next(S.fronts.size(), 0);
+        std::vector<i64> task_canon;                      // canonical index of every task pushed by the current launch
         auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0, int part) {
             if (kw <= 0 || c0 >= c1) return;
             if (!dry && part != 1) for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * kw * (double)(w.f - cc);
@@ -1143,7 +1147,8 @@ static void build_schedule(Symbolic &S) {
                         for (i32 i0 = std::max(I0, j0); i0 < std::min(I0 + SUP, w.f); i0 += TILE) {
                             const bool diag_blk = i0 < c0 + NB_OUT;
                             if ((part == 0 && !diag_blk) || (part == 1 && diag_blk)) continue;
-                            if (dry) ++*dry; else S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0});
+                            if (dry) { ++*dry; ++canon_count[(size_t)s]; }
+                            else { S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0}); task_canon.push_back(canon_next[(size_t)s]++); }
                         }
         };
         auto for_fronts = [&](auto &&fn) {              // dry runs see all of the rank's fronts of the level
@@ -1159,23 +1164,52 @@ static void build_schedule(Symbolic &S) {
         // k_update_reduce launch.  A tile with K = 3300 runs for ~0.9 ms whatever runs beside it: with
         // 8 blocks per rank (8-GPU sharding), for the root front, and for the diagonal-block tiles on
         // the side stream this is the critical path.
+        // Tail split (round 3): the tiles of a launch have the same K, i.e. the same duration T, and the chip holds UPD_SLOTS of
+        // them at a time (2 workgroups x 256 CUs): a launch of 2.4 x UPD_SLOTS tiles takes 3 T, the last T with 60 % of the
+        // chip idle -- and the launches with the longest tiles (the last block columns of the big fronts, K > 3000, T = 0.9 ms)
+        // have the fewest tiles.  The r = (tiles mod UPD_SLOTS) tiles of the last wave are therefore cut along K into
+        // p = UPD_SLOTS / r parts (at most 8, each >= 256 columns): the last wave takes T / p.  Which tiles: those with the
+        // highest canonical index over all of the rank's fronts of the level (not: of the stream group), so that the summation
+        // order of every entry -- and with it every bit of the factor -- is the same for any number of stream groups.
+        i64 UPD_SLOTS = 512;
+        if (const char *e = std::getenv("TLPK_TAIL_SLOTS")) UPD_SLOTS = std::atoll(e);       // tuning knob; 0 = no tail split
         auto emit_update_launch = [&](auto &&gen) {
             i64 t_level = 0;
+            for (i32 t = t0; t < t1; ++t) canon_count[(size_t)S.level_fronts[t]] = 0;
             dry = &t_level; gen(); dry = nullptr;
+            { i64 acc = 0; for (i32 t = t0; t < t1; ++t) { const i32 s = S.level_fronts[t]; canon_next[(size_t)s] = acc; acc += canon_count[(size_t)s]; } }
             const i64 f_upd = (i64)S.update_tasks.size();
+            task_canon.clear();
             gen();
             const i64 cnt = (i64)S.update_tasks.size() - f_upd;
             if (cnt == 0) return;
             i64 want = 256;
             if (const char *e = std::getenv("TLPK_SPLITK_TILES")) want = std::atoll(e);       // tuning knob; 0 = off
-            const i32 nsplit = (t_level > 0) ? (i32)std::min<i64>(8, want / t_level) : 1;
-            if (nsplit < 2) { push_launch(S.factor_launches, LK_UPDATE, f_upd, cnt); return; }
+            i32 nsplit = (t_level > 0) ? (i32)std::min<i64>(8, want / t_level) : 1;
+            i64 tail_from = t_level; i32 tail_parts = 1;      // tiles with canonical index >= tail_from are cut into tail_parts
+            // number of parts p in 1..8 that minimises the time of a wave of r equal tiles on UPD_SLOTS slots: ceil(r p / slots) / p
+            auto best_parts = [&](i64 r) {
+                i32 best = 1; double tbest = (double)((r + UPD_SLOTS - 1) / UPD_SLOTS);
+                for (i32 p = 2; p <= 8; ++p) {
+                    const double tp = (double)((r * p + UPD_SLOTS - 1) / UPD_SLOTS) / p;
+                    if (tp < tbest - 1e-9) { tbest = tp; best = p; }
+                }
+                return best;
+            };
+            if (nsplit < 2 && UPD_SLOTS > 0 && t_level > 0) {
+                const i64 r = t_level % UPD_SLOTS;
+                if (t_level < UPD_SLOTS) nsplit = best_parts(t_level);                    // a single, partly filled wave: cut every tile
+                else if (r > 0) { tail_parts = best_parts(r); tail_from = t_level - r; }  // the last wave
+            }
+            if (nsplit < 2 && tail_parts < 2) { push_launch(S.factor_launches, LK_UPDATE, f_upd, cnt); return; }
             std::vector<UpdateTask> orig(S.update_tasks.begin() + f_upd, S.update_tasks.end());
             S.update_tasks.resize(f_upd);
             const i64 f_red = (i64)S.reduce_tasks.size();
             i32 slot = 0;
-            for (const UpdateTask &t : orig) {
-                const i32 parts = std::min(nsplit, t.kw / 256);
+            for (size_t q = 0; q < orig.size(); ++q) {
+                const UpdateTask &t = orig[q];
+                const i32 limit = (nsplit >= 2) ? nsplit : (task_canon[q] >= tail_from ? tail_parts : 1);
+                const i32 parts = std::min(limit, t.kw / 256);
                 if (parts < 2) { S.update_tasks.push_back(t); continue; }
                 const i32 base = (t.kw / parts) / 16 * 16;              // multiples of the kernel's K slab
                 i32 k = 0;
