@@ -15,7 +15,8 @@ import os as _os
 # default); when the host application owns streams too, two of ours can land on one queue and
 # serialise (measured on config C4: 69.7 vs 76.6-80.2 ms per Newton step).  The variable is read
 # when the HIP runtime initialises, i.e. at the first HIP call of the process, so setting it here
-# works as long as this package is imported before that (libtlpk.so does the same on load).
+# works as long as this package is imported before that.  A tuning knob of the HOST process: libtlpk.so
+# itself never touches the environment (the Julia shim julia/libtlpk.jl sets it the same way).
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _lib  # noqa: F401,E402
