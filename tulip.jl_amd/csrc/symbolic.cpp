@@ -1164,14 +1164,15 @@ static void build_schedule(Symbolic &S) {
         // k_update_reduce launch.  A tile with K = 3300 runs for ~0.9 ms whatever runs beside it: with
         // 8 blocks per rank (8-GPU sharding), for the root front, and for the diagonal-block tiles on
         // the side stream this is the critical path.
-        // Tail split (round 3): the tiles of a launch have the same K, i.e. the same duration T, and the chip holds UPD_SLOTS of
-        // them at a time (2 workgroups x 256 CUs): a launch of 2.4 x UPD_SLOTS tiles takes 3 T, the last T with 60 % of the
-        // chip idle -- and the launches with the longest tiles (the last block columns of the big fronts, K > 3000, T = 0.9 ms)
-        // have the fewest tiles.  The r = (tiles mod UPD_SLOTS) tiles of the last wave are therefore cut along K into
-        // p = UPD_SLOTS / r parts (at most 8, each >= 256 columns): the last wave takes T / p.  Which tiles: those with the
-        // highest canonical index over all of the rank's fronts of the level (not: of the stream group), so that the summation
-        // order of every entry -- and with it every bit of the factor -- is the same for any number of stream groups.
-        i64 UPD_SLOTS = 512;
+        // Tail split (round 3, OFF by default: measured without gain).  The tiles of a launch have the same K, i.e. the same
+        // duration T, and the chip holds 512 of them at a time (2 workgroups x 256 CUs): on paper a launch of 2.4 x 512 tiles takes
+        // 3 T, the last T with 60 % of the slots empty, and cutting the r = (tiles mod slots) tiles of the last wave along K into
+        // p parts (p minimising ceil(r p / slots) / p) lifts the simulated slot efficiency of the C4 schedule from 0.84 to 0.98.
+        // On the device the update time did not move (32.1 -> 32.5 ms + 0.75 ms of reductions; profiles/r03_tail_split.txt): a
+        // workgroup that has its CU to itself runs at nearly twice the rate of two sharing the matrix pipes, so a half-empty last
+        // wave is not half idle.  TLPK_TAIL_SLOTS=512 turns the split on (tiles are chosen by their canonical index over ALL of
+        // the rank's fronts of the level, so that results do not depend on the number of stream groups).
+        i64 UPD_SLOTS = 0;
         if (const char *e = std::getenv("TLPK_TAIL_SLOTS")) UPD_SLOTS = std::atoll(e);       // tuning knob; 0 = no tail split
         auto emit_update_launch = [&](auto &&gen) {
             i64 t_level = 0;
