@@ -362,6 +362,7 @@ def main():
                 traffic, traffic_src = None, None
                 try:        # HBM bytes per launch from the committed PMC pass of this command (cannot be collected in-process)
                     pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_update.json")))
+                    pm = pm.get("workloads", {}).get(workload, pm)            # per-workload entries (round 3), or the single C4 entry
                     if pm.get("workload") == workload and world == 1:
                         traffic = pm["traffic_bytes_per_launch"]
                         traffic_src = pm.get("source", "profiles/pmc_k_update.json (rocprofv3 --pmc passes of this command, not collected in this run)")

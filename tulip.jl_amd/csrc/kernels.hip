@@ -30,6 +30,8 @@
 // ordered by the static schedule built on the host (symbolic.cpp: build_schedule).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "tlpk_device.hpp"
 
 namespace tlpk {
@@ -2074,7 +2076,12 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
 #define TLPK_LAUNCH_S(KERNEL, TASKS) do { if (sgn) hipLaunchKernelGGL(KERNEL<true>, g, dim3(256), 0, st, TASKS + L.first, a.ctx); \
                                           else hipLaunchKernelGGL(KERNEL<false>, g, dim3(256), 0, st, TASKS + L.first, a.ctx); } while (0)
     switch (L.kind) {
-    case LK_EXTEND_ADD: hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, a.ea_tasks + L.first, a.ctx); break;
+    case LK_EXTEND_ADD: {
+        // TLPK_EA_LDS (tuning knob): extra dynamic LDS per workgroup = fewer resident workgroups = a smaller working set of parent
+        // columns (the kernel's fabric traffic is parent lines evicted between two children's contributions)
+        static const unsigned ea_lds = [] { const char *e = std::getenv("TLPK_EA_LDS"); return e ? (unsigned)std::atoi(e) : 0u; }();
+        hipLaunchKernelGGL(k_extend_add, g, dim3(256), ea_lds, st, a.ea_tasks + L.first, a.ctx); break;
+    }
     case LK_POTRF: TLPK_LAUNCH_S(k_potrf, a.potrf_tasks); break;
     case LK_POTRF_WIDE: TLPK_LAUNCH_S(k_potrf_wide, a.potrf_tasks); break;
     case LK_POTRF_SMALL: TLPK_LAUNCH_S(k_potrf_small, a.potrf_tasks); break;

@@ -24,7 +24,11 @@ namespace tlpk {
 // Extend-add ranges of a parent front (one workgroup each): ea_cols(p) columns wide, counted from 0 inside the pivot
 // columns [0, ns) and from ns inside the update-matrix columns [ns, f).  Boundary k of ea_nbounds(p):
 //   k < npan: k * cols ; k == npan: ns ; k > npan: ns + (k - npan) * cols, the last one being f.
-static inline i32 ea_cols(const FrontDesc &p) { return (p.f >= 2048) ? EA_COLS : 4; }     // small fronts: more, narrower workgroups
+static inline i32 ea_cols_big() {              // TLPK_EA_COLS (tuning knob, 4 .. EA_COLS): parent columns per extend-add workgroup of the big fronts
+    static const i32 v = [] { const char *e = std::getenv("TLPK_EA_COLS"); const int c = e ? std::atoi(e) : EA_COLS; return (i32)std::max(4, std::min(c, EA_COLS)); }();
+    return v;
+}
+static inline i32 ea_cols(const FrontDesc &p) { return (p.f >= 2048) ? ea_cols_big() : 4; }     // small fronts: more, narrower workgroups
 static inline i32 ea_npan(const FrontDesc &p) { const i32 c = ea_cols(p); return (p.ns + c - 1) / c; }
 static inline i32 ea_nbounds(const FrontDesc &p) { const i32 c = ea_cols(p); return ea_npan(p) + (p.f - p.ns + c - 1) / c + 1; }
 static inline i32 ea_bound(const FrontDesc &p, i32 k) {
