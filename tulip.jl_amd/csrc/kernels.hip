@@ -760,14 +760,15 @@ __global__ __launch_bounds__(256) void k_trsm_thin(const TrsmTask *__restrict__ 
 // ------------------------------------------------------------------------------------------
 constexpr int UPD_KT = 16;                 // K depth staged per LDS round
 constexpr int UPD_LD = TILE + 16;          // LDS row stride (doubles), == 16 mod 32: conflict-free b64 reads
-constexpr int UPD_NLD = UPD_KT / 2;        // staging loads per thread per operand per round
 
 // FULL = interior tile: all 128 rows of both operand tiles exist, the tile lies strictly below
 // the diagonal and inside the column limit, so every 16x16 block is a target and no load needs a
 // guard except the K tail.  The hot loop is then straight-line code: 16 unguarded staging loads,
 // 4 x (8 LDS reads + 16 MFMAs).  Edge and diagonal tiles take the guarded generic path.
 // SIGNED (K2): T -= P[I,K] S_K P[J,K]': the column-tile operand is multiplied by the signs of its K columns while it is staged.
-template <bool FULL, bool SIGNED = false>
+// NW = waves per workgroup.  4: 2 x 2 waves, a 64 x 64 sub-tile each (16 accumulator blocks per wave).  8: 2 x 4 waves, 64 rows x 32
+// columns each (8 accumulator blocks, ~half the registers): twice the waves per SIMD to cover LDS / barrier / load waits.
+template <bool FULL, bool SIGNED, int NW>
 __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc &fd, const DevCtx &c,
                                             double (*As)[UPD_KT * UPD_LD], double (*Bs)[UPD_KT * UPD_LD]) {
     const double *sgk = SIGNED ? c.csign + fd.col0 + t.k0 : nullptr;          // sign of K column k: sgk[k]
@@ -776,16 +777,20 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
     const double *P = c.Lval + fd.loff;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
-    const int wr = wave >> 1, wc = wave & 1;        // 2 x 2 waves, each a 64 x 64 sub-tile
+    constexpr int CA = (NW == 4) ? 4 : 2;           // 16-column blocks per wave
+    constexpr int WCW = 16 * CA;                    // columns of a wave's sub-tile
+    constexpr int KS = NW / 2;                      // staging: threads with the same row sr take every KS-th k
+    constexpr int UPD_NLD = UPD_KT / KS;            // staging loads per thread per operand per round
+    const int wr = (NW == 4) ? (wave >> 1) : (wave >> 2), wc = (NW == 4) ? (wave & 1) : (wave & 3);
     const i32 ibase = t.i0 + wr * 64;               // target rows of this wave
-    const i32 jbase = t.j0 + wc * 64;               // target cols of this wave
+    const i32 jbase = t.j0 + wc * WCW;              // target cols of this wave
     const bool diag_tile = !FULL && !SIGNED && (t.i0 == t.j0);       // unsigned: the column tile IS the row tile (one staging buffer)
 
-    bool valid[4][4];
+    bool valid[CA][4];
     bool any = FULL;
     if constexpr (!FULL) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < CA; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const i32 cb = jbase + a * 16, rb = ibase + b * 16;   // block columns [cb,cb+16), rows [rb,rb+16)
@@ -793,14 +798,14 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
                 any |= valid[a][b];
             }
     }
-    v4f64 acc[4][4];
+    v4f64 acc[CA][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < CA; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
     const int lr = lane & 15, lk = lane >> 4;
-    const int sr = tid & 127, sk0 = tid >> 7;       // staging: row sr, k = sk0 + 2*it
+    const int sr = tid & 127, sk0 = tid >> 7;       // staging: row sr, k = sk0 + KS*it
     const i32 ra = t.i0 + sr, rb_ = t.j0 + sr;
     const bool raok = FULL || (ra < f), rbok = FULL || ((rb_ < f) && !diag_tile);
     const double *Pa = P + (i64)(t.k0 + sk0) * lda + ra;
@@ -811,24 +816,24 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         if (FULL && full_k) {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                pa[it] = Pa[(i64)(kk + 2 * it) * lda];
-                pb[it] = Pb[(i64)(kk + 2 * it) * lda];
-                if (SIGNED) pb[it] *= sgk[kk + sk0 + 2 * it];
+                pa[it] = Pa[(i64)(kk + KS * it) * lda];
+                pb[it] = Pb[(i64)(kk + KS * it) * lda];
+                if (SIGNED) pb[it] *= sgk[kk + sk0 + KS * it];
             }
         } else {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                const bool kok = (kk + sk0 + 2 * it) < t.kw;
-                pa[it] = (kok && raok) ? Pa[(i64)(kk + 2 * it) * lda] : 0.0;
-                pb[it] = (kok && rbok) ? Pb[(i64)(kk + 2 * it) * lda] : 0.0;
-                if (SIGNED) pb[it] *= sgk[min(kk + sk0 + 2 * it, t.kw - 1)];
+                const bool kok = (kk + sk0 + KS * it) < t.kw;
+                pa[it] = (kok && raok) ? Pa[(i64)(kk + KS * it) * lda] : 0.0;
+                pb[it] = (kok && rbok) ? Pb[(i64)(kk + KS * it) * lda] : 0.0;
+                if (SIGNED) pb[it] *= sgk[min(kk + sk0 + KS * it, t.kw - 1)];
             }
         }
     };
     auto store_slab = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < UPD_NLD; ++it) {
-            const int k = sk0 + 2 * it;
+            const int k = sk0 + KS * it;
             As[buf][k * UPD_LD + sr] = pa[it];
             if (FULL || !diag_tile) Bs[buf][k * UPD_LD + sr] = pb[it];
         }
@@ -848,7 +853,7 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         // temporaries and had to wait for them (s_waitcnt vmcnt(3) in the middle of a round: the two-round prefetch
         // distance shrank to half a round).
         const i32 rac = min(t.i0 + sr, f - 1), rbc = min(t.j0 + sr, f - 1);
-        const i64 step = (i64)UPD_KT * lda, two_f = 2 * (i64)lda;
+        const i64 step = (i64)UPD_KT * lda, two_f = KS * (i64)lda;
         const double *qa[UPD_NLD], *qb[UPD_NLD];
 #pragma unroll
         for (int it = 0; it < UPD_NLD; ++it) {
@@ -864,33 +869,33 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
                 pb[it] = *qb[it]; qb[it] += step;
-                if (SIGNED) pb[it] *= sgk[kb_idx + sk0 + 2 * it];
+                if (SIGNED) pb[it] *= sgk[kb_idx + sk0 + KS * it];
             }
             kb_idx += UPD_KT;
         };
         auto st_ab = [&](int buf) {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                As[buf][(sk0 + 2 * it) * UPD_LD + sr] = pa[it];
-                Bs[buf][(sk0 + 2 * it) * UPD_LD + sr] = pb[it];
+                As[buf][(sk0 + KS * it) * UPD_LD + sr] = pa[it];
+                Bs[buf][(sk0 + KS * it) * UPD_LD + sr] = pb[it];
             }
         };
         auto mfma_round = [&](int buf, auto &&hook) {
             const double *At = As[buf] + wr * 64 + lr + lk * UPD_LD;
-            const double *Bt = Bs[buf] + wc * 64 + lr + lk * UPD_LD;
+            const double *Bt = Bs[buf] + wc * WCW + lr + lk * UPD_LD;
 #pragma unroll
             for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
-                double av[4], bv[4];
+                double av[CA], bv[4];
                 if (any) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) av[a] = Bt[k4 * UPD_LD + a * 16];
+                    for (int a = 0; a < CA; ++a) av[a] = Bt[k4 * UPD_LD + a * 16];
 #pragma unroll
                     for (int b = 0; b < 4; ++b) bv[b] = At[k4 * UPD_LD + b * 16];
                 }
                 hook(k4);
                 if (any) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < CA; ++a)
 #pragma unroll
                         for (int b = 0; b < 4; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
@@ -920,13 +925,13 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
             const i32 kk = nrounds * UPD_KT;
             const double *pa_ptr = P + (i64)(t.k0 + kk + sk0) * lda + rac;
             const double *pb_ptr = P + (i64)(t.k0 + kk + sk0) * lda + rbc;
-            const i64 two_l = 2 * (i64)lda;
+            const i64 two_l = KS * (i64)lda;
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                const bool kok = (kk + sk0 + 2 * it) < t.kw;
+                const bool kok = (kk + sk0 + KS * it) < t.kw;
                 pa[it] = kok ? pa_ptr[it * two_l] : 0.0;
                 pb[it] = kok ? pb_ptr[it * two_l] : 0.0;
-                if (SIGNED) pb[it] *= sgk[min(kk + sk0 + 2 * it, t.kw - 1)];
+                if (SIGNED) pb[it] *= sgk[min(kk + sk0 + KS * it, t.kw - 1)];
             }
             st_ab(cur);
             __syncthreads();
@@ -948,16 +953,16 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
 #endif
         if (any) {
             const double *At = As[cur] + wr * 64 + lr + lk * UPD_LD;
-            const double *Bt = (diag_tile ? As[cur] : Bs[cur]) + wc * 64 + lr + lk * UPD_LD;
+            const double *Bt = (diag_tile ? As[cur] : Bs[cur]) + wc * WCW + lr + lk * UPD_LD;
 #pragma unroll
             for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
-                double av[4], bv[4];
+                double av[CA], bv[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) av[a] = Bt[k4 * UPD_LD + a * 16];   // column-tile rows
+                for (int a = 0; a < CA; ++a) av[a] = Bt[k4 * UPD_LD + a * 16];   // column-tile rows
 #pragma unroll
                 for (int b = 0; b < 4; ++b) bv[b] = At[k4 * UPD_LD + b * 16];   // row-tile rows
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < CA; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         if constexpr (FULL) {
@@ -984,19 +989,19 @@ epilogue:
         // split-K part: the raw tile goes to its scratch slot, k_update_reduce applies the parts in order
         double *Sp = c.spart + (i64)(t.pad1 - 1) * (TILE * TILE);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < CA; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 if constexpr (!FULL) { if (!valid[a][b]) continue; }
                 const i32 lrow = wr * 64 + b * 16 + lr;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) Sp[lrow + (wc * 64 + a * 16 + lk + 4 * q) * TILE] = acc[a][b][q];
+                for (int q = 0; q < 4; ++q) Sp[lrow + (wc * WCW + a * 16 + lk + 4 * q) * TILE] = acc[a][b][q];
             }
         return;
     }
 #if defined(UPD_VARIANT) && (UPD_VARIANT == 2 || UPD_VARIANT == 6)   /* ablation: no epilogue read-modify-write */
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < CA; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(acc[a][b]));
     return;
@@ -1005,7 +1010,7 @@ epilogue:
     double *Pw = c.Lval + fd.loff;
     double *Uw = front_u(c, fd);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < CA; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             if constexpr (!FULL) { if (!valid[a][b]) continue; }
@@ -1029,8 +1034,8 @@ epilogue:
         }
 }
 
-template <bool SIGNED>
-__global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict__ tasks, DevCtx c) {
+template <bool SIGNED, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_update(const UpdateTask *__restrict__ tasks, DevCtx c) {
     // double-buffered K-slabs: slab t+1 travels global -> registers while slab t is multiplied
     __shared__ double As[2][UPD_KT * UPD_LD];  // As[.][k][r] = P[i0 + r, k0 + kk + k]  (row tile)
     __shared__ double Bs[2][UPD_KT * UPD_LD];  // Bs[.][k][r] = P[j0 + r, k0 + kk + k]  (column tile)
@@ -1056,8 +1061,8 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdateTask *__restrict_
         tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20);       // XCC_ID
     }
 #endif
-    if (full) update_tile<true, SIGNED>(t, fd, c, As, Bs);
-    else update_tile<false, SIGNED>(t, fd, c, As, Bs);
+    if (full) update_tile<true, SIGNED, NW>(t, fd, c, As, Bs);
+    else update_tile<false, SIGNED, NW>(t, fd, c, As, Bs);
 #ifdef UPD_TRACE
     if (threadIdx.x == 0) tr[3] = wall_clock64();
 #endif
@@ -2087,7 +2092,17 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
     case LK_POTRF_SMALL: TLPK_LAUNCH_S(k_potrf_small, a.potrf_tasks); break;
     case LK_TRSM: TLPK_LAUNCH_S(k_trsm, a.trsm_tasks); break;
     case LK_TRSM_THIN: TLPK_LAUNCH_S(k_trsm_thin, a.trsm_tasks); break;
-    case LK_UPDATE: TLPK_LAUNCH_S(k_update, a.update_tasks); break;
+    case LK_UPDATE: {
+        // 512-thread workgroups, 2 x 4 waves of 64 x 32 sub-tiles, 4 waves per SIMD (round 3: k_update 32.3 -> 31.7 ms on C4, 101.2 -> 100.2 ms
+        // on the headline instance against 2 x 2 waves of 64 x 64 at 2 waves per SIMD; profiles/r03_update_8waves.txt).  TLPK_UPD_WAVES=4: the
+        // round-2 kernel.  That doubling the resident waves buys 2 % says the idle 22 % of the matrix pipes is not a latency-hiding problem.
+        static const int nw = [] { const char *e = std::getenv("TLPK_UPD_WAVES"); return (e && std::atoi(e) == 4) ? 4 : 8; }();
+        if (nw == 8) {
+            if (sgn) hipLaunchKernelGGL((k_update<true, 8>), g, dim3(512), 0, st, a.update_tasks + L.first, a.ctx);
+            else hipLaunchKernelGGL((k_update<false, 8>), g, dim3(512), 0, st, a.update_tasks + L.first, a.ctx);
+        } else TLPK_LAUNCH_S(k_update, a.update_tasks);
+        break;
+    }
     case LK_UPDATE_REDUCE: hipLaunchKernelGGL(k_update_reduce, dim3((unsigned)L.count * RED_SPLIT), dim3(256), 0, st, a.reduce_tasks + L.first, a.ctx); break;
     case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;
     case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(256), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;
