@@ -295,6 +295,7 @@ int graph_or_direct(tlpk_handle *h, const GraphKey &key, F &&body) {
         return rc != TLPK_OK ? rc : body();
     }
     if (h->graph_execs.size() >= 24) {                  // bounded cache (the interior-point loops use a handful of pointer sets)
+        (void)hipStreamSynchronize(h->stream);          // the evicted graph may still be in flight
         hipGraphExecDestroy(h->graph_execs.front());
         h->graph_execs.erase(h->graph_execs.begin()); h->graph_keys.erase(h->graph_keys.begin());
     }
