@@ -140,6 +140,12 @@ int tlpk_update_device(tlpk_handle *h, const double *d_theta_inv, const double *
                        const double *d_regD);
 int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xi_p,
                       const double *d_xi_d);
+/* tlpk_update_device without the wait for its status word.  Everything is enqueued; on block-angular handles the root (linking) front --
+ * a dense front of a few hundred columns whose factorisation is a serial chain of diagonal blocks, ~1.5 ms with the chip nearly idle --
+ * goes to a stream of its own, so that the block-level forward sweeps of the next solve overlap it.  The verdict arrives with the next
+ * tlpk_sync (TLPK_NOT_POSDEF; the handle stays usable); solves enqueued in between are speculative.  Unsharded handles; falls back to the
+ * blocking call where there is nothing to overlap (no root front, profile mode, graph replay). */
+int tlpk_update_device_async(tlpk_handle *h, const double *d_theta_inv, const double *d_regP, const double *d_regD);
 /* Two right-hand sides in one pass over the factor (the solve sweeps are HBM-bound on the bytes of L: the pair costs little more than
  * one solve).  Same semantics and bit-identical results as two tlpk_solve_device calls.  Single-rank handles.  Tulip's HSD iteration
  * has such a pair: the h-system and the predictor (HSD/step.jl:63,79); tlpk_ipm_hsolve_newton uses it. */
@@ -224,6 +230,9 @@ int tlpk_ipm_newton(tlpk_handle *h, int mode, const double *sc, double *out);
 /* step.jl:56-94: tlpk_ipm_hsolve + tlpk_ipm_newton(mode 0) with the two independent solves sharing one pass over the factor
  * (tlpk_solve2_device).  sc[8] as above except sc[2] = regG (h0 is formed inside); out[4] = { dtau, dkappa, max step, h0 } */
 int tlpk_ipm_hsolve_newton(tlpk_handle *h, const double *sc, double *out);
+/* step.jl:24-94: tlpk_ipm_factor without the wait for its status + tlpk_ipm_hsolve_newton: the paired solve's block-level forward sweeps
+ * overlap the factorisation of the root front (tlpk_update_device_async); returns TLPK_NOT_POSDEF where tlpk_ipm_factor would have */
+int tlpk_ipm_factor_hsolve_newton(tlpk_handle *h, double regP, double regD, const double *sc, double *out);
 int tlpk_ipm_accept(tlpk_handle *h);                         /* step.jl:112-118: candidate -> accepted direction */
 int tlpk_ipm_advance(tlpk_handle *h, double alpha, double *out);   /* step.jl:139-148; out[0] = xl'zl + xu'zu */
 /* what = 0 x, 1 xl, 2 xu, 3 zl, 4 zu (n), 5 y (m) */

@@ -686,3 +686,46 @@ def test_graph_replay_equals_direct_enqueue_bitwise(kind, monkeypatch):
         kkt.close()
     for a, b in zip(results["1"], results["0"]):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+def test_asynchronous_update_overlaps_the_root_front_and_reports_at_sync():
+    """tlpk_update_device_async: no wait for the status word; on a block-angular handle the root front is factorised on a stream of
+    its own while the next solve's block-level forward sweeps run; tlpk_sync delivers the verdict.  Results bit-identical to the
+    blocking call; a failing factorisation surfaces at sync() (also with a speculative solve enqueued behind it) and leaves the handle
+    usable; a following update completes a pending one."""
+    from helpers import DevBuf
+    A, rb = block_angular(nblocks=6, mk=300, nk=700, m0=80, nnz_in=3, link_prob=0.5, seed=61)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 9)
+    kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb))
+    P = lambda t: t.ptr                                                  # noqa: E731
+    d = [DevBuf(v) for v in (th, rp, rd, xp, xd)]
+    o = [DevBuf(sz) for sz in (n, m, n, m)]
+    kkt.update_device(P(d[0]), P(d[1]), P(d[2]))
+    kkt.solve_device(P(o[0]), P(o[1]), P(d[3]), P(d[4]))
+    for rep in range(3):
+        kkt.update_device_async(P(d[0]), P(d[1]), P(d[2]))
+        kkt.solve_device(P(o[2]), P(o[3]), P(d[3]), P(d[4]), sync=False)
+        kkt.sync()
+        assert np.array_equal(o[0].get(), o[2].get()) and np.array_equal(o[1].get(), o[3].get())
+    bad = rd.copy(); bad[m - 2] = -1e9                                   # a linking row: the ROOT front fails
+    dbad = DevBuf(bad)
+    kkt.update_device_async(P(d[0]), P(d[1]), P(dbad))
+    kkt.solve_device(P(o[2]), P(o[3]), P(d[3]), P(d[4]), sync=False)     # speculative
+    with pytest.raises(tk.PosDefException):
+        kkt.sync()
+    bad = rd.copy(); bad[5] = -1e9                                       # a block row
+    dbad2 = DevBuf(bad)
+    kkt.update_device_async(P(d[0]), P(d[1]), P(dbad2))
+    with pytest.raises(tk.PosDefException):
+        kkt.sync()
+    kkt.update_device_async(P(d[0]), P(d[1]), P(d[2]))                   # not waited for: the next update completes it
+    kkt.update_device(P(d[0]), P(d[1]), P(d[2]))
+    kkt.solve_device(P(o[2]), P(o[3]), P(d[3]), P(d[4]))
+    assert np.array_equal(o[0].get(), o[2].get()) and np.array_equal(o[1].get(), o[3].get())
+    # the paired solve behind an asynchronous update
+    kkt.update_device_async(P(d[0]), P(d[1]), P(d[2]))
+    kkt.solve2_device(P(o[2]), P(o[3]), P(d[3]), P(d[4]), P(o[0]), P(o[1]), P(d[3]), P(d[4]))
+    assert np.array_equal(o[0].get(), o[2].get()) and np.array_equal(o[1].get(), o[3].get())
+    kkt.close()

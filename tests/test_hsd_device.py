@@ -184,3 +184,29 @@ def test_paired_h_system_and_predictor_solves_change_nothing(system):
     assert a[0] == b[0] == "Trm_Optimal" and a[1] == b[1] and a[4] == b[4]
     assert a[2] == b[2] and a[3] == b[3]
     assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
+
+
+@pytest.mark.gpu
+def test_fused_factor_and_paired_solve_change_nothing_and_keep_the_retry_loop():
+    """tlpk_ipm_factor_hsolve_newton (factorisation without the wait for its status + the h-system / predictor pair): the whole HSD
+    run is bit-identical to the run with the blocking factorisation, on a block-angular LP (root front on its own stream) and on the
+    LP engineered to fail numerically (PosDefException -> regularisations x 100 -> retry: same bumps, same iterations)."""
+    from tulip_jl_amd.hsd_device import DeviceHSD
+    from helpers import block_angular
+    A, rb = block_angular(nblocks=5, mk=150, nk=400, m0=30, nnz_in=3, link_prob=0.5, seed=71)
+    m, n = A.shape
+    rng = np.random.default_rng(5)
+    xs = rng.uniform(0.0, 1.0, n) * (rng.random(n) < 0.6)
+    b = A @ xs; c = A.T @ rng.standard_normal(m) + rng.uniform(0.0, 1.0, n) * (xs == 0.0)
+    cases = [(A, b, c, np.zeros(n), np.full(n, np.inf), dict(row_block=rb))]
+    d = standard_form(read_free_mps(os.path.join(GOLDEN, "bump.mps")))
+    cases.append((d.A, d.b, d.c, d.l, d.u, {}))
+    for (A_, b_, c_, l_, u_, kw) in cases:
+        runs = []
+        for overlap in (True, False):
+            opt = DeviceHSD(A_, b_, c_, l_, u_, device=0, overlap_root=overlap, **kw).optimize()
+            runs.append((opt.status, opt.niter, opt.timers["n_bump"], opt.timers["n_update"], opt.primal_objective, opt._get(0, opt.n)))
+            opt.kkt.close()
+        a, b2 = runs
+        assert a[0] == b2[0] == "Trm_Optimal" and a[1:5] == b2[1:5] and np.array_equal(a[5], b2[5])
+    assert runs[0][2] > 0                                                # the engineered LP did bump

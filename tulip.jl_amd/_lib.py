@@ -64,7 +64,7 @@ EXPORTS = [
     "tlpk_create_multi", "tlpk_ipm_load", "tlpk_ipm_reset", "tlpk_ipm_residuals", "tlpk_ipm_factor", "tlpk_ipm_hsolve", "tlpk_ipm_targets",
     "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get",
     "tlpk_mpc_start", "tlpk_mpc_newton", "tlpk_mpc_gap", "tlpk_mpc_targets", "tlpk_mpc_advance",
-    "tlpk_detect_blocks", "tlpk_solve2_device", "tlpk_ipm_hsolve_newton",
+    "tlpk_detect_blocks", "tlpk_solve2_device", "tlpk_ipm_hsolve_newton", "tlpk_update_device_async", "tlpk_ipm_factor_hsolve_newton",
 ]
 
 
@@ -90,6 +90,8 @@ def lib():
     L.tlpk_solve.argtypes = [vp, pd, pd, pd, pd]
     L.tlpk_update_device.argtypes = [vp, vp, vp, vp]
     L.tlpk_solve_device.argtypes = [vp, vp, vp, vp, vp]
+    L.tlpk_update_device_async.argtypes = [vp, vp, vp, vp]
+    L.tlpk_update_device_async.restype = C.c_int
     L.tlpk_solve2_device.argtypes = [vp] + [vp] * 8
     L.tlpk_solve2_device.restype = C.c_int
     L.tlpk_sync.argtypes = [vp]
@@ -131,6 +133,8 @@ def lib():
     L.tlpk_ipm_hsolve.argtypes = [vp, pd]
     L.tlpk_ipm_targets.argtypes = [vp, C.c_double, C.c_double, C.c_double, pd]
     L.tlpk_ipm_newton.argtypes = [vp, C.c_int, pd, pd]
+    L.tlpk_ipm_factor_hsolve_newton.argtypes = [vp, C.c_double, C.c_double, pd, pd]
+    L.tlpk_ipm_factor_hsolve_newton.restype = C.c_int
     L.tlpk_ipm_hsolve_newton.argtypes = [vp, pd, pd]
     L.tlpk_ipm_hsolve_newton.restype = C.c_int
     L.tlpk_ipm_accept.argtypes = [vp]

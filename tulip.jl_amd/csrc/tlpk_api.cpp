@@ -95,12 +95,13 @@ void join_groups(tlpk_handle *h) {
 }
 
 // dir: 0 = forward-solve schedule, 1 = backward-solve schedule, -1 = factorisation (no sweeps)
-void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, size_t to, int dir = -1, int nrhs = 1) {
+// base != nullptr: the launches of group -1 (the root front) go to that stream instead of the handle's main stream
+void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, size_t to, int dir = -1, int nrhs = 1, hipStream_t base = nullptr) {
     size_t skip_update = (size_t)-1;
     for (size_t i = from; i < to; ++i) {
         if (L[i].group < 0) join_groups(h);
         if (L[i].kind == LK_ALLREDUCE_ROOT) continue;
-        hipStream_t st = h->stream;
+        hipStream_t st = (base && L[i].group < 0) ? base : h->stream;
         // profiling serialises everything on the main stream: per-launch HIP-event durations are
         // then the kernels' own durations, not time shared with other groups' kernels
         const bool marker = (L[i].kind == LK_SIDE_FORK || L[i].kind == LK_SIDE_JOIN);
@@ -405,6 +406,11 @@ static int create_device(tlpk_handle *h, const tlpk_options &def) {
         for (int g = 0; g < ng && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_side[g], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreate(&h->ev0);
         if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+        if (e == hipSuccess && h->S.root_front >= 0 && h->opt.nranks == 1) {       // a stream of its own for the root front (tlpk_update_device_async)
+            e = hipStreamCreateWithFlags(&h->rstream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_blocks, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_root, hipEventDisableTiming);
+        }
         if (e != hipSuccess) rc = hip_fail(h, e, "device init");
         if (rc == TLPK_OK) {
             // memory gate: refuse before allocating
@@ -483,6 +489,9 @@ void tlpk_destroy(tlpk_handle *h) {
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
         if (h->ev_fork) hipEventDestroy(h->ev_fork);
+        if (h->rstream) { hipStreamSynchronize(h->rstream); hipStreamDestroy(h->rstream); }
+        if (h->ev_blocks) hipEventDestroy(h->ev_blocks);
+        if (h->ev_root) hipEventDestroy(h->ev_root);
         for (int g = 0; g < MAX_GROUPS; ++g) {
             if (h->ev_side[g]) hipEventDestroy(h->ev_side[g]);
             if (h->sstream[g]) { hipStreamSynchronize(h->sstream[g]); hipStreamDestroy(h->sstream[g]); }
@@ -497,6 +506,7 @@ void tlpk_destroy(tlpk_handle *h) {
 }
 
 // ---- update ----
+static int update_async_wait(tlpk_handle *h);
 // everything of an update up to the reduction of the root panel, on the handle-owned copies of theta / regP / regD
 static int enq_update_local(tlpk_handle *h) {
     const Symbolic &S = h->S;
@@ -517,10 +527,10 @@ static int enq_update_local(tlpk_handle *h) {
     return TLPK_OK;
 }
 // the root front and the read-back of the status word
-static int enq_update_finish(tlpk_handle *h) {
+static int enq_update_finish(tlpk_handle *h, hipStream_t root_stream = nullptr) {
     const Symbolic &S = h->S;
-    run_launches(h, S.factor_launches, h->factor_marker, S.factor_launches.size());
-    HIPCHK(h, hipMemcpyAsync(h->h_info, h->d.ctx.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    run_launches(h, S.factor_launches, h->factor_marker, S.factor_launches.size(), -1, 1, root_stream);
+    HIPCHK(h, hipMemcpyAsync(h->h_info, h->d.ctx.info, sizeof(int), hipMemcpyDeviceToHost, root_stream ? root_stream : h->stream));
     return TLPK_OK;
 }
 
@@ -530,6 +540,8 @@ int tlpk_update_local(tlpk_handle *h, const double *d_theta, const double *d_reg
     if (!h->has_device) return TLPK_NO_DEVICE;
     HIPCHK(h, hipSetDevice(h->device));
     const Symbolic &S = h->S;
+    (void)S;
+    if (h->root_pending) { (void)update_async_wait(h); }      // an unchecked tlpk_update_device_async: complete it (its status is the caller's loss)
     h->factored = false; h->local_done = false; h->solve_local_done = false; h->fail_col = -1; h->solve_timed = false;
     prof_begin(h, true);
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
@@ -612,6 +624,42 @@ static int sharded_needs_split(tlpk_handle *h, const char *what) {
     return TLPK_OK;
 }
 
+// tlpk_update_device without the wait for its status word: everything is enqueued -- the root (linking) front on a stream of its own,
+// so that the block-level forward sweeps of a following solve overlap its (nearly idle: one workgroup per 64 columns) factorisation --
+// and the status is reported by the next tlpk_sync.  Solves enqueued in between are speculative: after a failed factorisation their
+// results are meaningless and tlpk_sync returns TLPK_NOT_POSDEF.
+static int update_async_wait(tlpk_handle *h) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->rstream) HIPCHK(h, hipStreamSynchronize(h->rstream));
+    HIPCHK(h, hipGetLastError());
+    float ms = 0.f; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->ms_update = ms;
+    h->root_pending = false; h->local_done = false;
+    if (h->h_info[0] != INT_MAX) { h->fail_col = h->h_info[0]; h->factored = false; return TLPK_NOT_POSDEF; }
+    h->factored = true;
+    return TLPK_OK;
+}
+
+int tlpk_update_device_async(tlpk_handle *h, const double *d_theta, const double *d_regP, const double *d_regD) {
+    if (int g = sharded_needs_split(h, "tlpk_update_device_async")) return g;
+    if (!h || !h->sub.empty() || !h->has_device || h->profile || h->serial || graph_usable(h) || !h->rstream)
+        return tlpk_update_device(h, d_theta, d_regP, d_regD);          // nothing to overlap / a mode that serialises anyway: the blocking call
+    h->update_whole = true;
+    int rc = tlpk_update_local(h, d_theta, d_regP, d_regD);             // argument checks, stored copies, ev0
+    h->update_whole = false;
+    if (rc != TLPK_OK) return rc;
+    if ((rc = enq_update_local(h)) != TLPK_OK) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_blocks, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->rstream, h->ev_blocks, 0));
+    if ((rc = enq_update_finish(h, h->rstream)) != TLPK_OK) return rc;
+    HIPCHK(h, hipEventRecord(h->ev1, h->rstream));
+    HIPCHK(h, hipEventRecord(h->ev_root, h->rstream));
+    HIPCHK(h, hipGetLastError());
+    h->root_pending = true;
+    h->factored = true;                                                  // tentatively: tlpk_sync delivers the verdict
+    return TLPK_OK;
+}
+
 int tlpk_update_device(tlpk_handle *h, const double *d_theta, const double *d_regP, const double *d_regD) {
     if (int g = sharded_needs_split(h, "tlpk_update_device")) return g;
     if (!h || !h->sub.empty() || !h->has_device || !graph_usable(h)) {
@@ -678,6 +726,7 @@ static int enq_solve_local(tlpk_handle *h, const double *d_xip, const double *d_
     return TLPK_OK;
 }
 static int enq_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xid) {
+    if (h->root_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_root, 0));      // the root front is being factorised on its own stream
     run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size(), 0);
     if (h->S.system == 1) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d); }     // L S L' x = b: z = S y between the sweeps
     run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1);
@@ -801,7 +850,9 @@ int tlpk_solve2_device(tlpk_handle *h, double *d_dx0, double *d_dy0, const doubl
             launch_single_solve(h->stream, h->d, r);
         }
     }
-    run_launches(h, h->S.fwd_launches, 0, h->S.fwd_launches.size(), 0, 2);
+    run_launches(h, h->S.fwd_launches, 0, h->fwd_marker, 0, 2);
+    if (h->root_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_root, 0));      // the root front is being factorised on its own stream
+    run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size(), 0, 2);
     if (k2) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d, 0); launch_apply_signs(h->stream, h->d, 1); }
     run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1, 2);
     for (int r = 0; r < 2; ++r) {
@@ -827,7 +878,10 @@ int tlpk_sync(tlpk_handle *h) {
     if (!h->sub.empty()) { int w = TLPK_OK; for (tlpk_handle *c : h->sub) { const int rc = tlpk_sync(c); if (rc != TLPK_OK) w = rc; } return w; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     HIPCHK(h, hipSetDevice(h->device));
+    int pending_rc = TLPK_OK;
+    if (h->root_pending) { pending_rc = update_async_wait(h); h->solve_timed = false; }      // verdict of tlpk_update_device_async
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (pending_rc != TLPK_OK) { (void)hipGetLastError(); prof_collect(h); return pending_rc; }
     if (h->solve_timed) {               // ev0/ev1 bracket a complete solve only then
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->ms_solve = ms;

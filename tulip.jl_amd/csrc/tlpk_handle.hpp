@@ -28,6 +28,9 @@ struct tlpk_handle {
     hipStream_t sstream[MAX_GROUPS] = {};         // side stream of each group: diagonal-block chains overlap the bulk update
     hipEvent_t ev_side[MAX_GROUPS] = {};
     bool forked = false;
+    hipStream_t rstream = nullptr;                // the root (linking) front of tlpk_update_device_async runs here, beside the next solve's block sweeps
+    hipEvent_t ev_blocks = nullptr, ev_root = nullptr;
+    bool root_pending = false;                    // an asynchronous update has not been waited for / checked yet
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_class;            // class of each recorded pair in the current call

@@ -246,6 +246,20 @@ int tlpk_ipm_newton(tlpk_handle *h, int mode, const double *sc, double *out) {
  * independent right-hand sides against the same factor -- they share one pass over L (tlpk_solve2_device: the sweeps are bound by
  * the bytes of L).  sc[8] as for tlpk_ipm_newton, except sc[2] = regG (h0 = dot products + kappa / tau + regG is formed here).  out[4] = { dtau, dkappa, largest step to the boundary, h0 }.  Same arithmetic as tlpk_ipm_hsolve followed by
  * tlpk_ipm_newton(mode 0): bit-identical vectors and scalars. */
+/* step.jl:24-94 in ONE call: tlpk_ipm_factor (theta_inv from the iterate, uniform regularisations, KKT.update!) WITHOUT the wait for its
+ * status, followed by tlpk_ipm_hsolve_newton: the block-level forward sweeps of the paired solve overlap the factorisation of the root
+ * (linking) front (tlpk_update_device_async).  TLPK_NOT_POSDEF is returned where tlpk_ipm_factor would have returned it -- the
+ * speculative solve has only written direction / h-system buffers -- and the caller retries with larger regularisations (step.jl:35-51). */
+int tlpk_ipm_factor_hsolve_newton(tlpk_handle *h, double regP, double regD, const double *sc, double *out) {
+    if (int rc = ipm_ready(h)) return rc;
+    if (!sc || !out) return TLPK_BADARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    ipm_launch_theta(h->stream, h->ipm->v, h->d_theta, h->d_regP, h->d_regD, regP, regD);
+    const int rc = tlpk_update_device_async(h, h->d_theta, h->d_regP, h->d_regD);
+    if (rc != TLPK_OK) return rc;
+    return tlpk_ipm_hsolve_newton(h, sc, out);
+}
+
 int tlpk_ipm_hsolve_newton(tlpk_handle *h, const double *sc, double *out) {
     if (int rc = ipm_ready(h)) return rc;
     if (!sc || !out) return TLPK_BADARG;

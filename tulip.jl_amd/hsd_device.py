@@ -36,9 +36,11 @@ class Options:
 
 
 class DeviceHSD:
-    def __init__(self, A, b, c, l, u, c0=0.0, objsense_min=True, options=None, system="K1", pair_solves=True, **backend_kw):
+    def __init__(self, A, b, c, l, u, c0=0.0, objsense_min=True, options=None, system="K1", pair_solves=True, overlap_root=True, **backend_kw):
         # pair_solves: the h-system and the predictor share one pass over the factor (tlpk_ipm_hsolve_newton; same arithmetic)
+        # overlap_root: the factorisation does not wait for its status before that pair is enqueued (tlpk_ipm_factor_hsolve_newton)
         self.pair_solves = bool(pair_solves)
+        self.overlap_root = bool(overlap_root)
         # system: "K1" normal equations | "K2" augmented system (the reference's default for Float64, KKT.jl:134-141)
         if int(backend_kw.get("ngpus", 1)) > 1 or int(backend_kw.get("nranks", 1)) > 1:
             raise ValueError("the device-resident interior-point loops are single-device: ngpus / nranks must be 1 "
@@ -125,9 +127,16 @@ class DeviceHSD:
         o = self.opt
         self.regP = max(o.PRegMin, self.regP / 10); self.regD = max(o.DRegMin, self.regD / 10); self.regG = max(o.PRegMin, self.regG / 10)
         nbump = 0
+        fused = self.pair_solves and self.overlap_root
         while nbump <= 3:
             try:
-                self._call(self.L.tlpk_ipm_factor(self.kkt._h, self.regP, self.regD))
+                if fused:
+                    # factorisation WITHOUT the wait for its status + the h-system / predictor pair: the block-level forward sweeps of
+                    # the pair overlap the root front's factorisation; a failed factorisation is reported here, like tlpk_ipm_factor's
+                    self._sc[:] = (self.tau, self.kappa, self.regG, self.rg, -self.tau * self.kappa, 0.0, 0.0, 0.0)
+                    self._call(self.L.tlpk_ipm_factor_hsolve_newton(self.kkt._h, self.regP, self.regD, _lib.as_pd(self._sc), _lib.as_pd(self._out)))
+                else:
+                    self._call(self.L.tlpk_ipm_factor(self.kkt._h, self.regP, self.regD))
                 self.timers["n_update"] += 1
                 break
             except PosDefException:
@@ -136,7 +145,10 @@ class DeviceHSD:
                 self.timers["n_bump"] += 1
         if not nbump < 3:                                                    # step.jl:51 (the reference's off-by-one is kept)
             raise PosDefException(0)
-        if self.pair_solves:
+        if fused:
+            self.timers["n_solve"] += 2; self.timers["n_paired"] = self.timers.get("n_paired", 0) + 1
+            dtau, dkappa, av, self.h0 = (float(v) for v in self._out[:4])
+        elif self.pair_solves:
             # h-system (step.jl:56-76) and predictor: independent right-hand sides, one pass over the factor
             self._sc[:] = (self.tau, self.kappa, self.regG, self.rg, -self.tau * self.kappa, 0.0, 0.0, 0.0)
             self._call(self.L.tlpk_ipm_hsolve_newton(self.kkt._h, _lib.as_pd(self._sc), _lib.as_pd(self._out)))

@@ -230,6 +230,10 @@ class HIPNormalEquations:
     def update_device(self, d_theta, d_regP, d_regD):
         _raise_for(_lib.lib().tlpk_update_device(self._h, d_theta, d_regP, d_regD), self._h)
 
+    def update_device_async(self, d_theta, d_regP, d_regD):
+        """tlpk_update_device_async: no wait; the verdict (PosDefException) comes from the next sync()."""
+        _raise_for(_lib.lib().tlpk_update_device_async(self._h, d_theta, d_regP, d_regD), self._h)
+
     def solve_device(self, d_dx, d_dy, d_xip, d_xid, sync=True):
         _raise_for(_lib.lib().tlpk_solve_device(self._h, d_dx, d_dy, d_xip, d_xid), self._h)
         if sync:
