@@ -70,9 +70,9 @@ def parse():
     ap.add_argument("--unpaired", action="store_true",
                     help="solve the right-hand sides of a step one by one (default: the first two as a pair, one pass over the factor "
                          "-- Tulip's HSD step solves the h-system and the predictor, independent right-hand sides, in every iteration)")
-    ap.add_argument("--blocking-update", action="store_true",
-                    help="wait for the status of update! before the solves are enqueued (default: the status is checked at the end of the step, "
-                         "the root front's factorisation overlaps the first solve's block-level sweeps)")
+    ap.add_argument("--async-update", action="store_true",
+                    help="do not wait for the status of update! before the solves are enqueued (tlpk_update_device_async: the root front's "
+                         "factorisation overlaps the first solve's block-level sweeps; measured slower, profiles/r03_async_update.txt)")
     ap.add_argument("--no-small-lp", action="store_true", help="skip the latency-bound legs (25fv47-class and pds-20-class LPs)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child-process mode of the cpu_baseline leg
@@ -286,9 +286,9 @@ def main():
         def newton_step(k, paired=None):
             paired = pair if paired is None else paired
             if not split:
-                # update! without the wait for its status word: the root front's factorisation (its own stream) overlaps the block-level
-                # forward sweeps of the first solve; the status arrives with the step's final sync (tlpk_update_device_async)
-                (k.update_device if args.blocking_update else k.update_device_async)(P(d_th), P(d_rp), P(d_rd))
+                # --async-update: update! without the wait for its status word (tlpk_update_device_async: the root front's factorisation
+                # on its own stream beside the first solve's block-level sweeps) -- measured 1.1 ms SLOWER per step on C4, off by default
+                (k.update_device_async if args.async_update else k.update_device)(P(d_th), P(d_rp), P(d_rd))
                 if paired:    # the h-system + predictor pair of an HSD step (HSD/step.jl:63,79): two right-hand sides, one pass over L
                     k.solve2_device(P(d_dx2), P(d_dy2), P(d_xp), P(d_xd), P(d_dx), P(d_dy), P(d_xp), P(d_xd), sync=False)
                 for _ in range(args.solves - (2 if paired else 0)):
@@ -334,7 +334,7 @@ def main():
                "config": {"workload": text, "solves_per_step": args.solves, "regime": args.regime,
                           "solve_schedule": ("1 pair (two right-hand sides in one pass over the factor: HSD's h-system + predictor) + %d single" % (args.solves - 2))
                                             if pair else "%d single" % args.solves,
-                          "update_status": "checked at the end of the step (tlpk_update_device_async)" if not (args.blocking_update or split) else "checked before the solves",
+                          "update_status": "checked at the end of the step (tlpk_update_device_async)" if (args.async_update and not split) else "checked before the solves",
                           "parallelism": "blocks/%d" % world, "stream_groups": int(kkt.symbolic("ngroups")[0]),
                           "nnzS": st["nnzS"], "nnzL": st["nnzL"], "nnzL_stored": st["nnzL_stored"],
                           "stored_over_nnzL": st["nnzL_stored"] / max(st["nnzL"], 1), "device_bytes": st["device_bytes"],

@@ -144,7 +144,9 @@ int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *
  * a dense front of a few hundred columns whose factorisation is a serial chain of diagonal blocks, ~1.5 ms with the chip nearly idle --
  * goes to a stream of its own, so that the block-level forward sweeps of the next solve overlap it.  The verdict arrives with the next
  * tlpk_sync (TLPK_NOT_POSDEF; the handle stays usable); solves enqueued in between are speculative.  Unsharded handles; falls back to the
- * blocking call where there is nothing to overlap (no root front, profile mode, graph replay). */
+ * blocking call where there is nothing to overlap (no root front, profile mode, graph replay).  MEASURED SLOWER than the blocking call on
+ * the bench workloads (C4 +1.1 ms, north-star instance +1.9 ms per step: the root front's ~20 dependent small launches queue behind the
+ * chip-filling sweep workgroups; profiles/r03_async_update.txt) -- kept as an option, not used by default. */
 int tlpk_update_device_async(tlpk_handle *h, const double *d_theta_inv, const double *d_regP, const double *d_regD);
 /* Two right-hand sides in one pass over the factor (the solve sweeps are HBM-bound on the bytes of L: the pair costs little more than
  * one solve).  Same semantics and bit-identical results as two tlpk_solve_device calls.  Single-rank handles.  Tulip's HSD iteration
