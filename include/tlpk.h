@@ -63,7 +63,8 @@ typedef struct tlpk_options {
     int64_t mem_budget_bytes;  /* 0 = 90 % of the device's free memory (or unlimited if device=-1) */
     int32_t system;            /* TLPK_SYSTEM_K1 (default) | TLPK_SYSTEM_K2 */
     int32_t refine_steps;      /* iterative-refinement steps per solve on the residuals of the augmented system (each step = one more
-                                  pair of sweeps); 0 = none = the reference's behaviour (spd.jl:68 leaves it as a TODO).  K1, nranks = 1 */
+                                  pair of sweeps); 0 = none = the reference's behaviour (spd.jl:68 leaves it as a TODO).  K1; one rank or a
+                                  tlpk_create_multi handle (sharded handles: tlpk_refine_local / tlpk_refine_finish, the caller owns the collective) */
     int32_t detect_blocks;     /* 1 (and row_block == NULL): find the block-angular structure of THIS matrix with tlpk_detect_blocks --
                                   the hook that survives Tulip's presolve, which renumbers the rows before KKT.setup sees them
                                   (model.jl:88-131).  No structure found: general sparse path (tlpk_create) / TLPK_BADARG (tlpk_create_multi) */
@@ -168,6 +169,17 @@ int tlpk_update_finish(tlpk_handle *h);
 int tlpk_solve_local(tlpk_handle *h, const double *d_xi_p, const double *d_xi_d);
 int tlpk_root_rhs(tlpk_handle *h, double **d_ptr, int64_t *count);
 int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xi_d);
+/* Iterative refinement on a sharded handle (K1), one step = one more split solve on the residuals of the augmented system
+ * (the equations of /root/reference/src/KKT/KKT.jl:70-75; the reference leaves refinement as a TODO, src/KKT/Cholmod/spd.jl:68):
+ *   tlpk_refine_local(h, dx, dy, xi_p, xi_d) -> allreduce(sum) of tlpk_root_rhs -> tlpk_refine_finish(h, dx, dy)
+ * after a finished solve, as often as wanted; dx / dy in the layout tlpk_solve_finish leaves (a rank's own columns and block rows,
+ * the linking rows replicated) are corrected in place.  Every rank forms the residuals of the rows / columns it owns and its PARTIAL
+ * sums of the linking rows; the reduction inside the solve completes them.  tlpk_options.refine_steps does this inside
+ * tlpk_solve_device (one rank) and inside tlpk_solve of a tlpk_create_multi handle (the library owns the reductions there); on a
+ * sharded handle the caller owns the collective, hence the split form.  With nranks = 1 the two calls compose to exactly one
+ * refinement step of tlpk_solve_device. */
+int tlpk_refine_local(tlpk_handle *h, const double *d_dx, const double *d_dy, const double *d_xi_p, const double *d_xi_d);
+int tlpk_refine_finish(tlpk_handle *h, double *d_dx, double *d_dy);
 /* Copy the root panel (which = 0) or root rhs (which = 1) out of (dir = 0) / into (dir = 1) a
  * caller-owned device buffer, on the handle's stream -- for callers whose communicator wants to
  * own the memory it reduces (torch.distributed tensors). */

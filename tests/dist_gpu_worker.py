@@ -84,7 +84,19 @@ def main():
         dy_link = dy[link].numpy().copy()
         dy = torch.where(link, dy / world, dy)
         dist.all_reduce(dx); dist.all_reduce(dy)
-        np.savez(out, dx=dx.numpy(), dy=dy.numpy(), dy_link=dy_link, nloc=kkt.stats()["n_local_blocks"])
+        # one iterative-refinement step, split like the solve: residuals rank by rank (partial sums on the linking rows), the
+        # reduction of the root right-hand side completes them
+        kkt.refine_local(P(d_dx), P(d_dy), P(d[3]), P(d[4]))
+        kkt.sync()
+        allreduce_device("rhs", kkt.root_rhs()[1])
+        kkt.refine_finish(P(d_dx), P(d_dy))
+        kkt.sync()
+        dxr, dyr = d_dx.cpu(), d_dy.cpu()
+        dyr_link = dyr[link].numpy().copy()
+        dyr = torch.where(link, dyr / world, dyr)
+        dist.all_reduce(dxr); dist.all_reduce(dyr)
+        np.savez(out, dx=dx.numpy(), dy=dy.numpy(), dy_link=dy_link, nloc=kkt.stats()["n_local_blocks"],
+                 dx_refined=dxr.numpy(), dy_refined=dyr.numpy(), dy_link_refined=dyr_link)
     finally:
         dist.destroy_process_group()
 

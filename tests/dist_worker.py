@@ -40,6 +40,17 @@ def main():
         rhs = torch.from_numpy(em.root_rhs())
         dist.all_reduce(rhs)
         dx, dy = em.solve_finish(xd, A)
+        extra = {}
+        if system == "K1":
+            # one iterative-refinement step, split like the solve (tlpk_refine_local -> all-reduce of the root rhs -> tlpk_refine_finish)
+            em.refine_local(dx, dy, xp, xd, A, th, rp, rd)
+            rhs = torch.from_numpy(em.root_rhs())
+            dist.all_reduce(rhs)
+            dxr, dyr = em.refine_finish(dx, dy, A)
+            tdxr = torch.from_numpy(dxr.copy()); dist.all_reduce(tdxr)
+            dyr_sh = dyr.copy(); dyr_sh[row_block < 0] /= world
+            tdyr = torch.from_numpy(dyr_sh); dist.all_reduce(tdyr)
+            extra = dict(dx_refined=tdxr.numpy(), dy_refined=tdyr.numpy())
         # assemble the global solution: block rows/cols from their owner, linking rows replicated
         tdx = torch.from_numpy(dx.copy()); dist.all_reduce(tdx)
         link = row_block < 0
@@ -53,7 +64,7 @@ def main():
         dist.all_reduce(own)
         st = kkt.stats()
         np.savez(out, dx=tdx.numpy(), dy=tdy.numpy(), own=own.numpy(), nloc=st["n_local_blocks"],
-                 rlen=st["root_panel_len"], dy_link=dy[link])
+                 rlen=st["root_panel_len"], dy_link=dy[link], **extra)
     finally:
         dist.destroy_process_group()
 

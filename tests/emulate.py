@@ -270,7 +270,8 @@ class Emulator:
                         self.U[front][rsel - ns, c - ns] -= G[rsel - i0, c - j0]
 
     # ---- solve! ----
-    def solve_local(self, xi_p, xi_d, A):
+    def solve_local(self, xi_p, xi_d, A, rhs_rank=None):
+        rank = self.rank if rhs_rank is None else rhs_rank                  # refinement: every rank adds its partial residual on linking rows
         if self.k2:                                                     # k_k2_rhs: [xi_d ; xi_p] permuted; sharded: own nodes, root nodes on rank 0
             nl = self.row_local[self.perm]
             self.xw = np.where((nl == 0) | ((nl == 2) & (self.rank != 0)), 0.0, np.concatenate([xi_d, xi_p])[self.perm])
@@ -279,7 +280,7 @@ class Emulator:
             Aloc = A @ __import__("scipy.sparse").sparse.diags(self.col_local.astype(float))
             xi = Aloc @ (self.D * xi_d)
             rl = self.row_local
-            xi = np.where(rl == 0, 0.0, xi + np.where((rl == 2) & (self.rank != 0), 0.0, xi_p))
+            xi = np.where(rl == 0, 0.0, xi + np.where((rl == 2) & (rank != 0), 0.0, xi_p))
             self.xw = xi[self.perm].copy()
         for s_ in np.nonzero(self.single & (self.local != 0))[0]:          # k_single_solve
             l = self.Lval[self.loff[s_]]
@@ -308,6 +309,20 @@ class Emulator:
         dy[self.row_local == 0] = 0.0
         dx = np.where(self.col_local != 0, self.D * (A.T @ dy - xi_d), 0.0)
         return dx, dy
+
+    # one iterative-refinement step in two halves (tlpk_refine_local / tlpk_refine_finish): residuals of the rows / columns this rank
+    # owns, partial sums on the linking rows (dx is zero outside the rank's columns; rank 0 adds xi_p - Rd dy there)
+    def refine_local(self, dx, dy, xi_p, xi_d, A, theta, regP, regD):
+        assert not self.k2
+        rl = self.row_local
+        base = np.where((rl == 2) & (self.rank != 0), 0.0, xi_p - regD * dy)
+        r1 = base - A @ dx
+        self._r2 = (xi_d + (theta + regP) * dx) - A.T @ dy
+        self.solve_local(r1, self._r2, A, rhs_rank=0)
+
+    def refine_finish(self, dx, dy, A):
+        cx, cy = self.solve_finish(self._r2, A)
+        return dx + cx, dy + cy
 
     def solve(self, xi_p, xi_d, A):
         self.solve_local(xi_p, xi_d, A)

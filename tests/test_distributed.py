@@ -62,6 +62,15 @@ def test_sharded_newton_step_matches_oracle(world, tmp_path):
         assert int(z["rlen"]) == PROBLEM["m0"] ** 2
         assert np.abs(z["dy_link"] - dyo[row_block < 0]).max() <= 1e-9 * max(1, np.abs(dyo).max())  # replicated
         nloc.append(int(z["nloc"]))
+        # one refinement step across the shards (residuals formed rank by rank, partial sums on the linking rows completed by the
+        # reduction inside the solve): still the oracle's solution, and the residuals of the augmented system do not grow
+        from helpers import kkt_residuals
+        assert np.abs(z["dx_refined"] - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max())
+        assert np.abs(z["dy_refined"] - dyo).max() <= 1e-9 * max(1, np.abs(dyo).max())
+        r0 = max(kkt_residuals(A, th, rp, rd, xp, xd, z["dx"], z["dy"]))
+        r1 = max(kkt_residuals(A, th, rp, rd, xp, xd, z["dx_refined"], z["dy_refined"]))
+        scale = max(np.abs(xp).max(), np.abs(xd).max())
+        assert r1 <= max(2.0 * r0, 1e-13 * scale), (r0, r1)
     assert sum(nloc) == PROBLEM["nblocks"] and all(v >= 1 for v in nloc)
 
 

@@ -355,6 +355,13 @@ def test_sharded_split_phase_on_device(world, tmp_path):
         assert np.abs(z["dx"] - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max())
         assert np.abs(z["dy"] - dyo).max() <= 1e-9 * max(1, np.abs(dyo).max())
         assert np.abs(z["dy_link"] - dyo[row_block < 0]).max() <= 1e-9 * max(1, np.abs(dyo).max())
+        # tlpk_refine_local / tlpk_refine_finish: one refinement step across the ranks
+        assert np.abs(z["dx_refined"] - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max())
+        assert np.abs(z["dy_refined"] - dyo).max() <= 1e-9 * max(1, np.abs(dyo).max())
+        assert np.abs(z["dy_link_refined"] - dyo[row_block < 0]).max() <= 1e-9 * max(1, np.abs(dyo).max())
+        r0 = max(kkt_residuals(A, th, rp, rd, xp, xd, z["dx"], z["dy"]))
+        r1 = max(kkt_residuals(A, th, rp, rd, xp, xd, z["dx_refined"], z["dy_refined"]))
+        assert r1 <= max(2.0 * r0, 1e-13 * max(np.abs(xp).max(), np.abs(xd).max())), (r0, r1)
 
 
 def test_c4_full_scale_identities_and_stream_groups():
@@ -562,6 +569,56 @@ def test_single_process_multi_device_mode(ngpus):
     r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
     assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp).max(), np.abs(xd).max()))
     tk.run_ls_tests(A, kkt)
+
+
+@pytest.mark.gpu
+def test_iterative_refinement_split_calls_and_multi_device():
+    """Refinement beyond one rank.  (1) tlpk_refine_local + tlpk_refine_finish on a single-rank handle compose to exactly the steps
+    tlpk_options.refine_steps runs inside tlpk_solve_device (bitwise).  (2) A tlpk_create_multi handle with refine_steps: every step
+    is one more split solve across the shards (residuals shard by shard, partial sums on the linking rows completed by the library's
+    reduction); on late-IPM data the larger residual of the augmented system must shrink as it does on one device, and the result
+    must agree with the single-device refined solve."""
+    from helpers import DevBuf
+    A, rb = block_angular(nblocks=6, mk=300, nk=650, m0=80, nnz_in=3, link_prob=0.5, seed=41)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 5, "late")
+    P = lambda t: t.ptr                                                  # noqa: E731
+    d_xp, d_xd = DevBuf(xp), DevBuf(xd)
+    ref = {}
+    for steps in (0, 2):
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb, refine=steps))
+        tk.update(kkt, th, rp, rd)
+        o = (DevBuf(n), DevBuf(m))
+        kkt.solve_device(P(o[0]), P(o[1]), P(d_xp), P(d_xd)); kkt.sync()
+        if steps == 0:
+            for _ in range(2):
+                kkt.refine_local(P(o[0]), P(o[1]), P(d_xp), P(d_xd))
+                kkt.refine_finish(P(o[0]), P(o[1]))
+            kkt.sync()
+            with pytest.raises(tk.DimensionMismatch):
+                kkt.refine_finish(P(o[0]), P(o[1]))                      # no refine_local before it
+        ref[steps] = (o[0].get(), o[1].get())
+        kkt.close()
+    assert np.array_equal(ref[0][0], ref[2][0]) and np.array_equal(ref[0][1], ref[2][1])
+    res = {}
+    for steps in (0, 2):
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb, ngpus=3, devices=[0, 0, 0], refine=steps))
+        tk.update(kkt, th, rp, rd)
+        dx = np.full(n, np.nan); dy = np.full(m, np.nan)
+        tk.solve(dx, dy, kkt, xp, xd)
+        res[steps] = (max(kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)), dx, dy)
+        dx2 = np.full(n, np.nan); dy2 = np.full(m, np.nan)
+        tk.solve(dx2, dy2, kkt, xp, xd)                                  # and again: same answer (buffers / flags left clean)
+        assert np.array_equal(dx, dx2) and np.array_equal(dy, dy2)
+        kkt.close()
+    r_single = max(kkt_residuals(A, th, rp, rd, xp, xd, *ref[2]))
+    print("multi-device refinement, late regime: residual %.3e -> %.3e (single device refined: %.3e)" % (res[0][0], res[2][0], r_single))
+    assert res[2][0] <= res[0][0]
+    assert res[2][0] <= 0.5 * res[0][0] or res[0][0] <= 1e-12 * (1 + np.abs(xp).max())
+    assert res[2][0] <= 10 * r_single + 1e-14
+    assert np.abs(res[2][1] - ref[2][0]).max() <= 1e-7 * max(1.0, np.abs(ref[2][0]).max())
+    with pytest.raises(Exception):
+        tk.setup(A, tk.K2(), tk.Backend(device=0, row_block=rb, ngpus=2, devices=[0, 0], refine=1))
 
 
 @pytest.mark.gpu

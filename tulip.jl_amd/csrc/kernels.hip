@@ -1962,12 +1962,15 @@ __global__ void k_dx(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ 
 // a second solve with (r1, r2) gives the correction that k_axpy2 adds.
 __global__ void k_resid_rows(i64 m, const i64 *__restrict__ Tp, const i32 *__restrict__ Tj, const double *__restrict__ Tx,
                              const double *__restrict__ xi_p, const double *__restrict__ regD, const double *__restrict__ dx,
-                             const double *__restrict__ dy, double *__restrict__ r1) {
+                             const double *__restrict__ dy, const char *__restrict__ row_local, int rank, double *__restrict__ r1) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     double s = 0.0;
     for (i64 q = Tp[i]; q < Tp[i + 1]; ++q) s += Tx[q] * dx[Tj[q]];
-    r1[i] = (xi_p[i] - regD[i] * dy[i]) - s;
+    // sharded: dx is zero outside this rank's columns, so a linking row gets the rank's partial sum, and only rank 0 adds
+    // xi_p - Rd dy there (the reduction of the root right-hand side inside the following solve completes the row)
+    const double base = (row_local[i] == 2 && rank != 0) ? 0.0 : (xi_p[i] - regD[i] * dy[i]);
+    r1[i] = base - s;
 }
 __global__ void k_resid_cols(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ Ai, const double *__restrict__ Ax,
                              const double *__restrict__ xi_d, const double *__restrict__ theta, const double *__restrict__ regP,
@@ -1977,6 +1980,14 @@ __global__ void k_resid_cols(i64 n, const i64 *__restrict__ Ap, const i32 *__res
     double s = 0.0;
     for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) s += Ax[p] * dy[Ai[p]];
     r2[j] = (xi_d[j] + (theta[j] + regP[j]) * dx[j]) - s;
+}
+// multi-device mode after a refined solve: a shard stores the entries it owns (its columns of dx, its block rows of dy) into the
+// lead device's job-wide vectors
+__global__ void k_publish(i64 n, const char *__restrict__ col_local, const double *__restrict__ dx, double *__restrict__ dx_job,
+                          i64 m, const char *__restrict__ row_local, const double *__restrict__ dy, double *__restrict__ dy_job) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && col_local[i]) dx_job[i] = dx[i];
+    if (i < m && row_local[i] == 1) dy_job[i] = dy[i];
 }
 __global__ void k_axpy2(i64 n, double *__restrict__ x, const double *__restrict__ dxc, i64 m, double *__restrict__ y, const double *__restrict__ dyc) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2144,9 +2155,13 @@ void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy
     if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw + (rhs ? a.ctx.xw2 : 0), dy, dy_shared, rank);
 }
 void launch_residuals(hipStream_t st, const DevArrays &a, const double *xi_p, const double *xi_d, const double *theta, const double *regP,
-                      const double *regD, const double *dx, const double *dy, double *r1, double *r2) {
-    if (a.m > 0) hipLaunchKernelGGL(k_resid_rows, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.Tp, a.Tj, a.Tx, xi_p, regD, dx, dy, r1);
+                      const double *regD, const double *dx, const double *dy, double *r1, double *r2, int rank) {
+    if (a.m > 0) hipLaunchKernelGGL(k_resid_rows, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.Tp, a.Tj, a.Tx, xi_p, regD, dx, dy, a.row_local, rank, r1);
     if (a.n > 0) hipLaunchKernelGGL(k_resid_cols, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, xi_d, theta, regP, dx, dy, r2);
+}
+void launch_publish(hipStream_t st, const DevArrays &a, const double *dx, double *dx_job, const double *dy, double *dy_job) {
+    const i64 len = std::max(a.n, a.m);
+    if (len > 0) hipLaunchKernelGGL(k_publish, dim3(nblk(len, 256)), dim3(256), 0, st, a.n, a.col_local, dx, dx_job, a.m, a.row_local, dy, dy_job);
 }
 void launch_axpy2(hipStream_t st, i64 n, double *x, const double *dxc, i64 m, double *y, const double *dyc) {
     const i64 len = std::max(n, m);

@@ -712,13 +712,15 @@ int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const d
 }
 
 // ---- solve ----
-static int enq_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
+// rhs_rank >= 0 overrides the rank the right-hand side kernel sees: rank 0 adds xi_p on the linking rows, and a refinement step on a
+// sharded handle passes every rank's PARTIAL residual of those rows (the all-reduce of the root right-hand side completes the sum)
+static int enq_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid, int rhs_rank = -1) {
     {
         ProfScope ps(h, TLPK_KC_SPMV);
         // tickets + hand-over words of both sweeps back to all ones: the data is its own flag, ticket + 1 = 0 is the first item
         if (h->S.sweep && h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes, h->stream));
         if (h->S.system == 1) launch_k2_rhs(h->stream, h->d, h->S.k2_n, d_xip, d_xid, 0, h->opt.rank);        // [xi_d ; xi_p] permuted (sqd.jl:62-66)
-        else launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, h->opt.rank);
+        else launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, rhs_rank >= 0 ? rhs_rank : h->opt.rank);
         launch_single_solve(h->stream, h->d);
     }
     run_launches(h, h->S.fwd_launches, 0, h->fwd_marker, 0);
@@ -772,7 +774,7 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->factored) return TLPK_NOT_FACTORED;
-    if (!h->solve_local_done) { h->last_error = "tlpk_solve_finish without a preceding tlpk_solve_local"; return TLPK_BADARG; }
+    if (!h->solve_local_done || h->refine_pending) { h->last_error = "tlpk_solve_finish without a preceding tlpk_solve_local"; return TLPK_BADARG; }
     h->solve_local_done = false;
     HIPCHK(h, hipSetDevice(h->device));
     if (int rc = enq_solve_finish(h, d_dx, d_dy, d_xid)) return rc;
@@ -807,13 +809,65 @@ int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     // optional iterative refinement on the residuals of the augmented system (KKT.jl:70-75): each step is one more solve with
     // (r1, r2) as right-hand side, its result added to (dx, dy).  Off by default = the reference (spd.jl:68).
     for (int it = 0; it < h->refine_steps && rc == TLPK_OK; ++it) {
-        launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, d_dx, d_dy, h->d_r1, h->d_r2);
+        launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, d_dx, d_dy, h->d_r1, h->d_r2, 0);
         rc = whole ? solve_whole(h, h->d_cx, h->d_cy, h->d_r1, h->d_r2) : tlpk_solve_local(h, h->d_r1, h->d_r2);
         if (rc == TLPK_OK && !whole) rc = tlpk_solve_finish(h, h->d_cx, h->d_cy, h->d_r2);
         if (rc == TLPK_OK) launch_axpy2(h->stream, h->S.n, d_dx, h->d_cx, h->S.m, d_dy, h->d_cy);
         HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     }
     return rc;
+}
+
+// Iterative refinement in two halves, for sharded handles (and any single-rank K1 handle): one step is one more solve, so it holds
+// one reduction of the root right-hand side, which the CALLER does between the halves --
+//     tlpk_refine_local(h, dx, dy, xi_p, xi_d);  all-reduce(tlpk_root_rhs);  tlpk_refine_finish(h, dx, dy)
+// after a completed solve (dx, dy in the layout tlpk_solve_finish leaves: a rank's own columns / block rows, the linking rows
+// replicated).  Every rank forms the residuals it owns; on the linking rows its PARTIAL sum over its own columns (rank 0 adds
+// xi_p - Rd dy), which the reduction inside the solve completes.  The buffers are allocated by the first call.
+static int refine_buffers(tlpk_handle *h) {
+    if (h->d_r1) return TLPK_OK;
+    const i64 nn = std::max<i64>(h->S.n, 1), mm = std::max<i64>(h->S.m, 1);
+    int rc = TLPK_OK;
+    if ((rc = dev_alloc(h, &h->d_r1, mm)) != TLPK_OK) return rc;
+    if ((rc = dev_alloc(h, &h->d_r2, nn)) != TLPK_OK) return rc;
+    if ((rc = dev_alloc(h, &h->d_cx, nn)) != TLPK_OK) return rc;
+    return dev_alloc(h, &h->d_cy, mm);
+}
+int tlpk_refine_local(tlpk_handle *h, const double *d_dx, const double *d_dy, const double *d_xip, const double *d_xid) {
+    if (!h || !d_dx || !d_dy || !d_xip || !d_xid) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
+    if (h->S.system == 1) { h->last_error = "iterative refinement: K1 only"; return TLPK_BADARG; }
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (!h->factored) return TLPK_NOT_FACTORED;
+    if (h->solve_local_done) { h->last_error = "tlpk_refine_local inside an unfinished solve"; return TLPK_BADARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (int rc = refine_buffers(h)) return rc;
+    prof_begin(h, false);
+    h->solve_timed = false;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    h->solve_epoch += 1;
+    launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, d_dx, d_dy, h->d_r1, h->d_r2, h->opt.rank);
+    if (int rc = enq_solve_local(h, h->d_r1, h->d_r2, 0)) return rc;
+    h->solve_local_done = true; h->refine_pending = true;
+    return TLPK_OK;
+}
+int tlpk_refine_finish(tlpk_handle *h, double *d_dx, double *d_dy) {
+    if (!h || !d_dx || !d_dy) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (!h->solve_local_done || !h->refine_pending) { h->last_error = "tlpk_refine_finish without a preceding tlpk_refine_local"; return TLPK_BADARG; }
+    h->solve_local_done = false; h->refine_pending = false;
+    HIPCHK(h, hipSetDevice(h->device));
+    double *keep = h->shared_dy; const bool keep_lo = h->dx_local_only;
+    h->shared_dy = nullptr; h->dx_local_only = false;                     // the correction stays rank-local
+    const int rc = enq_solve_finish(h, h->d_cx, h->d_cy, h->d_r2);
+    h->shared_dy = keep; h->dx_local_only = keep_lo;
+    if (rc != TLPK_OK) return rc;
+    launch_axpy2(h->stream, h->S.n, d_dx, h->d_cx, h->S.m, d_dy, h->d_cy);
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->solve_timed = true;
+    return TLPK_OK;
 }
 
 // Two right-hand sides against the same factor in ONE pass over L (the persistent sweeps are bound by the bytes of L: the
@@ -1081,6 +1135,37 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
         if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
     }
     if (int rc = multi_allreduce(h, false)) return rc;
+    if (h->refine_steps > 0) {
+        // iterative refinement: every shard keeps its solution rank-local (own columns / block rows, linking rows replicated), each
+        // step is one more split solve on the residuals with the same reduction in the middle, and the owned slices are published
+        // to the lead device's job-wide vectors at the end
+        for (tlpk_handle *c : h->sub) {
+            c->shared_dy = nullptr; c->dx_local_only = false;
+            const int rc = tlpk_solve_finish(c, c->d_dx, c->d_dy, c->d_xid);
+            if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+        }
+        for (int it = 0; it < h->refine_steps; ++it) {
+            for (tlpk_handle *c : h->sub) {
+                const int rc = tlpk_refine_local(c, c->d_dx, c->d_dy, c->d_xip, c->d_xid);
+                if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+            }
+            if (int rc = multi_allreduce(h, false)) return rc;
+            for (tlpk_handle *c : h->sub) {
+                const int rc = tlpk_refine_finish(c, c->d_dx, c->d_dy);
+                if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+            }
+        }
+        // the lead's own last kernels still read-modify-write ITS rank-local dx / dy (= the job-wide vectors): peers publish after them
+        HIPCHK(h, hipSetDevice(lead->device));
+        HIPCHK(h, hipEventRecord(h->multi_done, lead->stream));
+        for (size_t r = 1; r < h->sub.size(); ++r) {
+            tlpk_handle *c = h->sub[r];
+            HIPCHK(h, hipSetDevice(c->device));
+            HIPCHK(h, hipStreamWaitEvent(c->stream, h->multi_done, 0));
+            launch_publish(c->stream, c->d, c->d_dx, lead->d_dx, c->d_dy, lead->d_dy);      // owned columns / block rows only (P2P stores)
+            HIPCHK(h, hipEventRecord(h->multi_ev[r], c->stream));
+        }
+    } else
     for (size_t r = 0; r < h->sub.size(); ++r) {
         tlpk_handle *c = h->sub[r];
         // every rank fills its own entries of the lead device's dx / dy (P2P stores); its local dy feeds its k_dx
@@ -1149,6 +1234,13 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
                                                  : analyse_common(common, m, n, colptr, rowval, nzval, index_base, o);
             if (rc != TLPK_OK) h->last_error = common.error;
         }
+        // iterative refinement is driven from here (every step holds a reduction across the shards): the shards themselves are
+        // created without it
+        h->refine_steps = base.refine_steps;
+        if (base.refine_steps < 0 || (base.refine_steps > 0 && base.system == TLPK_SYSTEM_K2)) {
+            if (rc == TLPK_OK) { rc = TLPK_BADARG; h->last_error = "refine_steps: K1 only, >= 0"; }
+        }
+        base.refine_steps = 0;
         std::vector<int> rcs((size_t)ngpus, TLPK_OK);
         std::vector<tlpk_options> opts((size_t)ngpus, base);
         if (rc == TLPK_OK) {

@@ -44,7 +44,7 @@ struct tlpk_handle {
     double *d_r1 = nullptr, *d_r2 = nullptr, *d_cx = nullptr, *d_cy = nullptr;   // refinement: residuals and correction
     int *h_info = nullptr;
     double *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-pointer entry points (lazily allocated)
-    bool factored = false, local_done = false, solve_local_done = false, solve_timed = false;
+    bool factored = false, local_done = false, solve_local_done = false, solve_timed = false, refine_pending = false;
     i64 fail_col = -1;
     double ms_analyse = 0, ms_update = 0, ms_solve = 0;
     tlpk_kernel_times kt{};

@@ -34,7 +34,7 @@ HIP (gfx950) backend.  `row_block` is the optional block-angular structure hook:
 `ngpus > 1` (block-angular LPs, system `K1`): this ONE Julia process shards the
 diagonal blocks over `ngpus` devices of the node (`devices`: HIP ordinals, default `0:ngpus-1`); the
 linking-block reductions happen inside the library.  `streams`: concurrent stream groups (0 = auto).
-`refine`: iterative-refinement steps per `solve!` (0 = none, as `spd.jl:68`; `K1` on one GPU).
+`refine`: iterative-refinement steps per `solve!` (0 = none, as `spd.jl:68`; `K1`, one GPU or `ngpus > 1`).
 """
 struct Backend <: AbstractKKTBackend
     device::Int

@@ -71,7 +71,7 @@ class Backend:
         self.rank, self.nranks = int(rank), int(nranks)
         self.mem_budget_bytes = int(mem_budget_bytes)
         self.streams = int(streams)            # 0 = auto (2 concurrent block groups), 1 = single group
-        self.refine = int(refine)              # iterative-refinement steps per solve (0 = the reference's behaviour; K1, one rank)
+        self.refine = int(refine)              # iterative-refinement steps per solve (0 = the reference's behaviour; K1; one rank or ngpus > 1 -- sharded handles: refine_local / refine_finish)
         # single-process multi-GPU (block-angular LPs): one handle shards the diagonal blocks over `ngpus` devices
         self.ngpus = int(ngpus)
         self.devices = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
@@ -193,6 +193,13 @@ class HIPNormalEquations:
 
     def solve_finish(self, d_dx, d_dy, d_xid):
         _raise_for(_lib.lib().tlpk_solve_finish(self._h, d_dx, d_dy, d_xid), self._h)
+
+    def refine_local(self, d_dx, d_dy, d_xip, d_xid):
+        """First half of one iterative-refinement step on a sharded handle (then: all-reduce root_rhs(), refine_finish)."""
+        _raise_for(_lib.lib().tlpk_refine_local(self._h, d_dx, d_dy, d_xip, d_xid), self._h)
+
+    def refine_finish(self, d_dx, d_dy):
+        _raise_for(_lib.lib().tlpk_refine_finish(self._h, d_dx, d_dy), self._h)
 
     def root_panel(self):
         """(device address, count) of the root (linking) panel to all-reduce after update_local."""
