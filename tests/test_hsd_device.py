@@ -27,30 +27,93 @@ def test_ipm_entry_points_fail_loudly_without_device():
     assert L.tlpk_ipm_newton(None, 0, _lib.as_pd(out), _lib.as_pd(out)) == _lib.BADARG
 
 
-def test_device_loops_refuse_multi_gpu_backends_early():
-    """Round-2 advisor finding: Model(lp, row_block=..., ngpus=8) reached tlpk_ipm_* with a multi-device parent handle
-    (null device vectors -> GPU memory fault).  The host loops now refuse before any handle exists."""
+def test_device_loops_refuse_backends_they_cannot_drive():
+    """The loops need ONE handle for the whole LP: a sharded handle (nranks > 1) leaves its reductions to the caller, and on several
+    GPUs the loops solve the normal equations.  Refused before any handle exists (round-2 advisor finding: a multi-device parent
+    handle once reached tlpk_ipm_* with null device vectors)."""
     from tulip_jl_amd.hsd_device import DeviceHSD
     from tulip_jl_amd.mpc_device import DeviceMPC
     A = sp.csc_matrix(np.array([[1.0, 0, 1, 0], [0, 1, 0, 1]]))
     for cls in (DeviceHSD, DeviceMPC):
-        with pytest.raises(ValueError, match="single-device"):
-            cls(A, np.ones(2), np.ones(4), np.zeros(4), np.full(4, np.inf), device=0, row_block=np.array([0, 1]), ngpus=2)
+        with pytest.raises(ValueError, match="nranks must be 1"):
+            cls(A, np.ones(2), np.ones(4), np.zeros(4), np.full(4, np.inf), device=0, row_block=np.array([0, 1]), nranks=2)
+        with pytest.raises(ValueError, match="normal equations"):
+            cls(A, np.ones(2), np.ones(4), np.zeros(4), np.full(4, np.inf), device=0, row_block=np.array([0, 1]), ngpus=2, system="K2")
 
 
 @pytest.mark.gpu
-def test_ipm_entry_points_refuse_a_multi_device_handle():
+def test_ipm_entry_points_refuse_handles_they_cannot_drive():
     from helpers import block_angular
     A, rb = block_angular(nblocks=4, mk=60, nk=120, m0=10, nnz_in=3, link_prob=0.5, seed=3)
     m, n = A.shape
-    kkt = tk.setup(A, tk.K1(), tk.Backend(row_block=rb, ngpus=2, devices=[0, 0]))
     L = _lib.lib()
     v = np.ones(n)
-    assert L.tlpk_ipm_load(kkt._h, _lib.as_pd(np.ones(m)), _lib.as_pd(v), _lib.as_pd(v), _lib.as_pd(v)) == _lib.BADARG
-    assert b"single-device" in L.tlpk_last_error(kkt._h)
     out = np.zeros(16)
+    kkt = tk.setup(A, tk.K2(), tk.Backend(row_block=rb, ngpus=2, devices=[0, 0]))          # K2 on a multi-device handle
+    assert L.tlpk_ipm_load(kkt._h, _lib.as_pd(np.ones(m)), _lib.as_pd(v), _lib.as_pd(v), _lib.as_pd(v)) == _lib.BADARG
+    assert b"K1 only" in L.tlpk_last_error(kkt._h)
     assert L.tlpk_ipm_residuals(kkt._h, 1.0, _lib.as_pd(out)) == _lib.BADARG
+    kkt.close()
+    kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb, rank=0, nranks=2))         # a sharded handle
+    assert L.tlpk_ipm_load(kkt._h, _lib.as_pd(np.ones(m)), _lib.as_pd(v), _lib.as_pd(v), _lib.as_pd(v)) == _lib.BADARG
+    assert b"sharded" in L.tlpk_last_error(kkt._h)
     assert L.tlpk_ipm_factor(kkt._h, 1e-4, 1e-4) == _lib.BADARG
+    kkt.close()
+    kkt = tk.setup(A, tk.K1(), tk.Backend(row_block=rb, ngpus=2, devices=[0, 0]))          # not loaded yet
+    assert L.tlpk_ipm_residuals(kkt._h, 1.0, _lib.as_pd(out)) == _lib.BADARG
+    assert b"tlpk_ipm_load" in L.tlpk_last_error(kkt._h)
+    kkt.close()
+
+
+def _block_angular_lp_data(seed=7, ineq_bounds=False):
+    """A feasible, bounded LP on a block-angular matrix with a known optimal vertex (as tools/solve_c4_lp.py builds it)."""
+    from helpers import block_angular
+    A, rb = block_angular(nblocks=7, mk=120, nk=260, m0=30, nnz_in=3, link_prob=0.5, seed=seed)
+    m, n = A.shape
+    rng = np.random.default_rng(seed)
+    xs = rng.uniform(0.0, 1.0, n) * (rng.random(n) < 0.6)
+    b = A @ xs
+    ys = rng.standard_normal(m)
+    zs = rng.uniform(0.0, 1.0, n) * (xs == 0.0)
+    c = A.T @ ys + zs
+    l = np.zeros(n); u = np.full(n, np.inf)
+    if ineq_bounds:                         # some finite upper bounds and some free variables: every flag pattern
+        u[::5] = xs[::5] + 1.0
+        free = np.arange(3, n, 11); l[free] = -np.inf; c[free] = (A.T @ ys)[free]
+    return A, rb, b, c, l, u, float(c @ xs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["hsd", "mpc"])
+@pytest.mark.parametrize("ineq_bounds", [False, True])
+def test_device_loops_on_a_multi_device_handle(algo, ineq_bounds):
+    """the device-resident loops on a tlpk_create_multi handle.  Every shard holds the sub-LP of its diagonal blocks
+    (own columns with costs and bounds, own block rows, the linking rows with b on the lead), the unchanged kernels produce each shard's
+    share of every sum / maximum / minimum, the host combines them in shard order; KKT solves are split-phase with every shard's
+    partial xi_p on the linking rows; |rp|, |A x| on the linking rows are summed on the host.  Three shards on this box's one GPU must
+    walk the same iterates as the single-device loop: same status and iteration count, objectives / residual measures to 1e-9,
+    solution vectors to 1e-7 (the reductions are re-associated, nothing else differs)."""
+    from tulip_jl_amd.hsd_device import DeviceHSD
+    from tulip_jl_amd.mpc_device import DeviceMPC
+    cls = DeviceHSD if algo == "hsd" else DeviceMPC
+    A, rb, b, c, l, u, zopt = _block_angular_lp_data(ineq_bounds=ineq_bounds)
+    runs = {}
+    for name, kw in (("one", dict(device=0, row_block=rb)), ("three", dict(device=0, row_block=rb, ngpus=3, devices=[0, 0, 0]))):
+        opt = cls(A, b, c, l, u, **kw)
+        opt.optimize()
+        runs[name] = (opt.status, opt.niter, opt.primal_objective, opt.dual_objective, opt.rho, opt._get(0, opt.n), opt._get(5, opt.m), opt._get(3, opt.n),
+                      dict(opt.timers))
+        opt.kkt.close()
+    one, three = runs["one"], runs["three"]
+    print(algo, "one device:", one[:5], "| three shards:", three[:5])
+    assert one[0] == three[0] == "Trm_Optimal"
+    assert one[1] == three[1]
+    assert abs(one[2] - three[2]) <= 1e-9 * (1 + abs(one[2])) and abs(one[3] - three[3]) <= 1e-9 * (1 + abs(one[3]))
+    assert abs(three[2] - zopt) <= 1e-6 * (1 + abs(zopt))
+    assert max(three[4]) <= SQRT_EPS
+    for k in (5, 6, 7):
+        assert np.abs(one[k] - three[k]).max() <= 1e-7 * max(1.0, np.abs(one[k]).max()), k
+    assert one[8]["n_update"] == three[8]["n_update"] and one[8]["n_solve"] == three[8]["n_solve"]
 
 
 def device_hsd(lp, **kw):

@@ -10,6 +10,8 @@ from tulip_jl_amd.hsd_device import DeviceHSD   # noqa: E402
 from tulip_jl_amd.mpc_device import DeviceMPC   # noqa: E402
 from workloads import block_angular_lp   # noqa: E402
 
+NSHARDS = int(os.environ.get("NSHARDS", "1"))       # > 1: one tlpk_create_multi handle, NSHARDS shards -- on this box's single GPU unless DEVICES lists ordinals
+MULTI = dict(ngpus=NSHARDS, devices=[int(d) for d in os.environ.get("DEVICES", ",".join(["0"] * NSHARDS)).split(",")]) if NSHARDS > 1 else {}
 HEADLINE = os.environ.get("HEADLINE") == "1"       # the north-star instance: 100 blocks x (20 000 inequality rows x 10 000 vars) + 1000 linking rows
 A, row_block = block_angular_lp(100, 20000, 10000, 1000, 4, 0.5, ineq=True) if HEADLINE else block_angular_lp()
 m, n = A.shape
@@ -22,7 +24,7 @@ c = A.T @ ys + zs
 l = np.zeros(n); u = np.full(n, np.inf)
 for name, cls in (("HSD", DeviceHSD), ("MPC", DeviceMPC)):
     t0 = time.perf_counter()
-    opt = cls(A, b, c, l, u, device=0, row_block=row_block)
+    opt = cls(A, b, c, l, u, device=0, row_block=row_block, **MULTI)
     t_setup = time.perf_counter() - t0
     t0 = time.perf_counter()
     opt.optimize()

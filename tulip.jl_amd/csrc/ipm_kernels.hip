@@ -112,6 +112,7 @@ __global__ __launch_bounds__(IPM_T) void k_ipm_res_rows(IpmVecs v, double tau, d
         const double rp = tau * v.b[i] - ax;
         v.rp[i] = rp;
         s0 += v.b[i] * v.y[i];
+        if (v.row_skip && v.row_skip[i]) continue;                          // a shard's PARTIAL linking row: the host sums the shards' rows
         m0 = fmax(m0, fabs(rp)); m1 = fmax(m1, fabs(ax));
     }
     double *P = partials + (size_t)blockIdx.x * IPM_SLOTS;

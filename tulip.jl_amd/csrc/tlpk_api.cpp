@@ -470,6 +470,7 @@ void tlpk_destroy(tlpk_handle *h) {
     if (!h->sub.empty() || h->multi_tmp) {                // multi-device parent: owns its per-device handles, nothing else
         if (h->multi_rccl) for (size_t r = 0; r < h->sub.size(); ++r) if (h->multi_comm[r]) multi_comm_destroy(h->multi_comm[r]);
         for (tlpk_handle *c : h->sub) tlpk_destroy(c);
+        ipm_free(h);
         if (h->multi_tmp) { hipSetDevice(h->device); hipFree(h->multi_tmp); }
         if (h->multi_done) hipEventDestroy(h->multi_done);
         for (int r = 0; r < MAX_DEVICES; ++r) if (h->multi_ev[r]) hipEventDestroy(h->multi_ev[r]);
@@ -755,7 +756,7 @@ int tlpk_solve_local(tlpk_handle *h, const double *d_xip, const double *d_xid) {
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     h->solve_epoch += 1;
     if (h->solve_whole) return TLPK_OK;                  // tlpk_solve_device: the caller enqueues both halves (graph)
-    if (int rc = enq_solve_local(h, d_xip, d_xid)) return rc;
+    if (int rc = enq_solve_local(h, d_xip, d_xid, h->rhs_all_ranks ? 0 : -1)) return rc;
     h->solve_local_done = true;
     return TLPK_OK;
 }
@@ -1081,6 +1082,25 @@ void multi_comm_destroy(void *comm) { if (g_rccl.CommDestroy) g_rccl.CommDestroy
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// second half of an update: reduction of the root panel, every shard's root front, the verdict
+int multi_update_tail(tlpk_handle *h, double t_in) {
+    if (int rc = multi_allreduce(h, true)) return rc;
+    for (tlpk_handle *c : h->sub) {                      // every root front is enqueued before anybody waits
+        const int rc = update_finish_enqueue(c);
+        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    }
+    h->ms_enqueue_update = now_ms() - t_in;
+    int worst = TLPK_OK; h->fail_col = -1;
+    for (tlpk_handle *c : h->sub) {
+        const int rc = update_finish_wait(c);
+        if (rc == TLPK_NOT_POSDEF) { if (h->fail_col < 0 || c->fail_col < h->fail_col) h->fail_col = c->fail_col; if (worst == TLPK_OK) worst = rc; }
+        else if (rc != TLPK_OK) { h->last_error = c->last_error; worst = rc; }
+    }
+    h->ms_update = now_ms() - t_in;
+    h->factored = (worst == TLPK_OK);
+    return worst;
+}
+
 int multi_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
     tlpk_handle *lead = h->sub[0];
     const i64 n = h->S.n, m = h->S.m;
@@ -1100,21 +1120,7 @@ int multi_update(tlpk_handle *h, const double *theta, const double *regP, const 
         const int rc = tlpk_update_local(c, c->d_theta, c->d_regP, c->d_regD);
         if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
     }
-    if (int rc = multi_allreduce(h, true)) return rc;
-    for (tlpk_handle *c : h->sub) {                      // every root front is enqueued before anybody waits
-        const int rc = update_finish_enqueue(c);
-        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
-    }
-    h->ms_enqueue_update = now_ms() - t_in;
-    int worst = TLPK_OK; h->fail_col = -1;
-    for (tlpk_handle *c : h->sub) {
-        const int rc = update_finish_wait(c);
-        if (rc == TLPK_NOT_POSDEF) { if (h->fail_col < 0 || c->fail_col < h->fail_col) h->fail_col = c->fail_col; if (worst == TLPK_OK) worst = rc; }
-        else if (rc != TLPK_OK) { h->last_error = c->last_error; worst = rc; }
-    }
-    h->ms_update = now_ms() - t_in;
-    h->factored = (worst == TLPK_OK);
-    return worst;
+    return multi_update_tail(h, t_in);
 }
 
 int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const double *xi_d) {
@@ -1204,6 +1210,36 @@ void shard_ranges(tlpk_handle *c) {
 }
 
 }  // namespace
+
+// ---- the two KKT calls of the device-resident interior-point loops on a multi-device handle (tlpk_ipm.cpp) ----
+extern "C++" {
+int multi_update_resident(tlpk_handle *h) {
+    const double t_in = now_ms();
+    for (tlpk_handle *c : h->sub) {
+        const int rc = tlpk_update_local(c, c->d_theta, c->d_regP, c->d_regD);
+        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    }
+    return multi_update_tail(h, t_in);
+}
+int multi_solve_resident(tlpk_handle *h, double *const *dx, double *const *dy, const double *const *xip, const double *const *xid) {
+    if (!h->factored) return TLPK_NOT_FACTORED;
+    for (size_t r = 0; r < h->sub.size(); ++r) {
+        tlpk_handle *c = h->sub[r];
+        c->rhs_all_ranks = true;                         // every shard's xi_p counts on the linking rows (partial residuals)
+        const int rc = tlpk_solve_local(c, xip[r], xid[r]);
+        c->rhs_all_ranks = false;
+        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    }
+    if (int rc = multi_allreduce(h, false)) return rc;
+    for (size_t r = 0; r < h->sub.size(); ++r) {
+        tlpk_handle *c = h->sub[r];
+        c->shared_dy = nullptr; c->dx_local_only = false;                  // the solution stays shard-resident
+        const int rc = tlpk_solve_finish(c, dx[r], dy[r], xid[r]);
+        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    }
+    return TLPK_OK;
+}
+}  // extern "C++"
 
 int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, const double *nzval,
                       int index_base, const tlpk_options *uopt, int ngpus, const int32_t *devices) {

@@ -64,6 +64,7 @@ struct tlpk_handle {
     i64 col_lo = 0, col_hi = 0, row_lo = 0, row_hi = 0, link_lo = 0, link_hi = 0;   // child: slices of the job-wide input vectors it reads
     double *shared_dy = nullptr;        // child: job-wide dy on the lead device (P2P), filled with the rows this rank owns
     bool dx_local_only = false;         // child: dx is the job-wide vector, leave the other ranks' columns alone
+    bool rhs_all_ranks = false;         // child, device-resident IPM: this solve adds the shard's xi_p on the linking rows whatever its rank
     // hipGraph replay of the static schedules (tlpk_api.cpp: graph_or_direct): instantiated graphs and their keys
     bool use_graph = true;              // TLPK_GRAPH=0 turns it off; switched off for good if capture fails on this system
     bool force_graph = false;           // TLPK_GRAPH=2: also for schedules with concurrent stream groups
@@ -75,6 +76,11 @@ struct tlpk_handle {
 };
 
 void ipm_free(tlpk_handle *h);          // tlpk_ipm.cpp
+// tlpk_api.cpp, for the device-resident interior-point loops on a multi-device handle: KKT.update! from the theta / regP / regD every
+// shard holds on its device, and KKT.solve! with shard-resident vectors in the rank-local layout (every shard adds ITS xi_p on the
+// linking rows -- partial residuals --, the library's reduction completes them; nothing is gathered)
+int multi_update_resident(tlpk_handle *h);
+int multi_solve_resident(tlpk_handle *h, double *const *dx, double *const *dy, const double *const *xip, const double *const *xid);
 
 
 

@@ -28,6 +28,7 @@ struct IpmVecs {
     double *hxid;                                         // its right-hand side c - th_l lz - th_u uz (own vector: the h-system and the
                                                           // predictor are solved as a pair, tlpk_ipm_hsolve_newton)
     double *xil, *xiu, *xzl, *xzu, *xid, *xip;            // right-hand sides of the current Newton system
+    const char *row_skip;                                 // shard of a multi-device handle: 1 on the linking rows (partial sums there: no part in the maxima); else nullptr
 };
 
 void ipm_launch_init(hipStream_t st, const IpmVecs &v);
