@@ -41,7 +41,8 @@ typedef struct tlpk_handle tlpk_handle;
 #define TLPK_SYSTEM_K1 0     /* normal equations  A D A' + Rd, Cholesky            (Cholmod/spd.jl) */
 #define TLPK_SYSTEM_K2 1     /* augmented system [-(Theta^-1+Rp) A'; A Rd], signed Cholesky L S L' = the LDL' of a
                                 quasi-definite matrix without pivoting (Cholmod/sqd.jl, LDLFactorizations/ldlfact.jl);
-                                single GPU (nranks = 1); row_block gives per-block ordering, stream groups and a root front */
+                                row_block gives per-block ordering, stream groups and a root front; sharded / multi-device handles
+                                replicate the root front (pivots of both signs), its assembled entries come from rank 0 */
 
 /* ordering selector */
 #define TLPK_ORDER_AMD 0
@@ -223,7 +224,14 @@ int tlpk_get_factor(tlpk_handle *h, double *lval, int64_t cap);
  * solve and leaves every right-hand side to the host; here one call runs one routine of
  * /root/reference/src/IPM/HSD/{HSD.jl, step.jl} on device vectors owned by the handle and returns only
  * scalars.  The host keeps tau, kappa, the regularisation scalars and the control flow
- * (tulip.jl_amd/hsd_device.py mirrors HSD.jl:203-350).  Single-rank handles only.
+ * (tulip.jl_amd/hsd_device.py mirrors HSD.jl:203-350).
+ * Handles: one rank (K1 or K2), or a tlpk_create_multi handle (K1).  On several devices every shard holds the sub-LP of its
+ * diagonal blocks in vectors of the job's length (its columns with costs and bounds, its block rows of b, the linking rows with b
+ * on the lead shard and A restricted to its columns): the same kernels then produce each shard's share of every sum / maximum /
+ * minimum, the host combines them in shard order, the KKT solves run split-phase with every shard's partial xi_p on the linking
+ * rows (the library's reduction of the root right-hand side completes them), and |rp|inf, |A x|inf on the linking rows come from
+ * the shards' partial rows summed on the host.  The iterates equal the single-device ones up to the re-association of those
+ * sums.  Sharded handles (nranks > 1) are refused: their reductions belong to the caller.
  * --------------------------------------------------------------------------------------------- */
 /* b (m), c (n), l, u (n; +-Inf allowed) of the standard form (ipmdata.jl:64-173); sets the HSD starting point
  * (HSD.jl:238-247).  tlpk_ipm_reset restores the starting point. */
