@@ -578,15 +578,27 @@ __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restri
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
+#ifdef POTRF_TRACE   /* tools/potrf_trace.py: time stamps (100 MHz) of the phases, stored in the never-read block above the second diagonal block */
+    double *trace = c.Lval + fd.loff + (i64)(k0 + NB_IN) * fd.lda + k0;
+    int tslot = 0;
+#define PTRACE() do { __syncthreads(); if (threadIdx.x == 0 && w == NB_OUT) trace[tslot] = (double)wall_clock64(); ++tslot; } while (0)
+#else
+#define PTRACE() do { } while (0)
+#endif
+    PTRACE();
     potrf_block<SIGNED>(c, fd, k0, min(w, NB_IN), k0, Ws);
+    PTRACE();
     for (i32 ks = k0; ks + NB_IN < kend; ks += NB_IN) {          // step ks is factored: rows below, next diagonal block
         for (i32 r0 = ks + NB_IN; r0 < kend; r0 += NB_IN) {
             __syncthreads();                                     // own global stores visible, Ws free
             trsm_rows<SIGNED>(c, fd, ks, NB_IN, r0, kend, k0, Ws);
+            PTRACE();
         }
         __syncthreads();
         potrf_block<SIGNED>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
+        PTRACE();
     }
+#undef PTRACE
 }
 
 // Rows below the diagonal block of a block column: X = B * L11^{-T} for the whole (<= 256 wide)
