@@ -25,5 +25,6 @@ timeout 600 python bench.py --workload c3 --c3-rows 50000 --steps 3 --warmup 1 -
 NLIST=1,2,4,8 timeout 600 python tools/rank_local_timing.py > gpurun_out/r03_rank_local_timing.txt 2>&1
 timeout 300 python tools/solve_c4_lp.py > gpurun_out/r03_c4_lp_end_to_end.txt 2>&1
 HEADLINE=1 timeout 400 python tools/solve_c4_lp.py > gpurun_out/r03_headline_lp_end_to_end.txt 2>&1
+NSHARDS=2 timeout 400 python tools/solve_c4_lp.py > gpurun_out/r03_c4_lp_two_shards_one_gpu.txt 2>&1
 rm -rf gpurun_out/r03_prof_serial gpurun_out/r03_prof_concurrent gpurun_out/r03_pmc_c4_* gpurun_out/r03_pmc_headline_* gpurun_out/r03_pmc_mfma
 tail -3 gpurun_out/r03_rank_local_timing.txt; cat gpurun_out/r03_pmc_to_json.log; head -c 400 gpurun_out/r03_final_bench.json
