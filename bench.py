@@ -258,13 +258,14 @@ def main():
         d_dy = torch.empty(m, dtype=torch.float64, device=dev)
         d_dx2 = torch.empty(n, dtype=torch.float64, device=dev)
         d_dy2 = torch.empty(m, dtype=torch.float64, device=dev)
-        pair = (not args.unpaired) and args.solves >= 2 and not split
-        root_t = rhs_t = None
-        if split:                             # torch-owned buffers for the two collectives
+        pair = (not args.unpaired) and args.solves >= 2
+        root_t = rhs_t = rhs2_t = None
+        if split:                             # torch-owned buffers for the collectives
             _, c = kkt.root_panel()
             root_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
             _, c = kkt.root_rhs()
             rhs_t = torch.empty(c, dtype=torch.float64, device=dev) if c else None
+            rhs2_t = torch.empty(2 * c, dtype=torch.float64, device=dev) if c else None      # the two root right-hand sides of a pair: ONE all-reduce
         lib_streams = {}                      # handle -> torch view of the library's main stream of THAT handle
 
         def reduce_root(k, which, buf):
@@ -283,6 +284,22 @@ def main():
             lib_stream.wait_event(ev2)
             k.root_copy(which, "in", P(buf))
 
+        def reduce_pair(k, buf):
+            # the pair's two root right-hand sides travel in one buffer: one collective instead of two
+            if buf is None:
+                return
+            lib_stream = lib_streams.get(id(k))
+            if lib_stream is None:
+                lib_stream = lib_streams[id(k)] = torch.cuda.ExternalStream(k.stream_ptr(), device=dev)
+            half = buf.numel() // 2
+            k.root_copy("rhs", "out", P(buf)); k.root_copy("rhs2", "out", P(buf) + 8 * half)
+            ev = torch.cuda.Event(); ev.record(lib_stream)
+            torch.cuda.current_stream().wait_event(ev)
+            dist.all_reduce(buf)
+            ev2 = torch.cuda.Event(); ev2.record(torch.cuda.current_stream())
+            lib_stream.wait_event(ev2)
+            k.root_copy("rhs", "in", P(buf)); k.root_copy("rhs2", "in", P(buf) + 8 * half)
+
         def newton_step(k, paired=None):
             paired = pair if paired is None else paired
             if not split:
@@ -298,7 +315,11 @@ def main():
                 k.update_local(P(d_th), P(d_rp), P(d_rd))
                 reduce_root(k, "panel", root_t)
                 k.update_finish()
-                for _ in range(args.solves):
+                if paired:    # the same pair, split around ONE all-reduce of both root right-hand sides
+                    k.solve2_local(P(d_xp), P(d_xd), P(d_xp), P(d_xd))
+                    reduce_pair(k, rhs2_t)
+                    k.solve2_finish(P(d_dx2), P(d_dy2), P(d_xd), P(d_dx), P(d_dy), P(d_xd))
+                for _ in range(args.solves - (2 if paired else 0)):
                     k.solve_local(P(d_xp), P(d_xd))
                     reduce_root(k, "rhs", rhs_t)
                     k.solve_finish(P(d_dx), P(d_dy), P(d_xd))
@@ -433,7 +454,7 @@ def main():
                                "pcie_bytes_per_step": 8 * (2 * n + m) + args.solves * 16 * (m + n),
                                "note": "tlpk_update + %d x tlpk_solve with pageable host vectors through pinned staging; "
                                        "PCIe-inclusive, never reported as `value`" % args.solves}
-        if pair and world == 1:
+        if pair and world == 1 and not split:
             # the same step with every right-hand side solved on its own (the round-2 definition of the step), for comparison
             def unpaired_step():          # the round-2 definition of the step: blocking update!, four single solves
                 kkt.update_device(P(d_th), P(d_rp), P(d_rd))

@@ -170,6 +170,12 @@ int tlpk_update_finish(tlpk_handle *h);
 int tlpk_solve_local(tlpk_handle *h, const double *d_xi_p, const double *d_xi_d);
 int tlpk_root_rhs(tlpk_handle *h, double **d_ptr, int64_t *count);
 int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xi_d);
+/* The pair of tlpk_solve2_device in split-phase form (two right-hand sides, one pass over this rank's part of the factor):
+ *   tlpk_solve2_local -> allreduce(sum) of tlpk_root_rhs AND of tlpk_root_rhs2 -> tlpk_solve2_finish
+ * (the two root right-hand sides are separate buffers of tlpk_root_rhs's length).  Bit-identical to two split solves. */
+int tlpk_solve2_local(tlpk_handle *h, const double *d_xi_p0, const double *d_xi_d0, const double *d_xi_p1, const double *d_xi_d1);
+int tlpk_root_rhs2(tlpk_handle *h, double **d_ptr, int64_t *count);
+int tlpk_solve2_finish(tlpk_handle *h, double *d_dx0, double *d_dy0, const double *d_xi_d0, double *d_dx1, double *d_dy1, const double *d_xi_d1);
 /* Iterative refinement on a sharded handle (K1), one step = one more split solve on the residuals of the augmented system
  * (the equations of /root/reference/src/KKT/KKT.jl:70-75; the reference leaves refinement as a TODO, src/KKT/Cholmod/spd.jl:68):
  *   tlpk_refine_local(h, dx, dy, xi_p, xi_d) -> allreduce(sum) of tlpk_root_rhs -> tlpk_refine_finish(h, dx, dy)
@@ -181,7 +187,7 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
  * refinement step of tlpk_solve_device. */
 int tlpk_refine_local(tlpk_handle *h, const double *d_dx, const double *d_dy, const double *d_xi_p, const double *d_xi_d);
 int tlpk_refine_finish(tlpk_handle *h, double *d_dx, double *d_dy);
-/* Copy the root panel (which = 0) or root rhs (which = 1) out of (dir = 0) / into (dir = 1) a
+/* Copy the root panel (which = 0), the root rhs (which = 1) or the second root rhs of a pair (which = 2) out of (dir = 0) / into (dir = 1) a
  * caller-owned device buffer, on the handle's stream -- for callers whose communicator wants to
  * own the memory it reduces (torch.distributed tensors). */
 int tlpk_root_copy(tlpk_handle *h, int which, int dir, double *d_buf);

@@ -84,6 +84,26 @@ def main():
         dy_link = dy[link].numpy().copy()
         dy = torch.where(link, dy / world, dy)
         dist.all_reduce(dx); dist.all_reduce(dy)
+        # a PAIR of solves in one pass over this rank's factor (tlpk_solve2_local -> all-reduce of BOTH root right-hand sides ->
+        # tlpk_solve2_finish): bit-identical to two split solves with the same reduction
+        xp2 = torch.from_numpy(xp[::-1].copy()).to(dev); xd2 = torch.from_numpy(xd[::-1].copy()).to(dev)
+        s_dx = torch.empty_like(d_dx); s_dy = torch.empty_like(d_dy)
+        kkt.solve_local(P(xp2), P(xd2)); kkt.sync()
+        allreduce_device("rhs", kkt.root_rhs()[1])
+        kkt.solve_finish(P(s_dx), P(s_dy), P(xd2)); kkt.sync()
+        p_dx = [torch.empty_like(d_dx) for _ in range(2)]; p_dy = [torch.empty_like(d_dy) for _ in range(2)]
+        kkt.solve2_local(P(d[3]), P(d[4]), P(xp2), P(xd2)); kkt.sync()
+        allreduce_device("rhs", kkt.root_rhs()[1])
+        allreduce_device("rhs2", kkt.root_rhs2()[1])
+        kkt.solve2_finish(P(p_dx[0]), P(p_dy[0]), P(d[4]), P(p_dx[1]), P(p_dy[1]), P(xd2)); kkt.sync()
+        assert torch.equal(p_dx[0], d_dx) and torch.equal(p_dy[0], d_dy), "pair, first system"
+        assert torch.equal(p_dx[1], s_dx) and torch.equal(p_dy[1], s_dy), "pair, second system"
+        try:
+            kkt.solve2_finish(P(p_dx[0]), P(p_dy[0]), P(d[4]), P(p_dx[1]), P(p_dy[1]), P(xd2))
+        except tk.DimensionMismatch as e:
+            assert "tlpk_solve2_local" in str(e)
+        else:
+            raise AssertionError("solve2_finish without solve2_local did not fail")
         # one iterative-refinement step, split like the solve: residuals rank by rank (partial sums on the linking rows), the
         # reduction of the root right-hand side completes them
         kkt.refine_local(P(d_dx), P(d_dy), P(d[3]), P(d[4]))

@@ -695,6 +695,14 @@ def test_two_right_hand_sides_in_one_pass_equal_two_solves_bitwise(kind):
     assert eq(out[2], out[4]) and eq(out[3], out[5]) and eq(out[0], out[6]) and eq(out[1], out[7])
     kkt.solve_device(P(out[4]), P(out[5]), P(d_xp), P(d_xd))                                                   # and a single solve again
     assert eq(out[0], out[4]) and eq(out[1], out[5])
+    if kind != "small_fronts_only":
+        # the same pair in two halves (tlpk_solve2_local / tlpk_solve2_finish; one rank: nothing to reduce in between)
+        kkt.solve2_local(P(d_xp), P(d_xd), P(d_xp1), P(d_xd1))
+        kkt.solve2_finish(P(out[4]), P(out[5]), P(d_xd), P(out[6]), P(out[7]), P(d_xd1))
+        kkt.sync()
+        for a, b in ((0, 4), (1, 5), (2, 6), (3, 7)):
+            assert eq(out[a], out[b]), (kind, "split pair", a)
+        assert kkt.root_rhs2()[1] == kkt.root_rhs()[1]
     dx, dy = out[2].get(), out[3].get()
     r1, r2 = kkt_residuals(A, th, rp, rd, xp1, xd1, dx, dy)
     assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp1).max(), np.abs(xd1).max()))

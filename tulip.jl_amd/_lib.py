@@ -65,7 +65,7 @@ EXPORTS = [
     "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get",
     "tlpk_mpc_start", "tlpk_mpc_newton", "tlpk_mpc_gap", "tlpk_mpc_targets", "tlpk_mpc_advance",
     "tlpk_detect_blocks", "tlpk_solve2_device", "tlpk_ipm_hsolve_newton", "tlpk_update_device_async", "tlpk_ipm_factor_hsolve_newton",
-    "tlpk_refine_local", "tlpk_refine_finish",
+    "tlpk_refine_local", "tlpk_refine_finish", "tlpk_solve2_local", "tlpk_root_rhs2", "tlpk_solve2_finish",
 ]
 
 
@@ -108,6 +108,12 @@ def lib():
     L.tlpk_refine_local.restype = C.c_int
     L.tlpk_refine_finish.argtypes = [vp, vp, vp]
     L.tlpk_refine_finish.restype = C.c_int
+    L.tlpk_solve2_local.argtypes = [vp, vp, vp, vp, vp]
+    L.tlpk_solve2_local.restype = C.c_int
+    L.tlpk_root_rhs2.argtypes = [vp, C.POINTER(vp), p64]
+    L.tlpk_root_rhs2.restype = C.c_int
+    L.tlpk_solve2_finish.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.tlpk_solve2_finish.restype = C.c_int
     L.tlpk_root_copy.argtypes = [vp, C.c_int, C.c_int, vp]
     L.tlpk_root_copy.restype = C.c_int
     L.tlpk_info.argtypes = [vp, C.POINTER(Stats)]

@@ -570,10 +570,10 @@ int tlpk_root_panel(tlpk_handle *h, double **d_ptr, int64_t *count) {
 }
 
 int tlpk_root_copy(tlpk_handle *h, int which, int dir, double *d_buf) {
-    if (!h || !d_buf || (which != 0 && which != 1) || (dir != 0 && dir != 1)) return TLPK_BADARG;
+    if (!h || !d_buf || which < 0 || which > 2 || (dir != 0 && dir != 1)) return TLPK_BADARG;
     if (!h->has_device) return TLPK_NO_DEVICE;
     double *p = nullptr; int64_t n = 0;
-    int rc = which == 0 ? tlpk_root_panel(h, &p, &n) : tlpk_root_rhs(h, &p, &n);
+    int rc = which == 0 ? tlpk_root_panel(h, &p, &n) : (which == 1 ? tlpk_root_rhs(h, &p, &n) : tlpk_root_rhs2(h, &p, &n));
     if (rc != TLPK_OK || n == 0) return rc;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(dir == 0 ? d_buf : p, dir == 0 ? p : d_buf, (size_t)n * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -775,7 +775,7 @@ int tlpk_solve_finish(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (!h->factored) return TLPK_NOT_FACTORED;
-    if (!h->solve_local_done || h->refine_pending) { h->last_error = "tlpk_solve_finish without a preceding tlpk_solve_local"; return TLPK_BADARG; }
+    if (!h->solve_local_done || h->refine_pending || h->pair_pending) { h->last_error = "tlpk_solve_finish without a preceding tlpk_solve_local"; return TLPK_BADARG; }
     h->solve_local_done = false;
     HIPCHK(h, hipSetDevice(h->device));
     if (int rc = enq_solve_finish(h, d_dx, d_dy, d_xid)) return rc;
@@ -871,6 +871,42 @@ int tlpk_refine_finish(tlpk_handle *h, double *d_dx, double *d_dy) {
     return TLPK_OK;
 }
 
+// the two halves of a PAIR of solves (two right-hand sides in one pass over L), split like enq_solve_local / enq_solve_finish at the
+// reduction of the root right-hand sides (two of them: tlpk_root_rhs and tlpk_root_rhs2)
+static int enq_solve2_local(tlpk_handle *h, const double *const *xip, const double *const *xid, int rhs_rank) {
+    const bool k2 = h->S.system == 1;
+    const int rank = rhs_rank >= 0 ? rhs_rank : h->opt.rank;
+    {
+        ProfScope ps(h, TLPK_KC_SPMV);
+        if (h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes2, h->stream));
+        for (int r = 0; r < 2; ++r) {
+            if (k2) launch_k2_rhs(h->stream, h->d, h->S.k2_n, xip[r], xid[r], r, rank);
+            else launch_rhs(h->stream, h->d, h->d_D, xip[r], xid[r], rank, r);
+            launch_single_solve(h->stream, h->d, r);
+        }
+    }
+    run_launches(h, h->S.fwd_launches, 0, h->fwd_marker, 0, 2);
+    HIPCHK(h, hipGetLastError());
+    return TLPK_OK;
+}
+static int enq_solve2_finish(tlpk_handle *h, double *const *dx, double *const *dy, const double *const *xid) {
+    const bool k2 = h->S.system == 1;
+    if (h->root_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_root, 0));      // the root front is being factorised on its own stream
+    run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size(), 0, 2);
+    if (k2) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d, 0); launch_apply_signs(h->stream, h->d, 1); }
+    run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1, 2);
+    for (int r = 0; r < 2; ++r) {
+        ProfScope ps(h, TLPK_KC_SPMV);
+        if (k2) launch_k2_out(h->stream, h->d, h->S.k2_n, dx[r], dy[r], r, h->opt.rank, 0);
+        else {
+            launch_unpermute(h->stream, h->d, dy[r], nullptr, h->opt.rank, r);
+            launch_dx(h->stream, h->d, h->d_D, dy[r], xid[r], dx[r], 0);
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_info + 1, h->d.ctx.info + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    return TLPK_OK;
+}
+
 // Two right-hand sides against the same factor in ONE pass over L (the persistent sweeps are bound by the bytes of L: the
 // pair costs little more than one solve).  Tulip's HSD step has such a pair in every iteration: the h-system and the predictor
 // (/root/reference/src/IPM/HSD/step.jl:63 and :79 -- neither right-hand side depends on the other solve).  Results are bit-identical
@@ -890,38 +926,58 @@ int tlpk_solve2_device(tlpk_handle *h, double *d_dx0, double *d_dy0, const doubl
     prof_begin(h, false);
     h->solve_timed = false;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    const bool k2 = h->S.system == 1;
     const double *xip[2] = {d_xip0, d_xip1}, *xid[2] = {d_xid0, d_xid1};
     double *dx[2] = {d_dx0, d_dx1}, *dy[2] = {d_dy0, d_dy1};
     h->solve_epoch += 1;
     const GraphKey key{3, {d_dx0, d_dy0, d_xip0, d_xid0, d_dx1, d_dy1, d_xip1, d_xid1}};
     const int grc = graph_or_direct(h, key, [&]() -> int {
-    {
-        ProfScope ps(h, TLPK_KC_SPMV);
-        if (h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes2, h->stream));
-        for (int r = 0; r < 2; ++r) {
-            if (k2) launch_k2_rhs(h->stream, h->d, h->S.k2_n, xip[r], xid[r], r);
-            else launch_rhs(h->stream, h->d, h->d_D, xip[r], xid[r], h->opt.rank, r);
-            launch_single_solve(h->stream, h->d, r);
-        }
-    }
-    run_launches(h, h->S.fwd_launches, 0, h->fwd_marker, 0, 2);
-    if (h->root_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_root, 0));      // the root front is being factorised on its own stream
-    run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size(), 0, 2);
-    if (k2) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d, 0); launch_apply_signs(h->stream, h->d, 1); }
-    run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1, 2);
-    for (int r = 0; r < 2; ++r) {
-        ProfScope ps(h, TLPK_KC_SPMV);
-        if (k2) launch_k2_out(h->stream, h->d, h->S.k2_n, dx[r], dy[r], r);
-        else {
-            launch_unpermute(h->stream, h->d, dy[r], nullptr, h->opt.rank, r);
-            launch_dx(h->stream, h->d, h->d_D, dy[r], xid[r], dx[r], 0);
-        }
-    }
-    HIPCHK(h, hipMemcpyAsync(h->h_info + 1, h->d.ctx.info + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    return TLPK_OK;
+        const int q = enq_solve2_local(h, xip, xid, -1);
+        return q != TLPK_OK ? q : enq_solve2_finish(h, dx, dy, xid);
     });
     if (grc != TLPK_OK) return grc;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->solve_timed = true;
+    return TLPK_OK;
+}
+
+// The pair in two halves, for sharded handles: tlpk_solve2_local -> all-reduce of tlpk_root_rhs AND tlpk_root_rhs2 (the root right-hand
+// sides of the two systems; one collective over both buffers if the communicator allows) -> tlpk_solve2_finish.
+int tlpk_solve2_local(tlpk_handle *h, const double *d_xip0, const double *d_xid0, const double *d_xip1, const double *d_xid1) {
+    if (!h || !d_xip0 || !d_xid0 || !d_xip1 || !d_xid1) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (!h->factored) return TLPK_NOT_FACTORED;
+    if (!h->S.sweep) { h->last_error = "tlpk_solve2_local needs the persistent-sweep schedule (TLPK_SWEEP=0 is set)"; return TLPK_BADARG; }
+    if (h->solve_local_done) { h->last_error = "tlpk_solve2_local inside an unfinished solve"; return TLPK_BADARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    prof_begin(h, false);
+    h->solve_timed = false;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    h->solve_epoch += 1;
+    const double *xip[2] = {d_xip0, d_xip1}, *xid[2] = {d_xid0, d_xid1};
+    if (int rc = enq_solve2_local(h, xip, xid, h->rhs_all_ranks ? 0 : -1)) return rc;
+    h->solve_local_done = true; h->pair_pending = true;
+    return TLPK_OK;
+}
+int tlpk_root_rhs2(tlpk_handle *h, double **d_ptr, int64_t *count) {
+    if (!h || !d_ptr || !count) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    *d_ptr = h->nlink ? h->d.ctx.xw + h->d.ctx.xw2 + h->first_link : nullptr;
+    *count = h->nlink;
+    return TLPK_OK;
+}
+int tlpk_solve2_finish(tlpk_handle *h, double *d_dx0, double *d_dy0, const double *d_xid0, double *d_dx1, double *d_dy1, const double *d_xid1) {
+    if (!h || !d_dx0 || !d_dy0 || !d_xid0 || !d_dx1 || !d_dy1 || !d_xid1) return TLPK_BADARG;
+    if (!h->sub.empty()) { h->last_error = "multi-device handle: only tlpk_update / tlpk_solve / tlpk_info / tlpk_destroy apply"; return TLPK_BADARG; }
+    if (!h->has_device) return TLPK_NO_DEVICE;
+    if (!h->solve_local_done || !h->pair_pending) { h->last_error = "tlpk_solve2_finish without a preceding tlpk_solve2_local"; return TLPK_BADARG; }
+    h->solve_local_done = false; h->pair_pending = false;
+    HIPCHK(h, hipSetDevice(h->device));
+    double *dx[2] = {d_dx0, d_dx1}, *dy[2] = {d_dy0, d_dy1};
+    const double *xid[2] = {d_xid0, d_xid1};
+    if (int rc = enq_solve2_finish(h, dx, dy, xid)) return rc;
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
     h->solve_timed = true;
@@ -1017,13 +1073,17 @@ struct Rccl {
 Rccl g_rccl;
 constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0;          // rccl.h: ncclFloat64 = 8, ncclSum = 0
 
-int multi_allreduce_rccl(tlpk_handle *h, bool panel) {
+// which: 0 root panel, 1 root right-hand side, 2 root right-hand side of the second system of a pair
+int root_buf(tlpk_handle *c, int which, double **p, int64_t *cnt) {
+    return which == 0 ? tlpk_root_panel(c, p, cnt) : (which == 1 ? tlpk_root_rhs(c, p, cnt) : tlpk_root_rhs2(c, p, cnt));
+}
+int multi_allreduce_rccl(tlpk_handle *h, int which) {
     const int N = (int)h->sub.size();
     int rc = g_rccl.GroupStart();
     for (int r = 0; r < N && rc == 0; ++r) {
         tlpk_handle *c = h->sub[r];
         double *p = nullptr; int64_t cnt = 0;
-        const int q = panel ? tlpk_root_panel(c, &p, &cnt) : tlpk_root_rhs(c, &p, &cnt);
+        const int q = root_buf(c, which, &p, &cnt);
         if (q != TLPK_OK) { g_rccl.GroupEnd(); return q; }
         if (cnt == 0) { g_rccl.GroupEnd(); return TLPK_OK; }
         HIPCHK(h, hipSetDevice(c->device));
@@ -1037,17 +1097,17 @@ int multi_allreduce_rccl(tlpk_handle *h, bool panel) {
     return TLPK_OK;
 }
 
-int multi_allreduce(tlpk_handle *h, bool panel) {
-    if (h->multi_rccl) return multi_allreduce_rccl(h, panel);
+int multi_allreduce(tlpk_handle *h, int which) {
+    if (h->multi_rccl) return multi_allreduce_rccl(h, which);
     tlpk_handle *lead = h->sub[0];
     double *p0 = nullptr; int64_t cnt = 0;
-    int rc = panel ? tlpk_root_panel(lead, &p0, &cnt) : tlpk_root_rhs(lead, &p0, &cnt);
+    int rc = root_buf(lead, which, &p0, &cnt);
     if (rc != TLPK_OK || cnt == 0) return rc;
     const int N = (int)h->sub.size();
     for (int r = 1; r < N; ++r) {                        // gather: every peer sends on its own stream, after its local work
         tlpk_handle *c = h->sub[r];
         double *pr = nullptr; int64_t cr = 0;
-        rc = panel ? tlpk_root_panel(c, &pr, &cr) : tlpk_root_rhs(c, &pr, &cr);
+        rc = root_buf(c, which, &pr, &cr);
         if (rc != TLPK_OK || cr != cnt) { h->last_error = "root buffers of the ranks differ"; return TLPK_INTERNAL; }
         HIPCHK(h, hipSetDevice(c->device));
         HIPCHK(h, hipMemcpyPeerAsync(h->multi_tmp + (size_t)(r - 1) * (size_t)cnt, lead->device, pr, c->device, (size_t)cnt * 8, c->stream));
@@ -1065,7 +1125,7 @@ int multi_allreduce(tlpk_handle *h, bool panel) {
     for (int r = 1; r < N; ++r) {                        // copy back, on the peer's stream
         tlpk_handle *c = h->sub[r];
         double *pr = nullptr; int64_t cr = 0;
-        rc = panel ? tlpk_root_panel(c, &pr, &cr) : tlpk_root_rhs(c, &pr, &cr);
+        rc = root_buf(c, which, &pr, &cr);
         HIPCHK(h, hipSetDevice(c->device));
         HIPCHK(h, hipStreamWaitEvent(c->stream, h->multi_done, 0));
         HIPCHK(h, hipMemcpyPeerAsync(pr, c->device, red, lead->device, (size_t)cnt * 8, c->stream));
@@ -1084,7 +1144,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 // second half of an update: reduction of the root panel, every shard's root front, the verdict
 int multi_update_tail(tlpk_handle *h, double t_in) {
-    if (int rc = multi_allreduce(h, true)) return rc;
+    if (int rc = multi_allreduce(h, 0)) return rc;
     for (tlpk_handle *c : h->sub) {                      // every root front is enqueued before anybody waits
         const int rc = update_finish_enqueue(c);
         if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
@@ -1140,7 +1200,7 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
         const int rc = tlpk_solve_local(c, c->d_xip, c->d_xid);
         if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
     }
-    if (int rc = multi_allreduce(h, false)) return rc;
+    if (int rc = multi_allreduce(h, 1)) return rc;
     if (h->refine_steps > 0) {
         // iterative refinement: every shard keeps its solution rank-local (own columns / block rows, linking rows replicated), each
         // step is one more split solve on the residuals with the same reduction in the middle, and the owned slices are published
@@ -1155,7 +1215,7 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
                 const int rc = tlpk_refine_local(c, c->d_dx, c->d_dy, c->d_xip, c->d_xid);
                 if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
             }
-            if (int rc = multi_allreduce(h, false)) return rc;
+            if (int rc = multi_allreduce(h, 1)) return rc;
             for (tlpk_handle *c : h->sub) {
                 const int rc = tlpk_refine_finish(c, c->d_dx, c->d_dy);
                 if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
@@ -1230,11 +1290,31 @@ int multi_solve_resident(tlpk_handle *h, double *const *dx, double *const *dy, c
         c->rhs_all_ranks = false;
         if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
     }
-    if (int rc = multi_allreduce(h, false)) return rc;
+    if (int rc = multi_allreduce(h, 1)) return rc;
     for (size_t r = 0; r < h->sub.size(); ++r) {
         tlpk_handle *c = h->sub[r];
         c->shared_dy = nullptr; c->dx_local_only = false;                  // the solution stays shard-resident
         const int rc = tlpk_solve_finish(c, dx[r], dy[r], xid[r]);
+        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    }
+    return TLPK_OK;
+}
+// the pair of solves of an HSD iteration (h-system + predictor) in one pass over every shard's factor
+int multi_solve2_resident(tlpk_handle *h, double *const *dx0, double *const *dy0, const double *const *xip0, const double *const *xid0,
+                          double *const *dx1, double *const *dy1, const double *const *xip1, const double *const *xid1) {
+    if (!h->factored) return TLPK_NOT_FACTORED;
+    for (size_t r = 0; r < h->sub.size(); ++r) {
+        tlpk_handle *c = h->sub[r];
+        c->rhs_all_ranks = true;
+        const int rc = tlpk_solve2_local(c, xip0[r], xid0[r], xip1[r], xid1[r]);
+        c->rhs_all_ranks = false;
+        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    }
+    if (int rc = multi_allreduce(h, 1)) return rc;
+    if (int rc = multi_allreduce(h, 2)) return rc;
+    for (size_t r = 0; r < h->sub.size(); ++r) {
+        tlpk_handle *c = h->sub[r];
+        const int rc = tlpk_solve2_finish(c, dx0[r], dy0[r], xid0[r], dx1[r], dy1[r], xid1[r]);
         if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
     }
     return TLPK_OK;

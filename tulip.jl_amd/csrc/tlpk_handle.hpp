@@ -44,7 +44,7 @@ struct tlpk_handle {
     double *d_r1 = nullptr, *d_r2 = nullptr, *d_cx = nullptr, *d_cy = nullptr;   // refinement: residuals and correction
     int *h_info = nullptr;
     double *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-pointer entry points (lazily allocated)
-    bool factored = false, local_done = false, solve_local_done = false, solve_timed = false, refine_pending = false;
+    bool factored = false, local_done = false, solve_local_done = false, solve_timed = false, refine_pending = false, pair_pending = false;
     i64 fail_col = -1;
     double ms_analyse = 0, ms_update = 0, ms_solve = 0;
     tlpk_kernel_times kt{};
@@ -81,6 +81,8 @@ void ipm_free(tlpk_handle *h);          // tlpk_ipm.cpp
 // linking rows -- partial residuals --, the library's reduction completes them; nothing is gathered)
 int multi_update_resident(tlpk_handle *h);
 int multi_solve_resident(tlpk_handle *h, double *const *dx, double *const *dy, const double *const *xip, const double *const *xid);
+int multi_solve2_resident(tlpk_handle *h, double *const *dx0, double *const *dy0, const double *const *xip0, const double *const *xid0,
+                          double *const *dx1, double *const *dy1, const double *const *xip1, const double *const *xid1);
 
 
 

@@ -443,7 +443,7 @@ int tlpk_ipm_factor_hsolve_newton(tlpk_handle *h, double regP, double regD, cons
 
 /* step.jl:56-94 in ONE call: the h-system (step.jl:56-76) and the predictor's Newton system (mode 0 of tlpk_ipm_newton) are
  * independent right-hand sides against the same factor -- they share one pass over L (tlpk_solve2_device: the sweeps are bound by
- * the bytes of L; multi-device handles: two solves).  sc[8] as for tlpk_ipm_newton, except sc[2] = regG (h0 = dot products +
+ * the bytes of L; multi-device handles: the split-phase pair, two reductions of root right-hand sides).  sc[8] as for tlpk_ipm_newton, except sc[2] = regG (h0 = dot products +
  * kappa / tau + regG is formed here).  out[4] = { dtau, dkappa, largest step to the boundary, h0 }.  Same arithmetic as
  * tlpk_ipm_hsolve + tlpk_ipm_newton(mode 0): bit-identical vectors and scalars. */
 int tlpk_ipm_hsolve_newton(tlpk_handle *h, const double *sc, double *out) {
@@ -463,9 +463,14 @@ int tlpk_ipm_hsolve_newton(tlpk_handle *h, const double *sc, double *out) {
         IpmState &s = *h->ipm; const IpmDir &dst = s.D[s.cur];
         rc = tlpk_solve2_device(h, s.v.hx, s.v.hy, s.v.b, s.v.hxid, dst.x, dst.y, s.v.xip, s.v.xid);
     } else {
-        rc = solve_all(h, sh, [](IpmState &s, double *&dx, double *&dy, const double *&xp, const double *&xd) { dx = s.v.hx; dy = s.v.hy; xp = s.v.b; xd = s.v.hxid; });
-        if (rc == TLPK_OK)
-            rc = solve_all(h, sh, [](IpmState &s, double *&dx, double *&dy, const double *&xp, const double *&xd) { dx = s.D[s.cur].x; dy = s.D[s.cur].y; xp = s.v.xip; xd = s.v.xid; });
+        double *dx0[MAX_DEVICES], *dy0[MAX_DEVICES], *dx1[MAX_DEVICES], *dy1[MAX_DEVICES];
+        const double *xp0[MAX_DEVICES], *xd0[MAX_DEVICES], *xp1[MAX_DEVICES], *xd1[MAX_DEVICES];
+        for (int r = 0; r < sh.n; ++r) {
+            IpmState &s = *sh.c[r]->ipm;
+            dx0[r] = s.v.hx; dy0[r] = s.v.hy; xp0[r] = s.v.b; xd0[r] = s.v.hxid;
+            dx1[r] = s.D[s.cur].x; dy1[r] = s.D[s.cur].y; xp1[r] = s.v.xip; xd1[r] = s.v.xid;
+        }
+        rc = multi_solve2_resident(h, dx0, dy0, xp0, xd0, dx1, dy1, xp1, xd1);
     }
     if (rc != TLPK_OK) return rc;
     for (int r = 0; r < sh.n; ++r) {

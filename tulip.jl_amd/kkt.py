@@ -194,6 +194,19 @@ class HIPNormalEquations:
     def solve_finish(self, d_dx, d_dy, d_xid):
         _raise_for(_lib.lib().tlpk_solve_finish(self._h, d_dx, d_dy, d_xid), self._h)
 
+    def solve2_local(self, d_xip0, d_xid0, d_xip1, d_xid1):
+        """First half of a pair of solves on a sharded handle (then: all-reduce root_rhs() and root_rhs2(), solve2_finish)."""
+        _raise_for(_lib.lib().tlpk_solve2_local(self._h, d_xip0, d_xid0, d_xip1, d_xid1), self._h)
+
+    def solve2_finish(self, d_dx0, d_dy0, d_xid0, d_dx1, d_dy1, d_xid1):
+        _raise_for(_lib.lib().tlpk_solve2_finish(self._h, d_dx0, d_dy0, d_xid0, d_dx1, d_dy1, d_xid1), self._h)
+
+    def root_rhs2(self):
+        """(device address, count) of the root right-hand side of the SECOND system of a pair."""
+        p = C.c_void_p(); n = C.c_int64()
+        _raise_for(_lib.lib().tlpk_root_rhs2(self._h, C.byref(p), C.byref(n)), self._h)
+        return p.value, n.value
+
     def refine_local(self, d_dx, d_dy, d_xip, d_xid):
         """First half of one iterative-refinement step on a sharded handle (then: all-reduce root_rhs(), refine_finish)."""
         _raise_for(_lib.lib().tlpk_refine_local(self._h, d_dx, d_dy, d_xip, d_xid), self._h)
@@ -208,8 +221,8 @@ class HIPNormalEquations:
         return (p.value or 0), n.value
 
     def root_copy(self, which, direction, d_buf):
-        """which: 'panel' | 'rhs'; direction: 'out' (library -> d_buf) | 'in'; async on the stream."""
-        rc = _lib.lib().tlpk_root_copy(self._h, 0 if which == "panel" else 1, 0 if direction == "out" else 1, d_buf)
+        """which: 'panel' | 'rhs' | 'rhs2' (second system of a pair); direction: 'out' (library -> d_buf) | 'in'; async on the stream."""
+        rc = _lib.lib().tlpk_root_copy(self._h, {"panel": 0, "rhs": 1, "rhs2": 2}[which], 0 if direction == "out" else 1, d_buf)
         _raise_for(rc, self._h)
 
     def root_rhs(self):
