@@ -231,7 +231,7 @@ int tlpk_get_factor(tlpk_handle *h, double *lval, int64_t cap);
  * /root/reference/src/IPM/HSD/{HSD.jl, step.jl} on device vectors owned by the handle and returns only
  * scalars.  The host keeps tau, kappa, the regularisation scalars and the control flow
  * (tulip.jl_amd/hsd_device.py mirrors HSD.jl:203-350).
- * Handles: one rank (K1 or K2), or a tlpk_create_multi handle (K1).  On several devices every shard holds the sub-LP of its
+ * Handles: one rank, or a tlpk_create_multi handle (K1 or K2 either way).  On several devices every shard holds the sub-LP of its
  * diagonal blocks in vectors of the job's length (its columns with costs and bounds, its block rows of b, the linking rows with b
  * on the lead shard and A restricted to its columns): the same kernels then produce each shard's share of every sum / maximum /
  * minimum, the host combines them in shard order, the KKT solves run split-phase with every shard's partial xi_p on the linking

@@ -28,17 +28,14 @@ def test_ipm_entry_points_fail_loudly_without_device():
 
 
 def test_device_loops_refuse_backends_they_cannot_drive():
-    """The loops need ONE handle for the whole LP: a sharded handle (nranks > 1) leaves its reductions to the caller, and on several
-    GPUs the loops solve the normal equations.  Refused before any handle exists (round-2 advisor finding: a multi-device parent
-    handle once reached tlpk_ipm_* with null device vectors)."""
+    """The loops need ONE handle for the whole LP: a sharded handle (nranks > 1) leaves its reductions to the caller.  Refused before
+    any handle exists (round-2 advisor finding: a multi-device parent handle once reached tlpk_ipm_* with null device vectors)."""
     from tulip_jl_amd.hsd_device import DeviceHSD
     from tulip_jl_amd.mpc_device import DeviceMPC
     A = sp.csc_matrix(np.array([[1.0, 0, 1, 0], [0, 1, 0, 1]]))
     for cls in (DeviceHSD, DeviceMPC):
         with pytest.raises(ValueError, match="nranks must be 1"):
             cls(A, np.ones(2), np.ones(4), np.zeros(4), np.full(4, np.inf), device=0, row_block=np.array([0, 1]), nranks=2)
-        with pytest.raises(ValueError, match="normal equations"):
-            cls(A, np.ones(2), np.ones(4), np.zeros(4), np.full(4, np.inf), device=0, row_block=np.array([0, 1]), ngpus=2, system="K2")
 
 
 @pytest.mark.gpu
@@ -49,11 +46,6 @@ def test_ipm_entry_points_refuse_handles_they_cannot_drive():
     L = _lib.lib()
     v = np.ones(n)
     out = np.zeros(16)
-    kkt = tk.setup(A, tk.K2(), tk.Backend(row_block=rb, ngpus=2, devices=[0, 0]))          # K2 on a multi-device handle
-    assert L.tlpk_ipm_load(kkt._h, _lib.as_pd(np.ones(m)), _lib.as_pd(v), _lib.as_pd(v), _lib.as_pd(v)) == _lib.BADARG
-    assert b"K1 only" in L.tlpk_last_error(kkt._h)
-    assert L.tlpk_ipm_residuals(kkt._h, 1.0, _lib.as_pd(out)) == _lib.BADARG
-    kkt.close()
     kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb, rank=0, nranks=2))         # a sharded handle
     assert L.tlpk_ipm_load(kkt._h, _lib.as_pd(np.ones(m)), _lib.as_pd(v), _lib.as_pd(v), _lib.as_pd(v)) == _lib.BADARG
     assert b"sharded" in L.tlpk_last_error(kkt._h)
@@ -86,33 +78,37 @@ def _block_angular_lp_data(seed=7, ineq_bounds=False):
 @pytest.mark.gpu
 @pytest.mark.parametrize("algo", ["hsd", "mpc"])
 @pytest.mark.parametrize("ineq_bounds", [False, True])
-def test_device_loops_on_a_multi_device_handle(algo, ineq_bounds):
+@pytest.mark.parametrize("system", ["K1", "K2"])
+def test_device_loops_on_a_multi_device_handle(algo, ineq_bounds, system):
     """the device-resident loops on a tlpk_create_multi handle.  Every shard holds the sub-LP of its diagonal blocks
     (own columns with costs and bounds, own block rows, the linking rows with b on the lead), the unchanged kernels produce each shard's
     share of every sum / maximum / minimum, the host combines them in shard order; KKT solves are split-phase with every shard's
-    partial xi_p on the linking rows; |rp|, |A x| on the linking rows are summed on the host.  Three shards on this box's one GPU must
+    partial xi_p on the linking rows; |rp|, |A x| on the linking rows are summed on the host.  K2 (the reference's default system): the
+    replicated root front also holds variable nodes -- they belong to the lead shard's sub-LP.  Three shards on this box's one GPU must
     walk the same iterates as the single-device loop: same status and iteration count, objectives / residual measures to 1e-9,
-    solution vectors to 1e-7 (the reductions are re-associated, nothing else differs)."""
+    solution vectors to 1e-7 (K1) / 1e-5 (K2) (the reductions are re-associated, nothing else differs)."""
     from tulip_jl_amd.hsd_device import DeviceHSD
     from tulip_jl_amd.mpc_device import DeviceMPC
     cls = DeviceHSD if algo == "hsd" else DeviceMPC
     A, rb, b, c, l, u, zopt = _block_angular_lp_data(ineq_bounds=ineq_bounds)
     runs = {}
     for name, kw in (("one", dict(device=0, row_block=rb)), ("three", dict(device=0, row_block=rb, ngpus=3, devices=[0, 0, 0]))):
-        opt = cls(A, b, c, l, u, **kw)
+        opt = cls(A, b, c, l, u, system=system, **kw)
         opt.optimize()
         runs[name] = (opt.status, opt.niter, opt.primal_objective, opt.dual_objective, opt.rho, opt._get(0, opt.n), opt._get(5, opt.m), opt._get(3, opt.n),
                       dict(opt.timers))
         opt.kkt.close()
     one, three = runs["one"], runs["three"]
-    print(algo, "one device:", one[:5], "| three shards:", three[:5])
+    print(algo, system, "one device:", one[:5], "| three shards:", three[:5])
     assert one[0] == three[0] == "Trm_Optimal"
     assert one[1] == three[1]
     assert abs(one[2] - three[2]) <= 1e-9 * (1 + abs(one[2])) and abs(one[3] - three[3]) <= 1e-9 * (1 + abs(one[3]))
     assert abs(three[2] - zopt) <= 1e-6 * (1 + abs(zopt))
     assert max(three[4]) <= SQRT_EPS
+    # vectors: the termination point is only sqrt(eps)-accurate, the quasi-definite K2 factors amplify the re-association more than K1's
+    vtol = 1e-7 if system == "K1" else 1e-5
     for k in (5, 6, 7):
-        assert np.abs(one[k] - three[k]).max() <= 1e-7 * max(1.0, np.abs(one[k]).max()), k
+        assert np.abs(one[k] - three[k]).max() <= vtol * max(1.0, np.abs(one[k]).max()), k
     assert one[8]["n_update"] == three[8]["n_update"] and one[8]["n_solve"] == three[8]["n_solve"]
 
 

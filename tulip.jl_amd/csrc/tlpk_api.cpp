@@ -720,7 +720,7 @@ static int enq_solve_local(tlpk_handle *h, const double *d_xip, const double *d_
         ProfScope ps(h, TLPK_KC_SPMV);
         // tickets + hand-over words of both sweeps back to all ones: the data is its own flag, ticket + 1 = 0 is the first item
         if (h->S.sweep && h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes, h->stream));
-        if (h->S.system == 1) launch_k2_rhs(h->stream, h->d, h->S.k2_n, d_xip, d_xid, 0, h->opt.rank);        // [xi_d ; xi_p] permuted (sqd.jl:62-66)
+        if (h->S.system == 1) launch_k2_rhs(h->stream, h->d, h->S.k2_n, d_xip, d_xid, 0, rhs_rank >= 0 ? rhs_rank : h->opt.rank);        // [xi_d ; xi_p] permuted (sqd.jl:62-66)
         else launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, rhs_rank >= 0 ? rhs_rank : h->opt.rank);
         launch_single_solve(h->stream, h->d);
     }

@@ -51,7 +51,6 @@ int ipm_shards(tlpk_handle *h, Shards &sh, bool need_loaded = true) {
     if (!h->has_device) return TLPK_NO_DEVICE;
     if (h->opt.nranks > 1) { h->last_error = "the device-resident IPM vectors need a single-rank or a tlpk_create_multi handle (a sharded handle's reductions belong to its caller)"; return TLPK_BADARG; }
     if (!h->sub.empty()) {
-        if (h->S.system == 1) { h->last_error = "device-resident IPM on a multi-device handle: K1 only"; return TLPK_BADARG; }
         sh.multi = true; sh.n = (int)h->sub.size();
         for (int r = 0; r < sh.n; ++r) sh.c[r] = h->sub[(size_t)r];
     } else { sh.multi = false; sh.n = 1; sh.c[0] = h; }
@@ -162,8 +161,10 @@ int tlpk_ipm_load(tlpk_handle *h, const double *b, const double *c, const double
             if (!sp) rc = TLPK_OOM;
             else {
                 h->ipm = sp;
-                const std::vector<char> &rl = sh.c[0]->S.row_local;
-                for (size_t i = 0; i < rl.size(); ++i) if (rl[i] == 2) { sp->link_rows.push_back((i64)i); sp->b_link.push_back(b[i]); }
+                const Symbolic &S0 = sh.c[0]->S;
+                const bool k2 = S0.system == 1;
+                const i64 mm = k2 ? S0.k2_m : S0.m, off = k2 ? S0.k2_n : 0;
+                for (i64 i = 0; i < mm; ++i) if (S0.row_local[(size_t)(off + i)] == 2) { sp->link_rows.push_back(i); sp->b_link.push_back(b[i]); }
                 if (!sp->link_rows.empty()) {
                     sp->link_lo = sp->link_rows.front(); sp->link_hi = sp->link_rows.back() + 1;
                     if (hipHostMalloc((void **)&sp->h_link, (size_t)(sp->link_hi - sp->link_lo) * (size_t)sh.n * 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); rc = TLPK_OOM; }
@@ -187,52 +188,42 @@ static int ipm_load_impl(tlpk_handle *h, const double *b, const double *c, const
     v.m = m; v.n = n; v.row_skip = nullptr;
     int rc;
     const Symbolic &S = h->S;
-    if (shard) {
-        // A restricted to the shard's columns (CSC and CSR), full index space
+    // ownership of columns (variables) and rows (constraints) on a shard: K1 -- the column / row maps of the analyse phase; K2 -- the
+    // node map (variable nodes 0 .. n-1, constraint nodes n .. n+m-1): a node of the replicated root front belongs to the lead shard
+    auto own_col = [&](i64 j) { if (!shard) return true; if (!k2) return S.col_local[(size_t)j] != 0; const char nl = S.row_local[(size_t)j]; return nl == 1 || (nl == 2 && h->opt.rank == 0); };
+    auto row_kind = [&](i64 i) -> char { return k2 ? S.row_local[(size_t)(n + i)] : S.row_local[(size_t)i]; };      // 0 other shard, 1 own, 2 linking (replicated)
+    if (!shard && !k2) { v.Ap = h->d.Ap; v.Ai = h->d.Ai; v.Ax = h->d.Ax; v.Tp = h->d.Tp; v.Tj = h->d.Tj; v.Tx = h->d.Tx; }
+    else {
+        // host copy of A, column-major: K1 -- the analyse phase's copy; K2 -- rebuilt from the incidence matrix of the augmented system
+        // it holds (column p = entry p of A: 1 on variable node j, A[i,j] on constraint node n + i, in A's column-major entry order).
+        // A shard keeps the columns it owns (the others are empty).  Then the row-major copy.
         std::vector<i64> ap((size_t)n + 1, 0), tp((size_t)m + 1, 0);
         std::vector<i32> ai, tj; std::vector<double> ax, tx;
-        for (i64 j = 0; j < n; ++j) {
-            if (S.col_local[(size_t)j]) for (i64 q = S.Ap[(size_t)j]; q < S.Ap[(size_t)j + 1]; ++q) { ai.push_back(S.Ai[(size_t)q]); ax.push_back(S.Ax[(size_t)q]); }
-            ap[(size_t)j + 1] = (i64)ai.size();
+        if (!k2) {
+            for (i64 j = 0; j < n; ++j) {
+                if (own_col(j)) for (i64 q = S.Ap[(size_t)j]; q < S.Ap[(size_t)j + 1]; ++q) { ai.push_back(S.Ai[(size_t)q]); ax.push_back(S.Ax[(size_t)q]); }
+                ap[(size_t)j + 1] = (i64)ai.size();
+            }
+        } else {
+            const i64 nnz = S.n;
+            i64 jprev = 0;
+            for (i64 p = 0; p < nnz; ++p) {
+                if (S.Ap[(size_t)p + 1] - S.Ap[(size_t)p] != 2) { h->last_error = "K2 incidence matrix: unexpected column"; return TLPK_INTERNAL; }
+                const i64 q = S.Ap[(size_t)p];
+                const i32 a = S.Ai[(size_t)q], b2 = S.Ai[(size_t)q + 1];
+                const bool afirst = a < (i32)n;                   // the variable node is the smaller index
+                const i64 j = afirst ? a : b2; const i32 i = (afirst ? b2 : a) - (i32)n;
+                if (j < jprev) { h->last_error = "K2 incidence matrix: columns out of order"; return TLPK_INTERNAL; }
+                for (; jprev < j; ++jprev) ap[(size_t)jprev + 1] = (i64)ai.size();
+                if (own_col(j)) { ai.push_back(i); ax.push_back(S.Ax[(size_t)q + (afirst ? 1 : 0)]); }
+            }
+            for (; jprev < n; ++jprev) ap[(size_t)jprev + 1] = (i64)ai.size();
         }
-        for (i64 i = 0; i < m; ++i) {
-            for (i64 q = S.Tp[(size_t)i]; q < S.Tp[(size_t)i + 1]; ++q)
-                if (S.col_local[(size_t)S.Tj[(size_t)q]]) { tj.push_back(S.Tj[(size_t)q]); tx.push_back(S.Ax[(size_t)S.Tpos[(size_t)q]]); }
-            tp[(size_t)i + 1] = (i64)tj.size();
-        }
-        i64 *dp; i32 *di; double *dxv; char *dc;
-        if ((rc = dev_upload(h, &dp, ap)) != TLPK_OK) return rc; v.Ap = dp;
-        if ((rc = dev_upload(h, &di, ai)) != TLPK_OK) return rc; v.Ai = di;
-        if ((rc = dev_upload(h, &dxv, ax)) != TLPK_OK) return rc; v.Ax = dxv;
-        if ((rc = dev_upload(h, &dp, tp)) != TLPK_OK) return rc; v.Tp = dp;
-        if ((rc = dev_upload(h, &di, tj)) != TLPK_OK) return rc; v.Tj = di;
-        if ((rc = dev_upload(h, &dxv, tx)) != TLPK_OK) return rc; v.Tx = dxv;
-        std::vector<char> skip((size_t)m);
-        for (i64 i = 0; i < m; ++i) skip[(size_t)i] = S.row_local[(size_t)i] == 2;      // linking rows: partial sums, no part in the maxima
-        if ((rc = dev_upload(h, &dc, skip)) != TLPK_OK) return rc; v.row_skip = dc;
-    } else if (!k2) { v.Ap = h->d.Ap; v.Ai = h->d.Ai; v.Ax = h->d.Ax; v.Tp = h->d.Tp; v.Tj = h->d.Tj; v.Tx = h->d.Tx; }
-    else {
-        // K2 handle: the analyse phase holds the incidence matrix of the augmented system (column p = entry p of A: 1 on
-        // variable node j, A[i,j] on constraint node n + i, in A's column-major entry order) -- rebuild A (CSC + CSR) from
-        // it for the residual / right-hand-side kernels
-        const i64 nnz = S.n;
-        std::vector<i64> ap((size_t)n + 1, 0), tp((size_t)m + 1, 0);
-        std::vector<i32> ai((size_t)nnz), tj((size_t)nnz);
-        std::vector<double> ax((size_t)nnz), tx((size_t)nnz);
-        for (i64 p = 0; p < nnz; ++p) {
-            if (S.Ap[(size_t)p + 1] - S.Ap[(size_t)p] != 2) { h->last_error = "K2 incidence matrix: unexpected column"; return TLPK_INTERNAL; }
-            const i64 q = S.Ap[(size_t)p];
-            const i32 a = S.Ai[(size_t)q], b = S.Ai[(size_t)q + 1];
-            const bool afirst = a < (i32)n;                       // the variable node is the smaller index
-            const i32 j = afirst ? a : b, i = (afirst ? b : a) - (i32)n;
-            ai[(size_t)p] = i; ax[(size_t)p] = S.Ax[(size_t)q + (afirst ? 1 : 0)];
-            ++ap[(size_t)j + 1]; ++tp[(size_t)i + 1];
-        }
-        for (i64 j = 0; j < n; ++j) ap[(size_t)j + 1] += ap[(size_t)j];
+        for (size_t q = 0; q < ai.size(); ++q) ++tp[(size_t)ai[q] + 1];
         for (i64 i = 0; i < m; ++i) tp[(size_t)i + 1] += tp[(size_t)i];
-        // entries of A come column by column (p ascending = j non-decreasing): ap is consistent with ai / ax as stored
-        { std::vector<i64> cur(tp.begin(), tp.end() - 1); i64 p = 0;
-          for (i64 j = 0; j < n; ++j) for (; p < ap[(size_t)j + 1]; ++p) { const i64 c = cur[(size_t)ai[(size_t)p]]++; tj[(size_t)c] = (i32)j; tx[(size_t)c] = ax[(size_t)p]; } }
+        tj.resize(ai.size()); tx.resize(ai.size());
+        { std::vector<i64> cur(tp.begin(), tp.end() - 1);
+          for (i64 j = 0; j < n; ++j) for (i64 q = ap[(size_t)j]; q < ap[(size_t)j + 1]; ++q) { const i64 c2 = cur[(size_t)ai[(size_t)q]]++; tj[(size_t)c2] = (i32)j; tx[(size_t)c2] = ax[(size_t)q]; } }
         i64 *dp; i32 *di; double *dxv;
         if ((rc = dev_upload(h, &dp, ap)) != TLPK_OK) return rc; v.Ap = dp;
         if ((rc = dev_upload(h, &di, ai)) != TLPK_OK) return rc; v.Ai = di;
@@ -240,19 +231,25 @@ static int ipm_load_impl(tlpk_handle *h, const double *b, const double *c, const
         if ((rc = dev_upload(h, &dp, tp)) != TLPK_OK) return rc; v.Tp = dp;
         if ((rc = dev_upload(h, &di, tj)) != TLPK_OK) return rc; v.Tj = di;
         if ((rc = dev_upload(h, &dxv, tx)) != TLPK_OK) return rc; v.Tx = dxv;
+        if (shard) {
+            char *dc;
+            std::vector<char> skip((size_t)m);
+            for (i64 i = 0; i < m; ++i) skip[(size_t)i] = row_kind(i) == 2;      // linking rows: partial sums, no part in the maxima
+            if ((rc = dev_upload(h, &dc, skip)) != TLPK_OK) return rc; v.row_skip = dc;
+        }
     }
     // problem data: b, c, l .* lflag, u .* uflag, flags (ipmdata.jl:46-47); a shard: its sub-LP
     std::vector<double> lz((size_t)n), uz((size_t)n), lf((size_t)n), uf((size_t)n), bb, cc;
     for (i64 j = 0; j < n; ++j) {
-        const bool own = !shard || S.col_local[(size_t)j];
+        const bool own = own_col(j);
         const bool fl = own && std::isfinite(l[j]), fu = own && std::isfinite(u[j]);
         lf[(size_t)j] = fl ? 1.0 : 0.0; uf[(size_t)j] = fu ? 1.0 : 0.0;
         lz[(size_t)j] = fl ? l[j] : 0.0; uz[(size_t)j] = fu ? u[j] : 0.0;
     }
     if (shard) {
         bb.assign((size_t)m, 0.0); cc.assign((size_t)n, 0.0);
-        for (i64 i = 0; i < m; ++i) { const char rl = S.row_local[(size_t)i]; if (rl == 1 || (rl == 2 && h->opt.rank == 0)) bb[(size_t)i] = b[i]; }
-        for (i64 j = 0; j < n; ++j) if (S.col_local[(size_t)j]) cc[(size_t)j] = c[j];
+        for (i64 i = 0; i < m; ++i) { const char rl = row_kind(i); if (rl == 1 || (rl == 2 && h->opt.rank == 0)) bb[(size_t)i] = b[i]; }
+        for (i64 j = 0; j < n; ++j) if (own_col(j)) cc[(size_t)j] = c[j];
         b = bb.data(); c = cc.data();
     }
     double *p;
@@ -544,7 +541,10 @@ int tlpk_ipm_get(tlpk_handle *h, int what, double *host, int64_t len) {
         if (!sh.multi) { HIPCHK(h, hipMemcpy(host, src[what], (size_t)need * 8, hipMemcpyDeviceToHost)); continue; }
         // every entry from the shard that owns it (linking rows: the lead)
         HIPCHK(h, hipMemcpy(tmp.data(), src[what], (size_t)need * 8, hipMemcpyDeviceToHost));
-        if (what == 5) { const std::vector<char> &rl = c->S.row_local; for (int64_t i = 0; i < need; ++i) if (rl[(size_t)i] == 1 || (rl[(size_t)i] == 2 && r == 0)) host[i] = tmp[(size_t)i]; }
+        const bool k2 = c->S.system == 1;
+        const std::vector<char> &rl = c->S.row_local;
+        if (what == 5) { const int64_t off = k2 ? c->S.k2_n : 0; for (int64_t i = 0; i < need; ++i) { const char q = rl[(size_t)(off + i)]; if (q == 1 || (q == 2 && r == 0)) host[i] = tmp[(size_t)i]; } }
+        else if (k2) { for (int64_t j = 0; j < need; ++j) { const char q = rl[(size_t)j]; if (q == 1 || (q == 2 && r == 0)) host[j] = tmp[(size_t)j]; } }
         else { const std::vector<char> &cl = c->S.col_local; for (int64_t j = 0; j < need; ++j) if (cl[(size_t)j]) host[j] = tmp[(size_t)j]; }
     }
     return TLPK_OK;

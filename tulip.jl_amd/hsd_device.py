@@ -43,14 +43,12 @@ class DeviceHSD:
         self.pair_solves = bool(pair_solves)
         self.overlap_root = bool(overlap_root)
         # system: "K1" normal equations | "K2" augmented system (the reference's default for Float64, KKT.jl:134-141)
-        # one device, or ngpus > 1 (a block-angular LP on one multi-device handle, K1: every shard keeps the sub-LP of its diagonal
+        # one device, or ngpus > 1 (a block-angular LP on one multi-device handle, K1 or K2: every shard keeps the sub-LP of its diagonal
         # blocks on its device, the library reduces the root panel / root right-hand side and the host adds the shards' scalars).
         # Sharded handles (nranks > 1) leave their reductions to the caller, the loops cannot drive them.
         if int(backend_kw.get("nranks", 1)) > 1:
             raise ValueError("the device-resident interior-point loops need one handle for the whole LP: nranks must be 1 "
                              "(ngpus > 1 is fine; sharded handles serve the split-phase KKT.update! / KKT.solve!)")
-        if int(backend_kw.get("ngpus", 1)) > 1 and str(system).upper() == "K2":
-            raise ValueError("the device-resident interior-point loops on several GPUs solve the normal equations (system='K1')")
         self.kkt = setup(A, K2() if str(system).upper() == "K2" else K1(), Backend(**backend_kw))
         self.m, self.n = self.kkt.m, self.kkt.n
         self.opt = options or Options()
