@@ -31,7 +31,8 @@ struct IpmState {
 };
 
 // ---- one device or several ---------------------------------------------------------------------------------------------------
-// On a tlpk_create_multi handle (block-angular LP, K1) every shard holds the SUB-LP of its diagonal blocks in vectors of the job's
+// On a tlpk_create_multi handle (block-angular LP; K1, or K2 -- then the variable nodes of the replicated root front count as the
+// lead shard's columns) every shard holds the SUB-LP of its diagonal blocks in vectors of the job's
 // full length: its own columns with their costs and bounds (the other columns are empty: cost 0, no bounds, no entries of A), its
 // block rows of b, and the linking rows -- b on the lead shard only, A restricted to the shard's columns.  Every kernel of
 // ipm_kernels.hip then computes, unchanged, the shard's share of each sum / maximum / minimum (an empty column or row contributes
