@@ -136,7 +136,16 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
                     }
             }
         }
+        // TLPK_STAGGER=1 (experiment): group 1 starts an extend-add launch only after group 0's previous one has finished, so that the
+        // HBM-bound extend-add of one group runs beside the matrix-core-bound updates of the other instead of beside ITS extend-add
+        const bool stag = h->stagger && dir < 0 && !h->profile && !h->serial && cur.kind == LK_EXTEND_ADD && h->S.ngroups >= 2 && h->ev_stagger;
+        if (stag && L[i].group == 1 && h->stagger_armed) { hipStreamWaitEvent(st, h->ev_stagger, 0); h->stagger_armed = false; }
         ProfScope ps(h, kind_class(cur.kind), st);
+        if (stag && L[i].group == 0 && cur.count >= h->stagger_min) {
+            launch_tasks(st, h->d, cur, nullptr, nrhs);
+            hipEventRecord(h->ev_stagger, st); h->stagger_armed = true;
+            continue;
+        }
         if (cur.kind == LK_FWD_SWEEP || cur.kind == LK_BWD_SWEEP) {
             const i32 slot = (dir == 0 ? h->sweep_slot_fwd : h->sweep_slot_bwd)[i];
             SweepArgs sw{h->d.sweep_tickets + slot, h->d.sweep_xh + (dir == 0 ? 0 : h->S.m), 2 * h->S.m, h->poll[0], h->poll[1], h->poll[2]};
@@ -366,6 +375,7 @@ static int create_host(tlpk_handle *h, const tlpk_options &def, int64_t m, int64
     if (const char *e = std::getenv("TLPK_SERIAL")) h->serial = std::atoi(e) != 0;
     if (const char *e = std::getenv("TLPK_GRAPH")) { h->use_graph = std::atoi(e) != 0; h->force_graph = std::atoi(e) >= 2; }
     if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
+    if (const char *e = std::getenv("TLPK_STAGGER")) { h->stagger = std::atoi(e) != 0; if (std::atoi(e) > 1) h->stagger_min = std::atoi(e); }
     const auto t0 = std::chrono::steady_clock::now();
     if (rc == TLPK_OK) {
         if (common) { h->S = *common; h->opt.k2_n = common->k2_n; rc = analyse_rank(h->S, h->opt); }
@@ -404,6 +414,7 @@ static int create_device(tlpk_handle *h, const tlpk_options &def) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
         for (int g = 1; g < ng && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming);
         for (int g = 0; g < ng && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_side[g], hipEventDisableTiming);
+        if (e == hipSuccess && h->stagger) e = hipEventCreateWithFlags(&h->ev_stagger, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreate(&h->ev0);
         if (e == hipSuccess) e = hipEventCreate(&h->ev1);
         if (e == hipSuccess && h->S.root_front >= 0 && h->opt.nranks == 1) {       // a stream of its own for the root front (tlpk_update_device_async)
@@ -493,6 +504,7 @@ void tlpk_destroy(tlpk_handle *h) {
         if (h->rstream) { hipStreamSynchronize(h->rstream); hipStreamDestroy(h->rstream); }
         if (h->ev_blocks) hipEventDestroy(h->ev_blocks);
         if (h->ev_root) hipEventDestroy(h->ev_root);
+        if (h->ev_stagger) hipEventDestroy(h->ev_stagger);
         for (int g = 0; g < MAX_GROUPS; ++g) {
             if (h->ev_side[g]) hipEventDestroy(h->ev_side[g]);
             if (h->sstream[g]) { hipStreamSynchronize(h->sstream[g]); hipStreamDestroy(h->sstream[g]); }

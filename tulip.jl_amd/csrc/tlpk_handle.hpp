@@ -64,6 +64,7 @@ struct tlpk_handle {
     i64 col_lo = 0, col_hi = 0, row_lo = 0, row_hi = 0, link_lo = 0, link_hi = 0;   // child: slices of the job-wide input vectors it reads
     double *shared_dy = nullptr;        // child: job-wide dy on the lead device (P2P), filled with the rows this rank owns
     bool dx_local_only = false;         // child: dx is the job-wide vector, leave the other ranks' columns alone
+    bool stagger = false, stagger_armed = false; i64 stagger_min = 10000; hipEvent_t ev_stagger = nullptr;   // TLPK_STAGGER (experiment, tlpk_api.cpp: run_launches)
     bool rhs_all_ranks = false;         // child, device-resident IPM: this solve adds the shard's xi_p on the linking rows whatever its rank
     // hipGraph replay of the static schedules (tlpk_api.cpp: graph_or_direct): instantiated graphs and their keys
     bool use_graph = true;              // TLPK_GRAPH=0 turns it off; switched off for good if capture fails on this system
