@@ -61,10 +61,14 @@ class Emulator:
         self.spart = {}      # split-K scratch slot -> partial tile
         self.fail_col = None
 
-    # views
+    # The library stores a panel by 64-column slices (tlpk_host.hpp: pk_off): slice b keeps the rows from 64 b down, with leading
+    # dimension lda - 64 b.  The assembly targets (s_target) address that packed storage; the arithmetic below works on an unpacked
+    # f x ns copy per front, made from the packed storage at the first access after an assembly (blocks above the diagonal blocks: 0).
     def panel(self, s):
-        f, ns, lda = int(self.f[s]), int(self.ns[s]), int(self.lda[s])
-        return self.Lval[self.loff[s]: self.loff[s] + lda * ns].reshape((lda, ns), order="F")[:f]
+        cache = self.__dict__.setdefault("_P", {})
+        if s not in cache:
+            cache[s] = unpack_panel(self.Lval, int(self.loff[s]), int(self.f[s]), int(self.ns[s]), int(self.lda[s]))
+        return cache[s]
 
     def rows(self, s):
         return self.rowidx[self.rowoff[s]: self.rowoff[s] + self.f[s]]
@@ -85,6 +89,7 @@ class Emulator:
         self.D = np.concatenate([theta + regP, [1.0]]) if self.k2 else 1.0 / (theta + regP)   # K2: D2 = [theta + regP ; 1]
         self.regD = np.asarray(regD, dtype=float)
         self.Lval[:] = 0.0
+        self._P = {}
         contrib = self.pair_w * self.D[self.pair_j]
         nent = len(self.s_target)
         vals = np.add.reduceat(np.concatenate([contrib, [0.0]]), np.minimum(self.pair_ptr[:-1], len(contrib)))
@@ -115,7 +120,7 @@ class Emulator:
         s = self.root_front
         if s < 0:
             return self.Lval[:0]
-        return self.Lval[self.loff[s]: self.loff[s] + self.lda[s] * self.ns[s]]
+        return self.panel(s).reshape(-1)          # a view of the working copy: reduced in place (the same shape on every rank)
 
     def update_finish(self):
         self._run(self.factor_launches, False, start=self._resume)
@@ -445,6 +450,27 @@ class Emulator:
             for c in range(ns):
                 L[rows[c:], c0 + c] = P[c:, c]
         return L
+
+
+def pk_off(lda, col):
+    """Offset of the virtual row 0 of panel column `col` (tlpk_host.hpp)."""
+    b = col >> 6
+    return col * lda - 64 * b * (col - 32 * b - 31)
+
+
+def pk_len(lda, ns):
+    return pk_off(lda, ns) + 64 * (ns >> 6)
+
+
+def unpack_panel(lval, loff, f, ns, lda):
+    """f x ns array of a panel stored by 64-column slices; the never-stored blocks above the diagonal blocks read as 0."""
+    P = np.zeros((f, ns))
+    for b in range((ns + 63) // 64):
+        w = min(64, ns - 64 * b); ld = lda - 64 * b
+        start = loff + pk_off(lda, 64 * b) + 64 * b
+        blk = lval[start: start + w * ld].reshape((ld, w), order="F")
+        P[64 * b:, 64 * b: 64 * b + w] = blk[: f - 64 * b]
+    return P
 
 
 def panels_to_dense_L(kkt, lval):

@@ -268,6 +268,39 @@ def _lib3():
     return _LIB3
 
 
+def _pk_off(lda, col):
+    b = col >> 6
+    return col * lda - 64 * b * (col - 32 * b - 31)
+
+
+def _unpacked_targets(s_target, loff_p, loff_u, lda, ns):
+    """Assembly targets of the device layout (packed panels) -> offsets into unpacked panels at loff_u."""
+    t = np.asarray(s_target, dtype=np.int64)
+    out = np.full_like(t, -1)
+    live = np.nonzero(t >= 0)[0]
+    if live.size == 0:
+        return out
+    fronts = np.nonzero(loff_p >= 0)[0]
+    starts = loff_p[fronts]
+    order = np.argsort(starts, kind="stable")
+    fronts, starts = fronts[order], starts[order]
+    fs = fronts[np.searchsorted(starts, t[live], side="right") - 1]          # front of every entry
+    delta = t[live] - loff_p[fs]
+    L = lda[fs]
+    # slice b: the largest b with S_b <= delta, S_b = 64 b L - 2048 b (b - 1); at most ns / 64 slices -- a short loop over b
+    b = np.zeros_like(delta)
+    bmax = int((ns[fronts].max() + 63) // 64) if fronts.size else 1
+    for cand in range(1, bmax):
+        Sb = 64 * cand * L - 2048 * cand * (cand - 1)
+        b = np.where((delta >= Sb) & (64 * cand < ns[fs]), cand, b)
+    Sb = 64 * b * L - 2048 * b * (b - 1)
+    ld = L - 64 * b
+    col = 64 * b + (delta - Sb) // ld
+    row = 64 * b + (delta - Sb) % ld
+    out[live] = loff_u[fs] + row + col * L
+    return out
+
+
 class SupernodalK1:
     """CPU supernodal multifrontal Cholesky (OpenBLAS + OpenMP) on the symbolic structure of a libtlpk
     handle `kkt` (an analyse-only handle is enough): same ordering, same supernodes, same panel
@@ -289,7 +322,18 @@ class SupernodalK1:
         pair_w = np.ascontiguousarray(tl.symbolic_array_f64(kkt._h, "pair_w"))
         if pair_w.size != pair_ptr[-1]:
             raise RuntimeError("the handle has released its host assembly lists (device handles do): pass an analyse-only handle")
-        self.lval_len = int(kkt.stats()["nnzL_stored"])
+        # The device stores a panel by 64-column slices (tlpk_host.hpp: pk_off).  The comparator runs dense BLAS on whole panels and
+        # keeps them UNPACKED (f x ns, one leading dimension lda): its own offsets, the assembly targets translated; factor_panels()
+        # re-packs into the device layout, so that the two factors compare index by index.
+        f_, ns_, loff_p, lda_ = fr[0], fr[1], fr[3], fr[9]
+        own = loff_p >= 0
+        sizes = np.where(own, lda_ * ns_, 0)
+        loff_u = np.where(own, np.concatenate([[0], np.cumsum(sizes)[:-1]]), -1).astype(np.int64)
+        self._pack = (f_.copy(), ns_.copy(), loff_p.copy(), lda_.copy(), loff_u.copy())
+        self.lval_len_packed = int(kkt.stats()["nnzL_stored"])
+        self.lval_len = int(sizes.sum())
+        s_target = _unpacked_targets(s_target, loff_p, loff_u, lda_, ns_)
+        fr[3] = c64(loff_u)
         self._h = C.c_void_p()
         rc = lib.k1sn_create(C.byref(self._h), openblas_path().encode(), self.m, self.n, _p64(Ap), _p64(Ai), _pd(Ax), _p64(perm),
                              len(fr[0]), *[_p64(a) for a in fr], rowidx.size, _p64(rowidx), rel.size, _p64(rel),
@@ -321,11 +365,21 @@ class SupernodalK1:
         return {"assemble_s": t[0], "factor_s": t[1], "solve_s": t[2]}
 
     def factor_panels(self):
+        """The factor in the DEVICE's panel layout (64-column slices), entries the device never stores dropped."""
         buf = np.empty(max(self.lval_len, 1))
         rc = _lib3().k1sn_get_factor(self._h, _pd(buf), buf.size)
         if rc != OK:
             raise RuntimeError(f"k1sn_get_factor rc={rc}")
-        return buf[: self.lval_len]
+        f_, ns_, loff_p, lda_, loff_u = self._pack
+        out = np.zeros(max(self.lval_len_packed, 1))
+        for s in np.nonzero(loff_p >= 0)[0]:
+            f, ns, lda = int(f_[s]), int(ns_[s]), int(lda_[s])
+            P = buf[loff_u[s]: loff_u[s] + lda * ns].reshape((lda, ns), order="F")
+            for b in range((ns + 63) // 64):
+                w = min(64, ns - 64 * b); ld = lda - 64 * b
+                start = int(loff_p[s]) + _pk_off(lda, 64 * b) + 64 * b
+                out[start: start + w * ld] = P[64 * b:, 64 * b: 64 * b + w].reshape(-1, order="F")
+        return out[: self.lval_len_packed]
 
     def diag(self):
         """diag(L) in permuted order; L_jj^2 is the pivot of column j."""

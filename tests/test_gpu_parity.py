@@ -462,9 +462,10 @@ def test_c4_scale_factor_entrywise_vs_cpu_supernodal():
     Lg, Lc = kkt.factor_panels(), sn.factor_panels()
     f, ns, loff, lda = kkt.symbolic("front_f"), kkt.symbolic("front_ns"), kkt.symbolic("front_loff"), kkt.symbolic("front_lda")
     lmax = 0.0; worst = 0.0; checked = 0
+    from emulate import unpack_panel          # panels are stored by 64-column slices (tlpk_host.hpp: pk_off)
     for s in range(len(f)):
-        a = Lg[loff[s]: loff[s] + lda[s] * ns[s]].reshape((lda[s], ns[s]), order="F")[: f[s]]
-        b = Lc[loff[s]: loff[s] + lda[s] * ns[s]].reshape((lda[s], ns[s]), order="F")[: f[s]]
+        a = unpack_panel(Lg, int(loff[s]), int(f[s]), int(ns[s]), int(lda[s]))
+        b = unpack_panel(Lc, int(loff[s]), int(f[s]), int(ns[s]), int(lda[s]))
         mask = np.tril(np.ones((f[s], ns[s]), dtype=bool))                     # stored entries: row >= column
         lmax = max(lmax, float(np.abs(b[mask]).max()))
         worst = max(worst, float(np.abs(a[mask] - b[mask]).max()))

@@ -42,6 +42,11 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double *front_u(const DevCtx &c, const FrontDesc &fd) {
     return (fd.ubuf ? c.U1 : c.U0) + fd.uoff;
 }
+// Packed panels (tlpk_host.hpp: pk_off): a panel is stored by 64-column slices, slice b from its first row 64 b down with leading
+// dimension lda - 64 b.  pcol = pointer to the VIRTUAL row 0 of a panel column (valid for rows >= 64 (col / 64)); consecutive
+// columns of one slice are pld apart.
+__device__ __forceinline__ double *pcol(const DevCtx &c, const FrontDesc &fd, i32 col) { return c.Lval + fd.loff + pk_off(fd.lda, col); }
+__device__ __forceinline__ i32 pld(const FrontDesc &fd, i32 col) { return fd.lda - ((col >> 6) << 6); }
 
 // ------------------------------------------------------------------------------------------
 // elementwise / sparse kernels
@@ -113,10 +118,10 @@ __global__ void k_single_solve(i64 n, const i64 *__restrict__ dinvoff, const i32
 __global__ __launch_bounds__(256) void k_zero_panels(const i32 *__restrict__ tasks, DevCtx c) {
     const i32 s = tasks[2 * blockIdx.x], c0 = tasks[2 * blockIdx.x + 1];
     const FrontDesc fd = c.fronts[s];
-    const i32 lda = fd.lda, nc = min(NB_IN, fd.ns - c0);
-    double *P = c.Lval + fd.loff + (i64)c0 * lda;
+    const i32 lda = fd.lda, nc = min(NB_IN, fd.ns - c0), ld = pld(fd, c0);          // c0 = first column of a slice
+    double *P = pcol(c, fd, c0);
     for (i32 col = 0; col < nc; ++col)
-        for (i32 r = c0 + (i32)threadIdx.x; r < lda; r += 256) P[(i64)col * lda + r] = 0.0;
+        for (i32 r = c0 + (i32)threadIdx.x; r < lda; r += 256) P[(i64)col * ld + r] = 0.0;
 }
 
 __global__ __launch_bounds__(256) void k_zero_small(const i32 *__restrict__ fronts, i64 n, DevCtx c) {      // one wave per small front
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
                 const i32 tc = t.j0 + s_tc[ci][q - q0];
                 if (((tc - t.j0) & 3) != wave) continue;
                 const double *__restrict__ src = Uc + (i64)q * rsc;
-                double *__restrict__ dst = (tc < ns) ? (P + (i64)tc * lda) : (Up + (i64)(tc - ns) * rs - ns);
+                double *__restrict__ dst = (tc < ns) ? pcol(c, fd, tc) : (Up + (i64)(tc - ns) * rs - ns);
                 // targets of one column are distinct rows: batches of 4 x 64 independent read-modify-writes, short
                 // columns included (guards instead of a one-by-one tail: every trip is two dependent round trips).
                 // Tried and measured slower: fire-and-forget L2 adds (8.9 vs 7.1 ms: the scattered targets cost the L2
@@ -235,8 +240,8 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
     double (*colbuf)[NB_IN] = reinterpret_cast<double (*)[NB_IN]>(scratch + NB_IN * (NB_IN + 1));
     double (*rowbuf)[NB_IN] = colbuf + 2;
     double *dg = scratch + NB_IN * (NB_IN + 1) + 4 * NB_IN;
-    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
-    double *P = c.Lval + fd.loff + (i64)bk0 + (i64)bk0 * lda;
+    const i32 lda = pld(fd, bk0);                   // the block lies in ONE 64-column slice of the packed panel (bk0 is a multiple of 64): its leading dimension
+    double *P = pcol(c, fd, bk0) + bk0;             // origin (bk0, bk0)
     const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
     const bool rok = r < nb;
     double av[16], wv[16];
@@ -247,7 +252,7 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
     const i32 Kp = bk0 - kprev;
     if (Kp > 0) {
         const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-        const double *X = c.Lval + fd.loff + (i64)bk0 + (i64)kprev * lda;     // X[rr][k] = X[rr + k*f]
+        // X[rr][k] = panel(bk0 + rr, kprev + k): columns of earlier slices, 16 at a time inside one slice
         v4f64 dacc[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) dacc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -263,11 +268,11 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
             double bq[4], aq[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const i64 coff = (i64)(ks + 4 * u + lk) * lda;
-                bq[u] = X[(i64)rr_c + coff];
+                const double *Xc = pcol(c, fd, kprev + ks + 4 * u + lk) + bk0;
+                bq[u] = Xc[rr_c];
                 if (SIGNED) bq[u] *= sg[kprev + ks + 4 * u + lk];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) aq[u][a] = X[(i64)cr_c[a] + coff];
+                for (int a = 0; a < 4; ++a) aq[u][a] = Xc[cr_c[a]];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -461,8 +466,10 @@ template <bool SIGNED = false>
 __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, const i32 k0, const i32 nb,
                                           const i32 row0, const i32 rowlim, const i32 kprev, double *Ws) {
     const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
-    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
-    double *P = c.Lval + fd.loff;
+    // packed panel: the step's columns [k0, k0 + nb) lie in one 64-column slice (k0, kprev multiples of 64), the solved steps
+    // [kprev + c0, kprev + c0 + 64) in one each
+    double *P0 = pcol(c, fd, k0);                   // virtual row 0 of column k0
+    const i32 ld0 = pld(fd, k0);
     const double *W = front_dinv(c, fd, k0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -481,16 +488,18 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const i32 k = 4 * ks + lk;
-            const double v = P[(i64)rowc[b] + (i64)(k0 + min(k, nb - 1)) * lda];      // clamped, not guarded
+            const double v = P0[(i64)rowc[b] + (i64)min(k, nb - 1) * ld0];      // clamped, not guarded
             bf[b][ks] = (k < nb) ? v : 0.0;
         }
     v4f64 acc[4][NBR];
     const i32 Kp = k0 - kprev;
     for (i32 c0 = 0; c0 < Kp; c0 += NB_IN) {
         __syncthreads();
+        const double *Pc = pcol(c, fd, kprev + c0);
+        const i32 ldc = pld(fd, kprev + c0);
         for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
             const int cc = idx & (NB_IN - 1), k = idx >> 6;
-            const double v = P[(i64)(k0 + min(cc, nb - 1)) + (i64)(kprev + c0 + k) * lda];
+            const double v = Pc[(i64)(k0 + min(cc, nb - 1)) + (i64)k * ldc];
             Ws[k * LDW + cc] = (cc < nb) ? v : 0.0;
         }
         __syncthreads();
@@ -500,7 +509,7 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
             for (int b = 0; b < NBR; ++b)
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
-                    xf[b][ks] = P[(i64)rowc[b] + (i64)(kprev + c0 + 4 * ks + lk) * lda] * (SIGNED ? sg[kprev + c0 + 4 * ks + lk] : 1.0);
+                    xf[b][ks] = Pc[(i64)rowc[b] + (i64)(4 * ks + lk) * ldc] * (SIGNED ? sg[kprev + c0 + 4 * ks + lk] : 1.0);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -555,7 +564,7 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const i32 cc = a * 16 + lk + 4 * q;
-                    if (row < rowlim && cc < nb) P[(i64)row + (i64)(k0 + cc) * lda] = SIGNED ? acc[a][b][q] * sg[k0 + cc] : acc[a][b][q];
+                    if (row < rowlim && cc < nb) P0[(i64)row + (i64)cc * ld0] = SIGNED ? acc[a][b][q] * sg[k0 + cc] : acc[a][b][q];
                 }
             }
     }
@@ -578,27 +587,15 @@ __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restri
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
-#ifdef POTRF_TRACE   /* tools/potrf_trace.py: time stamps (100 MHz) of the phases, stored in the never-read block above the second diagonal block */
-    double *trace = c.Lval + fd.loff + (i64)(k0 + NB_IN) * fd.lda + k0;
-    int tslot = 0;
-#define PTRACE() do { __syncthreads(); if (threadIdx.x == 0 && w == NB_OUT) trace[tslot] = (double)wall_clock64(); ++tslot; } while (0)
-#else
-#define PTRACE() do { } while (0)
-#endif
-    PTRACE();
     potrf_block<SIGNED>(c, fd, k0, min(w, NB_IN), k0, Ws);
-    PTRACE();
     for (i32 ks = k0; ks + NB_IN < kend; ks += NB_IN) {          // step ks is factored: rows below, next diagonal block
         for (i32 r0 = ks + NB_IN; r0 < kend; r0 += NB_IN) {
             __syncthreads();                                     // own global stores visible, Ws free
             trsm_rows<SIGNED>(c, fd, ks, NB_IN, r0, kend, k0, Ws);
-            PTRACE();
         }
         __syncthreads();
         potrf_block<SIGNED>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
-        PTRACE();
     }
-#undef PTRACE
 }
 
 // Rows below the diagonal block of a block column: X = B * L11^{-T} for the whole (<= 256 wide)
@@ -627,18 +624,22 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     const bool active = rbase < rlim;
     const i32 rowc = min(rbase + lr, rlim - 1);     // clamped, stores are guarded
     double bf[4][16];                               // bf[i][ks] = B[row][k0 + 64 i + 4 ks + lk]
+    // packed panel: every 64-column step of the block column is one slice (k0 is a multiple of 64)
     if (w == NB_OUT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const double *Pi = pcol(c, fd, k0 + 64 * i) + rowc;
+            const i32 ldi = lda - (k0 + 64 * i);
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) bf[i][ks] = P[(i64)rowc + (i64)(k0 + 64 * i + 4 * ks + lk) * lda];
+            for (int ks = 0; ks < 16; ++ks) bf[i][ks] = Pi[(i64)(4 * ks + lk) * ldi];
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const i32 col = 64 * i + 4 * ks + lk;
-                const double v = P[(i64)rowc + (i64)(k0 + min(col, w - 1)) * lda];
+                const double v = pcol(c, fd, k0 + min(col, w - 1))[rowc];
                 bf[i][ks] = (col < w) ? v : 0.0;
             }
     }
@@ -649,10 +650,12 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     auto fetch = [&](const int i, const int j) {        // j < i: L[k0+64i.., k0+64j..) ; j == i: Linv_i
         const i32 nbi = min(NB_IN, w - 64 * i);
         if (j < i) {
+            const double *Pj = pcol(c, fd, k0 + 64 * j);
+            const i32 ldj = lda - (k0 + 64 * j);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int idx = tid + 256 * u, cc = idx & (NB_IN - 1), k = idx >> 6;
-                pre[u] = (cc < nbi) ? P[(i64)(k0 + 64 * i + cc) + (i64)(k0 + 64 * j + k) * lda] : 0.0;
+                pre[u] = (cc < nbi) ? Pj[(i64)(k0 + 64 * i + cc) + (i64)k * ldj] : 0.0;
             }
         } else {
             const double *W = front_dinv(c, fd, k0 + 64 * i);
@@ -721,12 +724,15 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     if (active && rbase + lr < rlim) {
         const i32 row = rbase + lr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            double *Pi = pcol(c, fd, k0 + 64 * i) + row;
+            const i32 ldi = lda - (k0 + 64 * i);
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const i32 col = 64 * i + 4 * ks + lk;
-                if (col < w) P[(i64)row + (i64)(k0 + col) * lda] = SIGNED ? bf[i][ks] * c.csign[fd.col0 + k0 + col] : bf[i][ks];
+                if (col < w) Pi[(i64)(4 * ks + lk) * ldi] = SIGNED ? bf[i][ks] * c.csign[fd.col0 + k0 + col] : bf[i][ks];
             }
+        }
     }
 }
 
@@ -739,13 +745,13 @@ __global__ __launch_bounds__(256) void k_trsm_thin(const TrsmTask *__restrict__ 
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 w = t.nb;
-    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
+    const i32 lda = pld(fd, t.k0);                  // leading dimension of the slice of the packed panel that holds the block column
     const double *W = front_dinv(c, fd, t.k0);          // w x w, column-major, ld = w, upper part zero
     for (int idx = threadIdx.x; idx < w * w; idx += 256) Wl[idx] = W[idx];
     __syncthreads();
     const i32 r = t.row0 + threadIdx.x;
     if (r >= t.pad1) return;                           // rows [row0, pad1) belong to this task
-    double *P = c.Lval + fd.loff + (i64)r + (i64)t.k0 * lda;
+    double *P = pcol(c, fd, t.k0) + r;              // thin block columns (w <= 32) never straddle a 64-column slice: fronts of <= 32 pivot columns, k0 = 0
     double b[TRSM_THIN_W];
 #pragma unroll
     for (int k = 0; k < TRSM_THIN_W; ++k) b[k] = P[(i64)min(k, w - 1) * lda];          // clamped, used only for k < w
@@ -820,24 +826,25 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
     const int sr = tid & 127, sk0 = tid >> 7;       // staging: row sr, k = sk0 + KS*it
     const i32 ra = t.i0 + sr, rb_ = t.j0 + sr;
     const bool raok = FULL || (ra < f), rbok = FULL || ((rb_ < f) && !diag_tile);
-    const double *Pa = P + (i64)(t.k0 + sk0) * lda + ra;
-    const double *Pb = P + (i64)(t.k0 + sk0) * lda + rb_;
+    // packed panel (tlpk_host.hpp: pk_off): K column k of the front starts at P + pk_off(lda, k); a 16-column slab lies in one slice
     double pa[UPD_NLD], pb[UPD_NLD];
 
     auto load_slab = [&](i32 kk, bool full_k) {
         if (FULL && full_k) {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                pa[it] = Pa[(i64)(kk + KS * it) * lda];
-                pb[it] = Pb[(i64)(kk + KS * it) * lda];
+                const double *Pk = P + pk_off(lda, t.k0 + kk + sk0 + KS * it);
+                pa[it] = Pk[ra];
+                pb[it] = Pk[rb_];
                 if (SIGNED) pb[it] *= sgk[kk + sk0 + KS * it];
             }
         } else {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
                 const bool kok = (kk + sk0 + KS * it) < t.kw;
-                pa[it] = (kok && raok) ? Pa[(i64)(kk + KS * it) * lda] : 0.0;
-                pb[it] = (kok && rbok) ? Pb[(i64)(kk + KS * it) * lda] : 0.0;
+                const double *Pk = P + pk_off(lda, t.k0 + min(kk + sk0 + KS * it, t.kw - 1));
+                pa[it] = (kok && raok) ? Pk[ra] : 0.0;
+                pb[it] = (kok && rbok) ? Pk[rb_] : 0.0;
                 if (SIGNED) pb[it] *= sgk[min(kk + sk0 + KS * it, t.kw - 1)];
             }
         }
@@ -864,26 +871,32 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         // base pointer every round, the compiler recycled the destination registers of loads still in flight as
         // temporaries and had to wait for them (s_waitcnt vmcnt(3) in the middle of a round: the two-round prefetch
         // distance shrank to half a round).
+        // Packed panel: the K columns of one staging load (sk0 + KS * it inside the slab) are wave-uniform, so the advance of its
+        // address from slab to slab -- UPD_KT columns of lda - 64 b inside slice b, a different amount across a slice boundary -- is
+        // scalar arithmetic: pk_off(next column) - pk_off(this column).
         const i32 rac = min(t.i0 + sr, f - 1), rbc = min(t.j0 + sr, f - 1);
-        const i64 step = (i64)UPD_KT * lda, two_f = KS * (i64)lda;
+        const int sk0u = __builtin_amdgcn_readfirstlane(sk0);
         const double *qa[UPD_NLD], *qb[UPD_NLD];
 #pragma unroll
         for (int it = 0; it < UPD_NLD; ++it) {
-            qa[it] = P + (i64)(t.k0 + sk0) * lda + rac + it * two_f;
-            qb[it] = P + (i64)(t.k0 + sk0) * lda + rbc + it * two_f;
+            const i64 o = pk_off(lda, t.k0 + sk0u + KS * it);
+            qa[it] = P + o + rac;
+            qb[it] = P + o + rbc;
         }
+        i32 ka_col = t.k0 + sk0u, kb_col = t.k0 + sk0u;  // K column (it = 0) of the slab ld_a / ld_b loads next
         auto ld_a = [&]() {
 #pragma unroll
-            for (int it = 0; it < UPD_NLD; ++it) { pa[it] = *qa[it]; qa[it] += step; }
+            for (int it = 0; it < UPD_NLD; ++it) { pa[it] = *qa[it]; qa[it] += pk_off(lda, ka_col + KS * it + UPD_KT) - pk_off(lda, ka_col + KS * it); }
+            ka_col += UPD_KT;
         };
         i32 kb_idx = 0;                                   // first K column of the slab ld_b loads next (SIGNED)
         auto ld_b = [&]() {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                pb[it] = *qb[it]; qb[it] += step;
+                pb[it] = *qb[it]; qb[it] += pk_off(lda, kb_col + KS * it + UPD_KT) - pk_off(lda, kb_col + KS * it);
                 if (SIGNED) pb[it] *= sgk[kb_idx + sk0 + KS * it];
             }
-            kb_idx += UPD_KT;
+            kb_idx += UPD_KT; kb_col += UPD_KT;
         };
         auto st_ab = [&](int buf) {
 #pragma unroll
@@ -935,14 +948,12 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         }
         if (t.kw % UPD_KT) {                              // K tail: one zero-filled slab
             const i32 kk = nrounds * UPD_KT;
-            const double *pa_ptr = P + (i64)(t.k0 + kk + sk0) * lda + rac;
-            const double *pb_ptr = P + (i64)(t.k0 + kk + sk0) * lda + rbc;
-            const i64 two_l = KS * (i64)lda;
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
                 const bool kok = (kk + sk0 + KS * it) < t.kw;
-                pa[it] = kok ? pa_ptr[it * two_l] : 0.0;
-                pb[it] = kok ? pb_ptr[it * two_l] : 0.0;
+                const double *Pk = P + pk_off(lda, t.k0 + min(kk + sk0 + KS * it, t.kw - 1));
+                pa[it] = kok ? Pk[rac] : 0.0;
+                pb[it] = kok ? Pk[rbc] : 0.0;
                 if (SIGNED) pb[it] *= sgk[min(kk + sk0 + KS * it, t.kw - 1)];
             }
             st_ab(cur);
@@ -1035,7 +1046,7 @@ epilogue:
                     // the same IEEE sum as load / subtract / store, bit for bit, without the wave waiting for
                     // the old value -- the read-modify-write form cost 46 us per tile whatever K, its loads
                     // serialised behind the stores to the same array)
-                    if (col < ns) unsafeAtomicAdd(Pw + (i64)row + (i64)col * lda, -acc[a][b][q]);
+                    if (col < ns) unsafeAtomicAdd(Pw + (i64)row + pk_off(lda, col), -acc[a][b][q]);
                     else {
                         double *dst = Uw + (i64)(row - ns) + (i64)(col - ns) * rs;
                         if (t.beta0) *dst = -acc[a][b][q];
@@ -1102,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_update_reduce(const UpdateTask *__restr
         if (row >= f || col >= t.jlim || row < col) continue;
         double sum = Sp[e];
         for (i32 sp = 1; sp < t.kw; ++sp) sum += Sp[(i64)sp * (TILE * TILE) + e];
-        if (col < ns) Pw[(i64)row + (i64)col * lda] -= sum;
+        if (col < ns) Pw[(i64)row + pk_off(lda, col)] -= sum;
         else {
             double *dst = Uw + (i64)(row - ns) + (i64)(col - ns) * rs;
             *dst = t.beta0 ? -sum : (*dst - sum);
@@ -1237,7 +1248,7 @@ __device__ __forceinline__ void load_frag(const DevCtx &c, const FrontDesc &fd, 
     const int i = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const double *M; i64 ld; i32 nr, nc;                   // matrix, leading dimension, rows, columns
     if (WHICH == 0) { M = front_dinv(c, fd, bk0); ld = na; nr = na; nc = na; }
-    else if (WHICH == 1) { M = c.Lval + fd.loff + (i64)(bk0 + NB_IN) + (i64)bk0 * lda; ld = lda; nr = nb2; nc = na; }
+    else if (WHICH == 1) { M = pcol(c, fd, bk0) + (bk0 + NB_IN); ld = lda - bk0; nr = nb2; nc = na; }       // packed panel: the slice of column bk0 (a multiple of 64)
     else { M = front_dinv(c, fd, bk0 + NB_IN); ld = nb2; nr = nb2; nc = nb2; }
     const i32 ir = min(i, nr - 1);
     double v[16];
@@ -1375,12 +1386,12 @@ __global__ __launch_bounds__(256) void k_fwd_update(const SolveTask *__restrict_
     const i32 f = fd.f, ns = fd.ns, nb = t.nb;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const bool fused = t.nslot > 0;                      // workgroup-uniform
-    const double *P = c.Lval + fd.loff + (i64)t.k0 * lda;
+    const double *P = c.Lval + fd.loff;             // packed panel: column k at P + pk_off(lda, k)
     const i32 r = t.row0 + threadIdx.x, rc = min(r, f - 1);
     // the first panel columns travel while the solved block is staged
     double pv[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) pv[j] = P[(i64)rc + (i64)min(j, nb - 1) * lda];
+    for (int j = 0; j < 16; ++j) pv[j] = P[(i64)rc + pk_off(lda, t.k0 + min(j, nb - 1))];
     if (threadIdx.x < SOLVE_NB) ys[threadIdx.x] = (threadIdx.x < nb) ? c.xw[fd.col0 + t.k0 + threadIdx.x] : 0.0;
     __syncthreads();
     double acc = 0.0;
@@ -1391,7 +1402,7 @@ __global__ __launch_bounds__(256) void k_fwd_update(const SolveTask *__restrict_
     // beyond nb
     for (i32 jb = 16; jb < nb; jb += 16) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) pv[j] = P[(i64)rc + (i64)min(jb + j, nb - 1) * lda];
+        for (int j = 0; j < 16; ++j) pv[j] = P[(i64)rc + pk_off(lda, t.k0 + min(jb + j, nb - 1))];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc += pv[j] * ys[jb + j];
     }
@@ -1432,7 +1443,7 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < SOLVE_NB) tacc[threadIdx.x] = 0.0;
     __syncthreads();
-    const double *P0 = c.Lval + fd.loff + (i64)t.k0 * lda;
+    const double *P0 = c.Lval + fd.loff;            // packed panel: column k at P0 + pk_off(lda, k)
     for (i32 rc = t.row0; rc < t.row0 + nrows; rc += BWD_ROWS) {
         const i32 nr = min(BWD_ROWS, t.row0 + nrows - rc);
         double xr[BWD_ROWS / 64];
@@ -1459,7 +1470,7 @@ __global__ __launch_bounds__(256, 4) void k_bwd_update(const SolveTask *__restri
         auto fetch = [&](double (&dst)[CB][BWD_ROWS / 64], const i32 j0) {
 #pragma unroll
             for (int jj = 0; jj < CB; ++jj) {
-                const double *col = P + (i64)min(j0 + jj, nb - 1) * lda;      // clamped: extra columns are dropped below
+                const double *col = P + pk_off(lda, t.k0 + min(j0 + jj, nb - 1));      // clamped: extra columns are dropped below
 #pragma unroll
                 for (int u = 0; u < BWD_ROWS / 64; ++u) dst[jj][u] = col[ro[u]];
             }
@@ -1617,7 +1628,7 @@ __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDe
         const i32 c0 = min(j, nin - 1) * SWEEP_NB + cp0 + 16 * q;
 #pragma unroll
         for (int u = 0; u < 16; ++u)                             // clamped column: x is zero beyond the block
-            b[u] = *reinterpret_cast<const double *>(Lb + (size_t)min(c0 + u, ns - 1) * (size_t)lda * 8u + roff);
+            b[u] = *reinterpret_cast<const double *>(Lb + (size_t)pk_off(lda, min(c0 + u, ns - 1)) * 8u + roff);      // packed panel
     };
     auto consume = [&](const double (&b)[16], const double (&xv)[NR], const int q) {
 #pragma unroll
@@ -1728,7 +1739,8 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_bwd_sweep(const SolveT
     const i32 nbelow = (t.slot > 0) ? (f + 63) / 64 - ns / 64 : 0;   // tiles below the pivot block, ENDING on multiples of 64 rows (line-aligned loads)
     const i32 ntiles = nbelow + t.nslot;
     // this wave's columns: wave-uniform bases (scalar registers) + 32-bit lane offsets
-    const char *Pb = reinterpret_cast<const char *>(c.Lval + fd.loff + (i64)t.k0 * lda);
+    const char *Pb = reinterpret_cast<const char *>(pcol(c, fd, t.k0));         // packed panel: the block's columns lie in the slice of t.k0
+    const i32 ldk = pld(fd, t.k0);
     // Held from the start, off the chain: this block's right-hand side and the fragment of the inverted diagonal
     // block for x[ci] = sum_k W[k][ci] t[k]: thread (ci = lane, part = wave) keeps W[16 part + kk][ci] (W is stored
     // column-major: 16 consecutive doubles per lane)
@@ -1760,7 +1772,7 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_bwd_sweep(const SolveT
         const unsigned rb = (unsigned)(r0 + min(lane, nr - 1)) * 8u;            // clamped row: its x is zeroed
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            b[u] = *reinterpret_cast<const double *>(Pb + (size_t)min(16 * wave + u, nb - 1) * (size_t)lda * 8u + rb);   // clamped column: dropped below
+            b[u] = *reinterpret_cast<const double *>(Pb + (size_t)min(16 * wave + u, nb - 1) * (size_t)ldk * 8u + rb);   // clamped column: dropped below
     };
     auto row_index = [&](const i32 q) -> i32 {                  // global index of this lane's row in a tile below the pivot block
         const i32 qc = min(q, max(nbelow - 1, 0));

@@ -752,7 +752,7 @@ int analyse_rank(Symbolic &S, const Options &opt) {
         // fabric traffic in the solve sweeps than algorithmic bytes with ld = f).
         w.lda = (w.f >= LDA_PAD_MIN_F) ? (w.f + 15) / 16 * 16 : w.f;
         if (w.lda != w.f || w.f >= LDA_PAD_MIN_F) S.lval_len = (S.lval_len + 15) / 16 * 16;
-        w.loff = S.lval_len; S.lval_len += (i64)w.lda * w.ns;
+        w.loff = S.lval_len; S.lval_len += pk_len(w.lda, w.ns);
         w.ucoff = S.uc_len; S.uc_len += (w.f - w.ns);
         w.dinvoff = S.dinv_len;
         S.dinv_len += (w.ns >= NB_IN) ? (i64)((w.ns + NB_IN - 1) / NB_IN) * NB_IN * NB_IN : (i64)w.ns * w.ns;
@@ -932,7 +932,7 @@ int analyse_rank(Symbolic &S, const Options &opt) {
                     if (!pass) {
                         for (i64 e = S.Sp[kk]; e < S.Sp[kk + 1]; ++e) {
                             const i32 ii = S.Si[e];
-                            S.s_target[e] = w.loff + pos_in_front[ii] + (i64)(kk - w.col0) * w.lda;
+                            S.s_target[e] = w.loff + pos_in_front[ii] + pk_off(w.lda, kk - w.col0);
                             S.s_local[e] = 1;
                         }
                         if (opt.system == 1) { if (k >= opt.k2_n && (!is_root || opt.rank == 0)) S.s_diag_row[S.Sp[kk]] = k - (i32)opt.k2_n; }   // constraint node: regD

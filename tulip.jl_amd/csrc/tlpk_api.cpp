@@ -577,7 +577,7 @@ int tlpk_root_panel(tlpk_handle *h, double **d_ptr, int64_t *count) {
     if (h->S.root_front < 0) { *d_ptr = nullptr; *count = 0; return TLPK_OK; }
     const FrontDesc &fd = h->S.fronts[h->S.root_front];
     *d_ptr = h->d.ctx.Lval + fd.loff;
-    *count = (i64)fd.lda * fd.ns;            // whole panel incl. the alignment rows (they stay zero)
+    *count = pk_len(fd.lda, fd.ns);          // whole (packed) panel incl. the alignment rows (they stay zero)
     return TLPK_OK;
 }
 
@@ -1474,7 +1474,7 @@ int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
     out->n_local_blocks = S.n_local_blocks; out->n_blocks = S.nblocks;
     out->flops_update = S.flops_update;
     out->flops_update_alg = S.flops_update_alg;
-    out->root_panel_len = (S.root_front >= 0) ? (i64)S.fronts[S.root_front].lda * S.fronts[S.root_front].ns : 0;
+    out->root_panel_len = (S.root_front >= 0) ? pk_len(S.fronts[S.root_front].lda, S.fronts[S.root_front].ns) : 0;
     return TLPK_OK;
 }
 
