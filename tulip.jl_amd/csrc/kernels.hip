@@ -826,14 +826,16 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
     const int sr = tid & 127, sk0 = tid >> 7;       // staging: row sr, k = sk0 + KS*it
     const i32 ra = t.i0 + sr, rb_ = t.j0 + sr;
     const bool raok = FULL || (ra < f), rbok = FULL || ((rb_ < f) && !diag_tile);
-    // packed panel (tlpk_host.hpp: pk_off): K column k of the front starts at P + pk_off(lda, k); a 16-column slab lies in one slice
+    // packed panel (tlpk_host.hpp: pk_off): K column k of the front starts at P + pk_off(lda, k); a 16-column slab lies in one slice.
+    // The K column of a staging load (sk0 + KS * it inside the slab) is wave-uniform: its offset is scalar arithmetic.
+    const int sk0u = __builtin_amdgcn_readfirstlane(sk0);
     double pa[UPD_NLD], pb[UPD_NLD];
 
     auto load_slab = [&](i32 kk, bool full_k) {
         if (FULL && full_k) {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                const double *Pk = P + pk_off(lda, t.k0 + kk + sk0 + KS * it);
+                const double *Pk = P + pk_off(lda, t.k0 + kk + sk0u + KS * it);
                 pa[it] = Pk[ra];
                 pb[it] = Pk[rb_];
                 if (SIGNED) pb[it] *= sgk[kk + sk0 + KS * it];
@@ -841,8 +843,8 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         } else {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                const bool kok = (kk + sk0 + KS * it) < t.kw;
-                const double *Pk = P + pk_off(lda, t.k0 + min(kk + sk0 + KS * it, t.kw - 1));
+                const bool kok = (kk + sk0u + KS * it) < t.kw;
+                const double *Pk = P + pk_off(lda, t.k0 + min(kk + sk0u + KS * it, t.kw - 1));
                 pa[it] = (kok && raok) ? Pk[ra] : 0.0;
                 pb[it] = (kok && rbok) ? Pk[rb_] : 0.0;
                 if (SIGNED) pb[it] *= sgk[min(kk + sk0 + KS * it, t.kw - 1)];
@@ -875,7 +877,6 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         // address from slab to slab -- UPD_KT columns of lda - 64 b inside slice b, a different amount across a slice boundary -- is
         // scalar arithmetic: pk_off(next column) - pk_off(this column).
         const i32 rac = min(t.i0 + sr, f - 1), rbc = min(t.j0 + sr, f - 1);
-        const int sk0u = __builtin_amdgcn_readfirstlane(sk0);
         const double *qa[UPD_NLD], *qb[UPD_NLD];
 #pragma unroll
         for (int it = 0; it < UPD_NLD; ++it) {
@@ -883,20 +884,34 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
             qa[it] = P + o + rac;
             qb[it] = P + o + rbc;
         }
-        i32 ka_col = t.k0 + sk0u, kb_col = t.k0 + sk0u;  // K column (it = 0) of the slab ld_a / ld_b loads next
+        // A slab of UPD_KT = 16 columns lies inside ONE slice b (the K ranges start on multiples of 16): the next slab is
+        // 16 (lda - 64 b) doubles further; when it opens slice b + 1, column j of the slab moves 64 (j + 1) doubles less
+        // (pk_off(c + 16) - pk_off(c) for c = 64 b + 48 + j).
+        i32 ka_slab = t.k0, kb_slab = t.k0;               // first K column of the slab ld_a / ld_b loads next
+        i64 step_a = (i64)UPD_KT * (lda - ((t.k0 >> 6) << 6)), step_b = step_a;       // 16 columns inside the current slice
         auto ld_a = [&]() {
 #pragma unroll
-            for (int it = 0; it < UPD_NLD; ++it) { pa[it] = *qa[it]; qa[it] += pk_off(lda, ka_col + KS * it + UPD_KT) - pk_off(lda, ka_col + KS * it); }
-            ka_col += UPD_KT;
+            for (int it = 0; it < UPD_NLD; ++it) { pa[it] = *qa[it]; qa[it] += step_a; }
+            ka_slab += UPD_KT;
+            if ((ka_slab & 63) == 0) {                    // (wave-uniform, every fourth slab) the next slab opens a new slice
+#pragma unroll
+                for (int it = 0; it < UPD_NLD; ++it) qa[it] -= 64 * (sk0u + KS * it + 1);
+                step_a -= 64 * UPD_KT;
+            }
         };
         i32 kb_idx = 0;                                   // first K column of the slab ld_b loads next (SIGNED)
         auto ld_b = [&]() {
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                pb[it] = *qb[it]; qb[it] += pk_off(lda, kb_col + KS * it + UPD_KT) - pk_off(lda, kb_col + KS * it);
+                pb[it] = *qb[it]; qb[it] += step_b;
                 if (SIGNED) pb[it] *= sgk[kb_idx + sk0 + KS * it];
             }
-            kb_idx += UPD_KT; kb_col += UPD_KT;
+            kb_idx += UPD_KT; kb_slab += UPD_KT;
+            if ((kb_slab & 63) == 0) {
+#pragma unroll
+                for (int it = 0; it < UPD_NLD; ++it) qb[it] -= 64 * (sk0u + KS * it + 1);
+                step_b -= 64 * UPD_KT;
+            }
         };
         auto st_ab = [&](int buf) {
 #pragma unroll
@@ -950,8 +965,8 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
             const i32 kk = nrounds * UPD_KT;
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                const bool kok = (kk + sk0 + KS * it) < t.kw;
-                const double *Pk = P + pk_off(lda, t.k0 + min(kk + sk0 + KS * it, t.kw - 1));
+                const bool kok = (kk + sk0u + KS * it) < t.kw;
+                const double *Pk = P + pk_off(lda, t.k0 + min(kk + sk0u + KS * it, t.kw - 1));
                 pa[it] = kok ? Pk[rac] : 0.0;
                 pb[it] = kok ? Pk[rbc] : 0.0;
                 if (SIGNED) pb[it] *= sgk[min(kk + sk0 + KS * it, t.kw - 1)];

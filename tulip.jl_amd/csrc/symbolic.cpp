@@ -983,6 +983,9 @@ int analyse_rank(Symbolic &S, const Options &opt) {
     }
     pt.mark("schedule");
     build_schedule(S);
+    // k_update walks its K range in slabs of 16 columns and relies on a slab lying inside ONE 64-column slice of the packed panel
+    for (const UpdateTask &u : S.update_tasks)
+        if ((u.k0 & 15) != 0) return fail(S, TLPK_INTERNAL, "update task: K range does not start on a multiple of 16 columns");
     pt.mark(nullptr);
     return TLPK_OK;
 }
