@@ -112,9 +112,9 @@ __global__ void k_single_solve(i64 n, const i64 *__restrict__ dinvoff, const i32
 }
 
 // Zero-fill of the factor storage before the assembly.  One workgroup per 64-column slice of a panel: rows from the slice's
-// first row down to lda.  The blocks ABOVE the 64 x 64 diagonal blocks (39 % of a square pivot block) are never read by any
-// kernel -- updates, trsm, extend-add, assembly and the sweeps address rows >= the block's first row only -- and stay
-// whatever the allocation held (a plain memset of Lval wrote 8.4 GB per factorisation on config C4, this writes 5.3).
+// first row down to lda -- all a slice stores (packed panels, tlpk_host.hpp: the blocks ABOVE the 64 x 64 diagonal blocks, 39 % of
+// a square pivot block, are read by no kernel -- updates, trsm, extend-add, assembly and the sweeps address rows >= the block's
+// first row only -- and have no storage).
 __global__ __launch_bounds__(256) void k_zero_panels(const i32 *__restrict__ tasks, DevCtx c) {
     const i32 s = tasks[2 * blockIdx.x], c0 = tasks[2 * blockIdx.x + 1];
     const FrontDesc fd = c.fronts[s];
