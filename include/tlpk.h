@@ -221,7 +221,10 @@ int tlpk_get_perm(const tlpk_handle *h, int64_t *perm /*m, 0-based, perm[new] = 
  * if buf != NULL, copies min(len, cap) int64 entries. */
 int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, int64_t cap);
 int64_t tlpk_symbolic_get_f64(const tlpk_handle *h, const char *what, double *buf, int64_t cap);
-/* Copy the numeric factor panels (device -> host), nnzL_stored doubles. */
+/* Copy the numeric factor panels (device -> host), nnzL_stored doubles.  Layout: front s (symbolic arrays front_f, front_ns, front_loff,
+ * front_lda) stores its f x ns panel column-major by 64-column slices -- slice b = columns [64 b, 64 b + 64) from row 64 b down, leading
+ * dimension lda - 64 b; entry (row, col) at loff + col * lda - 64 b (col - 32 b - 31) + row, b = col / 64 (fronts of <= 64 pivot
+ * columns: plain column-major with leading dimension lda). */
 int tlpk_get_factor(tlpk_handle *h, double *lval, int64_t cap);
 
 /* ---------------------------------------------------------------------------------------------
