@@ -314,3 +314,36 @@ def test_property_schedule_matches_oracle(m, n, density, seed, relax, ordering, 
     dxo, dyo = orc.solve(xp, xd)
     assert np.abs(dy - dyo).max() <= 1e-8 * max(1.0, np.abs(dyo).max())
     assert np.abs(dx - dxo).max() <= 1e-8 * max(1.0, np.abs(dxo).max())
+
+
+@pytest.mark.parametrize("kind", ["dense", "block_angular"])
+def test_packed_panels_of_fronts_with_several_slices(kind):
+    """Panels are stored by 64-column slices (tlpk_host.hpp: pk_off / pk_len): the storage length the analyse phase reports is the sum
+    of the packed panel lengths, the assembly targets address that storage (the numpy executor assembles through them and must
+    reproduce the oracle's solution on fronts of 3-4 slices), and the CPU comparator's factor, re-packed into the device layout,
+    decodes to the same L."""
+    import scipy.sparse as sp
+    from emulate import Emulator, panels_to_dense_L, pk_len
+    from helpers import block_angular, ipm_like_data
+    from oracle_binding import OracleK1, SupernodalK1
+    rng = np.random.default_rng(3)
+    if kind == "dense":
+        A, rb = sp.csc_matrix(rng.standard_normal((200, 420))), None
+    else:
+        A, rb = block_angular(nblocks=3, mk=150, nk=330, m0=140, nnz_in=6, link_prob=0.9, seed=5)
+    m, n = A.shape
+    kkt = tk.setup(A, tk.K1(), tk.Backend(device=-1, row_block=rb))
+    ns, lda, local = kkt.symbolic("front_ns"), kkt.symbolic("front_lda"), kkt.symbolic("front_local")
+    assert ns.max() >= 129                                                       # at least three slices somewhere
+    stored = sum(pk_len(int(l), int(k)) for l, k, o in zip(lda, ns, local) if o)
+    assert stored <= kkt.stats()["nnzL_stored"] < stored + 16 * len(ns)           # + alignment of the panel starts
+    assert kkt.stats()["nnzL_stored"] < 0.9 * float((lda * ns).sum())            # the blocks above the diagonal blocks are gone
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 1)
+    em = Emulator(kkt); em.update(th, rp, rd)
+    dx, dy = em.solve(xp, xd, A)
+    orc = OracleK1(A, kkt.perm()); orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    assert np.abs(dx - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max()) and np.abs(dy - dyo).max() <= 1e-9 * max(1, np.abs(dyo).max())
+    sn = SupernodalK1(A, kkt); sn.update(th, rp, rd)
+    Ls, Le, Lo = panels_to_dense_L(kkt, sn.factor_panels()), em.dense_L(), orc.get_L().toarray()
+    assert np.abs(Ls - Lo).max() <= 1e-10 * np.abs(Lo).max() and np.abs(Le - Lo).max() <= 1e-10 * np.abs(Lo).max()
