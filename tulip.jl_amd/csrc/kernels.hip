@@ -153,8 +153,6 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
     const EaTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
-    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
-    double *P = c.Lval + fd.loff;
     double *Up = front_u(c, fd);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -615,7 +613,6 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
-    double *P = c.Lval + fd.loff;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
@@ -1747,7 +1744,6 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_bwd_sweep(const SolveT
     const SolveTask t = tasks[s_item];
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, nb = t.nb;
-    const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const i32 *rows = c.rowidx + fd.rowoff;
     const double *xhf = a.xh + fd.col0;
     const i32 nblk = (ns + SWEEP_NB - 1) / SWEEP_NB;
