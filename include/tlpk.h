@@ -193,11 +193,13 @@ int tlpk_refine_finish(tlpk_handle *h, double *d_dx, double *d_dy);
 int tlpk_root_copy(tlpk_handle *h, int which, int dir, double *d_buf);
 
 /* Single-process multi-GPU (block-angular LPs only): ONE handle, driven by one host thread, shards the diagonal
- * blocks over `ngpus` devices of this node -- what a Julia process needs (`TlpHIP.Backend(row_block = rb, ngpus = 8)`).
- * `opt->row_block` is required, `opt->system` must be K1.  devices: ngpus HIP ordinals, or NULL for 0 .. ngpus-1
- * (an ordinal may repeat: several shards on one device, for testing).  The two reductions of a Newton step (root
- * panel, root right-hand side) are done inside the library over peer-to-peer copies, stream-ordered; results are
- * gathered on devices[0].  The handle accepts tlpk_update / tlpk_solve / tlpk_info / tlpk_get_perm / tlpk_destroy. */
+ * blocks over `ngpus` devices of this node -- what a Julia process needs (`TlpHIP.Backend(row_block = :auto, ngpus = 8)`).
+ * Needs `opt->row_block` or `opt->detect_blocks`; K1 or K2; `opt->refine_steps` is honoured (K1).  devices: ngpus HIP ordinals, or
+ * NULL for 0 .. ngpus-1 (an ordinal may repeat: several shards on one device, for testing).  One host analyse serves all shards; the
+ * two reductions of a Newton step (root panel, root right-hand side) are done inside the library, stream-ordered -- peer-to-peer
+ * copies + an ordered sum on devices[0], or ncclAllReduce (librccl.so through dlopen) with TLPK_MULTI_REDUCE=rccl --; results are
+ * gathered on devices[0].  The handle accepts tlpk_update / tlpk_solve / tlpk_sync / tlpk_info / tlpk_get_perm / tlpk_destroy and the
+ * device-resident loops (tlpk_ipm_*, tlpk_mpc_*); the device-pointer and split-phase calls belong to single and sharded handles. */
 int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
                       const double *nzval, int index_base, const tlpk_options *opt, int ngpus, const int32_t *devices);
 
