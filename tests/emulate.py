@@ -39,7 +39,7 @@ class Emulator:
             LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 4),
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
             LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),
-            LK["UPDATE"]: g("update_tasks").reshape(-1, 8),
+            LK["UPDATE"]: g("update_tasks").reshape(-1, 10),
             LK["UPDATE_REDUCE"]: g("reduce_tasks").reshape(-1, 8),
             LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 6),
             LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 6),
@@ -50,6 +50,7 @@ class Emulator:
             LK["FWD_SWEEP"]: g("fwd_sweep_tasks").reshape(-1, 6),
             LK["BWD_SWEEP"]: g("bwd_sweep_tasks").reshape(-1, 6),
         }
+        self.upd_seg = g("upd_seg")     # K-segment lists of the update tasks that skip structurally zero slabs
         self.flagoff = g("front_flagoff")
         self.factor_launches = g("factor_launches").reshape(-1, 3)
         self.fwd_launches = g("fwd_launches").reshape(-1, 3)
@@ -220,16 +221,25 @@ class Emulator:
 
     def _k3(self, T):      # update
         TILE = 128
-        for front, k0, kw, i0, j0, jlim, beta0, slot1 in T:
+        for front, k0, kw, i0, j0, jlim, beta0, slot1, seg, nsl in T:
             P = self.panel(front)
             f, ns = int(self.f[front]), int(self.ns[front])
             i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)
             if i1 <= i0 or j1 <= j0:
                 continue
-            Pj = P[j0:j1, k0:k0 + kw]
+            if seg:
+                # skip list: only the listed K slabs (+ the partial last slab) are multiplied, exactly as k_update does
+                nseg = int(self.upd_seg[seg - 1])
+                kcols = [np.arange(self.upd_seg[seg + 2 * q], self.upd_seg[seg + 2 * q] + 16 * self.upd_seg[seg + 2 * q + 1]) for q in range(nseg)]
+                kcols.append(np.arange(k0 + (kw // 16) * 16, k0 + kw))
+                kcols = np.concatenate(kcols)
+                assert kcols.size == 16 * nsl + kw % 16 and nsl >= 2 and kcols.min() >= k0 and kcols.max() < k0 + kw and np.all(np.diff(kcols) > 0)
+            else:
+                kcols = np.arange(k0, k0 + kw)
+            Pj = P[j0:j1][:, kcols]
             if self.k2:
-                Pj = Pj * self.sign[self.col0[front] + k0: self.col0[front] + k0 + kw][None, :]      # X S X'
-            G = P[i0:i1, k0:k0 + kw] @ Pj.T
+                Pj = Pj * self.sign[self.col0[front] + kcols][None, :]      # X S X'
+            G = P[i0:i1][:, kcols] @ Pj.T
             if slot1:            # split-K part: raw tile to its scratch slot (each slot written exactly once)
                 assert int(slot1) - 1 not in self.spart
                 self.spart[int(slot1) - 1] = G

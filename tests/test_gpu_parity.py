@@ -795,3 +795,27 @@ def test_asynchronous_update_overlaps_the_root_front_and_reports_at_sync():
     kkt.solve2_device(P(o[2]), P(o[3]), P(d[3]), P(d[4]), P(o[0]), P(o[1]), P(d[3]), P(d[4]))
     assert np.array_equal(o[0].get(), o[2].get()) and np.array_equal(o[1].get(), o[3].get())
     kkt.close()
+
+
+def test_update_skip_lists_of_structural_zeros(monkeypatch):
+    """k_update with K-segment lists (slabs in which an operand row range holds only amalgamation padding are skipped): every
+    factor entry against the simplicial oracle, and the same handle without lists gives the same factor to rounding."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from workloads import block_angular_lp
+    monkeypatch.setenv("TLPK_SKIP_MIN_F", "64")
+    monkeypatch.setenv("TLPK_SPLITK_TILES", "0")
+    A, rb = block_angular_lp(nblocks=2, mk=1600, nk=3200, m0=150)
+    kkt = gpu_setup(A, row_block=rb)
+    ut = kkt.symbolic("update_tasks").reshape(-1, 10)
+    assert (ut[:, 8] > 0).sum() >= 10
+    r1, r2 = compare_with_oracle(A, kkt, 2)
+    assert max(r1, r2) <= 1e-8
+    Ls = panels_to_dense_L(kkt, kkt.factor_panels())
+    monkeypatch.setenv("TLPK_SKIP", "0")
+    k0 = gpu_setup(A, row_block=rb)
+    assert (k0.symbolic("update_tasks").reshape(-1, 10)[:, 8] == 0).all()
+    th, rp, rd, xp, xd = ipm_like_data(*A.shape, 2)
+    tk.update(k0, th, rp, rd)
+    L0 = panels_to_dense_L(k0, k0.factor_panels())
+    assert np.abs(Ls - L0).max() <= 1e-12 * np.abs(L0).max()

@@ -270,3 +270,17 @@ def test_k2_single_process_multi_device_mode(ngpus):
         tk.update(kkt, th, rp, bad)
     tk.update(kkt, th, rp, rd)
     tk.run_ls_tests(A, kkt)
+
+
+@pytest.mark.gpu
+def test_k2_update_skip_lists(monkeypatch):
+    """The signed k_update instance with K-segment lists (structural zeros of amalgamated supernodes skipped) against the K2 oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from workloads import block_angular_lp
+    monkeypatch.setenv("TLPK_SKIP_MIN_F", "64")
+    monkeypatch.setenv("TLPK_SPLITK_TILES", "0")
+    A, row_block = block_angular_lp(nblocks=2, mk=2000, nk=4000, m0=150)
+    kkt, _, _ = gpu_compare(A, 4, row_block=row_block)
+    ut = kkt.symbolic("update_tasks").reshape(-1, 10)
+    assert (ut[:, 8] > 0).any(), "no signed update tile skips anything"

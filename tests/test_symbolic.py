@@ -95,7 +95,7 @@ def test_macro_columns_on_a_single_dense_front(monkeypatch):
     A = general_sparse_lp(1400)
     kkt = analyse_only(A)
     assert kkt.symbolic("front_ns").max() > 1200
-    ut = kkt.symbolic("update_tasks").reshape(-1, 8)
+    ut = kkt.symbolic("update_tasks").reshape(-1, 10)
     panel_updates = ut[ut[:, 6] == 0]                          # beta0 == 0: targets inside a panel
     assert (panel_updates[:, 1] > 0).any(), "no in-macro update (K starting at kM > 0)"
     # a macro update covers more than one 256-wide block column: its column limit is > j0 + 256
@@ -347,3 +347,55 @@ def test_packed_panels_of_fronts_with_several_slices(kind):
     sn = SupernodalK1(A, kkt); sn.update(th, rp, rd)
     Ls, Le, Lo = panels_to_dense_L(kkt, sn.factor_panels()), em.dense_L(), orc.get_L().toarray()
     assert np.abs(Ls - Lo).max() <= 1e-10 * np.abs(Lo).max() and np.abs(Le - Lo).max() <= 1e-10 * np.abs(Lo).max()
+
+
+def test_skip_lists_of_structural_zeros(monkeypatch):
+    """Update tiles skip the K slabs in which one of their operand row ranges holds only amalgamation padding (analyse step 13c).
+    The emulator multiplies exactly the listed slabs: a slab wrongly declared zero would show in L.  Also: the flags are the true
+    structure of L at 16 x 16 granularity (derived here from the elimination tree by an independent dense recursion)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from workloads import block_angular_lp
+    monkeypatch.setenv("TLPK_SKIP_MIN_F", "64")          # the benchmark shapes qualify by themselves (fronts of >= 256 rows, >= 256 tiles per launch)
+    monkeypatch.setenv("TLPK_SPLITK_TILES", "0")
+    A, rb = block_angular_lp(nblocks=2, mk=1600, nk=3200, m0=150)
+    kkt = analyse_only(A, row_block=rb)
+    ut = kkt.symbolic("update_tasks").reshape(-1, 10)
+    seg = kkt.symbolic("upd_seg")
+    assert (ut[:, 8] > 0).sum() >= 10, "no update tile skips anything: the test shape no longer exercises the lists"
+    for t in ut[ut[:, 8] > 0]:
+        nseg = seg[t[8] - 1]
+        starts, lens = seg[t[8]: t[8] + 2 * nseg: 2], seg[t[8] + 1: t[8] + 2 * nseg: 2]
+        assert lens.sum() == t[9] >= 2 and (starts % 16 == 0).all() and starts[0] >= t[1] and starts[-1] + 16 * lens[-1] <= t[1] + t[2] // 16 * 16
+        assert (starts[1:] > starts[:-1] + 16 * lens[:-1]).all(), "segments must be disjoint, ascending, with a gap between them"
+    st = kkt.stats()
+    monkeypatch.setenv("TLPK_SKIP", "0")
+    st0 = analyse_only(A, row_block=rb).stats()
+    assert st["flops_update"] < 0.99 * st0["flops_update"] and st["flops_update_alg"] == st0["flops_update_alg"]
+    check_against_oracle(A, kkt, 1, tol=1e-9)
+    # flags == true structure of L (16-row groups x 16-column slabs, below the slab's columns)
+    parent = kkt.symbolic("etree"); Sp = kkt.symbolic("s_colptr"); Si = kkt.symbolic("s_rowidx")
+    m = A.shape[0]
+    Lt = np.zeros((m, m), dtype=bool)                    # Lt[j] = structure of column j
+    for j in range(m):
+        Lt[j, Si[Sp[j]:Sp[j + 1]]] = True
+    for j in range(m):                                   # children before parents (postorder)
+        if parent[j] >= 0:
+            Lt[parent[j], j + 1:] |= Lt[j, j + 1:]
+    so = kkt.symbolic("skip_off"); sb = kkt.symbolic("skip_bits").view(np.uint64)
+    f_f, f_ns, f_c0, f_ro, rowidx = (kkt.symbolic(k) for k in ("front_f", "front_ns", "front_col0", "front_rowoff", "rowidx"))
+    checked = 0
+    for s in np.nonzero(so >= 0)[0]:
+        f, ns, c0 = int(f_f[s]), int(f_ns[s]), int(f_c0[s])
+        rows = rowidx[f_ro[s]: f_ro[s] + f]
+        M = Lt[c0:c0 + ns][:, rows].T                    # f x ns
+        nsl, ng = (ns + 15) // 16, (f + 15) // 16
+        W = (ng + 63) // 64
+        bits = sb[so[s]: so[s] + nsl * W].reshape(nsl, W)
+        for k in range(nsl):
+            truth = np.add.reduceat(M[:, 16 * k:16 * k + 16].any(axis=1).astype(int), np.arange(0, f, 16)) > 0
+            lib = np.array([(int(bits[k, g >> 6]) >> (g & 63)) & 1 for g in range(ng)], dtype=bool)
+            g0 = k + 1                                   # row groups below the slab's own columns
+            assert (lib[g0:] == truth[g0:]).all(), (s, k)
+            checked += ng - g0
+    assert checked > 1000

@@ -784,7 +784,7 @@ constexpr int UPD_LD = TILE + 16;          // LDS row stride (doubles), == 16 mo
 // NW = waves per workgroup.  4: 2 x 2 waves, a 64 x 64 sub-tile each (16 accumulator blocks per wave).  8: 2 x 4 waves, 64 rows x 32
 // columns each (8 accumulator blocks, ~half the registers): twice the waves per SIMD to cover LDS / barrier / load waits.
 template <bool FULL, bool SIGNED, int NW>
-__device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc &fd, const DevCtx &c,
+__device__ __forceinline__ void update_tile(const UpdateTask t, const FrontDesc &fd, const DevCtx &c,
                                             double (*As)[UPD_KT * UPD_LD], double (*Bs)[UPD_KT * UPD_LD]) {
     const double *sgk = SIGNED ? c.csign + fd.col0 + t.k0 : nullptr;          // sign of K column k: sgk[k]
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
@@ -857,7 +857,9 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         }
     };
 
-    if (t.kw >= 2 * UPD_KT) {
+    // K-segment list (UpdateTask.seg): the slabs in which both operand row ranges hold structural nonzeros; wave-uniform (scalar loads)
+    const i32 *segp = t.seg ? c.upd_seg + (t.seg - 1) : nullptr;
+    if (segp || t.kw >= 2 * UPD_KT) {
         // Main path (every tile with K >= 2 slabs): the staging work is spread INSIDE the MFMA block
         // instead of in front of it (ablation: the 16 loads + address arithmetic issued before the
         // first MFMA of a round cost ~19 % even with L2-hot data, i.e. pure issue time).  Registers
@@ -873,41 +875,55 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         // Packed panel: the K columns of one staging load (sk0 + KS * it inside the slab) are wave-uniform, so the advance of its
         // address from slab to slab -- UPD_KT columns of lda - 64 b inside slice b, a different amount across a slice boundary -- is
         // scalar arithmetic: pk_off(next column) - pk_off(this column).
-        const i32 rac = min(t.i0 + sr, f - 1), rbc = min(t.j0 + sr, f - 1);
-        const double *qa[UPD_NLD], *qb[UPD_NLD];
-#pragma unroll
-        for (int it = 0; it < UPD_NLD; ++it) {
-            const i64 o = pk_off(lda, t.k0 + sk0u + KS * it);
-            qa[it] = P + o + rac;
-            qb[it] = P + o + rbc;
-        }
+        // Addresses = wave-uniform base (scalar registers: the panel + the offset of the K column) + a constant 32-bit byte offset
+        // per lane (its clamped row): the advance from slab to slab -- and the jump to the next K segment of a skip list -- is
+        // scalar arithmetic only, no address registers per load (the kernel sits at the 128-register limit of 4 waves / SIMD).
+        // Both operands read the same K columns; ld_a and ld_b of a round load the SAME slab, the iterator moves after ld_b.
+        unsigned voa = (unsigned)min(t.i0 + sr, f - 1) * 8u, vob = (unsigned)min(t.j0 + sr, f - 1) * 8u;
+        const char *Pc = reinterpret_cast<const char *>(P);
+        const i32 nseg = segp ? segp[0] : 1;
         // A slab of UPD_KT = 16 columns lies inside ONE slice b (the K ranges start on multiples of 16): the next slab is
         // 16 (lda - 64 b) doubles further; when it opens slice b + 1, column j of the slab moves 64 (j + 1) doubles less
-        // (pk_off(c + 16) - pk_off(c) for c = 64 b + 48 + j).
-        i32 ka_slab = t.k0, kb_slab = t.k0;               // first K column of the slab ld_a / ld_b loads next
-        i64 step_a = (i64)UPD_KT * (lda - ((t.k0 >> 6) << 6)), step_b = step_a;       // 16 columns inside the current slice
+        // (pk_off(c + 16) - pk_off(c) for c = 64 b + 48 + j).  Skip lists: when the current K segment is used up the iterator
+        // jumps to the first column of the next one (offsets from pk_off again).
+        i32 k_slab = segp ? segp[1] : t.k0;               // first K column of the slab loaded next
+        i32 k_rem = segp ? segp[2] : (t.kw / UPD_KT);     // slabs left in the current segment
+        i32 k_seg = 0;
+        const char *sb[UPD_NLD];                          // address of (row 0 of) K column k_slab + sk0u + KS * it (scalar)
+#pragma unroll
+        for (int it = 0; it < UPD_NLD; ++it) sb[it] = Pc + pk_off(lda, k_slab + sk0u + KS * it) * 8;
+        i64 step = (i64)UPD_KT * 8 * (lda - ((k_slab >> 6) << 6));       // 16 columns inside the current slice, in bytes
+        // (the empty asm keeps the zero-extension of the lane offset in the block of the load: hoisted out of the loop, instruction selection
+        // no longer sees "scalar base + 32-bit lane offset" and goes back to a 64-bit vector add per load, whose temporaries are the
+        // destination registers of loads still in flight)
         auto ld_a = [&]() {
+            asm volatile("" : "+v"(voa));               // in place: a copy would land in a destination register of the previous loads
 #pragma unroll
-            for (int it = 0; it < UPD_NLD; ++it) { pa[it] = *qa[it]; qa[it] += step_a; }
-            ka_slab += UPD_KT;
-            if ((ka_slab & 63) == 0) {                    // (wave-uniform, every fourth slab) the next slab opens a new slice
-#pragma unroll
-                for (int it = 0; it < UPD_NLD; ++it) qa[it] -= 64 * (sk0u + KS * it + 1);
-                step_a -= 64 * UPD_KT;
-            }
+            for (int it = 0; it < UPD_NLD; ++it) pa[it] = *reinterpret_cast<const double *>(sb[it] + voa);
         };
-        i32 kb_idx = 0;                                   // first K column of the slab ld_b loads next (SIGNED)
+        const double *sgf = SIGNED ? c.csign + fd.col0 : nullptr;          // sign of the front's K column k: sgf[k]
         auto ld_b = [&]() {
+            asm volatile("" : "+v"(vob));
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
-                pb[it] = *qb[it]; qb[it] += step_b;
-                if (SIGNED) pb[it] *= sgk[kb_idx + sk0 + KS * it];
+                pb[it] = *reinterpret_cast<const double *>(sb[it] + vob);
+                if (SIGNED) pb[it] *= sgf[k_slab + sk0 + KS * it];
             }
-            kb_idx += UPD_KT; kb_slab += UPD_KT;
-            if ((kb_slab & 63) == 0) {
+            k_slab += UPD_KT;
+            if (--k_rem == 0 && ++k_seg < nseg) {         // (wave-uniform) next K segment
+                k_slab = segp[1 + 2 * k_seg];
+                k_rem = segp[2 + 2 * k_seg];
 #pragma unroll
-                for (int it = 0; it < UPD_NLD; ++it) qb[it] -= 64 * (sk0u + KS * it + 1);
-                step_b -= 64 * UPD_KT;
+                for (int it = 0; it < UPD_NLD; ++it) sb[it] = Pc + pk_off(lda, k_slab + sk0u + KS * it) * 8;
+                step = (i64)UPD_KT * 8 * (lda - ((k_slab >> 6) << 6));
+            } else {
+#pragma unroll
+                for (int it = 0; it < UPD_NLD; ++it) sb[it] += step;
+                if ((k_slab & 63) == 0) {                 // (wave-uniform, every fourth slab) the next slab opens a new slice
+#pragma unroll
+                    for (int it = 0; it < UPD_NLD; ++it) sb[it] -= 64 * 8 * (sk0u + KS * it + 1);
+                    step -= 64 * 8 * UPD_KT;
+                }
             }
         };
         auto st_ab = [&](int buf) {
@@ -947,7 +963,7 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
         if (threadIdx.x == 0) ((unsigned long long *)c.spart)[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
 #endif
         int cur = 0;
-        const i32 nrounds = t.kw / UPD_KT;
+        const i32 nrounds = segp ? t.nsl : t.kw / UPD_KT;
         for (i32 rd = 0; rd < nrounds; ++rd) {
             const bool have_next = rd + 1 < nrounds, have_next2 = rd + 2 < nrounds;
             mfma_round(cur, [&](int k4) {
@@ -959,13 +975,13 @@ __device__ __forceinline__ void update_tile(const UpdateTask &t, const FrontDesc
             cur ^= 1;
         }
         if (t.kw % UPD_KT) {                              // K tail: one zero-filled slab
-            const i32 kk = nrounds * UPD_KT;
+            const i32 kk = (t.kw / UPD_KT) * UPD_KT;
 #pragma unroll
             for (int it = 0; it < UPD_NLD; ++it) {
                 const bool kok = (kk + sk0u + KS * it) < t.kw;
                 const double *Pk = P + pk_off(lda, t.k0 + min(kk + sk0u + KS * it, t.kw - 1));
-                pa[it] = kok ? Pk[rac] : 0.0;
-                pb[it] = kok ? Pk[rbc] : 0.0;
+                pa[it] = kok ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(Pk) + voa) : 0.0;
+                pb[it] = kok ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(Pk) + vob) : 0.0;
                 if (SIGNED) pb[it] *= sgk[min(kk + sk0 + KS * it, t.kw - 1)];
             }
             st_ab(cur);
@@ -1085,7 +1101,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_update(const Updat
         const unsigned per = gridDim.x >> 3, whole = per << 3;
         if (b < whole) b = (b & 7u) * per + (b >> 3);
     }
-    const UpdateTask t = tasks[b];
+    // memberwise: a 48-byte struct copy went through scratch memory (and every wave-uniform field of the task into vector registers)
+    const UpdateTask *tp = tasks + b;
+    const UpdateTask t{tp->front, tp->k0, tp->kw, tp->i0, tp->j0, tp->jlim, tp->beta0, tp->pad1, tp->seg, tp->nsl, 0, 0};
     const FrontDesc fd = c.fronts[t.front];
     const bool full = (t.i0 + TILE <= fd.f) && (t.j0 + TILE <= t.jlim) && (t.i0 >= t.j0 + TILE);
 #ifdef UPD_TRACE   /* tools/update_bench.hip: per-workgroup time stamps (100 MHz) and placement */

@@ -573,9 +573,15 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
                 const double newz = cz[c] + cz[p] + extra_zeros;
                 const double total = (nc + np) * fnew;
                 const double width = nc + np;
-                const bool rule_a = extra_zeros == 0 || width <= 4 || (width <= 16 && newz <= 0.8 * total) ||
-                                    (width <= 48 && newz <= 0.1 * total) || newz <= 0.05 * total;
                 const double extra_flops = nc * (fnew * fnew - fc * fc);
+                // the zero-fraction classes bound MEMORY; the last, unbounded-width class also needs a bound on the padded FLOPS
+                // (a 5-row leaf column absorbed by a 4 500-row front costs 2e7 flops of zeros for 25 flops of work)
+                static const double ZFRAC = [] { const char *e = std::getenv("TLPK_RELAX_ZFRAC"); return e ? std::atof(e) : 0.05; }();
+                static const double AFLOPS = [] { const char *e = std::getenv("TLPK_RELAX_AFLOPS"); return e ? std::atof(e) : 1e300; }();
+                static const double AGAMMA = [] { const char *e = std::getenv("TLPK_RELAX_AGAMMA"); return e ? std::atof(e) : 0.0; }();
+                const bool rule_a = extra_zeros == 0 || width <= 4 || (width <= 16 && newz <= 0.8 * total) ||
+                                    (width <= 48 && newz <= 0.1 * total) ||
+                                    (newz <= ZFRAC * total && extra_flops <= AFLOPS + AGAMMA * rsc * rsc);
                 const bool rule_b = extra_flops < GAMMA * rsc * rsc && extra_zeros < 0.5 * rsc * rsc;
                 // a child almost as tall as its parent (a thin front with thousands of rows) ships an
                 // update matrix of ~fp^2 entries for a handful of columns: merging pads little
@@ -861,6 +867,92 @@ int analyse_rank(Symbolic &S, const Options &opt) {
         }, 64);
     }
 
+    pt.mark("structural zeros");
+    // ---- 13c. structural zeros of the amalgamated fronts.  A merged supernode is stored and factorised as a dense trapezoid, but
+    // the columns of an absorbed child are zero outside the child's own row structure: on the north-star instance a third of the
+    // flops of the left-looking update multiplied such zeros.  For every front with padding: one bit per (16-column K slab, 16-row
+    // group) = "some column of the slab has a TRUE nonzero of L in these rows"; build_schedule gives every update tile the list of
+    // K slabs in which BOTH of its operand row ranges have one.  True structures come from the column elimination tree: inside a front the
+    // columns form chains with nested structures (parent[j-1] == j and count[j-1] == count[j] + 1: struct(j) = struct(j-1) \ {j-1}), the
+    // structure of a chain head is its column of S, the structures of the etree children of the chain's columns that lie in the front,
+    // and the rows below the child FRONTS that enter the front at a column of the chain (the last column of a front holds all rows
+    // below the front).  Bits of rows above a column are never consulted (operand rows lie below the K columns), so plain ORs do.
+    {
+        i64 min_f = 256;
+        bool on = true;
+        if (const char *e = std::getenv("TLPK_SKIP")) on = std::atoi(e) != 0;                  // TLPK_SKIP=0: no skip lists
+        if (const char *e = std::getenv("TLPK_SKIP_MIN_F")) min_f = std::atoll(e);             // testing knob
+        S.skip_off.assign((size_t)ns_total, -1);
+        S.skip_bits.clear();
+        std::vector<i32> elig;
+        i64 acc = 0;
+        if (on)
+            for (i32 s = 0; s < ns_total; ++s) {
+                const FrontDesc &w = S.fronts[s];
+                if (!S.front_local[s] || w.ns < 2 * 16 || w.f < min_f || w.f <= w.ns) continue;
+                i64 stored = 0, truth = 0;
+                for (i32 c = 0; c < w.ns; ++c) { stored += w.f - c; truth += S.colcount[w.col0 + c]; }
+                if (stored == truth) continue;                 // no padding: nothing to skip
+                const i64 nsl = (w.ns + 15) / 16, W = ((w.f + 15) / 16 + 63) / 64;
+                S.skip_off[s] = acc; acc += nsl * W;
+                elig.push_back(s);
+            }
+        S.skip_bits.assign((size_t)acc, 0);
+        std::atomic<int> bad{0};
+        parallel_for_throw((i64)elig.size(), host_threads((i64)elig.size()), [&](unsigned, i64 q) {
+            const i32 s = elig[(size_t)q];
+            const FrontDesc &w = S.fronts[s];
+            const i32 ns = w.ns, f = w.f, col0 = w.col0;
+            const i64 W = ((f + 15) / 16 + 63) / 64;
+            std::vector<i32> head(ns), hid(ns, -1);
+            i32 nheads = 0;
+            for (i32 c = 0; c < ns; ++c) {
+                const bool chain = c > 0 && S.parent[col0 + c - 1] == col0 + c && S.colcount[col0 + c - 1] == S.colcount[col0 + c] + 1;
+                head[c] = chain ? head[c - 1] : c;
+                if (!chain) hid[c] = nheads++;
+            }
+            std::vector<uint64_t> B((size_t)nheads * W, 0);
+            auto setpos = [&](uint64_t *b, i32 pos) { b[(pos >> 4) >> 6] |= (uint64_t)1 << ((pos >> 4) & 63); };
+            const i32 *below = S.rowidx.data() + w.rowoff + ns;
+            for (i32 t = 0; t < w.nchild; ++t) {
+                const FrontDesc &cd = S.fronts[S.children[w.child_ptr + t]];
+                const i32 p = S.parent[cd.col0 + cd.ns - 1];
+                if (p < col0 || p >= col0 + ns) { bad = 1; return; }
+                uint64_t *hb = B.data() + (size_t)hid[head[p - col0]] * W;
+                for (i32 r = 0; r < cd.f - cd.ns; ++r) setpos(hb, S.rel[cd.reloff + r]);
+            }
+            for (i32 c = 0; c < ns; ++c) {
+                const i32 j = col0 + c;
+                uint64_t *hb = B.data() + (size_t)hid[head[c]] * W;
+                if (head[c] == c)
+                    for (i64 e = S.Sp[j]; e < S.Sp[j + 1]; ++e) {
+                        const i32 i = S.Si[e];
+                        i32 pos;
+                        if (i < col0 + ns) pos = i - col0;
+                        else {
+                            const i32 *it = std::lower_bound(below, below + (f - ns), i);
+                            if (it == below + (f - ns) || *it != i) { bad = 1; return; }
+                            pos = ns + (i32)(it - below);
+                        }
+                        setpos(hb, pos);
+                    }
+                const i32 p = S.parent[j];
+                if (p != -1 && p < col0 + ns && head[p - col0] != head[c]) {
+                    uint64_t *pb = B.data() + (size_t)hid[head[p - col0]] * W;
+                    for (i64 x = 0; x < W; ++x) pb[x] |= hb[x];
+                }
+            }
+            uint64_t *out = S.skip_bits.data() + S.skip_off[s];
+            for (i32 c = 0; c < ns; ++c) {
+                if (c > 0 && head[c] == head[c - 1] && (c & 15) != 0) continue;      // same chain as the previous column of this slab
+                const uint64_t *hb = B.data() + (size_t)hid[head[c]] * W;
+                uint64_t *ob = out + (size_t)(c >> 4) * W;
+                for (i64 x = 0; x < W; ++x) ob[x] |= hb[x];
+            }
+        }, 1);
+        if (bad) return fail(S, TLPK_INTERNAL, "structural-zero analysis: inconsistent front structure");
+    }
+
     pt.mark("gather lists");
     // ---- 13b. forward-solve gather lists: for every row t of a front, the entries of its
     // children's contribution vectors that land on it, in child order (the order the sums are
@@ -1096,6 +1188,25 @@ static void build_schedule(Symbolic &S) {
         for (i32 c0 = 0; c0 < w.ns; c0 += NB_IN) { S.zero_tasks.push_back((i32)s); S.zero_tasks.push_back(c0); }
     }
     auto in_scope = [&](i32 s) { return S.front_local[s] && !S.front_single[s] && (cur_g < 0 || S.front_group[s] == cur_g); };
+    // structural-zero flags of a 128-row operand window [r0, r0 + TILE) of front s, one byte per K slab (step 13c), built on first use
+    std::vector<std::vector<std::pair<i32, std::vector<char>>>> win_cache(S.fronts.size());
+    auto window_flags = [&](i32 s, i32 r0) -> const char * {
+        auto &lst = win_cache[(size_t)s];
+        for (auto &e : lst) if (e.first == r0) return e.second.data();
+        const FrontDesc &w = S.fronts[s];
+        const i64 nsl = (w.ns + 15) / 16, W = ((w.f + 15) / 16 + 63) / 64;
+        const uint64_t *bits = S.skip_bits.data() + S.skip_off[(size_t)s];
+        std::vector<char> fl((size_t)nsl, 0);
+        const i32 g0 = r0 / 16, g1 = (std::min(r0 + TILE, w.f) - 1) / 16;
+        for (i64 k = 0; k < nsl; ++k) {
+            const uint64_t *b = bits + k * W;
+            char any = 0;
+            for (i32 g = g0; g <= g1 && !any; ++g) any = (char)((b[g >> 6] >> (g & 63)) & 1);
+            fl[(size_t)k] = any;
+        }
+        lst.emplace_back(r0, std::move(fl));
+        return lst.back().second.data();
+    };
     auto push_launch = [&](std::vector<Launch> &L, i32 kind, i64 first, i64 count) {
         if (count > 0) L.push_back(Launch{kind, cur_g, first, count, cur_side, 0});
     };
@@ -1141,9 +1252,17 @@ static void build_schedule(Symbolic &S) {
         // produce (level order), whatever the stream group the front runs in -- what the tail split below is decided on.
         std::vector<i64> canon_count(S.fronts.size(), 0), canon_next(S.fronts.size(), 0);
         std::vector<i64> task_canon;                      // canonical index of every task pushed by the current launch
+        bool allow_skip = true;                           // off for split-K launches (few tiles: the parts are cut by K position)
+        std::vector<char> need_tmp;
+        // entries of a tile that are targets: row >= column, row < f, column < c1
+        auto tile_entries = [&](const FrontDesc &w, i32 i0, i32 j0, i32 c1) {
+            double e = 0;
+            const i32 r1 = std::min(i0 + TILE, w.f);
+            for (i32 col = j0; col < std::min(j0 + TILE, c1); ++col) e += std::max(0, r1 - std::max(i0, col));
+            return e;
+        };
         auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0, int part) {
             if (kw <= 0 || c0 >= c1) return;
-            if (!dry && part != 1) for (i32 cc = c0; cc < c1; ++cc) S.flops_update += 2.0 * kw * (double)(w.f - cc);
             // tiles in super-tile order (UPD_SUPER x UPD_SUPER tiles): tasks that are neighbours in the list
             // read the same row / column slabs of the panel, and k_update deals runs of 64 consecutive
             // tasks to one XCD (one L2)
@@ -1154,8 +1273,41 @@ static void build_schedule(Symbolic &S) {
                         for (i32 i0 = std::max(I0, j0); i0 < std::min(I0 + SUP, w.f); i0 += TILE) {
                             const bool diag_blk = i0 < c0 + NB_OUT;
                             if ((part == 0 && !diag_blk) || (part == 1 && diag_blk)) continue;
+                            // K slabs in which both operand row ranges of the tile have a structural nonzero (step 13c)
+                            i32 seg = 0, nsl = 0;
+                            double kexec = kw;
+                            const i32 nfull = kw / 16;
+                            if (allow_skip && S.skip_off[(size_t)s] >= 0 && nfull >= 2) {
+                                const char *fi = window_flags(s, i0), *fj = window_flags(s, j0);
+                                const i32 sl0 = k0 / 16;
+                                i32 cnt = 0;
+                                for (i32 k = 0; k < nfull; ++k) cnt += (fi[sl0 + k] & fj[sl0 + k]);
+                                if (cnt == 0 && !beta0 && kw % 16 == 0) { if (!dry) S.flops_update_skipped += 2.0 * kw * tile_entries(w, i0, j0, c1); continue; }   // the tile receives nothing
+                                if (cnt < nfull) {
+                                    need_tmp.assign((size_t)nfull, 0);
+                                    for (i32 k = 0; k < nfull; ++k) need_tmp[(size_t)k] = fi[sl0 + k] & fj[sl0 + k];
+                                    for (i32 k = nfull - 1; k >= 0 && cnt < 2; --k) if (!need_tmp[(size_t)k]) { need_tmp[(size_t)k] = 1; ++cnt; }   // the kernel's pipeline wants >= 2 slabs
+                                    nsl = cnt; kexec = 16.0 * cnt + kw % 16;
+                                    if (!dry) {
+                                        seg = (i32)S.upd_seg.size() + 1;
+                                        S.upd_seg.push_back(0);
+                                        i32 nseg = 0;
+                                        for (i32 k = 0; k < nfull;) {
+                                            if (!need_tmp[(size_t)k]) { ++k; continue; }
+                                            i32 e = k; while (e < nfull && need_tmp[(size_t)e]) ++e;
+                                            S.upd_seg.push_back(k0 + 16 * k); S.upd_seg.push_back(e - k); ++nseg;
+                                            k = e;
+                                        }
+                                        S.upd_seg[(size_t)seg - 1] = nseg;
+                                    }
+                                }
+                            }
                             if (dry) { ++*dry; ++canon_count[(size_t)s]; }
-                            else { S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0}); task_canon.push_back(canon_next[(size_t)s]++); }
+                            else {
+                                const double ent = tile_entries(w, i0, j0, c1);
+                                S.flops_update += 2.0 * kexec * ent; S.flops_update_skipped += 2.0 * (kw - kexec) * ent;
+                                S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0, seg, nsl}); task_canon.push_back(canon_next[(size_t)s]++);
+                            }
                         }
         };
         auto for_fronts = [&](auto &&fn) {              // dry runs see all of the rank's fronts of the level
@@ -1184,16 +1336,24 @@ static void build_schedule(Symbolic &S) {
         auto emit_update_launch = [&](auto &&gen) {
             i64 t_level = 0;
             for (i32 t = t0; t < t1; ++t) canon_count[(size_t)S.level_fronts[t]] = 0;
+            allow_skip = true;
             dry = &t_level; gen(); dry = nullptr;
+            i64 want = 256;
+            if (const char *e = std::getenv("TLPK_SPLITK_TILES")) want = std::atoll(e);       // tuning knob; 0 = off
+            i32 nsplit = (t_level > 0) ? (i32)std::min<i64>(8, want / t_level) : 1;
+            if (nsplit >= 2 || UPD_SLOTS > 0) {           // split-K launches cut the K range by position: no skip lists there
+                allow_skip = false;
+                for (i32 t = t0; t < t1; ++t) canon_count[(size_t)S.level_fronts[t]] = 0;
+                t_level = 0; dry = &t_level; gen(); dry = nullptr;
+                nsplit = (t_level > 0) ? (i32)std::min<i64>(8, want / t_level) : 1;
+            }
             { i64 acc = 0; for (i32 t = t0; t < t1; ++t) { const i32 s = S.level_fronts[t]; canon_next[(size_t)s] = acc; acc += canon_count[(size_t)s]; } }
             const i64 f_upd = (i64)S.update_tasks.size();
             task_canon.clear();
             gen();
+            allow_skip = true;
             const i64 cnt = (i64)S.update_tasks.size() - f_upd;
             if (cnt == 0) return;
-            i64 want = 256;
-            if (const char *e = std::getenv("TLPK_SPLITK_TILES")) want = std::atoll(e);       // tuning knob; 0 = off
-            i32 nsplit = (t_level > 0) ? (i32)std::min<i64>(8, want / t_level) : 1;
             i64 tail_from = t_level; i32 tail_parts = 1;      // tiles with canonical index >= tail_from are cut into tail_parts
             // number of parts p in 1..8 that minimises the time of a wave of r equal tiles on UPD_SLOTS slots: ceil(r p / slots) / p
             auto best_parts = [&](i64 r) {

@@ -204,6 +204,7 @@ int upload_all(tlpk_handle *h) {
     { i64 *p; UP(p, S.gth_src); d.ctx.gth_src = p; }
     UP(d.ea_tasks, S.ea_tasks); UP(d.potrf_tasks, S.potrf_tasks); UP(d.trsm_tasks, S.trsm_tasks);
     UP(d.update_tasks, S.update_tasks); UP(d.reduce_tasks, S.reduce_tasks);
+    { i32 *p; UP(p, S.upd_seg); d.ctx.upd_seg = p; }
     d.n_single = (i64)S.single_col.size();
     UP(d.single_loff, S.single_loff); UP(d.single_dinvoff, S.single_dinvoff); UP(d.single_col, S.single_col);
     UP(d.zero_tasks, S.zero_tasks); d.n_zero_tasks = (i64)S.zero_tasks.size() / 2;
@@ -1542,7 +1543,10 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "root_front") tmp.assign(1, S.root_front);
     else if (w == "potrf_tasks") { for (auto &t : S.potrf_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.kprev); } }
     else if (w == "trsm_tasks") { for (auto &t : S.trsm_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.kprev); tmp.push_back(t.pad1); } }
-    else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
+    else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); tmp.push_back(t.seg); tmp.push_back(t.nsl); } }
+    else if (w == "upd_seg") from32(S.upd_seg);
+    else if (w == "skip_off") tmp = S.skip_off;
+    else if (w == "skip_bits") { tmp.resize(S.skip_bits.size()); std::memcpy(tmp.data(), S.skip_bits.data(), S.skip_bits.size() * 8); }
     else if (w == "front_single") tmp.assign(S.front_single.begin(), S.front_single.end());
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); tmp.push_back(t.bidx); } }

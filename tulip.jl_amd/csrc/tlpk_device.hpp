@@ -23,6 +23,7 @@ struct DevCtx {
     int *info;          // info[0] = smallest failing pivot column (INT_MAX = none); info[1] != 0: a sweep gave up waiting
     int upd_remap;         // k_update blockIdx -> task mapping (0 identity, 1 XCD-contiguous, 2 runs of 64 tasks per XCD)
     const double *csign;   // K2 (augmented system): +1 / -1 per permuted column, the S of P K P' = L S L'; nullptr for K1
+    const i32 *upd_seg;    // K-segment lists of the update tasks (UpdateTask.seg)
     i64 xw2, uc2;          // two-right-hand-side solves: the second rhs / solution at xw + xw2, its contribution vectors at uc + uc2
 };
 

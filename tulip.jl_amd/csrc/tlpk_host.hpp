@@ -69,7 +69,11 @@ static_assert(sizeof(FrontDesc) == 88, "FrontDesc layout");
 
 struct PotrfTask { i32 front, k0, nb, kprev; };              // diagonal block of a block column: columns [k0, k0 + nb), nb <= NB_OUT; kprev = k0
 struct TrsmTask  { i32 front, k0, nb, row0, kprev, fuse_nb, pad1, pad2; };   // rows [row0, pad1) below the diagonal block [k0, k0 + nb) of a block column; kprev = k0, fuse_nb = 0 (unused)
-struct UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1; }; // pad1 = slot + 1: split-K part, the raw tile goes to scratch slot `slot`;
+// seg != 0: the tile skips the K slabs (16 columns) that are structurally zero in one of its two operand row ranges (padding of
+// amalgamated supernodes): upd_seg[seg - 1] = number of K segments, then (first column, slabs) per segment, all inside the full
+// slabs of [k0, k0 + kw); nsl = slabs to execute (>= 2); a partial last slab (kw % 16 columns) is always executed
+struct alignas(16) UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1, seg, nsl, pad2 = 0, pad3 = 0; };   // 48 bytes: scalar loads (a 40-byte struct was copied through scratch)
+ // pad1 = slot + 1: split-K part, the raw tile goes to scratch slot `slot`;
 // in reduce_tasks: k0 = first slot, kw = number of parts
 //  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
 struct EaTask    { i32 front, j0, j1, bidx; };                       // parent columns [j0, j1) = boundaries bidx, bidx + 1 of the front's extend-add ranges
@@ -157,6 +161,11 @@ struct Symbolic {
     // schedules
     std::vector<PotrfTask> potrf_tasks; std::vector<TrsmTask> trsm_tasks;
     std::vector<UpdateTask> update_tasks, reduce_tasks; std::vector<EaTask> ea_tasks;
+    std::vector<i32> upd_seg;              // K-segment lists of the update tasks that skip structurally zero slabs (UpdateTask.seg)
+    // structural-zero flags of the amalgamated fronts (analyse_rank step 13c; host only): skip_off[s] = -1, or the offset in skip_bits of
+    // front s: one bit per (16-column K slab, 16-row group), slab-major, skip_words(s) 64-bit words per slab
+    std::vector<i64> skip_off; std::vector<uint64_t> skip_bits;
+    double flops_update_skipped = 0;       // padded flops the skip lists leave out (flops_update counts what is executed)
     i64 spart_len = 0;                     // split-K scratch: TILE x TILE doubles per partial tile
     std::vector<SolveTask> fwd_gather_tasks, fwd_diag_tasks, fwd_update_tasks, bwd_update_tasks, fwd_small_tasks, bwd_small_tasks;
     std::vector<SolveTask> fwd_sweep_tasks, bwd_sweep_tasks;
