@@ -8,7 +8,7 @@ import numpy as np
 
 LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
           BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12,
-          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17, FWD_SWEEP=18, BWD_SWEEP=19)
+          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17, FWD_SWEEP=18, BWD_SWEEP=19, FRONT_ASSEMBLE=20)
 
 
 class Emulator:
@@ -25,6 +25,13 @@ class Emulator:
         self.reloff = g("front_reloff"); self.child_ptr = g("front_child_ptr"); self.nchild = g("front_nchild")
         self.local = g("front_local")
         self.single = g("front_single")
+        self.front_fa = g("front_fa")          # panel formed by k_front_assemble: no zero-fill, not in k_assemble, no panel-part extend-add
+        Sp = g("s_colptr")
+        self.col_of_entry = np.repeat(np.arange(len(Sp) - 1), np.diff(Sp))            # permuted column of every entry of S
+        fa_col = np.zeros(len(Sp) - 1, dtype=bool)
+        for s_ in np.nonzero(self.front_fa)[0]:
+            fa_col[self.col0[s_]: self.col0[s_] + self.ns[s_]] = True
+        self.fa_entry = fa_col[self.col_of_entry]
         self.row_local = g("row_local"); self.col_local = g("col_local")
         self.root_front = int(g("root_front")[0])
         self.rank = kkt.backend_options.rank
@@ -37,6 +44,7 @@ class Emulator:
         self.pair_w = _lib.symbolic_array_f64(kkt._h, "pair_w")
         self.tasks = {
             LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 4),
+            LK["FRONT_ASSEMBLE"]: g("fa_tasks").reshape(-1, 4),
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
             LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),
             LK["UPDATE"]: g("update_tasks").reshape(-1, 10),
@@ -95,13 +103,21 @@ class Emulator:
         nent = len(self.s_target)
         vals = np.add.reduceat(np.concatenate([contrib, [0.0]]), np.minimum(self.pair_ptr[:-1], len(contrib)))
         vals[self.pair_ptr[:-1] == self.pair_ptr[1:]] = 0.0
+        self._svals = {}
         for e in range(nent):
             if self.s_target[e] < 0:
                 continue
             v = vals[e]
             if self.s_diag_row[e] >= 0:
                 v += self.regD[self.s_diag_row[e]]
+            if self.fa_entry[e]:                    # k_front_assemble forms this panel: the value goes in with the tile that holds it
+                self._svals[e] = v
+                continue
             self.Lval[self.s_target[e]] = v
+        # storage of the panels k_front_assemble forms starts as NaN: nothing may rely on a zero-fill there
+        for s_ in np.nonzero(self.front_fa)[0]:
+            if self.local[s_] and self.loff[s_] >= 0:
+                self.Lval[int(self.loff[s_]): int(self.loff[s_]) + pk_len(int(self.lda[s_]), int(self.ns[s_]))] = np.nan
         self.U = {}
         self.fail_col = None
         for s_ in np.nonzero(self.single & (self.local != 0))[0]:      # k_single_factor
@@ -189,6 +205,41 @@ class Emulator:
                         P[tr, tc] += src
                     else:
                         Up[tr - ns, tc - ns] += src
+
+    def _k20(self, T):     # front assembly: tile = S entries + children (child order), written whole
+        FA_CW = 16
+        fa_e = np.nonzero(self.fa_entry & (self.s_target >= 0))[0]
+        fa_c = self.col_of_entry[fa_e]
+        for front, bc, br0, br1 in T:
+            f, ns, col0 = int(self.f[front]), int(self.ns[front]), int(self.col0[front])
+            npan = (ns + FA_CW - 1) // FA_CW
+
+            def bound(k):
+                return k * FA_CW if k < npan else min(f, ns + (k - npan) * FA_CW)
+            j0, j1 = bc * FA_CW, min(bc * FA_CW + FA_CW, ns)
+            i0, i1 = bound(br0), bound(br1)
+            assert 0 < i1 - i0 <= 256 and j0 < ns
+            tile = np.zeros((i1 - i0, j1 - j0))
+            loff, lda = int(self.loff[front]), int(self.lda[front])
+            for q in np.nonzero((fa_c >= col0 + j0) & (fa_c < col0 + j1))[0]:      # entries of S in the tile
+                e = fa_e[q]
+                tc = int(fa_c[q]) - col0
+                pos = int(self.s_target[e]) - loff - pk_off(lda, tc)
+                if i0 <= pos < i1:
+                    tile[pos - i0, tc - j0] = self._svals[e]
+            for ch in self.kids(front):                                            # children, in child order
+                rel = self.relidx(ch)
+                tab = self.ea_tab[self.eatab[ch]:]
+                q0, q1, r0, r1 = int(tab[bc]), int(tab[bc + 1]), int(tab[br0]), int(tab[br1])
+                assert (q0, q1, r0, r1) == tuple(int(np.searchsorted(rel, v)) for v in (j0, j0 + FA_CW if bc + 1 < npan else ns, i0, i1)), "lookup table"
+                Uc = self.U[ch]
+                for q in range(q0, q1):
+                    rr = np.arange(max(r0, q), r1)
+                    if rr.size:
+                        tile[rel[rr] - i0, rel[q] - j0] += Uc[rr, q]
+            rfirst = max(i0, (j0 >> 6) << 6)
+            P = self.panel(front)
+            P[rfirst:i1, j0:j1] = tile[rfirst - i0:, :]
 
     def _k1(self, T):      # potrf of a block column's diagonal block (nb <= 256)
         for front, k0, nb, _ in T:

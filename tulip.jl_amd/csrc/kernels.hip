@@ -60,12 +60,8 @@ __global__ void k_compute_d(i64 n, const double *__restrict__ theta, const doubl
 // One thread per stored entry of S (lower triangle): value = sum_t w_t * D[j_t] (+ regD[i] on the
 // diagonal), written to its slot in the panel storage.  Gather formulation: no atomics, fixed
 // summation order.
-__global__ void k_assemble(i64 nent, const i64 *__restrict__ target, const i32 *__restrict__ diag_row,
-                           const i64 *__restrict__ pptr, const double *__restrict__ pw,
-                           const i32 *__restrict__ pj, const double *__restrict__ D,
-                           const double *__restrict__ regD, double *__restrict__ Lval) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nent) return;
+__device__ __forceinline__ double asm_value(const i64 e, const i32 *__restrict__ diag_row, const i64 *__restrict__ pptr, const double *__restrict__ pw,
+                                            const i32 *__restrict__ pj, const double *__restrict__ D, const double *__restrict__ regD) {
     const i64 p0 = pptr[e], p1 = pptr[e + 1];
     double s = 0.0;
     // four products per trip, indices clamped and weights zeroed past the end: the index -> D[j]
@@ -83,7 +79,18 @@ __global__ void k_assemble(i64 nent, const i64 *__restrict__ target, const i32 *
     }
     const i32 dr = diag_row[e];
     if (dr >= 0) s += regD[dr];
-    Lval[target[e]] = s;
+    return s;
+}
+// target < 0: the entry belongs to a panel that k_front_assemble forms
+__global__ void k_assemble(i64 nent, const i64 *__restrict__ target, const i32 *__restrict__ diag_row,
+                           const i64 *__restrict__ pptr, const double *__restrict__ pw,
+                           const i32 *__restrict__ pj, const double *__restrict__ D,
+                           const double *__restrict__ regD, double *__restrict__ Lval) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nent) return;
+    const i64 tg = target[e];
+    if (tg < 0) return;
+    Lval[tg] = asm_value(e, diag_row, pptr, pw, pj, D, regD);
 }
 
 // Isolated 1 x 1 fronts, one thread each: L = sqrt(s), and the whole solve x = b / s in one step
@@ -204,6 +211,101 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Front assembly of the LARGE fronts (f >= fa_min_f(), symbolic.cpp): a workgroup FORMS one tile of the panel -- FA_CW = 16 parent
+// columns x <= 256 rows -- in LDS: zero, the entries of S = A D A' + Rd that land in it (the arithmetic of k_assemble), then the
+// children's update matrices in child order (the arithmetic and the order of k_extend_add), and writes the tile to the panel once.
+// Against zero-fill + k_assemble + k_extend_add on the panel: no zero-fill, no read of the panel, and the ~12 contributions an entry of a
+// big front receives from different children meet in LDS instead of pulling the entry's 128-byte line through the fabric 12 times
+// (round 3: 26 GB moved for 7.5 GB of algorithmic extend-add bytes on config C4).  Deterministic: a parent column belongs to one
+// wave for the whole tile, the targets of one (child, column) are distinct rows, LDS operations of a wave execute in order.
+// The extend-add lookup table serves both directions: boundary k of the parent's ranges -> first child row at or after it.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ i32 fa_bound(const FrontDesc &p, const i32 k) {          // symbolic.cpp: ea_bound with FA_CW columns
+    const i32 npan = (p.ns + FA_CW - 1) / FA_CW;
+    return (k < npan) ? k * FA_CW : min(p.f, p.ns + (k - npan) * FA_CW);
+}
+constexpr int FA_RH = FA_RB * FA_CW;        // rows of a tile (at most)
+__global__ __launch_bounds__(256) void k_front_assemble(const FaTask *__restrict__ tasks, DevCtx c, const i64 *__restrict__ colptr,
+                                                        const i64 *__restrict__ target, const i32 *__restrict__ diag_row,
+                                                        const i64 *__restrict__ pptr, const double *__restrict__ pw, const i32 *__restrict__ pj,
+                                                        const double *__restrict__ D, const double *__restrict__ regD) {
+    constexpr int CB = 128;                          // children per lookup batch
+    __shared__ double tile[FA_CW][FA_RH];            // tile[parent column - j0][parent row - i0]
+    __shared__ i32 s_q0[CB], s_q1[CB], s_r0[CB], s_r1[CB], s_rsc[CB];
+    __shared__ i64 s_uoff[CB], s_reloff[CB];
+    __shared__ int s_ubuf[CB];
+    __shared__ unsigned char s_tc[CB][FA_CW];        // parent column - j0 of the child's columns [q0, q1)
+    const FaTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    const i32 ns = fd.ns;
+    const i32 j0 = t.bc * FA_CW, j1 = min(j0 + FA_CW, ns);
+    const i32 i0 = fa_bound(fd, t.br0), i1 = fa_bound(fd, t.br1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < FA_CW * FA_RH; e += 256) (&tile[0][0])[e] = 0.0;
+    __syncthreads();
+    // entries of S: column tc of the front = column col0 + tc of the permuted S, its entries are consecutive in the assembly list
+    // with ascending rows; the position in the front is the target minus the address of the column's (virtual) row 0
+    for (i32 tc = j0 + wave; tc < j1; tc += 4) {
+        const i64 e0 = colptr[fd.col0 + tc], e1 = colptr[fd.col0 + tc + 1];
+        const i64 base = fd.loff + pk_off(fd.lda, tc);
+        for (i64 e = e0 + lane; e < e1; e += 64) {
+            const i32 pos = (i32)(target[e] - base);
+            if (pos >= i0 && pos < i1) tile[tc - j0][pos - i0] = asm_value(e, diag_row, pptr, pw, pj, D, regD);
+        }
+    }
+    __syncthreads();
+    for (i32 cb = 0; cb < fd.nchild; cb += CB) {
+        const i32 nb = min(CB, fd.nchild - cb);
+        if (cb > 0) __syncthreads();                // previous batch fully consumed
+        if (tid < nb) {
+            const FrontDesc cd = c.fronts[c.children[fd.child_ptr + cb + tid]];
+            const i32 *relc = c.rel + cd.reloff;
+            const i32 *tab = c.ea_tab + cd.eatab;
+            const i32 q0 = tab[t.bc], q1 = tab[t.bc + 1];
+            s_q0[tid] = q0; s_q1[tid] = q1; s_r0[tid] = tab[t.br0]; s_r1[tid] = tab[t.br1]; s_rsc[tid] = cd.f - cd.ns;
+            s_uoff[tid] = cd.uoff; s_reloff[tid] = cd.reloff; s_ubuf[tid] = cd.ubuf;
+#pragma unroll
+            for (int u = 0; u < FA_CW; ++u) if (q0 + u < q1) s_tc[tid][u] = (unsigned char)(relc[q0 + u] - j0);
+        }
+        __syncthreads();
+        for (i32 ci = 0; ci < nb; ++ci) {
+            const i32 q0 = s_q0[ci], q1 = s_q1[ci], r0 = s_r0[ci], r1 = s_r1[ci];
+            if (q0 >= q1 || r0 >= r1) continue;
+            const i32 rsc = s_rsc[ci];
+            const double *Uc = (s_ubuf[ci] ? c.U1 : c.U0) + s_uoff[ci];
+            const i32 *relc = c.rel + s_reloff[ci];
+            for (i32 q = q0; q < q1; ++q) {
+                const i32 tcl = s_tc[ci][q - q0];
+                if ((tcl & 3) != wave) continue;
+                const double *__restrict__ src = Uc + (i64)q * rsc;
+                double *__restrict__ dcol = tile[tcl] - i0;
+                // rows of the child inside the tile, on or below the child's diagonal: batches of 4 x 64 independent loads, then
+                // the adds (distinct rows of one LDS column)
+                for (i32 r = max(r0, q) + lane; r < r1; r += 256) {
+                    i32 tg[4]; double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const i32 ru = min(r + 64 * u, r1 - 1);
+                        tg[u] = relc[ru]; v[u] = src[ru];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (r + 64 * u < r1) dcol[tg[u]] += v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // the tile, once: every stored entry of its columns in rows [i0, i1) -- the packed panel keeps a column from the first row of its
+    // 64-column slice down (entries above the diagonal inside the 64 x 64 diagonal blocks: zero, as after the old zero-fill)
+    const i32 rfirst = max(i0, (j0 >> 6) << 6);
+    for (i32 tc = j0 + wave; tc < j1; tc += 4) {
+        double *P = pcol(c, fd, tc);
+        for (i32 r = rfirst + lane; r < i1; r += 64) P[r] = tile[tc - j0][r - i0];
     }
 }
 
@@ -881,13 +983,13 @@ __device__ __forceinline__ void update_tile(const UpdateTask t, const FrontDesc 
         // Both operands read the same K columns; ld_a and ld_b of a round load the SAME slab, the iterator moves after ld_b.
         unsigned voa = (unsigned)min(t.i0 + sr, f - 1) * 8u, vob = (unsigned)min(t.j0 + sr, f - 1) * 8u;
         const char *Pc = reinterpret_cast<const char *>(P);
-        const i32 nseg = segp ? segp[0] : 1;
+        const i32 nseg = __builtin_amdgcn_readfirstlane(segp ? segp[0] : 1);
         // A slab of UPD_KT = 16 columns lies inside ONE slice b (the K ranges start on multiples of 16): the next slab is
         // 16 (lda - 64 b) doubles further; when it opens slice b + 1, column j of the slab moves 64 (j + 1) doubles less
         // (pk_off(c + 16) - pk_off(c) for c = 64 b + 48 + j).  Skip lists: when the current K segment is used up the iterator
         // jumps to the first column of the next one (offsets from pk_off again).
-        i32 k_slab = segp ? segp[1] : t.k0;               // first K column of the slab loaded next
-        i32 k_rem = segp ? segp[2] : (t.kw / UPD_KT);     // slabs left in the current segment
+        i32 k_slab = __builtin_amdgcn_readfirstlane(segp ? segp[1] : t.k0);               // first K column of the slab loaded next
+        i32 k_rem = __builtin_amdgcn_readfirstlane(segp ? segp[2] : (t.kw / UPD_KT));     // slabs left in the current segment
         i32 k_seg = 0;
         const char *sb[UPD_NLD];                          // address of (row 0 of) K column k_slab + sk0u + KS * it (scalar)
 #pragma unroll
@@ -910,19 +1012,19 @@ __device__ __forceinline__ void update_tile(const UpdateTask t, const FrontDesc 
                 if (SIGNED) pb[it] *= sgf[k_slab + sk0 + KS * it];
             }
             k_slab += UPD_KT;
-            if (--k_rem == 0 && ++k_seg < nseg) {         // (wave-uniform) next K segment
-                k_slab = segp[1 + 2 * k_seg];
-                k_rem = segp[2 + 2 * k_seg];
+            // common path without a taken branch (a slab round is ~4 000 cycles, a taken branch refills the instruction buffer): the
+            // slice-boundary fix-up -- every fourth slab -- is a scalar select, the end of a K segment the only branch
+            const bool cross = (k_slab & 63) == 0;        // (wave-uniform) the next slab opens a new slice
 #pragma unroll
-                for (int it = 0; it < UPD_NLD; ++it) sb[it] = Pc + pk_off(lda, k_slab + sk0u + KS * it) * 8;
-                step = (i64)UPD_KT * 8 * (lda - ((k_slab >> 6) << 6));
-            } else {
+            for (int it = 0; it < UPD_NLD; ++it) sb[it] += step - (cross ? (i64)(64 * 8) * (sk0u + KS * it + 1) : 0);
+            step -= cross ? 64 * 8 * UPD_KT : 0;
+            if (__builtin_expect(--k_rem == 0, 0)) {      // (wave-uniform) end of the K segment: jump to the next one, if any
+                if (++k_seg < nseg) {
+                    k_slab = __builtin_amdgcn_readfirstlane(segp[1 + 2 * k_seg]);
+                    k_rem = __builtin_amdgcn_readfirstlane(segp[2 + 2 * k_seg]);
 #pragma unroll
-                for (int it = 0; it < UPD_NLD; ++it) sb[it] += step;
-                if ((k_slab & 63) == 0) {                 // (wave-uniform, every fourth slab) the next slab opens a new slice
-#pragma unroll
-                    for (int it = 0; it < UPD_NLD; ++it) sb[it] -= 64 * 8 * (sk0u + KS * it + 1);
-                    step -= 64 * 8 * UPD_KT;
+                    for (int it = 0; it < UPD_NLD; ++it) sb[it] = Pc + pk_off(lda, k_slab + sk0u + KS * it) * 8;
+                    step = (i64)UPD_KT * 8 * (lda - ((k_slab >> 6) << 6));
                 }
             }
         };
@@ -2114,7 +2216,7 @@ void launch_zero_panels(hipStream_t st, const DevArrays &a) {
 }
 void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD) {
     if (a.n_asm > 0)
-        hipLaunchKernelGGL(k_assemble, dim3(nblk(a.n_asm, 256)), dim3(256), 0, st, a.n_asm, a.asm_target, a.asm_diag,
+        hipLaunchKernelGGL(k_assemble, dim3(nblk(a.n_asm, 256)), dim3(256), 0, st, a.n_asm, a.asm_target_small, a.asm_diag,
                            a.asm_ptr, a.pair_w, a.pair_j, D, regD, a.ctx.Lval);
 }
 void launch_single_factor(hipStream_t st, const DevArrays &a) {
@@ -2151,6 +2253,10 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
         static const unsigned ea_lds = [] { const char *e = std::getenv("TLPK_EA_LDS"); return e ? (unsigned)std::atoi(e) : 0u; }();
         hipLaunchKernelGGL(k_extend_add, g, dim3(256), ea_lds, st, a.ea_tasks + L.first, a.ctx); break;
     }
+    case LK_FRONT_ASSEMBLE:
+        hipLaunchKernelGGL(k_front_assemble, g, dim3(256), 0, st, a.fa_tasks + L.first, a.ctx, a.asm_colptr, a.asm_target, a.asm_diag, a.asm_ptr,
+                           a.pair_w, a.pair_j, a.asm_D, a.asm_regD);
+        break;
     case LK_POTRF: TLPK_LAUNCH_S(k_potrf, a.potrf_tasks); break;
     case LK_POTRF_WIDE: TLPK_LAUNCH_S(k_potrf_wide, a.potrf_tasks); break;
     case LK_POTRF_SMALL: TLPK_LAUNCH_S(k_potrf_small, a.potrf_tasks); break;

@@ -28,11 +28,27 @@ static inline i32 ea_cols_big() {              // TLPK_EA_COLS (tuning knob, 4 .
     static const i32 v = [] { const char *e = std::getenv("TLPK_EA_COLS"); const int c = e ? std::atoi(e) : EA_COLS; return (i32)std::max(4, std::min(c, EA_COLS)); }();
     return v;
 }
-static inline i32 ea_cols(const FrontDesc &p) { return (p.f >= 2048) ? ea_cols_big() : 4; }     // small fronts: more, narrower workgroups
-static inline i32 ea_npan(const FrontDesc &p) { const i32 c = ea_cols(p); return (p.ns + c - 1) / c; }
-static inline i32 ea_nbounds(const FrontDesc &p) { const i32 c = ea_cols(p); return ea_npan(p) + (p.f - p.ns + c - 1) / c + 1; }
-static inline i32 ea_bound(const FrontDesc &p, i32 k) {
-    const i32 c = ea_cols(p), npan = ea_npan(p);
+// Front assembly (k_front_assemble, FaTask) -- an experiment of round 4, OFF by default (TLPK_FA_MIN_F=512 turns it on): the panel of a front
+// is FORMED tile by tile in LDS (S entries + children in child order, written once) instead of zero-fill + k_assemble + read-modify-write
+// extend-add.  Its extend-add ranges are FA_CW = 16 columns wide, the same boundaries cut the rows of a tile.  Chosen per front in analyse_rank
+// (Symbolic::front_fa): >= fa_min_f() rows and on average >= fa_density() contributions per entry of the front.
+// Measured (profiles/r04_front_assembly.txt): on every large front (TLPK_FA_DENSITY=0) config C4 extend-add + assembly 6.9 -> 9.0 ms, north-star
+// instance 12.4 -> 27.4 ms -- a tile sees ~100..400 children that each bring a few dozen entries, i.e. two dependent memory round trips per
+// (child, tile) with nothing to overlap them, where the column-oriented k_extend_add streams whole child columns; on the linking (root) front only
+// (one dense update matrix per diagonal block, the default density threshold): 7.16 vs 7.05 ms, no gain.  Parity-green (also on NaN-poisoned storage).
+static inline i32 fa_min_f() {
+    static const i32 v = [] { const char *e = std::getenv("TLPK_FA_MIN_F"); const int c = e ? std::atoi(e) : 0; return (i32)(c <= 0 ? INT32_MAX : c); }();
+    return v;
+}
+static inline double fa_density() {
+    static const double v = [] { const char *e = std::getenv("TLPK_FA_DENSITY"); return e ? std::atof(e) : 4.0; }();
+    return v;
+}
+static inline i32 ea_cols(const FrontDesc &p, bool fa) { return fa ? FA_CW : ((p.f >= 2048) ? ea_cols_big() : 4); }     // small fronts: more, narrower workgroups
+static inline i32 ea_npan(const FrontDesc &p, bool fa) { const i32 c = ea_cols(p, fa); return (p.ns + c - 1) / c; }
+static inline i32 ea_nbounds(const FrontDesc &p, bool fa) { const i32 c = ea_cols(p, fa); return ea_npan(p, fa) + (p.f - p.ns + c - 1) / c + 1; }
+static inline i32 ea_bound(const FrontDesc &p, bool fa, i32 k) {
+    const i32 c = ea_cols(p, fa), npan = ea_npan(p, fa);
     return (k < npan) ? k * c : std::min(p.f, p.ns + (k - npan) * c);
 }
 
@@ -841,26 +857,37 @@ int analyse_rank(Symbolic &S, const Options &opt) {
     // range boundary the child stores the first of its columns that lands at or after it, so that a workgroup
     // finds "the child's columns in my range" with two loads instead of two binary searches in HBM.
     {
+        // fronts whose panel is formed by k_front_assemble (see fa_min_f above)
+        S.front_fa.assign((size_t)ns_total, 0);
+        for (i32 s = 0; s < ns_total; ++s) {
+            const FrontDesc &w = S.fronts[s];
+            if (!S.front_local[s] || w.f < fa_min_f() || w.nchild == 0 || (w.f == 1 && w.ns == 1)) continue;
+            double contrib = 0;
+            for (i32 t = 0; t < w.nchild; ++t) { const FrontDesc &cd = S.fronts[S.children[w.child_ptr + t]]; const double r = cd.f - cd.ns; contrib += 0.5 * r * r; }
+            if (contrib >= fa_density() * 0.5 * (double)w.f * w.f && w.ns >= FA_CW) S.front_fa[(size_t)s] = 1;     // contributions per entry of the front
+        }
         i64 acc = 0;
         for (i32 s = 0; s < ns_total; ++s) {
             FrontDesc &w = S.fronts[s];
             w.eatab = -1;
             if (w.parent == -1) continue;
             const FrontDesc &p = S.fronts[w.parent];
-            if (acc > (i64)INT32_MAX - (ea_nbounds(p) + 1)) return fail(S, TLPK_TOO_LARGE, "extend-add lookup table exceeds 2^31 entries");
+            const bool pfa = S.front_fa[(size_t)w.parent];
+            if (acc > (i64)INT32_MAX - (ea_nbounds(p, pfa) + 1)) return fail(S, TLPK_TOO_LARGE, "extend-add lookup table exceeds 2^31 entries");
             w.eatab = (i32)acc;
-            acc += ea_nbounds(p);
+            acc += ea_nbounds(p, pfa);
         }
         S.ea_tab.assign((size_t)acc, 0);
         parallel_for_throw(ns_total, host_threads(ns_total), [&](unsigned, i64 s) {
             const FrontDesc &w = S.fronts[s];
             if (w.parent == -1) return;
             const FrontDesc &p = S.fronts[w.parent];
-            const i32 rsc = w.f - w.ns, nb = ea_nbounds(p);
+            const bool pfa = S.front_fa[(size_t)w.parent];
+            const i32 rsc = w.f - w.ns, nb = ea_nbounds(p, pfa);
             const i32 *rel = S.rel.data() + w.reloff;
             i32 q = 0;
             for (i32 k = 0; k < nb; ++k) {
-                const i32 bound = ea_bound(p, k);
+                const i32 bound = ea_bound(p, pfa, k);
                 while (q < rsc && rel[q] < bound) ++q;
                 S.ea_tab[(size_t)w.eatab + k] = q;
             }
@@ -1182,7 +1209,7 @@ static void build_schedule(Symbolic &S) {
     // blocks above the diagonal blocks are never read)
     S.zero_tasks.clear(); S.zero_small.clear();
     for (size_t s = 0; s < S.fronts.size(); ++s) {
-        if (!S.front_local[s]) continue;
+        if (!S.front_local[s] || S.front_fa[s]) continue;       // (panels formed by k_front_assemble are written whole)
         const FrontDesc &w = S.fronts[s];
         if ((i64)w.lda * w.ns <= 4096) { S.zero_small.push_back((i32)s); continue; }      // whole panel by one wave
         for (i32 c0 = 0; c0 < w.ns; c0 += NB_IN) { S.zero_tasks.push_back((i32)s); S.zero_tasks.push_back(c0); }
@@ -1224,13 +1251,32 @@ static void build_schedule(Symbolic &S) {
                 if (!in_scope(s)) continue;
                 const FrontDesc &w = S.fronts[s];
                 if (w.nchild == 0) continue;
+                if (!u_part && S.front_fa[(size_t)s]) continue;      // panel part: k_front_assemble
                 const i32 jbeg = u_part ? w.ns : 0, jend = u_part ? w.f : w.ns;
-                const i32 cols = ea_cols(w);
-                i32 k = u_part ? ea_npan(w) : 0;                  // boundary index of j (section 13a)
+                const bool fa = S.front_fa[(size_t)s];
+                const i32 cols = ea_cols(w, fa);
+                i32 k = u_part ? ea_npan(w, fa) : 0;              // boundary index of j (section 13a)
                 for (i32 j = jbeg; j < jend; j += cols, ++k) S.ea_tasks.push_back(EaTask{s, j, std::min(j + cols, jend), k});
             }
             push_launch(S.factor_launches, LK_EXTEND_ADD, first, (i64)S.ea_tasks.size() - first);
         };
+        {
+            // panels of the large fronts: tiles of FA_CW columns x <= 256 rows, every stored entry of the panel written exactly once
+            // (rows from the first row of the column tile's 64-column slice down: what the packed panel stores)
+            const i64 first = (i64)S.fa_tasks.size();
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (!in_scope(s) || !S.front_fa[(size_t)s]) continue;
+                const FrontDesc &w = S.fronts[s];
+                const i32 npan = ea_npan(w, true), nbnd = ea_nbounds(w, true);
+                for (i32 bc = 0; bc < npan; ++bc) {
+                    const i32 j0 = bc * FA_CW;
+                    for (i32 br0 = ((j0 >> 6) << 6) / FA_CW; br0 < nbnd - 1; br0 += FA_RB)
+                        S.fa_tasks.push_back(FaTask{s, bc, br0, std::min(br0 + FA_RB, nbnd - 1)});
+                }
+            }
+            push_launch(S.factor_launches, LK_FRONT_ASSEMBLE, first, (i64)S.fa_tasks.size() - first);
+        }
         push_ea(false);
         if (root_level) S.factor_launches.push_back(Launch{LK_ALLREDUCE_ROOT, -1, 0, 0});
         // (b) blocked partial factorisation.  Outer level LEFT-looking: before the 256-wide block

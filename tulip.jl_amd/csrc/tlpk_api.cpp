@@ -33,7 +33,7 @@ namespace {
 
 int kind_class(i32 kind) {
     switch (kind) {
-    case LK_EXTEND_ADD: return TLPK_KC_EXTEND_ADD;
+    case LK_EXTEND_ADD: case LK_FRONT_ASSEMBLE: return TLPK_KC_EXTEND_ADD;
     case LK_POTRF: case LK_POTRF_WIDE: case LK_POTRF_SMALL: return TLPK_KC_POTRF;
     case LK_TRSM: case LK_TRSM_THIN: return TLPK_KC_TRSM;
     case LK_UPDATE: return TLPK_KC_UPDATE;
@@ -186,6 +186,20 @@ int upload_all(tlpk_handle *h) {
             ptr.push_back(np);
         }
         d.n_asm = (i64)tgt.size();
+        {
+            // per permuted column: its first entry in the compacted list (entries are in column order); and the target list of
+            // k_assemble: -1 for the entries of the fronts whose panels k_front_assemble forms
+            std::vector<i64> colptr((size_t)S.m + 1, 0), tsmall(tgt);
+            i64 cnt = 0;
+            for (i64 kk = 0; kk < S.m; ++kk) {
+                colptr[(size_t)kk] = cnt;
+                const bool fa = !S.front_fa.empty() && S.front_fa[(size_t)S.sn_of_col[(size_t)kk]];
+                for (i64 e = S.Sp[(size_t)kk]; e < S.Sp[(size_t)kk + 1]; ++e) if (S.s_local[(size_t)e]) { if (fa) tsmall[(size_t)cnt] = -1; ++cnt; }
+            }
+            colptr[(size_t)S.m] = cnt;
+            if (cnt != d.n_asm) { h->last_error = "assembly list: column pointers do not match the compacted entries"; return TLPK_INTERNAL; }
+            UP(d.asm_colptr, colptr); UP(d.asm_target_small, tsmall);
+        }
         // pairs of local entries are contiguous per entry; entries of non-local fronts have none,
         // so the pair arrays are already compact and in the same order.
         (void)all_local;
@@ -202,6 +216,7 @@ int upload_all(tlpk_handle *h) {
     d.ctx.fronts = fr; d.ctx.rowidx = ri; d.ctx.rel = re; d.ctx.children = ch;
     { i64 *p; UP(p, S.gth_ptr); d.ctx.gth_ptr = p; }
     { i64 *p; UP(p, S.gth_src); d.ctx.gth_src = p; }
+    UP(d.fa_tasks, S.fa_tasks);
     UP(d.ea_tasks, S.ea_tasks); UP(d.potrf_tasks, S.potrf_tasks); UP(d.trsm_tasks, S.trsm_tasks);
     UP(d.update_tasks, S.update_tasks); UP(d.reduce_tasks, S.reduce_tasks);
     { i32 *p; UP(p, S.upd_seg); d.ctx.upd_seg = p; }
@@ -224,6 +239,7 @@ int upload_all(tlpk_handle *h) {
     AL(h->d_theta, nn); AL(h->d_regP, nn); AL(h->d_regD, S.m); AL(h->d_D, nn);
     AL(h->d_xip, S.m); AL(h->d_xid, nn); AL(h->d_dx, nn); AL(h->d_dy, S.m);
     AL(d.rhs_w, std::max<i64>(2 * S.n, 1));
+    d.asm_D = h->d_D; d.asm_regD = h->d_regD;
     // a shard of a multi-device handle receives only its slices of the input vectors: the rest stays zero (never used in arithmetic
     // that reaches a result, but never uninitialised either)
     HIPCHK(h, hipMemset(h->d_theta, 0, (size_t)nn * 8)); HIPCHK(h, hipMemset(h->d_regP, 0, (size_t)nn * 8)); HIPCHK(h, hipMemset(h->d_xid, 0, (size_t)nn * 8));
@@ -1549,6 +1565,8 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "skip_bits") { tmp.resize(S.skip_bits.size()); std::memcpy(tmp.data(), S.skip_bits.data(), S.skip_bits.size() * 8); }
     else if (w == "front_single") tmp.assign(S.front_single.begin(), S.front_single.end());
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
+    else if (w == "fa_tasks") { for (auto &t : S.fa_tasks) { tmp.push_back(t.front); tmp.push_back(t.bc); tmp.push_back(t.br0); tmp.push_back(t.br1); } }
+    else if (w == "front_fa") tmp.assign(S.front_fa.begin(), S.front_fa.end());
     else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); tmp.push_back(t.bidx); } }
     else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks" || w == "fwd_small_tasks" || w == "bwd_small_tasks" ||
              w == "fwd_sweep_tasks" || w == "bwd_sweep_tasks") {

@@ -53,6 +53,10 @@ struct DevArrays {
     i64 *asm_target = nullptr; i32 *asm_diag = nullptr; i64 *asm_ptr = nullptr;
     double *pair_w = nullptr; i32 *pair_j = nullptr;
     // task arrays
+    FaTask *fa_tasks = nullptr;              // k_front_assemble tiles
+    i64 *asm_colptr = nullptr;               // per permuted column: first entry of the (compacted) assembly list; k_front_assemble walks the columns of its tile
+    i64 *asm_target_small = nullptr;         // asm_target with -1 for the entries k_front_assemble forms: what k_assemble writes
+    const double *asm_D = nullptr, *asm_regD = nullptr;   // handle-owned D = 1 / (theta + regP) (K2: D2) and regD, read by the assembly kernels
     EaTask *ea_tasks = nullptr; PotrfTask *potrf_tasks = nullptr; TrsmTask *trsm_tasks = nullptr;
     UpdateTask *update_tasks = nullptr, *reduce_tasks = nullptr;
     i64 n_single = 0; i64 *single_loff = nullptr, *single_dinvoff = nullptr; i32 *single_col = nullptr;   // isolated 1 x 1 fronts

@@ -76,6 +76,11 @@ struct alignas(16) UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1, se
  // pad1 = slot + 1: split-K part, the raw tile goes to scratch slot `slot`;
 // in reduce_tasks: k0 = first slot, kw = number of parts
 //  // tile rows i0.., cols j0..<jlim; beta0: U targets are written, not accumulated
+// front assembly (k_front_assemble): the tile [rows of boundaries br0 .. br1) x [columns of boundary bc, bc + 1) of the panel of a large front is
+// FORMED in LDS -- entries of S, then the children's update matrices in child order -- and written once (no zero-fill, no read-modify-write)
+struct FaTask    { i32 front, bc, br0, br1; };
+constexpr int FA_CW = 16;      // parent columns per tile = the extend-add column range of the large fronts
+constexpr int FA_RB = 16;      // row boundaries per tile: <= FA_RB * FA_CW = 256 rows
 struct EaTask    { i32 front, j0, j1, bidx; };                       // parent columns [j0, j1) = boundaries bidx, bidx + 1 of the front's extend-add ranges
 struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };
 // sweep items (LK_FWD_SWEEP): k0/nb = first row / rows of the chunk (<= SWEEP_NB pivot rows or <= SOLVE_NB rows below),
@@ -96,7 +101,8 @@ enum LaunchKind : i32 {
     LK_FWD_SMALL, LK_BWD_SMALL,  // whole fronts of <= SMALL_NS pivot columns: one wave per front and sweep
     LK_POTRF_SMALL,     // pivot blocks of fronts with <= SMALL_NS pivot columns: one wave per front
     LK_FWD_SWEEP,       // whole forward substitution of every (non-small) front of a level in ONE launch: workgroups
-    LK_BWD_SWEEP        // own row chunks / column blocks and hand solved blocks over through flags (k_fwd_sweep / k_bwd_sweep)
+    LK_BWD_SWEEP,       // own row chunks / column blocks and hand solved blocks over through flags (k_fwd_sweep / k_bwd_sweep)
+    LK_FRONT_ASSEMBLE   // panels of the large fronts of a level formed tile by tile: S entries + children (k_front_assemble)
 };
 struct Launch { i32 kind; i32 group; i64 first; i64 count; i32 side = 0; i32 pad = 0; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
 
@@ -161,6 +167,8 @@ struct Symbolic {
     // schedules
     std::vector<PotrfTask> potrf_tasks; std::vector<TrsmTask> trsm_tasks;
     std::vector<UpdateTask> update_tasks, reduce_tasks; std::vector<EaTask> ea_tasks;
+    std::vector<FaTask> fa_tasks;          // tiles of the panels formed by k_front_assemble
+    std::vector<char> front_fa;            // front whose panel is formed by k_front_assemble (no zero-fill, not in k_assemble, no panel-part extend-add)
     std::vector<i32> upd_seg;              // K-segment lists of the update tasks that skip structurally zero slabs (UpdateTask.seg)
     // structural-zero flags of the amalgamated fronts (analyse_rank step 13c; host only): skip_off[s] = -1, or the offset in skip_bits of
     // front s: one bit per (16-column K slab, 16-row group), slab-major, skip_words(s) 64-bit words per slab
