@@ -38,6 +38,10 @@ namespace tlpk {
 
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double readlane_f64(const double v, const int l) {      // l wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 
 __device__ __forceinline__ double *front_u(const DevCtx &c, const FrontDesc &fd) {
     return (fd.ubuf ? c.U1 : c.U0) + fd.uoff;
@@ -477,6 +481,222 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
 }
 
 // ------------------------------------------------------------------------------------------
+// potrf_block without a barrier per column (round 4; tools/potrf64_probe.hip, profiles/r03_potrf_phases.txt): the 64-column loop of potrf_block
+// costs ~1050 cycles per column, of which ~485 are the LDS hand-over of the pivot column (write -> barrier -> read) and ~280 the LDS
+// bandwidth of four waves' broadcast reads.  Here ONE wave factors the block: lane r owns row r, the block is walked in four 16-column
+// panels held in registers, every broadcast inside a panel is a v_readlane (no LDS round trip, no barrier), the left-looking update of a
+// panel by the previous panels and the off-diagonal blocks of the inverse run on the matrix cores with operands in LDS:
+//     panel p:   A[:, p] -= L[:, <p] S L[p, <p]'        (MFMA, operands from the transposed copy Mt of the finished panels)
+//                16 column steps on [A_pp | I]           (readlane broadcasts; gives L[:, p] and W_pp = L_pp^-1)
+//     inverse:   W_ij = -W_ii sum_{k=j}^{i-1} L_ik W_kj   by block distance (MFMA)
+// One LDS array holds both factors: Mt[x][y] = L[row y][column x] in the blocks BELOW the diagonal blocks (y-block > x-block) and
+// W[row x][column y] in the blocks on and below them (x-block >= y-block) -- the matrix-core products never read a diagonal block of L.
+// The other three waves of the workgroup wait at the barrier that follows (they join in again for the rows below the block, trsm_rows).
+// Same results as potrf_block up to rounding (same eliminations, different summation order in the panel updates); a pivot of the wrong sign
+// is reported and replaced in the same way.  Partial blocks (nb < 64): rows >= nb are rows of the identity.
+// MEASURED (round 4, tools/potrf_wave_bench.hip, profiles/r04_potrf_wave.txt): parity-green (K1, K2, partial blocks, failure reporting), and SLOWER
+// than potrf_block in the kernels -- 43.9 vs 34.4 us per 64 x 64 block, k_potrf_wide 230 vs 196 us per 256-wide block, potrf class on config C4
+// 4.9 vs 3.8 ms: the 16 column steps of a panel take 4.3 us (270 ns per column against 530 ns in potrf_block, as the probe promised), but the
+// rest of a panel -- 48 predicated stores with their address arithmetic, the LDS copies the matrix-core products need, the serial panel updates
+// -- costs another 5 us on the same single wave, and the probe's 21 us had left exactly that out.  Kept behind TLPK_POTRF_WAVE=1 (default: potrf_block).
+// ------------------------------------------------------------------------------------------
+constexpr int PW_W = 16;                          // panel width
+constexpr int PW_LDT = 17;                        // leading dimension of the small transposition arrays
+constexpr int LDW_ = NB_IN + 16;                  // == LDW (declared below): == 16 mod 32, conflict-free ds_read_b64 of the MFMA operands
+constexpr int POTRF_WAVE_LDS = NB_IN * LDW_ + 4 * PW_W * PW_LDT + NB_IN * PW_LDT;      // doubles: Mt | Wd[4] | Ts
+#define TLPK_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <bool SIGNED = false>
+__device__ __forceinline__ void potrf_block_wave(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb,
+                                                 const i32 kprev, double *scratch) {
+    const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
+    double *Mt = scratch;                                        // NB_IN x LDW_   (first: Ds, then As = the block to factor, row for row)
+    double *Wd = scratch + NB_IN * LDW_;                         // Wd[p][t * PW_LDT + r] = W_pp[r][t]  (column-major copies of the diagonal blocks)
+    double *Ts = Wd + 4 * PW_W * PW_LDT;                         // transposition scratch, one NB_IN/4 x PW_LDT piece per wave in the inverse phase
+    double *Ds = scratch;
+    const i32 lda = pld(fd, bk0);
+    double *P = pcol(c, fd, bk0) + bk0;                          // origin (bk0, bk0)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+#ifdef POTRF_TRACE   /* tools/potrf_wave_bench.hip: 100 MHz stamps of the phases, one row of 32 per workgroup in c.spart */
+    unsigned long long *ptr_ = (unsigned long long *)c.spart + (size_t)blockIdx.x * 32;
+    int pti_ = 0;
+#define PT_STAMP() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (tid == 0 && pti_ < 32) ptr_[pti_] = wall_clock64(); ++pti_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PT_STAMP() do {} while (0)
+#endif
+    PT_STAMP();
+    // the block itself, requested by all 256 threads before anything else (thread (r, cg): columns cg + 4 q; clamped addresses, selects afterwards)
+    const int r = lane;
+    const bool rok = r < nb;
+    double pv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pv[q] = P[(i64)min(r, nb - 1) + (i64)min(wave + 4 * q, nb - 1) * lda];
+    // left-looking over the already factored 64-wide steps of this block column (all four waves; as in potrf_block)
+    const i32 Kp = bk0 - kprev;
+    if (Kp > 0) {
+        v4f64 dacc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) dacc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        const i32 rrow = 16 * wave + lr;
+        const i32 rr_c = min(rrow, nb - 1);
+        i32 cr_c[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cr_c[a] = min(16 * a + lr, nb - 1);
+        for (i32 ks = 0; ks < Kp; ks += 16) {
+            double bq[4], aq[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double *Xc = pcol(c, fd, kprev + ks + 4 * u + lk) + bk0;
+                bq[u] = Xc[rr_c];
+                if (SIGNED) bq[u] *= sg[kprev + ks + 4 * u + lk];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) aq[u][a] = Xc[cr_c[a]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    dacc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[u][a], bq[u], dacc[a], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ds[(16 * a + lk + 4 * q) * LDW_ + rrow] = dacc[a][q];
+        __syncthreads();
+    }
+    // As = block - Ds, in place of Ds (same stride, same rows); rows / columns beyond nb: identity
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int col = wave + 4 * q;
+        const double dv = (Kp > 0) ? Ds[col * LDW_ + r] : 0.0;
+        Mt[col * LDW_ + r] = (rok && col < nb) ? ((r >= col) ? (pv[q] - dv) : 0.0) : ((r == col) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    PT_STAMP();
+    double *W = front_dinv(c, fd, bk0);                          // column-major nb x nb, ld = nb, upper part zero
+    if (wave == 0) {
+    // The chain: no global loads from here on (the stores are fire-and-forget: a load in between would make every panel wait for the stores of
+    // the previous one).  Panel p reads rows [16 p, 16 p + 16) of As before it writes those rows of Mt.
+    i32 failcol = NB_IN;                                         // first pivot of the wrong sign (NB_IN: none)
+    // (the panel loop is NOT unrolled: four copies of the 16 column steps next to trsm_rows in k_potrf_wide pushed the kernel past 256
+    // registers into scratch)
+#pragma unroll 1
+    for (int p = 0; p < 4; ++p) {
+        double a[PW_W], w[PW_W];
+#pragma unroll
+        for (int cc = 0; cc < PW_W; ++cc) { a[cc] = Mt[(PW_W * p + cc) * LDW_ + r]; w[cc] = (r == PW_W * p + cc) ? 1.0 : 0.0; }
+        TLPK_LDS_FENCE();                                        // this panel's rows of As are consumed
+        if (p > 0) {
+            // U[row][cc] = sum_{k < 16 p} L[row][k] s_k L[16 p + cc][k] for the row blocks b >= p
+#pragma unroll 1
+            for (int b = p; b < 4; ++b) {
+                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+                for (int k4 = 0; k4 < PW_W * p; k4 += 4) {
+                    double x = Mt[(k4 + lk) * LDW_ + PW_W * p + lr];
+                    if (SIGNED) x *= sg[bk0 + min(k4 + lk, nb - 1)];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, Mt[(k4 + lk) * LDW_ + PW_W * b + lr], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Ts[(PW_W * b + lr) * PW_LDT + lk + 4 * q] = acc[q];
+            }
+            TLPK_LDS_FENCE();
+#pragma unroll
+            for (int cc = 0; cc < PW_W; ++cc) a[cc] -= (r >= PW_W * p) ? Ts[r * PW_LDT + cc] : 0.0;
+            TLPK_LDS_FENCE();
+        }
+        PT_STAMP();
+#pragma unroll
+        for (int j = 0; j < PW_W; ++j) {
+            const int J = PW_W * p + j;
+            double d = readlane_f64(a[j], J);
+            const double sj = (SIGNED && J < nb) ? sg[bk0 + J] : 1.0;
+            const bool bad = !(sj * d > 0.0);                                   // (wave-uniform) reported once, after the block: no branch, no atomic on the chain
+            failcol = bad ? min(failcol, J) : failcol;
+            d = bad ? sj : d;
+            if (SIGNED) d = fabs(d);
+            double isq = __builtin_amdgcn_rsq(d);
+            isq = isq * (1.5 - 0.5 * d * isq * isq);
+            isq = isq * (1.5 - 0.5 * d * isq * isq);
+            double sq = d * isq;
+            sq = fma(0.5 * isq, fma(-sq, sq, d), sq);
+            const double inv2 = SIGNED ? isq * isq * sj : isq * isq;            // 1 / (signed pivot)
+            if (SIGNED) isq *= sj;                                              // column scale s_j / sqrt|d|
+            // (the row's position relative to the panel goes through an empty asm in every step: the 32 lane masks r > J, r == J of a panel are
+            // otherwise hoisted out of the column loop into 64 scalar registers and spilled through v_writelane)
+            int rq = r - PW_W * p;
+            asm volatile("" : "+v"(rq));
+            const bool below = rq > j, diag = rq == j;
+            const double arj = below ? a[j] * inv2 : 0.0;
+#pragma unroll
+            for (int cc = j + 1; cc < PW_W; ++cc) a[cc] = fma(-arj, readlane_f64(a[j], PW_W * p + cc), a[cc]);
+#pragma unroll
+            for (int cc = 0; cc <= j; ++cc) w[cc] = fma(-arj, readlane_f64(w[cc], J), w[cc]);
+            a[j] = diag ? sq : (below ? a[j] * isq : a[j]);
+            __builtin_amdgcn_sched_barrier(0);          // keep the broadcasts of a step inside the step: hoisted across steps they overflow the scalar registers (spilled through v_writelane)
+        }
+        PT_STAMP();
+        double lii = 1.0;
+#pragma unroll
+        for (int cc = 0; cc < PW_W; ++cc) lii = (r == PW_W * p + cc) ? a[cc] : lii;
+        const double ili = 1.0 / lii;
+        const bool inblk = (r >= PW_W * p) && (r < PW_W * p + PW_W);
+#pragma unroll
+        for (int cc = 0; cc < PW_W; ++cc) {
+            const int col = PW_W * p + cc;
+            const double lv = (r >= col) ? a[cc] : 0.0;
+            if (r >= PW_W * (p + 1)) Mt[col * LDW_ + r] = lv;                    // L below the diagonal blocks, transposed
+            if (rok && col < nb && r >= col) P[(i64)r + (i64)col * lda] = lv;
+            if (inblk) {
+                const double wv = (r >= col) ? w[cc] * ili : 0.0;
+                Mt[r * LDW_ + col] = wv;                                         // W, row-major, diagonal block (zeros above the diagonal)
+                Wd[p * PW_W * PW_LDT + cc * PW_LDT + (r - PW_W * p)] = wv;
+                if (rok && col < nb) W[(i64)r + (i64)col * nb] = wv;
+            } else if (rok && col < nb && r < PW_W * p) W[(i64)r + (i64)col * nb] = 0.0;      // blocks above the diagonal blocks: zero, as potrf_block leaves them
+        }
+        TLPK_LDS_FENCE();
+    }
+    if (failcol < NB_IN && r == 0) atomicMin(c.info, fd.col0 + bk0 + failcol);
+    }
+    PT_STAMP();
+    // off-diagonal blocks of the inverse, by block distance: W_ij = -W_ii (sum_{k=j}^{i-1} L_ik W_kj); the blocks of one distance are independent:
+    // one wave each, a barrier between the distances
+#pragma unroll 1
+    for (int dist = 1; dist < 4; ++dist) {
+        __syncthreads();
+        const int i = dist + wave, j = wave;
+        if (i < 4) {                                            // (wave-uniform)
+            double *Tw = Ts + wave * (PW_W * PW_LDT);
+            // G[rr][cc] = sum_k sum_t L_ik[rr][t] W_kj[t][cc]: first operand M1[cc][t] = W_kj[t][cc], second M2[rr][t] = L_ik[rr][t]
+            v4f64 g = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int k = j; k < i; ++k) {
+#pragma unroll
+                for (int k4 = 0; k4 < PW_W; k4 += 4)
+                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[(PW_W * k + k4 + lk) * LDW_ + PW_W * j + lr], Mt[(PW_W * k + k4 + lk) * LDW_ + PW_W * i + lr], g, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Tw[lr * PW_LDT + lk + 4 * q] = g[q];      // G[rr = lr][cc = lk + 4q] -> Tw[t = rr][cc]
+            TLPK_LDS_FENCE();
+            // H[rr][cc] = sum_t W_ii[rr][t] G[t][cc]: first operand M1[cc][t] = G[t][cc], second M2[rr][t] = W_ii[rr][t]
+            v4f64 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k4 = 0; k4 < PW_W; k4 += 4)
+                h = __builtin_amdgcn_mfma_f64_16x16x4f64(Tw[(k4 + lk) * PW_LDT + lr], Wd[i * PW_W * PW_LDT + (k4 + lk) * PW_LDT + lr], h, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = PW_W * i + lr, cc = PW_W * j + lk + 4 * q;
+                Mt[rr * LDW_ + cc] = -h[q];
+                if (rr < nb && cc < nb) W[(i64)rr + (i64)cc * nb] = -h[q];
+            }
+        }
+    }
+    PT_STAMP();
+}
+
+// ------------------------------------------------------------------------------------------
 // trsm on the matrix cores: X = B * L11^{-T} as the product with the inverted diagonal block,
 // computed transposed (D[c][r] = sum_k Linv[c][k] * B[r][k]) so that consecutive lanes write
 // consecutive panel rows.  The operand fragments of a 16-row strip stay in registers: each
@@ -674,27 +894,33 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 // already been applied by the left-looking k_update): 64-wide steps, each a potrf of the step's
 // diagonal block followed by the trsm of the rows below it INSIDE the block -- one workgroup runs
 // the whole chain, so the factorisation's critical path costs one launch per block column.
-template <bool SIGNED>
+// WAVE: the 64 x 64 diagonal blocks by potrf_block_wave (one wave, no barrier per column) instead of potrf_block (TLPK_POTRF_WAVE=0: the
+// round-1..3 kernels)
+static_assert(LDW_ == LDW, "potrf_block_wave: LDS stride");
+template <bool SIGNED, bool WAVE>
 __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {      // t.nb <= NB_IN
-    __shared__ double scratch[POTRF_SCRATCH];
+    __shared__ double scratch[WAVE ? POTRF_WAVE_LDS : POTRF_SCRATCH];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    potrf_block<SIGNED>(c, fd, t.k0, t.nb, t.k0, scratch);
+    if (WAVE) potrf_block_wave<SIGNED>(c, fd, t.k0, t.nb, t.k0, scratch);
+    else potrf_block<SIGNED>(c, fd, t.k0, t.nb, t.k0, scratch);
 }
-template <bool SIGNED>
+template <bool SIGNED, bool WAVE>
 __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restrict__ tasks, DevCtx c) {
-    __shared__ double Ws[NB_IN * LDW];
+    __shared__ double Ws[WAVE ? POTRF_WAVE_LDS : NB_IN * LDW];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
-    potrf_block<SIGNED>(c, fd, k0, min(w, NB_IN), k0, Ws);
+    if (WAVE) potrf_block_wave<SIGNED>(c, fd, k0, min(w, NB_IN), k0, Ws);
+    else potrf_block<SIGNED>(c, fd, k0, min(w, NB_IN), k0, Ws);
     for (i32 ks = k0; ks + NB_IN < kend; ks += NB_IN) {          // step ks is factored: rows below, next diagonal block
         for (i32 r0 = ks + NB_IN; r0 < kend; r0 += NB_IN) {
             __syncthreads();                                     // own global stores visible, Ws free
             trsm_rows<SIGNED>(c, fd, ks, NB_IN, r0, kend, k0, Ws);
         }
         __syncthreads();
-        potrf_block<SIGNED>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
+        if (WAVE) potrf_block_wave<SIGNED>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
+        else potrf_block<SIGNED>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
     }
 }
 
@@ -1723,10 +1949,6 @@ __device__ __forceinline__ void poll_block2(const double *xh0, const double *xh1
     asm volatile("" ::: "memory");
     o0 = __longlong_as_double((long long)v0); o1 = __longlong_as_double((long long)v1);
 }
-__device__ __forceinline__ double readlane_f64(const double v, const int l) {      // l wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
 
 // PIVOT item: rows [k0, k0 + nb) (nb <= 64) are a pivot block; lane = row, wave = quarter of the 64 columns of a
 // consumed block.  BELOW item: <= 128 rows below the pivot block; waves 0/1 = rows 0..63 / 64..127 of the chunk
@@ -2257,8 +2479,16 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
         hipLaunchKernelGGL(k_front_assemble, g, dim3(256), 0, st, a.fa_tasks + L.first, a.ctx, a.asm_colptr, a.asm_target, a.asm_diag, a.asm_ptr,
                            a.pair_w, a.pair_j, a.asm_D, a.asm_regD);
         break;
-    case LK_POTRF: TLPK_LAUNCH_S(k_potrf, a.potrf_tasks); break;
-    case LK_POTRF_WIDE: TLPK_LAUNCH_S(k_potrf_wide, a.potrf_tasks); break;
+    case LK_POTRF: case LK_POTRF_WIDE: {
+        static const bool wv = [] { const char *e = std::getenv("TLPK_POTRF_WAVE"); return e && std::atoi(e) != 0; }();     // off: measured slower, see potrf_block_wave
+#define TLPK_LAUNCH_P(KERNEL) do { if (sgn) { if (wv) hipLaunchKernelGGL((KERNEL<true, true>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
+                                              else hipLaunchKernelGGL((KERNEL<true, false>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); } \
+                                    else { if (wv) hipLaunchKernelGGL((KERNEL<false, true>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
+                                           else hipLaunchKernelGGL((KERNEL<false, false>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); } } while (0)
+        if (L.kind == LK_POTRF) TLPK_LAUNCH_P(k_potrf); else TLPK_LAUNCH_P(k_potrf_wide);
+#undef TLPK_LAUNCH_P
+        break;
+    }
     case LK_POTRF_SMALL: TLPK_LAUNCH_S(k_potrf_small, a.potrf_tasks); break;
     case LK_TRSM: TLPK_LAUNCH_S(k_trsm, a.trsm_tasks); break;
     case LK_TRSM_THIN: TLPK_LAUNCH_S(k_trsm_thin, a.trsm_tasks); break;
