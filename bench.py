@@ -74,6 +74,7 @@ def parse():
                     help="do not wait for the status of update! before the solves are enqueued (tlpk_update_device_async: the root front's "
                          "factorisation overlaps the first solve's block-level sweeps; measured slower, profiles/r03_async_update.txt)")
     ap.add_argument("--no-small-lp", action="store_true", help="skip the latency-bound legs (25fv47-class and pds-20-class LPs)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the general sparse leg (BASELINE configs[2] shape at --c3-rows rows; N=1, workload c4 only)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child-process mode of the cpu_baseline leg
     ap.add_argument("--force-collectives", action="store_true",
@@ -515,6 +516,23 @@ def main():
                 out["headline"]["cpu_baseline"] = hc
         except Exception as e:          # the headline leg must never cost the main line
             out["headline"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not split and args.workload == "c4" and not args.no_c3:
+        # BASELINE configs[2] (general sparse LP, one supernodal tree ending in a dense front): as specified (5e5 rows) the factor is
+        # ~0.43 TB packed -- beyond one GPU (memory gate, tests/test_gpu_parity.py::test_memory_gate); the same generator at a size that keeps
+        # the default run short, with its own rooflines.  The largest run of the shape is builder-side: 2e5 rows, 160 GB on the device.
+        try:
+            cres, _, _ = run("c3", 2, 1, not args.no_roofline)
+            out["c3"] = {"ms_per_step": cres["ms_per_step"], "value": cres["value"], "unit": "iter/s", "workload": cres["config"]["workload"],
+                         "nnzL": cres["config"]["nnzL"], "flops_chol": cres["config"]["flops_chol"], "max_front": cres["config"]["max_front"],
+                         "frac_step": cres["frac_step"], "residual_inf": cres["config"]["residual_inf"], "ms_analyse": cres["config"]["ms_analyse"],
+                         "stored_over_nnzL": cres["config"]["stored_over_nnzL"], "device_bytes": cres["config"]["device_bytes"],
+                         "largest_run_of_the_shape": "2e5 rows: one 194 870-column dense front, nnz(L) = 1.7e10, 160 GB on the device, 39.5 s per step "
+                                                     "(profiles/r03_c3_200k_rows_bench.json; bench.py --workload c3 --c3-rows 200000)"}
+            for k in ("roofline", "solve_roofline", "kernel_ms"):
+                if k in cres:
+                    out["c3"][k] = cres[k]
+        except Exception as e:
+            out["c3"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not split and args.workload == "c4" and not args.no_small_lp:
         # The small configs (BASELINE configs[1], configs[4] classes): a Newton step here is bound by launch latency and the
         # serial chain of diagonal blocks, not by the matrix cores -- reported as measured, next to the CPU comparator.

@@ -69,7 +69,8 @@ typedef struct tlpk_options {
     int32_t detect_blocks;     /* 1 (and row_block == NULL): find the block-angular structure of THIS matrix with tlpk_detect_blocks --
                                   the hook that survives Tulip's presolve, which renumbers the rows before KKT.setup sees them
                                   (model.jl:88-131).  No structure found: general sparse path (tlpk_create) / TLPK_BADARG (tlpk_create_multi) */
-    int32_t reserved0;
+    int32_t keep_on_too_large; /* 1: tlpk_create returns a LIVE analyse-only handle together with TLPK_TOO_LARGE (tlpk_info / tlpk_last_error then describe what did not
+                                  fit; the caller must destroy it).  0 (default): no handle on any failure -- the message is in tlpk_last_create_error() */
     int64_t max_link_rows;     /* detect_blocks: most linking rows to accept; 0 = max(64, m / 20) */
 } tlpk_options;
 
@@ -122,8 +123,9 @@ void tlpk_default_options(tlpk_options *opt);
 /* A is m x n CSC with int64 indices (Julia SparseMatrixCSC{Float64,Int}); index_base in {0,1}.
  * A is copied; nothing is retained.  Runs the whole analyse phase and uploads the symbolic
  * structures.  Does NOT perform the throw-away numeric factorisation of spd.jl:14-17.
- * Return value != TLPK_OK: *out = NULL, EXCEPT for TLPK_TOO_LARGE, which returns a live analyse-only handle
- * (tlpk_info / tlpk_last_error carry the diagnostics: symbolic nnz(L), bytes needed); the caller destroys it. */
+ * Return value != TLPK_OK: *out = NULL and tlpk_last_create_error() holds the diagnostic (for TLPK_TOO_LARGE: the bytes needed against the
+ * budget, and -- K1 with a dense column of A -- the hint that KKT_System = K2 does not form A*D*A').  Only with opt->keep_on_too_large = 1 does
+ * TLPK_TOO_LARGE return a live analyse-only handle (tlpk_info: symbolic nnz(L) ...), which the caller destroys. */
 int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr,
                 const int64_t *rowval, const double *nzval, int index_base,
                 const tlpk_options *opt);
@@ -285,6 +287,8 @@ int tlpk_mpc_advance(tlpk_handle *h, double ap, double ad, double *out);        
 
 const char *tlpk_strerror(int code);
 const char *tlpk_last_error(const tlpk_handle *h);
+/* message of the last FAILED tlpk_create / tlpk_create_multi of the calling thread ("" after a successful one): a failed create returns no handle */
+const char *tlpk_last_create_error(void);
 const char *tlpk_backend_name(void);         /* "HIP (gfx950)" */
 const char *tlpk_system_name(void);          /* "Normal equations (K1)" */
 const char *tlpk_linear_system(const tlpk_handle *h);   /* KKT.linear_system of this handle: "... (K1)" | "Augmented system (K2)" */

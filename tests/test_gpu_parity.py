@@ -819,3 +819,48 @@ def test_update_skip_lists_of_structural_zeros(monkeypatch):
     tk.update(k0, th, rp, rd)
     L0 = panels_to_dense_L(k0, k0.factor_panels())
     assert np.abs(Ls - L0).max() <= 1e-12 * np.abs(L0).max()
+
+
+def test_c3_shape_20k_rows_factor_entrywise_vs_cpu_supernodal():
+    """BASELINE configs[2] shape (general sparse LP A = [A0 I], 25 nnz per structural column) at 2e4 rows: one supernodal tree that ends in a
+    ~19 500-column dense front (nnz(L) ~ 1.9e8, macro columns, split-K, 300 chained hand-overs per sweep) -- EVERY stored entry of the device
+    factor against the CPU supernodal comparator (same ordering and supernodes), and dx, dy.  Tolerance 1e-9 x max|L|: the front is ~76
+    blocked steps deep."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle_binding import SupernodalK1
+    from workloads import general_sparse_lp, kernel_inputs
+    from emulate import unpack_panel
+    A = general_sparse_lp(20000)
+    m, n = A.shape
+    th, rp, rd, xp, xd = kernel_inputs(m, n, 7, "mid")
+    kkt = gpu_setup(A)
+    assert kkt.symbolic("front_ns").max() > 15000
+    tk.update(kkt, th, rp, rd)
+    dx = np.zeros(n); dy = np.zeros(m)
+    tk.solve(dx, dy, kkt, xp, xd)
+    ana = tk.setup(A, tk.K1(), tk.Backend(device=-1))
+    assert (ana.perm() == kkt.perm()).all()
+    sn = SupernodalK1(A, ana)
+    sn.update(th, rp, rd)
+    dxc, dyc = sn.solve(xp, xd)
+    Lg, Lc = kkt.factor_panels(), sn.factor_panels()
+    f, ns, loff, lda = (kkt.symbolic(k) for k in ("front_f", "front_ns", "front_loff", "front_lda"))
+    lmax = worst = 0.0; checked = 0
+    for s in range(len(f)):
+        a = unpack_panel(Lg, int(loff[s]), int(f[s]), int(ns[s]), int(lda[s]))
+        b = unpack_panel(Lc, int(loff[s]), int(f[s]), int(ns[s]), int(lda[s]))
+        if f[s] > 4096:                                   # the big front: compare slice by slice (a boolean mask of 19 500^2 would not fit comfortably)
+            for c0 in range(0, int(ns[s]), 1024):
+                c1 = min(c0 + 1024, int(ns[s]))
+                d = np.abs(np.tril(a[c0:, c0:c1] - b[c0:, c0:c1]))
+                worst = max(worst, float(d.max())); lmax = max(lmax, float(np.abs(np.tril(b[c0:, c0:c1])).max()))
+                checked += int((f[s] - c0) * (c1 - c0) - (c1 - c0) * (c1 - c0 - 1) // 2)
+            continue
+        mask = np.tril(np.ones((f[s], ns[s]), dtype=bool))
+        lmax = max(lmax, float(np.abs(b[mask]).max())); worst = max(worst, float(np.abs(a[mask] - b[mask]).max())); checked += int(mask.sum())
+    print(f"c3 shape, 2e4 rows: {checked} factor entries compared, max |L_gpu - L_cpu| = {worst:.3e}, max|L| = {lmax:.3e}")
+    assert checked >= kkt.stats()["nnzL"]
+    assert worst <= 1e-9 * lmax
+    assert np.abs(dy - dyc).max() <= 1e-8 * max(1.0, np.abs(dyc).max())
+    assert np.abs(dx - dxc).max() <= 1e-8 * max(1.0, np.abs(dxc).max())

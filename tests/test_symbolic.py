@@ -252,8 +252,42 @@ def test_degenerate_shapes():
 
 def test_memory_gate():
     A = random_lp_matrix(200, 400, 4, 3)
-    with pytest.raises(tk.OutOfMemoryError):
+    with pytest.raises(tk.OutOfMemoryError, match="factor exceeds mem_budget_bytes"):       # the text travels through tlpk_last_create_error()
         tk.setup(A, tk.K1(), tk.Backend(device=-1, mem_budget_bytes=1024))
+
+
+def test_failed_create_returns_no_handle_and_leaves_its_message():
+    """tlpk_create: rc != 0 means *out == NULL (a C caller that treats rc != 0 as "no handle" must not leak the host symbolic data);
+    the diagnostic is tlpk_last_create_error().  opt.keep_on_too_large = 1 keeps the analyse-only handle that describes what did not fit."""
+    import ctypes as C
+    from tulip_jl_amd import _lib
+    L = _lib.lib()
+    A = random_lp_matrix(200, 400, 4, 3).tocsc()
+    colptr = np.ascontiguousarray(A.indptr, dtype=np.int64); rowval = np.ascontiguousarray(A.indices, dtype=np.int64)
+    nz = np.ascontiguousarray(A.data, dtype=np.float64)
+    opt = _lib.Options(); L.tlpk_default_options(C.byref(opt))
+    opt.device = -1; opt.mem_budget_bytes = 1024
+    h = C.c_void_p()
+    rc = L.tlpk_create(C.byref(h), 200, 400, _lib.as_p64(colptr), _lib.as_p64(rowval), _lib.as_pd(nz), 0, C.byref(opt))
+    assert rc == _lib.TOO_LARGE and not h.value
+    assert b"mem_budget_bytes" in L.tlpk_last_create_error()
+    opt.keep_on_too_large = 1
+    rc = L.tlpk_create(C.byref(h), 200, 400, _lib.as_p64(colptr), _lib.as_p64(rowval), _lib.as_pd(nz), 0, C.byref(opt))
+    assert rc == _lib.TOO_LARGE and h.value
+    st = _lib.Stats(); L.tlpk_info(h, C.byref(st))
+    assert st.nnzL > 0 and b"mem_budget_bytes" in L.tlpk_last_error(h)
+    L.tlpk_destroy(h)
+    # a multi-device create that cannot work says why (round-3 advisor finding: the message used to be thrown away)
+    opt2 = _lib.Options(); L.tlpk_default_options(C.byref(opt2)); opt2.device = -1; opt2.detect_blocks = 1
+    h2 = C.c_void_p()
+    dv = (C.c_int32 * 2)(0, 0)
+    rc = L.tlpk_create_multi(C.byref(h2), 200, 400, _lib.as_p64(colptr), _lib.as_p64(rowval), _lib.as_pd(nz), 0, C.byref(opt2), 2, dv)
+    assert rc != _lib.OK and not h2.value and len(L.tlpk_last_create_error()) > 0
+    # and a successful create clears it
+    opt.mem_budget_bytes = 0; opt.keep_on_too_large = 0
+    rc = L.tlpk_create(C.byref(h), 200, 400, _lib.as_p64(colptr), _lib.as_p64(rowval), _lib.as_pd(nz), 0, C.byref(opt))
+    assert rc == _lib.OK and L.tlpk_last_create_error() == b""
+    L.tlpk_destroy(h)
 
 
 def test_numeric_calls_fail_loudly_without_device():

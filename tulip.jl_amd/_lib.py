@@ -27,7 +27,7 @@ class Options(C.Structure):
                 ("nranks", C.c_int32), ("streams", C.c_int32),
                 ("user_perm", p64), ("row_block", p64), ("mem_budget_bytes", C.c_int64),
                 ("system", C.c_int32), ("refine_steps", C.c_int32),
-                ("detect_blocks", C.c_int32), ("reserved0", C.c_int32), ("max_link_rows", C.c_int64)]
+                ("detect_blocks", C.c_int32), ("keep_on_too_large", C.c_int32), ("max_link_rows", C.c_int64)]
 
 
 class Stats(C.Structure):
@@ -65,7 +65,7 @@ EXPORTS = [
     "tlpk_ipm_newton", "tlpk_ipm_accept", "tlpk_ipm_advance", "tlpk_ipm_get",
     "tlpk_mpc_start", "tlpk_mpc_newton", "tlpk_mpc_gap", "tlpk_mpc_targets", "tlpk_mpc_advance",
     "tlpk_detect_blocks", "tlpk_solve2_device", "tlpk_ipm_hsolve_newton", "tlpk_update_device_async", "tlpk_ipm_factor_hsolve_newton",
-    "tlpk_refine_local", "tlpk_refine_finish", "tlpk_solve2_local", "tlpk_root_rhs2", "tlpk_solve2_finish",
+    "tlpk_refine_local", "tlpk_refine_finish", "tlpk_solve2_local", "tlpk_root_rhs2", "tlpk_solve2_finish", "tlpk_last_create_error",
 ]
 
 
@@ -130,6 +130,8 @@ def lib():
     L.tlpk_strerror.restype = C.c_char_p
     L.tlpk_last_error.argtypes = [vp]
     L.tlpk_last_error.restype = C.c_char_p
+    L.tlpk_last_create_error.argtypes = []
+    L.tlpk_last_create_error.restype = C.c_char_p
     L.tlpk_backend_name.restype = C.c_char_p
     L.tlpk_system_name.restype = C.c_char_p
     L.tlpk_linear_system.argtypes = [vp]

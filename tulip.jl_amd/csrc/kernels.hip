@@ -2210,11 +2210,11 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_bwd_sweep(const SolveT
 //   backward: t = b - L21' x_below (lanes along rows, shuffle reduction), then x = W' t
 // ------------------------------------------------------------------------------------------
 constexpr int SMALL_RPL = SMALL_ROWS / 64;       // rows below per lane
-__global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
-    if (t.front < 0) return;
-    const FrontDesc fd = c.fronts[t.front];
+// (round 4) The bodies are instantiated for (NSM pivot columns, RPL rows below per lane) = (4, 1), (4, 4), (16, 1), (16, 4) and chosen per front
+// (wave-uniform): most small fronts of the inequality LPs have one or two pivot columns and a handful of rows, and the single (16, 4) body
+// requested 64 + 32 clamped duplicate loads per lane for each of them -- 1.4 ms of a 7 ms solve on the north-star instance.
+template <int NSM, int RPL>
+__device__ __forceinline__ void fwd_small_body(const FrontDesc &fd, const DevCtx &c, const int lane) {
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *__restrict__ W = front_dinv(c, fd, 0);          // ns x ns, column-major, ld = ns, upper part zero
@@ -2224,41 +2224,47 @@ __global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__
     // every load of the step is requested up front (clamped addresses, selects afterwards): the wave is
     // alone with its front, so each dependent round trip would be paid in full
     const i32 ic = min(lane, ns - 1);
-    double wv[SMALL_NS], bv[SMALL_NS], lv[SMALL_RPL][SMALL_NS], uv[SMALL_RPL];
+    double wv[NSM], bv[NSM], lv[RPL][NSM], uv[RPL];
 #pragma unroll
-    for (int k = 0; k < SMALL_NS; ++k) {
+    for (int k = 0; k < NSM; ++k) {
         const i32 kc = min(k, ns - 1);
         wv[k] = W[(i64)ic + (i64)kc * ns];
         bv[k] = xs[kc];
     }
 #pragma unroll
-    for (int u = 0; u < SMALL_RPL; ++u) {
+    for (int u = 0; u < RPL; ++u) {
         const i32 rr = min(lane + 64 * u, max(rs - 1, 0));         // row below, clamped (rs may be 0: stays inside the panel)
         uv[u] = (rs > 0) ? uc[rr] : 0.0;
 #pragma unroll
-        for (int k = 0; k < SMALL_NS; ++k) lv[u][k] = P[(i64)min(ns + rr, f - 1) + (i64)min(k, ns - 1) * lda];
+        for (int k = 0; k < NSM; ++k) lv[u][k] = P[(i64)min(ns + rr, f - 1) + (i64)min(k, ns - 1) * lda];
     }
     double y = 0.0;
 #pragma unroll
-    for (int k = 0; k < SMALL_NS; ++k) y += (k < ns && k <= lane) ? wv[k] * bv[k] : 0.0;
+    for (int k = 0; k < NSM; ++k) y += (k < ns && k <= lane) ? wv[k] * bv[k] : 0.0;
     if (lane < ns) xs[lane] = y;
-    double yv[SMALL_NS];
+    double yv[NSM];
 #pragma unroll
-    for (int k = 0; k < SMALL_NS; ++k) yv[k] = __shfl(y, k);        // only k < ns is used
+    for (int k = 0; k < NSM; ++k) yv[k] = __shfl(y, k);        // only k < ns is used
 #pragma unroll
-    for (int u = 0; u < SMALL_RPL; ++u) {
+    for (int u = 0; u < RPL; ++u) {
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < SMALL_NS; ++k) acc += (k < ns) ? lv[u][k] * yv[k] : 0.0;
+        for (int k = 0; k < NSM; ++k) acc += (k < ns) ? lv[u][k] * yv[k] : 0.0;
         if (lane + 64 * u < rs) uc[lane + 64 * u] = uv[u] - acc;
     }
 }
-
-__global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
+__global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
+    const bool few = fd.ns <= 4, shortf = fd.f - fd.ns <= 64;      // wave-uniform
+    if (few) { if (shortf) fwd_small_body<4, 1>(fd, c, lane); else fwd_small_body<4, SMALL_RPL>(fd, c, lane); }
+    else { if (shortf) fwd_small_body<SMALL_NS, 1>(fd, c, lane); else fwd_small_body<SMALL_NS, SMALL_RPL>(fd, c, lane); }
+}
+
+template <int NSM, int RPL>
+__device__ __forceinline__ void bwd_small_body(const FrontDesc &fd, const DevCtx &c, const int lane) {
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *__restrict__ P = c.Lval + fd.loff;
@@ -2266,44 +2272,53 @@ __global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__
     const i32 *__restrict__ rows = c.rowidx + fd.rowoff;
     double *xs = c.xw + fd.col0;
     const i32 ic = min(lane, ns - 1);
-    double wv[SMALL_NS], bv[SMALL_NS], lv[SMALL_RPL][SMALL_NS], xr[SMALL_RPL];
-    i32 gi[SMALL_RPL];
+    double wv[NSM], bv[NSM], lv[RPL][NSM], xr[RPL];
+    i32 gi[RPL];
 #pragma unroll
-    for (int u = 0; u < SMALL_RPL; ++u) gi[u] = rows[min(ns + lane + 64 * u, f - 1)];   // rows below: values of the ancestors
+    for (int u = 0; u < RPL; ++u) gi[u] = rows[min(ns + lane + 64 * u, f - 1)];   // rows below: values of the ancestors
 #pragma unroll
-    for (int k = 0; k < SMALL_NS; ++k) {
+    for (int k = 0; k < NSM; ++k) {
         const i32 kc = min(k, ns - 1);
         wv[k] = W[(i64)kc + (i64)ic * ns];                           // column `lane` of W
         bv[k] = xs[kc];
     }
 #pragma unroll
-    for (int u = 0; u < SMALL_RPL; ++u) {
+    for (int u = 0; u < RPL; ++u) {
         const i32 r = min(ns + lane + 64 * u, f - 1);
 #pragma unroll
-        for (int k = 0; k < SMALL_NS; ++k) lv[u][k] = P[(i64)r + (i64)min(k, ns - 1) * lda];
+        for (int k = 0; k < NSM; ++k) lv[u][k] = P[(i64)r + (i64)min(k, ns - 1) * lda];
         const double xv = c.xw[gi[u]];
         xr[u] = (lane + 64 * u < rs) ? xv : 0.0;
     }
-    double acc[SMALL_NS];
+    double acc[NSM];
 #pragma unroll
-    for (int k = 0; k < SMALL_NS; ++k) {
+    for (int k = 0; k < NSM; ++k) {
         double a = 0.0;
 #pragma unroll
-        for (int u = 0; u < SMALL_RPL; ++u) a += lv[u][k] * xr[u];
+        for (int u = 0; u < RPL; ++u) a += lv[u][k] * xr[u];
         acc[k] = (k < ns) ? a : 0.0;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-        for (int k = 0; k < SMALL_NS; ++k) acc[k] += __shfl_down(acc[k], off);
+        for (int k = 0; k < NSM; ++k) acc[k] += __shfl_down(acc[k], off);
     }
     double x = 0.0;                                                  // x[i] = sum_{k >= i} W[k][i] (b[k] - sum[k])
 #pragma unroll
-    for (int k = 0; k < SMALL_NS; ++k) {
+    for (int k = 0; k < NSM; ++k) {
         const double tk = bv[k] - __shfl(acc[k], 0);
         x += (k < ns && k >= lane) ? wv[k] * tk : 0.0;
     }
     if (lane < ns) xs[lane] = x;
+}
+__global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
+    if (t.front < 0) return;
+    const FrontDesc fd = c.fronts[t.front];
+    const bool few = fd.ns <= 4, shortf = fd.f - fd.ns <= 64;      // wave-uniform
+    if (few) { if (shortf) bwd_small_body<4, 1>(fd, c, lane); else bwd_small_body<4, SMALL_RPL>(fd, c, lane); }
+    else { if (shortf) bwd_small_body<SMALL_NS, 1>(fd, c, lane); else bwd_small_body<SMALL_NS, SMALL_RPL>(fd, c, lane); }
 }
 
 // dy_shared != nullptr (single-process multi-device mode): the rows this rank OWNS (its block rows; the linking rows

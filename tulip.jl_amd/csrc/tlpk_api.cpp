@@ -18,6 +18,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 
 #include "../../include/tlpk.h"
 #include "tlpk_device.hpp"
@@ -30,6 +33,68 @@ namespace {
 // GPU_MAX_HW_QUEUES (more hardware queues than the runtime's default 4) is a tuning knob of the HOST
 // process: the Python and Julia glue set it before the HIP runtime initialises (tulip.jl_amd/__init__.py,
 // julia/libtlpk.jl).  The library itself never touches the environment.
+
+// One persistent host thread per shard of a multi-device handle (round 4).  A Newton step of one shard is ~220 + 4 x 40 launches; enqueued by ONE
+// thread, shard after shard, eight shards cost the host ~8 x 1.5 ms against a device budget of ~14 ms per step (round-3 review).  The calls below
+// hand the per-shard part of a phase to the pool: shard 0 runs on the calling thread, shard r on worker r - 1; a phase ends when all have returned
+// (the reductions between the phases are enqueued by the caller).  Every worker sets its shard's device itself (hipSetDevice is per thread).
+// TLPK_SHARD_THREADS=0: the caller runs all shards in turn (the round-3 behaviour; for the A/B in profiles/).
+struct ShardPool {
+    std::vector<std::thread> th;
+    std::mutex mu; std::condition_variable cv, cv_done;
+    const std::function<int(int)> *job = nullptr;
+    unsigned long long gen = 0; int pending = 0, n = 0; bool stop = false; std::vector<int> rcs;
+    void worker(int r) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<int(int)> *f;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; f = job; }
+            int rc;
+            try { rc = (*f)(r); } catch (...) { rc = TLPK_INTERNAL; }
+            { std::lock_guard<std::mutex> lk(mu); rcs[(size_t)r] = rc; if (--pending == 0) cv_done.notify_one(); }
+        }
+    }
+    explicit ShardPool(int nshards) : n(nshards), rcs((size_t)nshards, TLPK_OK) {
+        try { for (int r = 1; r < nshards; ++r) th.emplace_back(&ShardPool::worker, this, r); } catch (...) { /* fewer workers: run() covers the rest itself */ }
+    }
+    ~ShardPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
+    // fn(r) for every shard; returns the result of the lowest-numbered shard that failed (and its index in *who)
+    int run(const std::function<int(int)> &fn, int *who) {
+        const int nw = (int)th.size();
+        { std::lock_guard<std::mutex> lk(mu); job = &fn; pending = nw; ++gen; }
+        if (nw) cv.notify_all();
+        int rc0;
+        try { rc0 = fn(0); } catch (...) { rc0 = TLPK_INTERNAL; }
+        rcs[0] = rc0;
+        for (int r = nw + 1; r < n; ++r) { try { rcs[(size_t)r] = fn(r); } catch (...) { rcs[(size_t)r] = TLPK_INTERNAL; } }      // shards without a worker
+        if (nw) { std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return pending == 0; }); }
+        for (int r = 0; r < n; ++r) if (rcs[(size_t)r] != TLPK_OK) { if (who) *who = r; return rcs[(size_t)r]; }
+        return TLPK_OK;
+    }
+};
+// fn(shard handle, index) for every shard of a multi-device handle, concurrently; on failure the shard's message becomes the parent's
+int for_shards(tlpk_handle *h, const std::function<int(tlpk_handle *, int)> &fn) {
+    static const bool threads = [] { const char *e = std::getenv("TLPK_SHARD_THREADS"); return !e || std::atoi(e) != 0; }();
+    const int N = (int)h->sub.size();
+    auto one = [&](int r) -> int {
+        tlpk_handle *c = h->sub[(size_t)r];
+        if (hipSetDevice(c->device) != hipSuccess) { c->last_error = "hipSetDevice failed"; return TLPK_HIPERR; }
+        return fn(c, r);
+    };
+    int who = -1, rc = TLPK_OK;
+    if (threads && N > 1) {
+        if (!h->shard_pool) h->shard_pool = new ShardPool(N);
+        const std::function<int(int)> f = one;
+        rc = static_cast<ShardPool *>(h->shard_pool)->run(f, &who);
+    } else {
+        for (int r = 0; r < N && rc == TLPK_OK; ++r) { rc = one(r); if (rc != TLPK_OK) who = r; }
+    }
+    if (rc != TLPK_OK && who >= 0) h->last_error = h->sub[(size_t)who]->last_error;
+    (void)hipSetDevice(h->sub[0]->device);
+    return rc;
+}
+
+void shard_pool_delete(void *p) { delete static_cast<ShardPool *>(p); }
 
 int kind_class(i32 kind) {
     switch (kind) {
@@ -338,7 +403,14 @@ inline i64 user_m(const tlpk_handle *h) { return h->S.system == 1 ? h->S.k2_m : 
 
 }  // namespace
 
+// diagnostic of the last FAILED tlpk_create / tlpk_create_multi of this thread: a failed create returns no handle, so tlpk_last_error
+// has nothing to be asked on (round-3 advisor finding: the messages "no block-angular structure found", the RCCL / shard memory-gate texts
+// could never reach the caller)
+static thread_local std::string g_create_error;
+
 extern "C" {
+
+const char *tlpk_last_create_error(void) { return g_create_error.c_str(); }
 
 void tlpk_default_options(tlpk_options *opt) {
     if (!opt) return;
@@ -452,6 +524,14 @@ static int create_device(tlpk_handle *h, const tlpk_options &def) {
                                 8.0 * (double)h->S.rowidx.size();
             if (need > budget) {
                 h->last_error = "factor needs " + std::to_string(need / 1e9) + " GB, budget " + std::to_string(budget / 1e9) + " GB";
+                if (h->S.system == 0 && !h->S.Ap.empty()) {
+                    // K1 forms A D A': one column of A with c entries makes a c x c dense block of S ("dense columns")
+                    i64 cmax = 0, jmax = -1;
+                    for (i64 j = 0; j < h->S.n; ++j) { const i64 cj = h->S.Ap[(size_t)j + 1] - h->S.Ap[(size_t)j]; if (cj > cmax) { cmax = cj; jmax = j; } }
+                    if (cmax >= 1000 && (double)cmax * (double)cmax >= 0.05 * (double)h->S.nnzL)
+                        h->last_error += "; column " + std::to_string(jmax) + " of A has " + std::to_string(cmax) + " entries (a dense column fills the normal equations): "
+                                         "the augmented system KKT_System = K2 (TLPK_SYSTEM_K2) does not form A*D*A'";
+                }
                 rc = TLPK_TOO_LARGE;
             }
         }
@@ -485,8 +565,12 @@ int tlpk_create(tlpk_handle **out, int64_t m, int64_t n, const int64_t *colptr, 
     } catch (...) {
         rc = TLPK_INTERNAL; h->last_error = "unexpected exception";
     }
-    // a failed create still returns the handle when it carries useful diagnostics (TOO_LARGE)
-    if (rc != TLPK_OK && rc != TLPK_TOO_LARGE) { tlpk_destroy(h); return rc; }
+    if (rc != TLPK_OK) {
+        g_create_error = h->last_error;
+        // no live handle on failure (a C caller that treats rc != 0 as "no handle" would leak the host symbolic data) -- unless the caller
+        // asks for the analyse-only handle that describes what did not fit
+        if (!(rc == TLPK_TOO_LARGE && def.keep_on_too_large)) { tlpk_destroy(h); return rc; }
+    } else g_create_error.clear();
     *out = h;
     return rc;
 }
@@ -497,6 +581,7 @@ void tlpk_destroy(tlpk_handle *h) {
     if (!h) return;
     if (!h->sub.empty() || h->multi_tmp) {                // multi-device parent: owns its per-device handles, nothing else
         if (h->multi_rccl) for (size_t r = 0; r < h->sub.size(); ++r) if (h->multi_comm[r]) multi_comm_destroy(h->multi_comm[r]);
+        shard_pool_delete(h->shard_pool); h->shard_pool = nullptr;
         for (tlpk_handle *c : h->sub) tlpk_destroy(c);
         ipm_free(h);
         if (h->multi_tmp) { hipSetDevice(h->device); hipFree(h->multi_tmp); }
@@ -1174,10 +1259,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 // second half of an update: reduction of the root panel, every shard's root front, the verdict
 int multi_update_tail(tlpk_handle *h, double t_in) {
     if (int rc = multi_allreduce(h, 0)) return rc;
-    for (tlpk_handle *c : h->sub) {                      // every root front is enqueued before anybody waits
-        const int rc = update_finish_enqueue(c);
-        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
-    }
+    if (int rc = for_shards(h, [](tlpk_handle *c, int) { return update_finish_enqueue(c); })) return rc;      // every root front is enqueued before anybody waits
     h->ms_enqueue_update = now_ms() - t_in;
     int worst = TLPK_OK; h->fail_col = -1;
     for (tlpk_handle *c : h->sub) {
@@ -1199,16 +1281,14 @@ int multi_update(tlpk_handle *h, const double *theta, const double *regP, const 
     for (tlpk_handle *c : h->sub) { HIPCHK(h, hipSetDevice(c->device)); HIPCHK(h, hipStreamSynchronize(c->stream)); }   // staging area free again
     double *p0 = lead->pin_in, *p1 = p0 + n, *p2 = p1 + n;
     std::memcpy(p0, theta, (size_t)n * 8); std::memcpy(p1, regP, (size_t)n * 8); std::memcpy(p2, regD, (size_t)m * 8);
-    for (tlpk_handle *c : h->sub) {
-        HIPCHK(h, hipSetDevice(c->device));
-        // only what this shard reads: its columns of theta / regP, its block rows and the linking rows of regD
-        HIPCHK(h, upload_range(c->d_theta, p0, c->col_lo, c->col_hi, c->stream));
-        HIPCHK(h, upload_range(c->d_regP, p1, c->col_lo, c->col_hi, c->stream));
-        HIPCHK(h, upload_range(c->d_regD, p2, c->row_lo, c->row_hi, c->stream));
-        HIPCHK(h, upload_range(c->d_regD, p2, c->link_lo, c->link_hi, c->stream));
-        const int rc = tlpk_update_local(c, c->d_theta, c->d_regP, c->d_regD);
-        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
-    }
+    if (int rc = for_shards(h, [&](tlpk_handle *c, int) -> int {
+            // only what this shard reads: its columns of theta / regP, its block rows and the linking rows of regD
+            HIPCHK(c, upload_range(c->d_theta, p0, c->col_lo, c->col_hi, c->stream));
+            HIPCHK(c, upload_range(c->d_regP, p1, c->col_lo, c->col_hi, c->stream));
+            HIPCHK(c, upload_range(c->d_regD, p2, c->row_lo, c->row_hi, c->stream));
+            HIPCHK(c, upload_range(c->d_regD, p2, c->link_lo, c->link_hi, c->stream));
+            return tlpk_update_local(c, c->d_theta, c->d_regP, c->d_regD);
+        })) return rc;
     return multi_update_tail(h, t_in);
 }
 
@@ -1221,14 +1301,12 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
     for (tlpk_handle *c : h->sub) { HIPCHK(h, hipSetDevice(c->device)); HIPCHK(h, hipStreamSynchronize(c->stream)); }
     double *pi0 = lead->pin_in, *pi1 = pi0 + m;
     std::memcpy(pi0, xi_p, (size_t)m * 8); std::memcpy(pi1, xi_d, (size_t)n * 8);
-    for (tlpk_handle *c : h->sub) {
-        HIPCHK(h, hipSetDevice(c->device));
-        HIPCHK(h, upload_range(c->d_xip, pi0, c->row_lo, c->row_hi, c->stream));
-        HIPCHK(h, upload_range(c->d_xip, pi0, c->link_lo, c->link_hi, c->stream));
-        HIPCHK(h, upload_range(c->d_xid, pi1, c->col_lo, c->col_hi, c->stream));
-        const int rc = tlpk_solve_local(c, c->d_xip, c->d_xid);
-        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
-    }
+    if (int rc = for_shards(h, [&](tlpk_handle *c, int) -> int {
+            HIPCHK(c, upload_range(c->d_xip, pi0, c->row_lo, c->row_hi, c->stream));
+            HIPCHK(c, upload_range(c->d_xip, pi0, c->link_lo, c->link_hi, c->stream));
+            HIPCHK(c, upload_range(c->d_xid, pi1, c->col_lo, c->col_hi, c->stream));
+            return tlpk_solve_local(c, c->d_xip, c->d_xid);
+        })) return rc;
     if (int rc = multi_allreduce(h, 1)) return rc;
     if (h->refine_steps > 0) {
         // iterative refinement: every shard keeps its solution rank-local (own columns / block rows, linking rows replicated), each
@@ -1260,16 +1338,14 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
             launch_publish(c->stream, c->d, c->d_dx, lead->d_dx, c->d_dy, lead->d_dy);      // owned columns / block rows only (P2P stores)
             HIPCHK(h, hipEventRecord(h->multi_ev[r], c->stream));
         }
-    } else
-    for (size_t r = 0; r < h->sub.size(); ++r) {
-        tlpk_handle *c = h->sub[r];
+    } else if (int rc = for_shards(h, [&](tlpk_handle *c, int r) -> int {
         // every rank fills its own entries of the lead device's dx / dy (P2P stores); its local dy feeds its k_dx
         c->shared_dy = lead->d_dy; c->dx_local_only = true;
-        const int rc = tlpk_solve_finish(c, lead->d_dx, (c->S.system == 1) ? lead->d_dy : (r == 0 ? h->multi_tmp + h->multi_dy0_off : c->d_dy), c->d_xid);
-        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
-        HIPCHK(h, hipSetDevice(c->device));
-        if (r > 0) HIPCHK(h, hipEventRecord(h->multi_ev[r], c->stream));
-    }
+        const int q = tlpk_solve_finish(c, lead->d_dx, (c->S.system == 1) ? lead->d_dy : (r == 0 ? h->multi_tmp + h->multi_dy0_off : c->d_dy), c->d_xid);
+        if (q != TLPK_OK) return q;
+        if (r > 0) HIPCHK(c, hipEventRecord(h->multi_ev[r], c->stream));
+        return TLPK_OK;
+    })) return rc;
     HIPCHK(h, hipSetDevice(lead->device));
     for (size_t r = 1; r < h->sub.size(); ++r) HIPCHK(h, hipStreamWaitEvent(lead->stream, h->multi_ev[r], 0));
     double *po0 = lead->pin_out, *po1 = po0 + m;
@@ -1304,27 +1380,34 @@ void shard_ranges(tlpk_handle *c) {
 extern "C++" {
 int multi_update_resident(tlpk_handle *h) {
     const double t_in = now_ms();
-    for (tlpk_handle *c : h->sub) {
-        const int rc = tlpk_update_local(c, c->d_theta, c->d_regP, c->d_regD);
-        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
-    }
+    if (int rc = for_shards(h, [](tlpk_handle *c, int) { return tlpk_update_local(c, c->d_theta, c->d_regP, c->d_regD); })) return rc;
     return multi_update_tail(h, t_in);
 }
 int multi_solve_resident(tlpk_handle *h, double *const *dx, double *const *dy, const double *const *xip, const double *const *xid) {
     if (!h->factored) return TLPK_NOT_FACTORED;
-    for (size_t r = 0; r < h->sub.size(); ++r) {
-        tlpk_handle *c = h->sub[r];
-        c->rhs_all_ranks = true;                         // every shard's xi_p counts on the linking rows (partial residuals)
-        const int rc = tlpk_solve_local(c, xip[r], xid[r]);
-        c->rhs_all_ranks = false;
-        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
-    }
+    if (int rc = for_shards(h, [&](tlpk_handle *c, int r) {
+            c->rhs_all_ranks = true;                     // every shard's xi_p counts on the linking rows (partial residuals)
+            const int q = tlpk_solve_local(c, xip[r], xid[r]);
+            c->rhs_all_ranks = false;
+            return q;
+        })) return rc;
     if (int rc = multi_allreduce(h, 1)) return rc;
-    for (size_t r = 0; r < h->sub.size(); ++r) {
-        tlpk_handle *c = h->sub[r];
-        c->shared_dy = nullptr; c->dx_local_only = false;                  // the solution stays shard-resident
-        const int rc = tlpk_solve_finish(c, dx[r], dy[r], xid[r]);
-        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    if (int rc = for_shards(h, [&](tlpk_handle *c, int r) {
+            c->shared_dy = nullptr; c->dx_local_only = false;              // the solution stays shard-resident
+            return tlpk_solve_finish(c, dx[r], dy[r], xid[r]);
+        })) return rc;
+    // iterative refinement (Backend(ngpus = N, refine = k) under the device-resident loops; round-3 advisor finding: only the host-pointer
+    // tlpk_solve refined): one more split solve per step on the residuals every shard forms for the rows / columns it owns -- with the SAME
+    // convention as the solve above, every shard's xi_p counting on the linking rows
+    for (int it = 0; it < h->refine_steps; ++it) {
+        if (int rc = for_shards(h, [&](tlpk_handle *c, int r) {
+                c->rhs_all_ranks = true;
+                const int q = tlpk_refine_local(c, dx[r], dy[r], xip[r], xid[r]);
+                c->rhs_all_ranks = false;
+                return q;
+            })) return rc;
+        if (int rc = multi_allreduce(h, 1)) return rc;
+        if (int rc = for_shards(h, [&](tlpk_handle *c, int r) { return tlpk_refine_finish(c, dx[r], dy[r]); })) return rc;
     }
     return TLPK_OK;
 }
@@ -1332,21 +1415,21 @@ int multi_solve_resident(tlpk_handle *h, double *const *dx, double *const *dy, c
 int multi_solve2_resident(tlpk_handle *h, double *const *dx0, double *const *dy0, const double *const *xip0, const double *const *xid0,
                           double *const *dx1, double *const *dy1, const double *const *xip1, const double *const *xid1) {
     if (!h->factored) return TLPK_NOT_FACTORED;
-    for (size_t r = 0; r < h->sub.size(); ++r) {
-        tlpk_handle *c = h->sub[r];
-        c->rhs_all_ranks = true;
-        const int rc = tlpk_solve2_local(c, xip0[r], xid0[r], xip1[r], xid1[r]);
-        c->rhs_all_ranks = false;
-        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+    // refinement, or the launch-per-block schedule (TLPK_SWEEP=0, which has no two-rhs kernels): two ordinary solves, as tlpk_solve2_device
+    // does on one device (round-3 advisor finding: the pair aborted here with BADARG while the single-device loop worked)
+    if (h->refine_steps > 0 || !h->sub[0]->S.sweep) {
+        if (int rc = multi_solve_resident(h, dx0, dy0, xip0, xid0)) return rc;
+        return multi_solve_resident(h, dx1, dy1, xip1, xid1);
     }
+    if (int rc = for_shards(h, [&](tlpk_handle *c, int r) {
+            c->rhs_all_ranks = true;
+            const int q = tlpk_solve2_local(c, xip0[r], xid0[r], xip1[r], xid1[r]);
+            c->rhs_all_ranks = false;
+            return q;
+        })) return rc;
     if (int rc = multi_allreduce(h, 1)) return rc;
     if (int rc = multi_allreduce(h, 2)) return rc;
-    for (size_t r = 0; r < h->sub.size(); ++r) {
-        tlpk_handle *c = h->sub[r];
-        const int rc = tlpk_solve2_finish(c, dx0[r], dy0[r], xid0[r], dx1[r], dy1[r], xid1[r]);
-        if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
-    }
-    return TLPK_OK;
+    return for_shards(h, [&](tlpk_handle *c, int r) { return tlpk_solve2_finish(c, dx0[r], dy0[r], xid0[r], dx1[r], dy1[r], xid1[r]); });
 }
 }  // extern "C++"
 
@@ -1458,7 +1541,8 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
             }
         }
     }
-    if (rc != TLPK_OK) { std::string msg = h->last_error; tlpk_destroy(h); (void)msg; return rc; }
+    if (rc != TLPK_OK) { g_create_error = h->last_error.empty() ? std::string(tlpk_strerror(rc)) : h->last_error; tlpk_destroy(h); return rc; }     // tlpk_last_create_error()
+    g_create_error.clear();
     *out = h;
     return TLPK_OK;
 }

@@ -31,7 +31,7 @@ HIP (gfx950) backend.  `row_block` is the optional block-angular structure hook:
   * a `Vector{Int}` of length m (block id ≥ 0, or -1 for a linking row), indexed by the rows of the matrix
     `KKT.setup` receives -- only meaningful with `Presolve_Level = 0`;
   * a `BlockAngularMatrix` built through `MatrixFactory` (below) carries its own map; `setup` picks it up.
-`ngpus > 1` (block-angular LPs, system `K1`): this ONE Julia process shards the
+`ngpus > 1` (block-angular LPs, systems `K1` and `K2`): this ONE Julia process shards the
 diagonal blocks over `ngpus` devices of the node (`devices`: HIP ordinals, default `0:ngpus-1`); the
 linking-block reductions happen inside the library.  `streams`: concurrent stream groups (0 = auto).
 `refine`: iterative-refinement steps per `solve!` (0 = none, as `spd.jl:68`; `K1`, one GPU or `ngpus > 1`).
@@ -121,9 +121,14 @@ linear_system(kkt::HIPNormalEquations) = LibTLPK.linear_system(kkt.handle)   # "
 function _check(rc, handle, what)
     rc == LibTLPK.TLPK_OK && return nothing
     rc == LibTLPK.TLPK_NOT_POSDEF && throw(PosDefException(0))            # spd.jl:47
-    rc == LibTLPK.TLPK_BADARG && throw(DimensionMismatch("$what: " * LibTLPK.last_error(handle)))
-    (rc == LibTLPK.TLPK_OOM || rc == LibTLPK.TLPK_TOO_LARGE) && throw(OutOfMemoryError())
-    error("$what: " * LibTLPK.strerror(rc) * " " * LibTLPK.last_error(handle))
+    # a failed create returns no handle: its message is the thread's last create error
+    msg = handle == C_NULL ? LibTLPK.last_create_error() : LibTLPK.last_error(handle)
+    rc == LibTLPK.TLPK_BADARG && throw(DimensionMismatch("$what: " * msg))
+    if rc == LibTLPK.TLPK_OOM || rc == LibTLPK.TLPK_TOO_LARGE
+        isempty(msg) || @warn "$what: $msg"        # e.g. "factor needs 860 GB ...; column j of A has c entries ...: KKT_System = K2 ..."
+        throw(OutOfMemoryError())                   # -> Trm_MemoryLimit (HSD.jl:327-329)
+    end
+    error("$what: " * LibTLPK.strerror(rc) * " " * msg)
 end
 
 # Convert to sparse matrix if other type is used (cholmod.jl:65)

@@ -51,12 +51,14 @@ Base.@kwdef mutable struct Options
     system::Int32 = 0            # TLPK_SYSTEM_K1 | TLPK_SYSTEM_K2
     refine_steps::Int32 = 0
     detect_blocks::Int32 = 0     # 1: the library finds the block-angular structure of the matrix it is given
-    reserved0::Int32 = 0
+    keep_on_too_large::Int32 = 0   # 1: tlpk_create returns a live analyse-only handle with TLPK_TOO_LARGE
     max_link_rows::Int64 = 0
 end
 
 strerror(code::Integer) = unsafe_string(ccall((:tlpk_strerror, libtlpk[]), Cstring, (Cint,), code))
 last_error(h::Ptr{Cvoid}) = unsafe_string(ccall((:tlpk_last_error, libtlpk[]), Cstring, (Ptr{Cvoid},), h))
+# a failed tlpk_create / tlpk_create_multi returns no handle: the diagnostic of the calling thread's last failed create
+last_create_error() = unsafe_string(ccall((:tlpk_last_create_error, libtlpk[]), Cstring, ()))
 backend_name() = unsafe_string(ccall((:tlpk_backend_name, libtlpk[]), Cstring, ()))
 system_name() = unsafe_string(ccall((:tlpk_system_name, libtlpk[]), Cstring, ()))
 linear_system(h::Ptr{Cvoid}) = unsafe_string(ccall((:tlpk_linear_system, libtlpk[]), Cstring, (Ptr{Cvoid},), h))

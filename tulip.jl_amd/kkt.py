@@ -95,10 +95,10 @@ def _raise_for(code, handle=None, what=""):
     if code == _lib.OK:
         return
     msg = _lib.strerror(code)
-    if handle:
-        detail = _lib.lib().tlpk_last_error(handle).decode()
-        if detail:
-            msg = f"{msg}: {detail}"
+    # a failed create returns no handle: its diagnostic is tlpk_last_create_error()
+    detail = _lib.lib().tlpk_last_error(handle).decode() if handle else (_lib.lib().tlpk_last_create_error().decode() if what.startswith("KKT.setup") else "")
+    if detail:
+        msg = f"{msg}: {detail}"
     if code == _lib.NOT_POSDEF:
         raise PosDefException(0)
     if code == _lib.BADARG:
