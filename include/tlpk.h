@@ -208,8 +208,9 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
 /* Block-angular structure of an m x n CSC matrix (int64 indices, index_base in {0,1}): row_block[i] = block id >= 0 of row i,
  * or -1 for a linking row -- the vector tlpk_options.row_block takes.  Rows are adjacent when they share a column; the densest
  * rows are removed (at most max_link_rows, 0 = max(64, m / 20)) until no connected component of the rest holds more than half of
- * the remaining rows; the smallest such set of linking rows is found by bisection; small components (isolated rows) are packed into
- * the blocks.  *n_blocks = number of diagonal blocks, 1 = no block structure (then every row_block[i] = 0 and the caller should
+ * the remaining rows -- or, for an LP with one dominant block, at most 80 % of them next to a second component of block size
+ * (TLPK_DETECT_MAX_FRACTION) --; a small such set of linking rows is found by a geometric probe + bisection (the acceptance test is not
+ * monotone in the number of removed rows, so "small", not "smallest"); small components (isolated rows) are packed into the blocks.  *n_blocks = number of diagonal blocks, 1 = no block structure (then every row_block[i] = 0 and the caller should
  * pass row_block = NULL).  Host only, deterministic, O(nnz log max_link_rows).  n_blocks / n_link may be NULL. */
 int tlpk_detect_blocks(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int index_base,
                        int64_t max_link_rows, int64_t *row_block /*m*/, int64_t *n_blocks, int64_t *n_link);

@@ -43,7 +43,7 @@ class Emulator:
         from tulip_jl_amd import _lib
         self.pair_w = _lib.symbolic_array_f64(kkt._h, "pair_w")
         self.tasks = {
-            LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 4),
+            LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 6),
             LK["FRONT_ASSEMBLE"]: g("fa_tasks").reshape(-1, 4),
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
             LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),
@@ -182,7 +182,7 @@ class Emulator:
 
     def _k0(self, T):      # extend-add
         # group tasks by front: emulation processes whole columns ranges, children in order
-        for front, j0, j1, bidx in T:
+        for front, j0, j1, bidx, br0, br1 in T:
             f, ns = int(self.f[front]), int(self.ns[front])
             rs = f - ns
             if front not in self.U:
@@ -197,10 +197,14 @@ class Emulator:
                 q0, q1 = (int(v) for v in self.ea_tab[self.eatab[c] + bidx: self.eatab[c] + bidx + 2])
                 assert (q0, q1) == (np.searchsorted(relc, j0), np.searchsorted(relc, j1)), "extend-add lookup table"
                 assert q1 - q0 <= 16
+                rlo, rhi = (int(self.ea_tab[self.eatab[c] + br0]), int(self.ea_tab[self.eatab[c] + br1])) if br1 else (0, rsc)      # row band of the task
                 for q in range(q0, q1):
                     tc = relc[q]
-                    src = Uc[q:, q]
-                    tr = relc[q:]
+                    lo = max(q, rlo)
+                    if lo >= rhi:
+                        continue
+                    src = Uc[lo:rhi, q]
+                    tr = relc[lo:rhi]
                     if tc < ns:
                         P[tr, tc] += src
                     else:

@@ -169,3 +169,25 @@ def test_multi_device_handle_with_detected_blocks():
         tk.solve(dx, dy, kkt, xp, xd)
         res.append((dx, dy)); kkt.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_one_dominant_block_is_still_a_structure():
+    """Two diagonal blocks at 70 / 30 (+ linking rows): no component holds <= half of the rows, the dominant-block rule accepts it; one
+    giant component + isolated rows (a general sparse LP with slack-only rows) is NOT a structure."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+
+    def blk(mr, nc):
+        rows = rng.integers(0, mr, size=(nc, 3)).ravel(); cols = np.repeat(np.arange(nc), 3)
+        M = sp.csc_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(mr, nc)); M.sum_duplicates(); return M
+    A1, A2 = blk(700, 1500), blk(300, 700)
+    link = sp.random(20, 2200, density=0.3, random_state=3, format="csc")
+    A = sp.vstack([sp.block_diag([A1, A2], format="csc"), link], format="csc")
+    rb, nb, nl = detect_blocks(A)
+    assert nb == 2 and nl == 20 and (rb[-20:] == -1).all()
+    b1, b2 = np.bincount(rb[:700]).argmax(), np.bincount(rb[700:1000]).argmax()       # (a row that no column touches may be dealt to either block)
+    assert b1 != b2 and (rb[:700] == b1).mean() > 0.95 and (rb[700:1000] == b2).mean() > 0.95
+    # one connected component of 80 % of the rows + isolated slack-only rows: general sparse path
+    G = sp.hstack([sp.vstack([blk(800, 1600), sp.csc_matrix((200, 1600))]), sp.identity(1000, format="csc")], format="csc")
+    rb, nb, nl = detect_blocks(G)
+    assert nb == 1

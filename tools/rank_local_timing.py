@@ -9,7 +9,8 @@ import torch
 import tulip_jl_amd as tk
 from workloads import block_angular_lp, kernel_inputs
 
-A, row_block = block_angular_lp()
+HEADLINE = os.environ.get("HEADLINE") == "1"      # the north-star instance (100 blocks x (20 000 inequality rows x 10 000 vars) + 1000 linking rows)
+A, row_block = block_angular_lp(100, 20000, 10000, 1000, 4, 0.5, ineq=True) if HEADLINE else block_angular_lp()
 m, n = A.shape
 th, rp, rd, xp, xd = kernel_inputs(m, n, 7, "mid")
 dev = torch.device("cuda", 0)
@@ -40,6 +41,7 @@ for N in [int(v) for v in os.environ.get("NLIST", "1,2,4,8").split(",")]:
         torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
         print(f"  {fn.__name__}: {ms:.1f} ms/step", flush=True)
     kkt.set_profile(True); step(); kt = kkt.kernel_times(); kkt.set_profile(False)
-    print(f"nranks={N}: rank 0 owns {kkt.stats()['n_local_blocks']} blocks, {ms:.1f} ms/step local work; "
+    rp_, cnt_p = kkt.root_panel(); rr_, cnt_r = kkt.root_rhs()
+    print(f"nranks={N}: root panel {cnt_p} doubles, root rhs {cnt_r} doubles; rank 0 owns {kkt.stats()['n_local_blocks']} blocks, {ms:.1f} ms/step local work; "
           f"serialised per class: " + ", ".join(f"{k} {v['ms']:.1f}" for k, v in kt.items()), flush=True)
     kkt.close()

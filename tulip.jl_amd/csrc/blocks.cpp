@@ -9,8 +9,10 @@
 // What: rows are vertices, two rows are adjacent when they share a column.  Remove the k DENSEST rows ("linking" rows: a
 // linking row of a block-angular LP touches columns of many blocks, a block row a handful of its own block's columns) and
 // take the connected components of the rest.  The removed sets are nested in k, so the size of the largest component is
-// non-increasing in k: the smallest k <= max_link_rows for which no component holds more than half of the remaining rows
-// is found by a geometric probe + bisection (each probe is one union-find pass over the columns, O(nnz)).  Then
+// non-increasing in k: a small k <= max_link_rows for which no component holds more than half of the remaining rows (or: at most
+// 80 % next to a second component of block size -- LPs with one dominant block) is found by a geometric probe + bisection (each probe is
+// one union-find pass over the columns, O(nnz); the remaining-row count m - k shrinks too, so the acceptance test is not strictly
+// monotone and the bisection returns a valid k, not necessarily the smallest).  Then
 //   * removed rows whose columns all lie in ONE component (or in none) go back into a block (least dense first),
 //   * components are packed into blocks: a component with at least 1/64 of the rows of the largest is a block of its own,
 //     the small ones (isolated rows: an inequality row that only holds its slack) are dealt to the currently smallest
@@ -18,6 +20,7 @@
 //   * blocks are numbered by their first row, so that contiguous block ranges (the sharding unit) follow the row order.
 // No structure (fewer than two blocks): n_blocks = 1, every row in block 0 -- the caller then takes the general sparse path.
 #include <algorithm>
+#include <cstdlib>
 #include <cstdint>
 #include <functional>
 #include <new>
@@ -79,6 +82,7 @@ extern "C" int tlpk_detect_blocks(int64_t m64, int64_t n64, const int64_t *colpt
         kmax = std::min<i64>(kmax, m - 2);
         std::vector<char> link((size_t)m, 0);
         std::vector<i32> comp((size_t)m), csize;
+        i64 second = 0;
         // one probe: components of the rows that are not among the k densest; returns the size of the largest
         auto probe = [&](i64 k) -> i64 {
             std::fill(link.begin(), link.end(), 0);
@@ -100,9 +104,25 @@ extern "C" int tlpk_detect_blocks(int64_t m64, int64_t n64, const int64_t *colpt
                 comp[(size_t)i] = r;
                 best = std::max<i64>(best, ++csize[(size_t)r]);
             }
+            second = 0;                             // size of the second largest component
+            bool seen_best = false;
+            for (i32 i = 0; i < m; ++i) {
+                const i64 c = csize[(size_t)i];
+                if (c == best && !seen_best) { seen_best = true; continue; }
+                second = std::max(second, c);
+            }
             return best;
         };
-        auto good = [&](i64 k) { return 2 * probe(k) <= (m - k); };
+        // A set of k linking rows is accepted when no component holds more than half of the remaining rows, or -- a block-angular LP with one
+        // DOMINANT block (two blocks at 60 / 40, one large block and several smaller ones; round-3 advisor finding) -- when the largest holds at most
+        // max_fraction of them AND a second component of block size exists (one giant component + isolated rows is not a structure).
+        // TLPK_DETECT_MAX_FRACTION (default 0.8) tunes it.
+        static const double max_fraction = [] { const char *e = std::getenv("TLPK_DETECT_MAX_FRACTION"); const double v = e ? std::atof(e) : 0.8; return std::min(0.95, std::max(0.5, v)); }();
+        auto good = [&](i64 k) {
+            const i64 best = probe(k);
+            if (2 * best <= (m - k)) return true;
+            return (double)best <= max_fraction * (double)(m - k) && second >= std::max<i64>(32, best / 64);
+        };
         i64 lo = -1, hi = -1;                       // lo: largest k known bad, hi: smallest k known good
         for (i64 k = 0;; k = (k == 0) ? 1 : std::min(kmax, 4 * k)) {
             if (good(k)) { hi = k; break; }

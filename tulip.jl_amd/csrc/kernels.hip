@@ -26,8 +26,11 @@
 // crosses a launch, or -- the solve sweeps -- goes through relaxed agent-scope atomic stores and loads on both
 // sides with the data as its own flag (cdna_hip_programming.md, Guideline 16).
 //
-// Every kernel is deterministic (no floating-point atomics): sums that cross workgroups are
-// ordered by the static schedule built on the host (symbolic.cpp: build_schedule).
+// Every kernel is deterministic: sums that cross workgroups are ordered by the static schedule built on the host
+// (symbolic.cpp: build_schedule).  The one floating-point atomic in this file -- k_update's epilogue, a fire-and-forget fp64 add executed
+// by the L2 -- is deterministic because the schedule gives every target entry exactly ONE adder per launch (one tile per target block and
+// launch; split-K parts go to scratch and are summed in order by k_update_reduce): the add is then the same IEEE operation as load /
+// subtract / store, without the wave waiting for the old value.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
     // dependent loads) are done for a whole batch of children at once, one child per thread;
     // doing them child after child made this kernel latency-bound (6 ms at 1.5 TB/s on config C4).
     constexpr int CB = 256;                         // children per batch
-    __shared__ i32 s_q0[CB], s_q1[CB], s_rsc[CB];
+    __shared__ i32 s_q0[CB], s_q1[CB], s_rsc[CB], s_rlo[CB], s_rhi[CB];
     __shared__ i64 s_uoff[CB], s_reloff[CB];
     __shared__ int s_ubuf[CB];
     __shared__ unsigned char s_tc[CB][EA_COLS];     // parent column - j0 of the child's columns [q0, q1)
@@ -179,6 +182,8 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
             // <= EA_COLS parent columns themselves, loaded side by side
             const i32 q0 = c.ea_tab[cd.eatab + t.bidx], q1 = c.ea_tab[cd.eatab + t.bidx + 1];
             s_q0[tid] = q0; s_q1[tid] = q1; s_rsc[tid] = rsc;
+            // row band of the task (boundaries br0 .. br1 of the parent's ranges; br1 == 0: every row): the child's rows inside it, from the same table
+            s_rlo[tid] = t.br1 ? c.ea_tab[cd.eatab + t.br0] : 0; s_rhi[tid] = t.br1 ? c.ea_tab[cd.eatab + t.br1] : rsc;
             s_uoff[tid] = cd.uoff; s_reloff[tid] = cd.reloff; s_ubuf[tid] = cd.ubuf;
 #pragma unroll
             for (int u = 0; u < EA_COLS; ++u) if (q0 + u < q1) s_tc[tid][u] = (unsigned char)(relc[q0 + u] - t.j0);
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
         for (i32 ci = 0; ci < nb; ++ci) {
             const i32 q0 = s_q0[ci], q1 = s_q1[ci];
             if (q0 >= q1) continue;
-            const i32 rsc = s_rsc[ci];
+            const i32 rsc = s_rsc[ci], rlo = s_rlo[ci], rhi = s_rhi[ci];
+            if (rlo >= rhi) continue;
             const double *Uc = (s_ubuf[ci] ? c.U1 : c.U0) + s_uoff[ci];
             const i32 *relc = c.rel + s_reloff[ci];
             for (i32 q = q0; q < q1; ++q) {
@@ -201,17 +207,17 @@ __global__ __launch_bounds__(256) void k_extend_add(const EaTask *__restrict__ t
                 // more than the old-value round trip costs the waves); a flattened trip iterator with the loads of
                 // trip n + 1 issued before the read-modify-write of trip n (6.3 vs 5.5 ms: the per-trip bookkeeping
                 // costs more than the hidden round trip).
-                for (i32 r = q + lane; r < rsc; r += 256) {
+                for (i32 r = max(q, rlo) + lane; r < rhi; r += 256) {
                     i32 tg[4]; double v[4], d[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const i32 ru = min(r + 64 * u, rsc - 1);
+                        const i32 ru = min(r + 64 * u, rhi - 1);
                         tg[u] = relc[ru]; v[u] = src[ru];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) d[u] = dst[tg[u]];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) if (r + 64 * u < rsc) dst[tg[u]] = d[u] + v[u];
+                    for (int u = 0; u < 4; ++u) if (r + 64 * u < rhi) dst[tg[u]] = d[u] + v[u];
                 }
             }
         }
@@ -2551,6 +2557,18 @@ void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const doubl
         hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, w, xi_p, xi_d,
                            a.row_local, a.col_local, rank, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
     }
+}
+// reduce-scatter step of the multi-device reductions: this shard's slice, summed over ALL ranks in rank order (its own contribution at position
+// own_rank, the peers' slices from the staging area: rank s at slot s, or s - 1 behind own_rank) -- every slice gets the same order whoever owns it
+__global__ void k_sum_ranked(i64 len, double *__restrict__ inout, const double *__restrict__ stage, int nranks, int own_rank, i64 stride) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    double v = 0.0;
+    for (int s_ = 0; s_ < nranks; ++s_) v += (s_ == own_rank) ? inout[i] : stage[(i64)(s_ < own_rank ? s_ : s_ - 1) * stride + i];
+    inout[i] = v;
+}
+void launch_sum_ranked(hipStream_t st, i64 len, double *inout, const double *stage, int nranks, int own_rank, i64 stride) {
+    if (len > 0) hipLaunchKernelGGL(k_sum_ranked, dim3(nblk(len, 256)), dim3(256), 0, st, len, inout, stage, nranks, own_rank, stride);
 }
 void launch_sum_to(hipStream_t st, i64 len, double *out, const double *own, const double *src, int nsrc, i64 stride) {
     if (len > 0) hipLaunchKernelGGL(k_sum_to, dim3(nblk(len, 256)), dim3(256), 0, st, len, out, own, src, nsrc, stride);

@@ -1256,7 +1256,16 @@ static void build_schedule(Symbolic &S) {
                 const bool fa = S.front_fa[(size_t)s];
                 const i32 cols = ea_cols(w, fa);
                 i32 k = u_part ? ea_npan(w, fa) : 0;              // boundary index of j (section 13a)
-                for (i32 j = jbeg; j < jend; j += cols, ++k) S.ea_tasks.push_back(EaTask{s, j, std::min(j + cols, jend), k});
+                // TLPK_EA_BANDS (experiment): the rows of a big parent are cut into bands of whole boundary ranges, one workgroup per (column range, band)
+                static const i32 nbands = [] { const char *e = std::getenv("TLPK_EA_BANDS"); return e ? std::max(1, std::atoi(e)) : 1; }();
+                const i32 nbnd = ea_nbounds(w, fa);
+                const i32 bands = (w.f >= 2048) ? nbands : 1;
+                for (i32 j = jbeg; j < jend; j += cols, ++k) {
+                    if (bands == 1) { S.ea_tasks.push_back(EaTask{s, j, std::min(j + cols, jend), k, 0, 0, 0, 0}); continue; }
+                    // rows >= j only matter (lower triangle): bands over the boundaries [k, nbnd - 1)
+                    const i32 span = nbnd - 1 - k, per = (span + bands - 1) / bands;
+                    for (i32 b0 = k; b0 < nbnd - 1; b0 += std::max(per, 1)) S.ea_tasks.push_back(EaTask{s, j, std::min(j + cols, jend), k, b0, std::min(b0 + std::max(per, 1), nbnd - 1), 0, 0});
+                }
             }
             push_launch(S.factor_launches, LK_EXTEND_ADD, first, (i64)S.ea_tasks.size() - first);
         };
@@ -1400,6 +1409,19 @@ static void build_schedule(Symbolic &S) {
             allow_skip = true;
             const i64 cnt = (i64)S.update_tasks.size() - f_upd;
             if (cnt == 0) return;
+            // Longest first (TLPK_UPD_LPT, round 4): tiles that skip K slabs are shorter than their neighbours; dealt out last they fill the tail of
+            // the launch instead of leaving long tiles to finish alone.  Stable: tiles of equal length keep the super-tile order (L2 locality).
+            static const bool lpt = [] { const char *e = std::getenv("TLPK_UPD_LPT"); return e && std::atoi(e) != 0; }();
+            if (lpt && nsplit < 2 && UPD_SLOTS == 0) {
+                auto len = [](const UpdateTask &t) { return t.seg ? 16 * t.nsl + t.kw % 16 : t.kw; };
+                std::vector<size_t> idx((size_t)cnt);
+                std::iota(idx.begin(), idx.end(), 0);
+                std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return len(S.update_tasks[(size_t)f_upd + a]) > len(S.update_tasks[(size_t)f_upd + b]); });
+                std::vector<UpdateTask> tmp_t((size_t)cnt); std::vector<i64> tmp_c((size_t)cnt);
+                for (size_t q = 0; q < (size_t)cnt; ++q) { tmp_t[q] = S.update_tasks[(size_t)f_upd + idx[q]]; tmp_c[q] = task_canon[idx[q]]; }
+                std::copy(tmp_t.begin(), tmp_t.end(), S.update_tasks.begin() + f_upd);
+                task_canon.swap(tmp_c);
+            }
             i64 tail_from = t_level; i32 tail_parts = 1;      // tiles with canonical index >= tail_from are cut into tail_parts
             // number of parts p in 1..8 that minimises the time of a wave of r equal tiles on UPD_SLOTS slots: ceil(r p / slots) / p
             auto best_parts = [&](i64 r) {

@@ -74,7 +74,8 @@ struct ShardPool {
 };
 // fn(shard handle, index) for every shard of a multi-device handle, concurrently; on failure the shard's message becomes the parent's
 int for_shards(tlpk_handle *h, const std::function<int(tlpk_handle *, int)> &fn) {
-    static const bool threads = [] { const char *e = std::getenv("TLPK_SHARD_THREADS"); return !e || std::atoi(e) != 0; }();
+    const char *te = std::getenv("TLPK_SHARD_THREADS");      // (read per call: tests and A/B runs switch it inside one process)
+    const bool threads = !te || std::atoi(te) != 0;
     const int N = (int)h->sub.size();
     auto one = [&](int r) -> int {
         tlpk_handle *c = h->sub[(size_t)r];
@@ -586,7 +587,7 @@ void tlpk_destroy(tlpk_handle *h) {
         ipm_free(h);
         if (h->multi_tmp) { hipSetDevice(h->device); hipFree(h->multi_tmp); }
         if (h->multi_done) hipEventDestroy(h->multi_done);
-        for (int r = 0; r < MAX_DEVICES; ++r) if (h->multi_ev[r]) hipEventDestroy(h->multi_ev[r]);
+        for (int r = 0; r < MAX_DEVICES; ++r) { if (h->multi_ev[r]) hipEventDestroy(h->multi_ev[r]); if (h->multi_ev2[r]) hipEventDestroy(h->multi_ev2[r]); }
         delete h;
         return;
     }
@@ -1211,8 +1212,57 @@ int multi_allreduce_rccl(tlpk_handle *h, int which) {
     return TLPK_OK;
 }
 
+// Reduce-scatter + all-gather over peer copies (round 4; the default): shard r owns slice r of the buffer.  Every shard sends the OTHER shards'
+// slices of its buffer to their owners (its own stream, after its local work), the owner adds the N contributions to its slice in RANK order
+// (k_sum_ranked: bitwise the same sum whoever owns the slice) and sends the reduced slice to every peer.  2 (N - 1) copies of 1/N of the
+// buffer per shard, all of them between different pairs of devices at the same time -- the gather-to-lead form moved 2 (N - 1) whole buffers
+// through the lead's links one after the other.  Deterministic; exercisable with several shards on one GPU.
+int multi_allreduce_rs(tlpk_handle *h, int which) {
+    const int N = (int)h->sub.size();
+    double *p[MAX_DEVICES]; int64_t cnt = 0;
+    for (int r = 0; r < N; ++r) {
+        int64_t cr = 0;
+        const int rc = root_buf(h->sub[(size_t)r], which, &p[r], &cr);
+        if (rc != TLPK_OK) return rc;
+        if (r == 0) cnt = cr; else if (cr != cnt) { h->last_error = "root buffers of the ranks differ"; return TLPK_INTERNAL; }
+    }
+    if (cnt == 0) return TLPK_OK;
+    const i64 sl = std::min<i64>(h->rs_slice, ((cnt + N - 1) / N + 15) / 16 * 16);      // slice length: multiples of 16 doubles
+    auto lo = [&](int r) { return std::min<i64>(cnt, (i64)r * sl); };
+    auto len = [&](int r) { return std::min<i64>(cnt, (i64)(r + 1) * sl) - lo(r); };
+    for (int s_ = 0; s_ < N; ++s_) {                    // scatter: shard s sends slice r of its buffer to shard r
+        tlpk_handle *c = h->sub[(size_t)s_];
+        HIPCHK(h, hipSetDevice(c->device));
+        for (int r = 0; r < N; ++r) {
+            if (r == s_ || len(r) <= 0) continue;
+            tlpk_handle *o = h->sub[(size_t)r];
+            HIPCHK(h, hipMemcpyPeerAsync(o->rs_stage + (size_t)(s_ < r ? s_ : s_ - 1) * (size_t)h->rs_slice, o->device, p[s_] + lo(r), c->device, (size_t)len(r) * 8, c->stream));
+        }
+        HIPCHK(h, hipEventRecord(h->multi_ev[s_], c->stream));
+    }
+    for (int r = 0; r < N; ++r) {                       // reduce the own slice, send it to everybody
+        tlpk_handle *c = h->sub[(size_t)r];
+        HIPCHK(h, hipSetDevice(c->device));
+        for (int s_ = 0; s_ < N; ++s_) if (s_ != r) HIPCHK(h, hipStreamWaitEvent(c->stream, h->multi_ev[s_], 0));
+        if (len(r) > 0) {
+            launch_sum_ranked(c->stream, len(r), p[r] + lo(r), c->rs_stage, N, r, h->rs_slice);
+            for (int t = 0; t < N; ++t)
+                if (t != r) HIPCHK(h, hipMemcpyPeerAsync(p[t] + lo(r), h->sub[(size_t)t]->device, p[r] + lo(r), c->device, (size_t)len(r) * 8, c->stream));
+        }
+        HIPCHK(h, hipEventRecord(h->multi_ev2[r], c->stream));
+    }
+    for (int t = 0; t < N; ++t) {                       // nobody goes on before every slice of its buffer has arrived
+        tlpk_handle *c = h->sub[(size_t)t];
+        HIPCHK(h, hipSetDevice(c->device));
+        for (int r = 0; r < N; ++r) if (r != t) HIPCHK(h, hipStreamWaitEvent(c->stream, h->multi_ev2[r], 0));
+    }
+    HIPCHK(h, hipSetDevice(h->sub[0]->device));
+    return TLPK_OK;
+}
+
 int multi_allreduce(tlpk_handle *h, int which) {
     if (h->multi_rccl) return multi_allreduce_rccl(h, which);
+    if (h->multi_mode == 1 && h->sub.size() > 1) return multi_allreduce_rs(h, which);
     tlpk_handle *lead = h->sub[0];
     double *p0 = nullptr; int64_t cnt = 0;
     int rc = root_buf(lead, which, &p0, &cnt);
@@ -1361,8 +1411,20 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
 // index ranges a shard reads from the job-wide input vectors
 void shard_ranges(tlpk_handle *c) {
     const Symbolic &S = c->S;
-    if (S.system == 1) {             // K2: the Symbolic describes the incidence matrix of the augmented system; every shard takes the
-        c->col_lo = 0; c->col_hi = S.k2_n; c->row_lo = 0; c->row_hi = S.k2_m; c->link_lo = c->link_hi = 0;     // user vectors whole
+    if (S.system == 1) {
+        // K2: the Symbolic describes the augmented matrix -- node j < n is user column j, node n + i user row i; row_local of a node = 0 (another
+        // shard's), 1 (this shard's block) or 2 (replicated root front).  A shard reads theta / regP / xi_d of the variable nodes it owns (the lead
+        // also those of the root front: everything assembled into the root comes from rank 0), regD / xi_p of its constraint nodes and of the
+        // linking constraints (round 3 uploaded the whole user vectors to every shard)
+        const i64 n = S.k2_n, mm = S.k2_m;
+        auto span = [&](i64 a, i64 b, auto pred, i64 &lo, i64 &hi) {
+            lo = hi = 0; bool any = false;
+            for (i64 v = a; v < b; ++v) if (pred(S.row_local[(size_t)v])) { if (!any) { lo = v - a; any = true; } hi = v - a + 1; }
+        };
+        const bool lead = S.front_local.empty() ? true : (c->opt.rank == 0);
+        span(0, n, [&](char f) { return f == 1 || (f == 2 && lead); }, c->col_lo, c->col_hi);
+        span(n, n + mm, [](char f) { return f == 1; }, c->row_lo, c->row_hi);
+        span(n, n + mm, [](char f) { return f == 2; }, c->link_lo, c->link_hi);
         return;
     }
     auto range = [](const std::vector<char> &v, char what, i64 &lo, i64 &hi) {
@@ -1511,6 +1573,28 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
         hipError_t e = hipSetDevice(lead->device);
         if (e == hipSuccess) e = hipMalloc((void **)&h->multi_tmp, (size_t)std::max<i64>(tmp_len, 1) * 8);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->multi_done, hipEventDisableTiming);
+        {
+            // TLPK_MULTI_REDUCE = rs (default: reduce-scatter + all-gather over peer copies) | gather (round 2/3: gather to the lead, ordered sum, broadcast) | rccl
+            const char *mr = std::getenv("TLPK_MULTI_REDUCE");
+            h->multi_mode = (mr && std::string(mr) == "gather") ? 0 : 1;
+            h->rs_slice = ((cnt + ngpus - 1) / ngpus + 15) / 16 * 16;
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->multi_ev[0], hipEventDisableTiming);
+        for (int r = 0; r < ngpus && e == hipSuccess; ++r) {
+            e = hipSetDevice(h->sub[r]->device);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->multi_ev2[r], hipEventDisableTiming);
+            if (e == hipSuccess && ngpus > 1) {
+                void *q = nullptr;
+                e = hipMalloc(&q, (size_t)std::max<i64>((i64)(ngpus - 1) * h->rs_slice, 1) * 8);
+                if (e == hipSuccess) { h->sub[r]->rs_stage = (double *)q; h->sub[r]->allocs.push_back(q); }
+            }
+            for (int t = 0; t < ngpus && e == hipSuccess; ++t)                     // every shard stores into every other shard's buffers
+                if (h->sub[t]->device != h->sub[r]->device) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(h->sub[t]->device, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) e = pe;
+                    (void)hipGetLastError();
+                }
+        }
         for (int r = 1; r < ngpus && e == hipSuccess; ++r) {
             e = hipSetDevice(h->sub[r]->device);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&h->multi_ev[r], hipEventDisableTiming);
@@ -1651,7 +1735,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "fa_tasks") { for (auto &t : S.fa_tasks) { tmp.push_back(t.front); tmp.push_back(t.bc); tmp.push_back(t.br0); tmp.push_back(t.br1); } }
     else if (w == "front_fa") tmp.assign(S.front_fa.begin(), S.front_fa.end());
-    else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); tmp.push_back(t.bidx); } }
+    else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); tmp.push_back(t.bidx); tmp.push_back(t.br0); tmp.push_back(t.br1); } }
     else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks" || w == "fwd_small_tasks" || w == "bwd_small_tasks" ||
              w == "fwd_sweep_tasks" || w == "bwd_sweep_tasks") {
         const std::vector<SolveTask> &v = (w == "fwd_gather_tasks") ? S.fwd_gather_tasks : (w == "fwd_diag_tasks") ? S.fwd_diag_tasks :

@@ -82,6 +82,7 @@ void launch_publish(hipStream_t st, const DevArrays &a, const double *dx, double
 void launch_axpy2(hipStream_t st, i64 n, double *x, const double *dxc, i64 m, double *y, const double *dyc);
 void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx, int local_only = 0);
 void launch_sum_to(hipStream_t st, i64 len, double *out, const double *own, const double *src, int nsrc, i64 stride);
+void launch_sum_ranked(hipStream_t st, i64 len, double *inout, const double *stage, int nranks, int own_rank, i64 stride);
 void launch_k2_diag(hipStream_t st, i64 n, const double *theta, const double *regP, double *D2);
 void launch_k2_rhs(hipStream_t st, const DevArrays &a, i64 n, const double *xi_p, const double *xi_d, int rhs = 0, int rank = 0);
 void launch_apply_signs(hipStream_t st, const DevArrays &a, int rhs = 0);

@@ -60,6 +60,9 @@ struct tlpk_handle {
     i64 multi_red_off = 0, multi_dy0_off = 0;   // ... followed by the reduced buffer and the lead's rank-local dy
     hipEvent_t multi_ev[MAX_DEVICES] = {}; hipEvent_t multi_done = nullptr;
     void *multi_comm[MAX_DEVICES] = {}; bool multi_rccl = false;   // TLPK_MULTI_REDUCE=rccl: one ncclComm_t per shard
+    int multi_mode = 1;                 // parent: reduction of the root panel / rhs: 0 gather to the lead + broadcast, 1 reduce-scatter + all-gather over peer copies (default), 2 RCCL
+    hipEvent_t multi_ev2[MAX_DEVICES] = {}; i64 rs_slice = 0;     // parent: 'slice broadcast' events, slice length (doubles) of the largest reduced buffer
+    double *rs_stage = nullptr;         // child: staging of the peers' contributions to THIS shard's slice ((N - 1) x rs_slice doubles)
     void *shard_pool = nullptr;         // parent: one persistent host thread per shard (tlpk_api.cpp: ShardPool) -- the shards' launches are enqueued concurrently
     double ms_enqueue_update = 0;       // parent: host time from the entry of tlpk_update until every shard's work is enqueued
     i64 col_lo = 0, col_hi = 0, row_lo = 0, row_hi = 0, link_lo = 0, link_hi = 0;   // child: slices of the job-wide input vectors it reads

@@ -81,7 +81,7 @@ struct alignas(16) UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1, se
 struct FaTask    { i32 front, bc, br0, br1; };
 constexpr int FA_CW = 16;      // parent columns per tile = the extend-add column range of the large fronts
 constexpr int FA_RB = 16;      // row boundaries per tile: <= FA_RB * FA_CW = 256 rows
-struct EaTask    { i32 front, j0, j1, bidx; };                       // parent columns [j0, j1) = boundaries bidx, bidx + 1 of the front's extend-add ranges
+struct EaTask    { i32 front, j0, j1, bidx, br0, br1, pad0, pad1; };   // rows of the boundaries [br0, br1) only (br1 = 0: all rows): row bands shrink a workgroup's working set of parent lines (TLPK_EA_BANDS)                       // parent columns [j0, j1) = boundaries bidx, bidx + 1 of the front's extend-add ranges
 struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };
 // sweep items (LK_FWD_SWEEP): k0/nb = first row / rows of the chunk (<= SWEEP_NB pivot rows or <= SOLVE_NB rows below),
 //   slot = 1 pivot block (solve + publish) | 0 rows below, nslot = SWEEP_NB-wide solved blocks to consume (0 .. nslot-1);
