@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtlpk.so")
+LIB_PATH = os.environ.get("TLPK_LIB") or os.path.join(HERE, "libtlpk.so")      # TLPK_LIB: another build of the SAME source tree (A/B of kernel builds)
 
 OK, NOT_POSDEF, BADARG, OOM, HIPERR, NO_DEVICE, TOO_LARGE, NOT_FACTORED, INTERNAL = range(9)
 ORDER_AMD, ORDER_NATURAL, ORDER_USER = 0, 1, 2

@@ -955,25 +955,24 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     const bool active = rbase < rlim;
     const i32 rowc = min(rbase + lr, rlim - 1);     // clamped, stores are guarded
     double bf[4][16];                               // bf[i][ks] = B[row][k0 + 64 i + 4 ks + lk]
-    // packed panel: every 64-column step of the block column is one slice (k0 is a multiple of 64)
-    if (w == NB_OUT) {
+    // packed panel: every 64-column step of the block column is one slice (k0 is a multiple of 64); columns beyond w read the
+    // step's last column (in bounds) and count as zero.  The rows of step i are loaded two steps ahead of their use (not all
+    // four up front: the registers of the late steps are free for the operand prefetch meanwhile, nothing is spilled while
+    // the loads are in flight).
+    auto load_step = [&](const int i) {
+        const i32 wi = min(max(w - 64 * i, 1), NB_IN);                 // columns of step i (>= 1: the address stays in bounds)
+        const i32 ci = min(64 * i, w - 1) & ~63;                       // an existing slice for steps beyond w
+        const double *Pi = pcol(c, fd, k0 + ci) + rowc;
+        const i32 ldi = lda - (k0 + ci);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double *Pi = pcol(c, fd, k0 + 64 * i) + rowc;
-            const i32 ldi = lda - (k0 + 64 * i);
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) bf[i][ks] = Pi[(i64)(4 * ks + lk) * ldi];
+        for (int ks = 0; ks < 16; ++ks) {
+            const i32 col = 4 * ks + lk;
+            const double v = Pi[(i64)min(col, wi - 1) * ldi];
+            bf[i][ks] = (64 * i + col < w) ? v : 0.0;
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const i32 col = 64 * i + 4 * ks + lk;
-                const double v = pcol(c, fd, k0 + min(col, w - 1))[rowc];
-                bf[i][ks] = (col < w) ? v : 0.0;
-            }
-    }
+    };
+    load_step(0);
+    load_step(1);
     // The 64 x 64 operand blocks are staged in the order (i=0: Linv_0), (i=1: L_10, Linv_1),
     // (i=2: L_20, L_21, Linv_2), ...; block n+1 is fetched into registers while the matrix cores
     // work on block n (global latency off the workgroup's serial chain).
@@ -1010,6 +1009,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (64 * i < w) {                            // wave-uniform
+            if (i + 2 < 4) load_step(i + 2);
             v4f64 acc[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -1049,19 +1049,16 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bf[i][4 * a + q] = acc[a][q];
-            }
-        }
-    }
-    if (active && rbase + lr < rlim) {
-        const i32 row = rbase + lr;
+                // the step's columns are final: store them now, the later steps of the block column run while the stores drain
+                if (rbase + lr < rlim) {
+                    double *Pi = pcol(c, fd, k0 + 64 * i) + rbase + lr;
+                    const i32 ldi = lda - (k0 + 64 * i);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double *Pi = pcol(c, fd, k0 + 64 * i) + row;
-            const i32 ldi = lda - (k0 + 64 * i);
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const i32 col = 64 * i + 4 * ks + lk;
-                if (col < w) Pi[(i64)(4 * ks + lk) * ldi] = SIGNED ? bf[i][ks] * c.csign[fd.col0 + k0 + col] : bf[i][ks];
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const i32 col = 64 * i + 4 * ks + lk;
+                        if (col < w) Pi[(i64)(4 * ks + lk) * ldi] = SIGNED ? bf[i][ks] * c.csign[fd.col0 + k0 + col] : bf[i][ks];
+                    }
+                }
             }
         }
     }
@@ -2264,7 +2261,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__
     const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
-    const bool few = fd.ns <= 4, shortf = fd.f - fd.ns <= 64;      // wave-uniform
+    const bool few = fd.ns <= 4 && !c.small_full, shortf = fd.f - fd.ns <= 64 && !c.small_full;      // wave-uniform
     if (few) { if (shortf) fwd_small_body<4, 1>(fd, c, lane); else fwd_small_body<4, SMALL_RPL>(fd, c, lane); }
     else { if (shortf) fwd_small_body<SMALL_NS, 1>(fd, c, lane); else fwd_small_body<SMALL_NS, SMALL_RPL>(fd, c, lane); }
 }
@@ -2322,7 +2319,7 @@ __global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__
     const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
-    const bool few = fd.ns <= 4, shortf = fd.f - fd.ns <= 64;      // wave-uniform
+    const bool few = fd.ns <= 4 && !c.small_full, shortf = fd.f - fd.ns <= 64 && !c.small_full;      // wave-uniform
     if (few) { if (shortf) bwd_small_body<4, 1>(fd, c, lane); else bwd_small_body<4, SMALL_RPL>(fd, c, lane); }
     else { if (shortf) bwd_small_body<SMALL_NS, 1>(fd, c, lane); else bwd_small_body<SMALL_NS, SMALL_RPL>(fd, c, lane); }
 }

@@ -312,6 +312,7 @@ int upload_all(tlpk_handle *h) {
     HIPCHK(h, hipMemset(h->d_regD, 0, (size_t)std::max<i64>(S.m, 1) * 8)); HIPCHK(h, hipMemset(h->d_xip, 0, (size_t)std::max<i64>(S.m, 1) * 8));
     if (h->refine_steps > 0) { AL(h->d_r1, S.m); AL(h->d_r2, nn); AL(h->d_cx, nn); AL(h->d_cy, S.m); }
     d.ctx.csign = nullptr;
+    d.ctx.small_full = std::getenv("TLPK_SMALL_FULL") ? std::atoi(std::getenv("TLPK_SMALL_FULL")) : 0;
     d.ctx.upd_remap = 2;
     if (const char *e = std::getenv("TLPK_UPD_REMAP")) d.ctx.upd_remap = std::atoi(e);      // tuning knob
     if (S.system == 1) { double *p; if ((rc = dev_upload(h, &p, S.csign)) != TLPK_OK) return rc; d.ctx.csign = p; }

@@ -24,6 +24,7 @@ struct DevCtx {
     int upd_remap;         // k_update blockIdx -> task mapping (0 identity, 1 XCD-contiguous, 2 runs of 64 tasks per XCD)
     const double *csign;   // K2 (augmented system): +1 / -1 per permuted column, the S of P K P' = L S L'; nullptr for K1
     const i32 *upd_seg;    // K-segment lists of the update tasks (UpdateTask.seg)
+    int small_full;        // TLPK_SMALL_FULL=1 (debugging): the small-front solve kernels always take their (16 columns, 256 rows) body
     i64 xw2, uc2;          // two-right-hand-side solves: the second rhs / solution at xw + xw2, its contribution vectors at uc + uc2
 };
 
