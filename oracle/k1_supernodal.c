@@ -16,7 +16,8 @@
  * perturbation; xi = xi_p + A*(D.*xi_d); dy = S\xi; dx = D.*(A'dy - xi_d)), supernodal
  * multifrontal numeric phase (Duff & Reid 1983; Liu 1992; Chen, Davis, Hager, Rajamanickam, ACM TOMS
  * 35(3) 2008 section 3) on the OpenBLAS that ships with SciPy (dlopen'ed: `scipy_dpotrf_`,
- * `scipy_dtrsm_`, `scipy_dsyrk_`, `scipy_dgemv_`, `scipy_dtrsv_`), tree-level parallel with OpenMP
+ * `scipy_dtrsm_`, `scipy_dsyrk_`, `scipy_dgemv_`, `scipy_dtrsv_`), tree-level parallel with OpenMP; the triangular
+ * solves additionally split every large front over the whole team (round 4: see solve_level)
  * (levels with many fronts: one front per thread, BLAS single-threaded; levels with few fronts:
  * one front at a time, BLAS on all threads).
  *
@@ -61,6 +62,7 @@ typedef struct k1sn {
     i64 m, n, nnzA, nf, nnzS, lval_len, nlevels;
     /* A: CSC, 0-based */
     i64 *Ap, *Ai; double *Ax;
+    i64 *Tp, *Tj; double *Tx;                     /* the same matrix by rows (solve: xi = xi_p + A (D .* xi_d), one row per thread, fixed order) */
     i64 *perm;                                    /* perm[new] = old */
     /* fronts */
     i64 *f, *ns, *col0, *loff, *rowoff, *reloff, *child_ptr, *nchild, *depth, *lda;
@@ -93,7 +95,7 @@ static double *dupd(const double *src, i64 n) {
 
 void k1sn_free(k1sn *h) {
     if (!h) return;
-    free(h->Ap); free(h->Ai); free(h->Ax); free(h->perm);
+    free(h->Ap); free(h->Ai); free(h->Ax); free(h->perm); free(h->Tp); free(h->Tj); free(h->Tx);
     free(h->f); free(h->ns); free(h->col0); free(h->loff); free(h->rowoff); free(h->reloff);
     free(h->child_ptr); free(h->nchild); free(h->depth); free(h->lda); free(h->rowidx); free(h->rel); free(h->children);
     free(h->level_ptr); free(h->level_fronts); free(h->ucoff);
@@ -190,6 +192,15 @@ int k1sn_create(k1sn **out, const char *blas_path, i64 m, i64 n, const i64 *Ap, 
         for (i64 s = 0; s < nf; ++s) work += (double)f[s] * (double)f[s] * (double)ns[s];
         if (nthreads >= 0 && work < 2.0e8) h->nthreads = 1;
         h->setnt(h->nthreads);
+    }
+    {   /* rows of A (column indices ascending inside a row: the order of the column loop it replaces) */
+        h->Tp = (i64 *)calloc((size_t)(m + 2), sizeof(i64)); h->Tj = (i64 *)malloc((size_t)(h->nnzA > 0 ? h->nnzA : 1) * sizeof(i64));
+        h->Tx = (double *)malloc((size_t)(h->nnzA > 0 ? h->nnzA : 1) * 8);
+        if (!h->Tp || !h->Tj || !h->Tx) { k1sn_free(h); return 3; }
+        for (i64 p = 0; p < h->nnzA; ++p) h->Tp[Ai[p] + 2]++;
+        for (i64 i = 0; i < m; ++i) h->Tp[i + 2] += h->Tp[i + 1];
+        for (i64 j = 0; j < n; ++j)
+            for (i64 p = Ap[j]; p < Ap[j + 1]; ++p) { const i64 q = h->Tp[Ai[p] + 1]++; h->Tj[q] = j; h->Tx[q] = Ax[p]; }
     }
     h->fail_col = -1;
     *out = h;
@@ -313,6 +324,111 @@ static void bwd_front(k1sn *h, i64 s) {
     h->dtrsv("L", "T", "N", &bn, P, &bf, x, &inc);
 }
 
+/* ---- threaded triangular solves ------------------------------------------------------------------------------
+ * A level of the tree is solved by ONE OpenMP team (BLAS calls single-threaded inside it):
+ *   - fronts with a large panel (>= SOLVE_BIG entries) one after the other, each split over the whole team: the pivot block in
+ *     SOLVE_KB-wide steps (dtrsv on the diagonal block by one thread, the dgemv of the rows below / columns before it cut into
+ *     one slice per thread) -- a 100-MB panel streams at the bandwidth of all cores instead of one;
+ *   - the other fronts one per thread, handed out in chunks (a level of 10^5 tiny fronts must not pay one atomic per front).
+ * Summation order per entry is fixed (slices partition rows / columns, never a sum): results do not depend on the thread count. */
+#define SOLVE_BIG ((i64)1 << 20)
+#define SOLVE_KB  256
+
+static void gather_children(k1sn *h, i64 s) {
+    const i64 ns = h->ns[s], rs = h->f[s] - ns;
+    double *x = h->xw + h->col0[s], *ucs = h->uc + h->ucoff[s];
+    for (i64 r = 0; r < rs; ++r) ucs[r] = 0.0;
+    for (i64 ci = 0; ci < h->nchild[s]; ++ci) {
+        const i64 c = h->children[h->child_ptr[s] + ci];
+        const i64 rsc = h->f[c] - h->ns[c];
+        const i64 *relc = h->rel + h->reloff[c];
+        const double *ucc = h->uc + h->ucoff[c];
+        for (i64 r = 0; r < rsc; ++r) { const i64 pos = relc[r]; if (pos < ns) x[pos] += ucc[r]; else ucs[pos - ns] += ucc[r]; }
+    }
+}
+
+/* slice [a, b) number t of T of the range [lo, hi), boundaries on multiples of 8 entries (cache lines) */
+static void slice_of(i64 lo, i64 hi, int t, int T, i64 *a, i64 *b) {
+    const i64 len = hi - lo, per = ((len + T - 1) / T + 7) & ~(i64)7;
+    *a = lo + (i64)t * per; *b = *a + per;
+    if (*a > hi) *a = hi;
+    if (*b > hi) *b = hi;
+}
+
+/* called by every thread of the team (t of T); contains barriers */
+static void fwd_front_team(k1sn *h, i64 s, int t, int T) {
+    const i64 f = h->f[s], ns = h->ns[s], ld = h->lda[s];
+    const double *P = h->Lval + h->loff[s];
+    double *x = h->xw + h->col0[s], *ucs = h->uc + h->ucoff[s];
+    const blasint inc = 1, bf = (blasint)ld;
+    const double mone = -1.0, one = 1.0;
+    if (t == 0) gather_children(h, s);
+#pragma omp barrier
+    for (i64 k = 0; k < ns; k += SOLVE_KB) {
+        const i64 kb = (ns - k < SOLVE_KB) ? ns - k : SOLVE_KB;
+        const blasint bkb = (blasint)kb;
+        if (t == 0) h->dtrsv("L", "N", "N", &bkb, P + k + k * ld, &bf, x + k, &inc);
+#pragma omp barrier
+        i64 a, b;
+        slice_of(k + kb, f, t, T, &a, &b);                       /* rows below the step, pivot rows and update rows alike */
+        if (b > a) {
+            /* rows [a, b) may straddle ns: the pivot part updates x, the rest the contribution vector */
+            const i64 a1 = a, b1 = (b < ns) ? b : ns, a2 = (a > ns) ? a : ns, b2 = b;
+            if (b1 > a1) { const blasint br = (blasint)(b1 - a1); h->dgemv("N", &br, &bkb, &mone, P + a1 + k * ld, &bf, x + k, &inc, &one, x + a1, &inc); }
+            if (b2 > a2) { const blasint br = (blasint)(b2 - a2); h->dgemv("N", &br, &bkb, &mone, P + a2 + k * ld, &bf, x + k, &inc, &one, ucs + (a2 - ns), &inc); }
+        }
+#pragma omp barrier
+    }
+}
+static void bwd_front_team(k1sn *h, i64 s, int t, int T) {
+    const i64 f = h->f[s], ns = h->ns[s], rs = f - ns, ld = h->lda[s];
+    const double *P = h->Lval + h->loff[s];
+    double *x = h->xw + h->col0[s], *xb = h->uc + h->ucoff[s];
+    const i64 *rows = h->rowidx + h->rowoff[s] + ns;
+    const blasint inc = 1, bf = (blasint)ld;
+    const double mone = -1.0, one = 1.0;
+    { i64 a, b; slice_of(0, rs, t, T, &a, &b); for (i64 r = a; r < b; ++r) xb[r] = h->xw[rows[r]]; }
+#pragma omp barrier
+    /* x -= L21' xb: every thread owns a slice of the pivot columns */
+    if (rs > 0) {
+        i64 a, b; slice_of(0, ns, t, T, &a, &b);
+        if (b > a) { const blasint brs = (blasint)rs, bc = (blasint)(b - a); h->dgemv("T", &brs, &bc, &mone, P + ns + a * ld, &bf, xb, &inc, &one, x + a, &inc); }
+    }
+#pragma omp barrier
+    const i64 nkb = (ns + SOLVE_KB - 1) / SOLVE_KB;
+    for (i64 kk = nkb - 1; kk >= 0; --kk) {
+        const i64 k = kk * SOLVE_KB, kb = (ns - k < SOLVE_KB) ? ns - k : SOLVE_KB;
+        const blasint bkb = (blasint)kb;
+        if (t == 0) h->dtrsv("L", "T", "N", &bkb, P + k + k * ld, &bf, x + k, &inc);
+#pragma omp barrier
+        /* x[0, k) -= L[k .. k + kb, 0 .. k)' x[k .. k + kb): slices of the columns before the step */
+        i64 a, b; slice_of(0, k, t, T, &a, &b);
+        if (b > a) { const blasint bc = (blasint)(b - a); h->dgemv("T", &bkb, &bc, &mone, P + k + a * ld, &bf, x + k, &inc, &one, x + a, &inc); }
+#pragma omp barrier
+    }
+}
+
+static void solve_level(k1sn *h, i64 d, int backward) {
+    const i64 a = h->level_ptr[d], b = h->level_ptr[d + 1];
+    if (h->nthreads <= 1) {
+        for (i64 t = a; t < b; ++t) { const i64 s = h->level_fronts[t]; if (backward) bwd_front(h, s); else fwd_front(h, s); }
+        return;
+    }
+    /* fronts of a level are sorted by decreasing work: the big ones form a prefix */
+    i64 nbig = 0;
+    while (a + nbig < b && h->f[h->level_fronts[a + nbig]] * h->ns[h->level_fronts[a + nbig]] >= SOLVE_BIG) ++nbig;
+    if (nbig >= 2 * (i64)h->nthreads) nbig = 0;                 /* enough big fronts to give every thread its own */
+    const i64 nsmall = b - a - nbig;
+    const i64 chunk = (nsmall > 64 * (i64)h->nthreads) ? 32 : 1;
+#pragma omp parallel num_threads(h->nthreads)
+    {
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+        for (i64 q = 0; q < nbig; ++q) { const i64 s = h->level_fronts[a + q]; if (backward) bwd_front_team(h, s, t, T); else fwd_front_team(h, s, t, T); }
+#pragma omp for schedule(dynamic, chunk)
+        for (i64 q = a + nbig; q < b; ++q) { const i64 s = h->level_fronts[q]; if (backward) bwd_front(h, s); else fwd_front(h, s); }
+    }
+}
+
 int k1sn_solve(k1sn *h, double *dx, double *dy, const double *xi_p, const double *xi_d) {
     if (!h || !dx || !dy || !xi_p || !xi_d) return 2;
     if (!h->factored) return 7;
@@ -320,15 +436,19 @@ int k1sn_solve(k1sn *h, double *dx, double *dy, const double *xi_p, const double
     const i64 m = h->m, n = h->n;
     double *xi = (double *)malloc((size_t)(m > 0 ? m : 1) * 8);
     if (!xi) return 3;
-    memcpy(xi, xi_p, (size_t)m * 8);
-    for (i64 j = 0; j < n; ++j) {                                                                /* spd.jl:56-57 */
-        const double t = h->D[j] * xi_d[j];
-        for (i64 p = h->Ap[j]; p < h->Ap[j + 1]; ++p) xi[h->Ai[p]] += h->Ax[p] * t;
+#pragma omp parallel for schedule(static, 1024) num_threads(h->nthreads)
+    for (i64 i = 0; i < m; ++i) {                                                                /* spd.jl:56-57, row by row (columns ascending) */
+        double v = xi_p[i];
+        for (i64 q = h->Tp[i]; q < h->Tp[i + 1]; ++q) { const i64 j = h->Tj[q]; v += h->Tx[q] * (h->D[j] * xi_d[j]); }
+        xi[i] = v;
     }
+#pragma omp parallel for schedule(static, 4096) num_threads(h->nthreads)
     for (i64 ii = 0; ii < m; ++ii) h->xw[ii] = xi[h->perm[ii]];
-    for (i64 d = h->nlevels - 1; d >= 0; --d) FOR_LEVEL_FRONTS(h, d, fwd_front(h, s));          /* spd.jl:61 */
-    for (i64 d = 0; d < h->nlevels; ++d) FOR_LEVEL_FRONTS(h, d, bwd_front(h, s));
+    if (h->nthreads > 1) h->setnt(1);                                                            /* the team below is ours: BLAS calls stay single-threaded */
+    for (i64 d = h->nlevels - 1; d >= 0; --d) solve_level(h, d, 0);                              /* spd.jl:61 */
+    for (i64 d = 0; d < h->nlevels; ++d) solve_level(h, d, 1);
     if (h->nthreads > 1) h->setnt(h->nthreads);
+#pragma omp parallel for schedule(static, 4096) num_threads(h->nthreads)
     for (i64 ii = 0; ii < m; ++ii) dy[h->perm[ii]] = h->xw[ii];
 #pragma omp parallel for schedule(static, 1024) num_threads(h->nthreads)
     for (i64 j = 0; j < n; ++j) {                                                                /* spd.jl:64-66 */

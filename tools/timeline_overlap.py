@@ -3,12 +3,18 @@ with each kernel class ALONE, how much of the non-update work is hidden behind k
     python tools/timeline_overlap.py gpurun_out/r03_trace_c4_kernels.csv"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-ev = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "")) for r in rows]
+norm = lambda n: n.replace("void ", "").replace("tlpk::", "")
+ev = [(norm(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "")) for r in rows]
 ev.sort(key=lambda e: e[1])
 starts = [i for i, e in enumerate(ev) if e[0].startswith("k_compute_d")]
 if len(starts) < 2:
     sys.exit("need two steps in the trace")
-a, b = starts[-2], starts[-1]
+# STEP=<k>: the k-th step of the trace (default: the last complete one); the list of steps goes to stderr
+for i in range(len(starts) - 1):
+    print("step %d: %d kernels, %.2f ms" % (i, starts[i + 1] - starts[i], (ev[starts[i + 1]][1] - ev[starts[i]][1]) / 1e6), file=sys.stderr)
+import os
+k = int(os.environ.get("STEP", len(starts) - 2))
+a, b = starts[k], starts[k + 1]
 step = ev[a:b]
 t0 = step[0][1]; t1 = max(e[2] for e in step)
 def cls(n):

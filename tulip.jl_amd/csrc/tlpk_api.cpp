@@ -112,7 +112,7 @@ int kind_class(i32 kind) {
 // profile helpers: record an event pair around one launch
 struct ProfScope {
     tlpk_handle *h; bool on; size_t idx; hipStream_t st;
-    ProfScope(tlpk_handle *h_, int cls, hipStream_t st_ = nullptr) : h(h_), on(h_->profile), idx(0), st(st_ ? st_ : h_->stream) {
+    ProfScope(tlpk_handle *h_, int cls, hipStream_t st_ = nullptr, const Launch *L = nullptr) : h(h_), on(h_->profile), idx(0), st(st_ ? st_ : h_->stream) {
         if (!on) return;
         if (h->ev_used + 2 > h->ev_pool.size()) {
             const size_t old = h->ev_pool.size();
@@ -121,6 +121,7 @@ struct ProfScope {
         }
         idx = h->ev_used; h->ev_used += 2;
         h->ev_class.push_back(cls);
+        h->ev_launch.push_back(L ? std::array<long long, 3>{L->kind, L->first, L->count} : std::array<long long, 3>{-1, 0, 0});
         hipEventRecord(h->ev_pool[idx], st);
     }
     ~ProfScope() { if (on) hipEventRecord(h->ev_pool[idx + 1], st); }
@@ -129,17 +130,22 @@ void prof_begin(tlpk_handle *h, bool reset) {
     if (!h->profile) return;
     // pending (not yet collected) event pairs of earlier async solves stay queued: the pool grows
     // until the next prof_collect, which runs after a stream synchronisation
-    if (reset) { std::memset(&h->kt, 0, sizeof(h->kt)); h->ev_used = 0; h->ev_class.clear(); }
+    if (reset) { std::memset(&h->kt, 0, sizeof(h->kt)); h->ev_used = 0; h->ev_class.clear(); h->ev_launch.clear(); }
 }
 void prof_collect(tlpk_handle *h) {          // stream must be synchronised
     if (!h->profile) return;
+    // TLPK_PROF_DUMP=<file>: one line per timed launch (class, kind, first task, task count, ms) -- tools/update_launch_eff.py
+    const char *dump = std::getenv("TLPK_PROF_DUMP");
+    FILE *df = (dump && *dump) ? std::fopen(dump, "a") : nullptr;
     for (size_t i = 0; i < h->ev_class.size(); ++i) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]);
         h->kt.ms[h->ev_class[i]] += ms;
         h->kt.launches[h->ev_class[i]] += 1;
+        if (df) std::fprintf(df, "%d %lld %lld %lld %.6f\n", h->ev_class[i], h->ev_launch[i][0], h->ev_launch[i][1], h->ev_launch[i][2], (double)ms);
     }
-    h->ev_used = 0; h->ev_class.clear();
+    if (df) { std::fprintf(df, "#\n"); std::fclose(df); }
+    h->ev_used = 0; h->ev_class.clear(); h->ev_launch.clear();
 }
 
 // Stream groups: launches tagged with group g >= 1 go to their own stream.  fork = the group
@@ -206,7 +212,7 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
         // HBM-bound extend-add of one group runs beside the matrix-core-bound updates of the other instead of beside ITS extend-add
         const bool stag = h->stagger && dir < 0 && !h->profile && !h->serial && cur.kind == LK_EXTEND_ADD && h->S.ngroups >= 2 && h->ev_stagger;
         if (stag && L[i].group == 1 && h->stagger_armed) { hipStreamWaitEvent(st, h->ev_stagger, 0); h->stagger_armed = false; }
-        ProfScope ps(h, kind_class(cur.kind), st);
+        ProfScope ps(h, kind_class(cur.kind), st, &cur);
         if (stag && L[i].group == 0 && cur.count >= h->stagger_min) {
             launch_tasks(st, h->d, cur, nullptr, nrhs);
             hipEventRecord(h->ev_stagger, st); h->stagger_armed = true;
@@ -1673,7 +1679,7 @@ int tlpk_kernel_timing(const tlpk_handle *h, tlpk_kernel_times *out) {
 int tlpk_set_profile(tlpk_handle *h, int on) {
     if (!h) return TLPK_BADARG;
     h->profile = on != 0;
-    h->ev_used = 0; h->ev_class.clear();
+    h->ev_used = 0; h->ev_class.clear(); h->ev_launch.clear();
     std::memset(&h->kt, 0, sizeof(h->kt));
     return TLPK_OK;
 }

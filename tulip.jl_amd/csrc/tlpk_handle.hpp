@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/tlpk.h"
@@ -34,6 +35,7 @@ struct tlpk_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_class;            // class of each recorded pair in the current call
+    std::vector<std::array<long long, 3>> ev_launch;   // (kind, first, count) of the launch behind each pair (-1: not a schedule launch): TLPK_PROF_DUMP
     size_t ev_used = 0;
     DevArrays d;
     std::vector<void *> allocs;
