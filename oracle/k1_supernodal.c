@@ -82,6 +82,25 @@ typedef struct k1sn {
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
+/* CPUs granted by the CFS bandwidth controller (rounded up), 0 = no limit found */
+static int cgroup_cpu_quota(void) {
+    double quota = -1.0, period = -1.0;
+    FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (fp) {
+        char q[64];
+        if (fscanf(fp, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+        fclose(fp);
+    } else {
+        FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fpp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (fq && fpp && fscanf(fq, "%lf", &quota) == 1 && fscanf(fpp, "%lf", &period) == 1) { /* read */ } else quota = -1.0;
+        if (fq) fclose(fq);
+        if (fpp) fclose(fpp);
+    }
+    if (quota <= 0.0 || period <= 0.0) return 0;
+    const int n = (int)((quota + period - 1.0) / period);
+    return n > 0 ? n : 1;
+}
+
 static i64 *dup64(const i64 *src, i64 n) {
     i64 *p = (i64 *)malloc((size_t)(n > 0 ? n : 1) * sizeof(i64));
     if (p && n > 0) memcpy(p, src, (size_t)n * sizeof(i64));
@@ -131,6 +150,13 @@ int k1sn_create(k1sn **out, const char *blas_path, i64 m, i64 n, const i64 *Ap, 
     h->m = m; h->n = n; h->nnzA = Ap[n]; h->nf = nf; h->nnzS = nnzS; h->lval_len = lval_len;
 #ifdef _OPENMP
     h->nthreads = nthreads > 0 ? nthreads : omp_get_max_threads();
+    if (nthreads == 0) {
+        /* "all cores" means the cores this process may USE: inside a container the CFS quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us) is usually
+         * far below the number of online CPUs.  Measured on the GPU box (256 hardware threads online, quota 16 CPUs): 64 threads are throttled into
+         * each other -- factorisation 2.4 s and 0.40 s per solve of config C4, against 1.4 s and 0.11 s with 16 threads. */
+        const int q = cgroup_cpu_quota();
+        if (q > 0 && q < h->nthreads) h->nthreads = q;
+    }
 #else
     h->nthreads = 1; (void)nthreads;
 #endif
@@ -207,6 +233,10 @@ int k1sn_create(k1sn **out, const char *blas_path, i64 m, i64 n, const i64 *Ap, 
     return 0;
 }
 
+#define SMALL_PANEL 2048       /* fronts with at most this many panel entries never call the BLAS (see fwd_front) */
+
+static i64 small_factor_limit(void) { static i64 v = -1; if (v < 0) { const char *e = getenv("K1SN_SMALL_FACTOR"); v = e ? atoll(e) : SMALL_PANEL; } return v; }
+
 /* one front: extend-add of the children's update matrices, dense partial factorisation */
 static void factor_front(k1sn *h, i64 s, i64 *fail) {
     const i64 f = h->f[s], ns = h->ns[s], rs = f - ns, ld = h->lda[s];       /* panel: f x ns, leading dimension ld >= f */
@@ -228,14 +258,36 @@ static void factor_front(k1sn *h, i64 s, i64 *fail) {
         free(h->U[c]); h->U[c] = NULL;
     }
     blasint info = 0, bn = (blasint)ns, bf = (blasint)ld, brs = (blasint)rs;
-    h->dpotrf("L", &bn, P, &bf, &info);
+    const int small = f * ns <= small_factor_limit();
+    if (small) {
+        /* right-looking column Cholesky of the f x ns panel, then U -= L21 L21' (lower triangle): see fwd_front */
+        for (i64 j = 0; j < ns && info == 0; ++j) {
+            double *Pj = P + j * ld;
+            const double d = Pj[j];
+            if (!(d > 0.0)) { info = (blasint)(j + 1); break; }
+            const double r = sqrt(d);
+            Pj[j] = r;
+            for (i64 i = j + 1; i < f; ++i) Pj[i] /= r;
+            for (i64 k = j + 1; k < ns; ++k) {
+                double *Pk = P + k * ld;
+                const double ljk = Pj[k];
+                for (i64 i = k; i < f; ++i) Pk[i] -= Pj[i] * ljk;
+            }
+        }
+        if (info == 0)
+            for (i64 j = 0; j < ns; ++j) {
+                const double *Pj = P + j * ld + ns;
+                for (i64 c = 0; c < rs; ++c) { const double l = Pj[c]; double *Uc = Us + c * rs; for (i64 r = c; r < rs; ++r) Uc[r] -= Pj[r] * l; }
+            }
+    } else
+        h->dpotrf("L", &bn, P, &bf, &info);
     if (info != 0) {                                       /* not positive definite: spd.jl:46-47 */
         const i64 col = h->col0[s] + (info > 0 ? info - 1 : 0);
 #pragma omp critical(k1sn_fail)
         { if (*fail == -1 || col < *fail) *fail = col; }
         return;
     }
-    if (rs > 0) {
+    if (rs > 0 && !small) {
         const double one = 1.0, mone = -1.0;
         h->dtrsm("R", "L", "T", "N", &brs, &bn, &one, P, &bf, P + ns, &bf);
         h->dsyrk("L", "N", &brs, &bn, &mone, P + ns, &bf, &one, Us, &brs);
@@ -294,30 +346,50 @@ int k1sn_update(k1sn *h, const double *theta, const double *regP, const double *
     return 0;
 }
 
+/* Fronts with a panel of at most SMALL_PANEL entries (most fronts of a sparse LP: 10^5 of them per tree level on the north-star LP) are
+ * handled by plain loops.  OpenBLAS's interface routines take a process-wide lock for their work buffer on EVERY call: 16 threads
+ * calling dtrsv / dgemv (dpotrf / dtrsm / dsyrk) on 20 x 3 panels spent ~20 us per front queueing for it -- 0.35 s per sweep of one tree level
+ * (measured, tools/cpu_solve_probe.py), 90 % of a solve. */
+
+static void gather_children(k1sn *h, i64 s);
+
 static void fwd_front(k1sn *h, i64 s) {
-    const i64 f = h->f[s], ns = h->ns[s], rs = f - ns;
+    const i64 f = h->f[s], ns = h->ns[s], rs = f - ns, ld = h->lda[s];
     const double *P = h->Lval + h->loff[s];
     double *x = h->xw + h->col0[s], *ucs = h->uc + h->ucoff[s];
-    for (i64 r = 0; r < rs; ++r) ucs[r] = 0.0;
-    for (i64 ci = 0; ci < h->nchild[s]; ++ci) {
-        const i64 c = h->children[h->child_ptr[s] + ci];
-        const i64 rsc = h->f[c] - h->ns[c];
-        const i64 *relc = h->rel + h->reloff[c];
-        const double *ucc = h->uc + h->ucoff[c];
-        for (i64 r = 0; r < rsc; ++r) { const i64 pos = relc[r]; if (pos < ns) x[pos] += ucc[r]; else ucs[pos - ns] += ucc[r]; }
+    gather_children(h, s);
+    if (f * ns <= SMALL_PANEL) {
+        for (i64 j = 0; j < ns; ++j) {
+            const double *Pj = P + j * ld;
+            const double xj = x[j] / Pj[j];
+            x[j] = xj;
+            for (i64 i = j + 1; i < ns; ++i) x[i] -= Pj[i] * xj;
+            for (i64 r = 0; r < rs; ++r) ucs[r] -= Pj[ns + r] * xj;
+        }
+        return;
     }
-    const blasint bn = (blasint)ns, bf = (blasint)h->lda[s], brs = (blasint)rs, inc = 1;
+    const blasint bn = (blasint)ns, bf = (blasint)ld, brs = (blasint)rs, inc = 1;
     h->dtrsv("L", "N", "N", &bn, P, &bf, x, &inc);
     if (rs > 0) { const double mone = -1.0, one = 1.0; h->dgemv("N", &brs, &bn, &mone, P + ns, &bf, x, &inc, &one, ucs, &inc); }
 }
 static void bwd_front(k1sn *h, i64 s) {
-    const i64 f = h->f[s], ns = h->ns[s], rs = f - ns;
+    const i64 f = h->f[s], ns = h->ns[s], rs = f - ns, ld = h->lda[s];
     const double *P = h->Lval + h->loff[s];
     double *x = h->xw + h->col0[s], *xb = h->uc + h->ucoff[s];     /* the contribution vector is free again: reuse it */
     const i64 *rows = h->rowidx + h->rowoff[s] + ns;
-    const blasint bn = (blasint)ns, bf = (blasint)h->lda[s], brs = (blasint)rs, inc = 1;
+    for (i64 r = 0; r < rs; ++r) xb[r] = h->xw[rows[r]];
+    if (f * ns <= SMALL_PANEL) {
+        for (i64 j = ns - 1; j >= 0; --j) {
+            const double *Pj = P + j * ld;
+            double v = x[j];
+            for (i64 r = 0; r < rs; ++r) v -= Pj[ns + r] * xb[r];
+            for (i64 i = j + 1; i < ns; ++i) v -= Pj[i] * x[i];
+            x[j] = v / Pj[j];
+        }
+        return;
+    }
+    const blasint bn = (blasint)ns, bf = (blasint)ld, brs = (blasint)rs, inc = 1;
     if (rs > 0) {
-        for (i64 r = 0; r < rs; ++r) xb[r] = h->xw[rows[r]];
         const double mone = -1.0, one = 1.0;
         h->dgemv("T", &brs, &bn, &mone, P + ns, &bf, xb, &inc, &one, x, &inc);
     }
@@ -333,6 +405,7 @@ static void bwd_front(k1sn *h, i64 s) {
  * Summation order per entry is fixed (slices partition rows / columns, never a sum): results do not depend on the thread count. */
 #define SOLVE_BIG ((i64)1 << 20)
 #define SOLVE_KB  256
+#define SOLVE_MIN_SLICE 512
 
 static void gather_children(k1sn *h, i64 s) {
     const i64 ns = h->ns[s], rs = h->f[s] - ns;
@@ -349,7 +422,10 @@ static void gather_children(k1sn *h, i64 s) {
 
 /* slice [a, b) number t of T of the range [lo, hi), boundaries on multiples of 8 entries (cache lines) */
 static void slice_of(i64 lo, i64 hi, int t, int T, i64 *a, i64 *b) {
-    const i64 len = hi - lo, per = ((len + T - 1) / T + 7) & ~(i64)7;
+    const i64 len = hi - lo;
+    if (len < (i64)T * SOLVE_MIN_SLICE) { T = (int)(len / SOLVE_MIN_SLICE); if (T < 1) T = 1; }     /* thin slices stream badly: fewer, longer ones */
+    if (t >= T) { *a = *b = hi; return; }
+    const i64 per = ((len + T - 1) / T + 7) & ~(i64)7;
     *a = lo + (i64)t * per; *b = *a + per;
     if (*a > hi) *a = hi;
     if (*b > hi) *b = hi;
@@ -408,25 +484,36 @@ static void bwd_front_team(k1sn *h, i64 s, int t, int T) {
     }
 }
 
+/* K1SN_SOLVE_TEAM: 0 = every front on one thread; 1 (default) = the large fronts of a level with fewer than nthreads/2 fronts are split over the team
+ * (a level of >= nthreads/2 fronts has one front per thread: measured on the 2 x 64-core host, 64 threads -- slicing each of the 64 3 500-column fronts
+ * of config C4 into 64 row slices of ~70 rows made the solve 4x SLOWER than one front per thread: 568-byte runs per column, two barriers per
+ * 256-column step across both sockets); 2 = split every large front (that experiment).  K1SN_TRACE=1: one line per level and direction on stderr. */
+static int solve_team_mode(void) { const char *e = getenv("K1SN_SOLVE_TEAM"); return e ? atoi(e) : 1; }
+
 static void solve_level(k1sn *h, i64 d, int backward) {
     const i64 a = h->level_ptr[d], b = h->level_ptr[d + 1];
     if (h->nthreads <= 1) {
         for (i64 t = a; t < b; ++t) { const i64 s = h->level_fronts[t]; if (backward) bwd_front(h, s); else fwd_front(h, s); }
         return;
     }
+    const double t0 = now_s();
+    const int mode = solve_team_mode();
     /* fronts of a level are sorted by decreasing work: the big ones form a prefix */
     i64 nbig = 0;
-    while (a + nbig < b && h->f[h->level_fronts[a + nbig]] * h->ns[h->level_fronts[a + nbig]] >= SOLVE_BIG) ++nbig;
-    if (nbig >= 2 * (i64)h->nthreads) nbig = 0;                 /* enough big fronts to give every thread its own */
+    if (mode == 2 || (mode == 1 && 2 * (b - a) < (i64)h->nthreads))
+        while (a + nbig < b && h->f[h->level_fronts[a + nbig]] * h->ns[h->level_fronts[a + nbig]] >= SOLVE_BIG) ++nbig;
     const i64 nsmall = b - a - nbig;
-    const i64 chunk = (nsmall > 64 * (i64)h->nthreads) ? 32 : 1;
+    const long chunk = (nsmall > 64 * (i64)h->nthreads) ? 32 : 1;
 #pragma omp parallel num_threads(h->nthreads)
     {
         const int t = omp_get_thread_num(), T = omp_get_num_threads();
         for (i64 q = 0; q < nbig; ++q) { const i64 s = h->level_fronts[a + q]; if (backward) bwd_front_team(h, s, t, T); else fwd_front_team(h, s, t, T); }
 #pragma omp for schedule(dynamic, chunk)
-        for (i64 q = a + nbig; q < b; ++q) { const i64 s = h->level_fronts[q]; if (backward) bwd_front(h, s); else fwd_front(h, s); }
+        for (long q = (long)(a + nbig); q < (long)b; ++q) { const i64 s = h->level_fronts[q]; if (backward) bwd_front(h, s); else fwd_front(h, s); }
     }
+    if (getenv("K1SN_TRACE"))
+        fprintf(stderr, "k1sn %s level %lld: %lld fronts (%lld split over the team), largest %lld x %lld, %.4f s\n", backward ? "bwd" : "fwd", (long long)d,
+                (long long)(b - a), (long long)nbig, (long long)h->f[h->level_fronts[a]], (long long)h->ns[h->level_fronts[a]], now_s() - t0);
 }
 
 int k1sn_solve(k1sn *h, double *dx, double *dy, const double *xi_p, const double *xi_d) {
@@ -458,6 +545,7 @@ int k1sn_solve(k1sn *h, double *dx, double *dy, const double *xi_p, const double
     }
     free(xi);
     h->t_solve = now_s() - t0;
+    if (getenv("K1SN_TRACE")) fprintf(stderr, "k1sn solve: %.4f s on %d threads\n", h->t_solve, h->nthreads);
     return 0;
 }
 

@@ -8,7 +8,10 @@ timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/r04_final_bench.
 B="--steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-headline --no-host-abi --no-small-lp --no-c3 --unpaired"
 S="--steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-headline --no-host-abi --no-small-lp --no-c3"
 TLPK_STREAMS=1 TLPK_SERIAL=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04_prof_serial -- python bench.py $S > gpurun_out/r04_prof_serial.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04_prof_concurrent -- python bench.py $S > gpurun_out/r04_prof_concurrent.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04_prof_concurrent -- python bench.py $S --no-roofline > gpurun_out/r04_prof_concurrent.log 2>&1
+STEP=4 python tools/timeline_overlap.py $(ls gpurun_out/r04_prof_concurrent/*/*kernel_trace.csv | head -1) > gpurun_out/r04_timeline_c4.txt 2>&1
+timeout 300 python tools/update_launch_eff.py c4 > gpurun_out/r04_update_launch_eff.txt 2>&1
+timeout 300 python tools/update_launch_eff.py headline >> gpurun_out/r04_update_launch_eff.txt 2>&1
 for wl in c4 headline; do
   for c in FETCH_SIZE WRITE_SIZE; do
     TLPK_STREAMS=1 TLPK_SERIAL=1 timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/r04_pmc_${wl}_$c -- python bench.py --workload $wl $B > gpurun_out/r04_pmc_${wl}_$c.log 2>&1
