@@ -39,7 +39,7 @@ for t, d, c in pts:
 tot = collections.Counter()
 for n, s, e, q in step: tot[cls(n)] += e - s
 ms = lambda x: x / 1e6
-print("one Newton step (unpaired: 1 update + 4 solves): %d kernels, span %.2f ms, device idle (no kernel running) %.2f ms" % (len(step), ms(t1 - t0), ms(idle)))
+print("one Newton step (1 update + 4 right-hand sides): %d kernels, span %.2f ms, device idle (no kernel running) %.2f ms" % (len(step), ms(t1 - t0), ms(idle)))
 print("%-16s %10s %12s" % ("class", "sum of durations", "running ALONE"))
 for k, v in tot.most_common(): print("%-16s %10.2f ms %10.2f ms" % (k, ms(v), ms(alone[k])))
 print("time with k_update running: %.2f ms" % ms(sum(v for c, v in combo.items() if "k_update" in c)))
