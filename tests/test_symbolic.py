@@ -138,17 +138,17 @@ def test_isolated_singleton_fronts():
 
 def test_sharded_schedule_with_split_k_and_wide_root():
     """Two ranks emulated in one process (the all-reduces are plain sums here): a block-angular LP
-    whose root front is wider than two block columns, so that its few update tiles are split along K
-    (partial tiles + ordered reduce launches) on every rank, and the block fronts exercise the wide
-    potrf / single-pass trsm / side-stream launch kinds."""
-    A, row_block = block_angular(nblocks=4, mk=260, nk=520, m0=600, nnz_in=3, link_prob=0.9, seed=21)
+    whose root front has four block columns, so that its few update tiles are split along K
+    (partial tiles + ordered reduce launches; also with TLPK_LOOKAHEAD=1, where only K >= 512 pieces are split) on
+    every rank, and the block fronts exercise the wide potrf / single-pass trsm / side-stream launch kinds."""
+    A, row_block = block_angular(nblocks=4, mk=260, nk=520, m0=900, nnz_in=3, link_prob=0.9, seed=21)
     m, n = A.shape
     th, rp, rd, xp, xd = ipm_like_data(m, n, 4)
     ems = []
     for rank in range(2):
         kkt = analyse_only(A, row_block=row_block, rank=rank, nranks=2)
         kinds = kkt.symbolic("factor_launches").reshape(-1, 3)[:, 0].tolist()
-        assert 13 in kinds, "no split-K reduce launch on the 600-column root front"
+        assert 13 in kinds, "no split-K reduce launch on the 900-column root front"
         ems.append(Emulator(kkt))
     for em in ems:
         em.update(th, rp, rd, stop_at_marker=True)

@@ -1490,13 +1490,33 @@ static void build_schedule(Symbolic &S) {
             if (tiles_bc <= 0 || 2 * tiles_bc >= TILES_WANTED) return (i32)1;
             return (i32)std::min<i64>(G_MAX, (TILES_WANTED + tiles_bc - 1) / tiles_bc);
         };
-        i32 G = 1, io_macro = 0;                           // current macro column: block columns [io_macro, io_macro + G)
+        // macro column of every block column: block columns [mac_first[io], mac_first[io] + mac_G[io])
+        std::vector<i32> mac_first((size_t)nouter + 2, 0), mac_G((size_t)nouter + 2, 1);
+        {
+            i32 G = 1, io_macro = 0;
+            for (i32 io = 0; io <= nouter + 1; ++io) {
+                if (io >= io_macro + G) { io_macro = io; G = macro_width(io * NB_OUT); }
+                else if (io == 0) G = macro_width(0);
+                mac_first[(size_t)io] = io_macro; mac_G[(size_t)io] = G;
+            }
+        }
+        auto k_first = [&](i32 io) { return (io == mac_first[(size_t)io]) ? 0 : mac_first[(size_t)io] * NB_OUT; };   // block column io still needs K = [k_first, ko)
+        // Look-ahead for the diagonal blocks (round 4).  The chain potrf(io) -> trsm(io) -> [update of the diagonal block of io + 1] -> potrf(io + 1) is
+        // the critical path of a level with one big front (pds-class LPs: 31 block columns), of the root front, and of every rank of a sharded job.
+        // The left-looking update of that diagonal block had K = [0, ko + 256): a few tiles with K up to the whole front, cut by split-K and followed by a
+        // reduction -- 0.15 .. 0.3 ms on the chain per block column.  Now the part K = [k_first, ko) (everything but the block column just finished) rides in
+        // the rows-below launch of block column io (same operands, same readiness: block columns < io), off the chain; behind trsm(io) only
+        // K = [ko, ko + 256) is left: 3 tiles x 16 slabs.
+        // MEASURED (profiles/r04_lookahead.txt) and OFF by default (TLPK_LOOKAHEAD=1 turns it on): pds-class LP 18.86 -> 18.5 ms per step -- split-K had already
+        // cut the long-K diagonal update to ~0.1 ms and the chain is the potrf kernel itself (7.8 of 13.8 ms) --, C4 / north-star LP unchanged, and the C3
+        // shape LOSES 11 % (675 -> 750 ms: inside its 16-wide macro columns the look-ahead tiles are a second long-K tail in every rows-below launch).
+        static const bool lookahead = [] { const char *e = std::getenv("TLPK_LOOKAHEAD"); return e && std::atoi(e) != 0; }();
         for (i32 io = 0; io <= nouter; ++io) {
             const i32 ko = io * NB_OUT;
-            if (io >= io_macro + G) { io_macro = io; G = macro_width(ko); }
-            else if (io == 0) G = macro_width(0);
+            const i32 io_macro = mac_first[(size_t)io], G = mac_G[(size_t)io];
             const i32 gi = io - io_macro, kM = io_macro * NB_OUT;
             const i32 ka = (gi == 0) ? 0 : kM;             // this block column still needs K = [ka, ko)
+            const i32 kd = lookahead ? std::max(ka, ko - NB_OUT) : ka;      // ... its diagonal block only K = [kd, ko): the rest came with block column io - 1
             // Block column io.  The left-looking update of its DIAGONAL block and the factorisation
             // of that block (k_potrf*: a serial chain inside one workgroup per front) go to the
             // group's side stream; the update of the rows below runs concurrently on the group's
@@ -1508,7 +1528,7 @@ static void build_schedule(Symbolic &S) {
             if (overlap)
                 emit_update_launch([&]() {
                     for_fronts([&](i32 s, const FrontDesc &w) {
-                        if (ko < w.ns) push_update_region(s, w, ka, ko - ka, ko, std::min(ko + NB_OUT, w.ns), 0, 0);
+                        if (ko < w.ns) push_update_region(s, w, kd, ko - kd, ko, std::min(ko + NB_OUT, w.ns), 0, 0);
                     });
                 });
             if (io < nouter) {
@@ -1542,6 +1562,11 @@ static void build_schedule(Symbolic &S) {
                             push_update_region(s, w, ka, ko - ka, ko, std::min(ko + NB_OUT, w.ns), 0, overlap ? 1 : 2);
                             if (gi == 0 && G > 1)
                                 push_update_region(s, w, 0, kM, ko + NB_OUT, std::min(kM + G * NB_OUT, w.ns), 0, 2);
+                            // look-ahead: the diagonal block of block column io + 1, K = [k_first(io + 1), ko)
+                            if (lookahead && io >= 1 && io + 1 < my_nouter) {
+                                const i32 k1 = k_first(io + 1);
+                                if (ko > k1) push_update_region(s, w, k1, ko - k1, ko + NB_OUT, std::min(ko + 2 * NB_OUT, w.ns), 0, 0);
+                            }
                         } else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f, 1, 2);
                     });
                 });
