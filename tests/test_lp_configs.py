@@ -196,3 +196,18 @@ def test_ipm_parity_north_star_shape_hip_vs_cpu_supernodal_backend():
     assert ok, "\n".join(lines)
     for alg, (res, checks) in results.items():
         assert res[0].status == "Trm_Optimal" and res[1].status == "Trm_Optimal" and all(checks.values()), (alg, checks)
+
+
+@pytest.mark.gpu
+def test_hsd_parity_on_the_full_bench_workload_hip_vs_cpu_supernodal_backend():
+    """The protocol at FULL bench size: the LP on the constraint matrix of BASELINE configs[3] as bench.py runs it (64 diagonal blocks,
+    m = 321 000, n = 640 000), Tulip's default loop (HSD) to optimality with the KKT backend swapped between the HIP library and the
+    CPU comparator.  (MPC at this size: profiles/r03_ipm_parity_c4.txt; the driver-run MPC comparison is the 16-block test above.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    from ipm_parity_at_scale import run
+    lines = []
+    ok, results = run(64, False, ["hip", "supernodal"], algorithms=("HSD",), out=lines.append)
+    assert ok, "\n".join(lines)
+    res, checks = results["HSD"]
+    assert res[0].status == "Trm_Optimal" and res[1].status == "Trm_Optimal" and all(checks.values()), checks
