@@ -8,7 +8,7 @@ import numpy as np
 
 LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
           BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12,
-          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17, FWD_SWEEP=18, BWD_SWEEP=19, FRONT_ASSEMBLE=20)
+          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17, FWD_SWEEP=18, BWD_SWEEP=19, FRONT_ASSEMBLE=20, WAIT_UPPER=21)
 
 
 class Emulator:
@@ -26,6 +26,8 @@ class Emulator:
         self.local = g("front_local")
         self.single = g("front_single")
         self.front_fa = g("front_fa")          # panel formed by k_front_assemble: no zero-fill, not in k_assemble, no panel-part extend-add
+        self.front_upper = g("front_upper")    # zero-fill + assembly deferred to a stream of their own: nothing may touch the panel before the group's WAIT_UPPER marker
+        self.front_group = g("front_group")
         Sp = g("s_colptr")
         self.col_of_entry = np.repeat(np.arange(len(Sp) - 1), np.diff(Sp))            # permuted column of every entry of S
         fa_col = np.zeros(len(Sp) - 1, dtype=bool)
@@ -118,6 +120,13 @@ class Emulator:
         for s_ in np.nonzero(self.front_fa)[0]:
             if self.local[s_] and self.loff[s_] >= 0:
                 self.Lval[int(self.loff[s_]): int(self.loff[s_]) + pk_len(int(self.lda[s_]), int(self.ns[s_]))] = np.nan
+        # upper fronts (symbolic.cpp step 13d): their zero-fill + assembly complete only at the WAIT_UPPER marker of their stream group -- until then the
+        # storage holds NaN here, so that a launch that touches it too early poisons the factor
+        self._upper_pending = {}
+        for s_ in np.nonzero(self.front_upper)[0]:
+            a, b = int(self.loff[s_]), int(self.loff[s_]) + pk_len(int(self.lda[s_]), int(self.ns[s_]))
+            self._upper_pending[int(s_)] = self.Lval[a:b].copy()
+            self.Lval[a:b] = np.nan
         self.U = {}
         self.fail_col = None
         for s_ in np.nonzero(self.single & (self.local != 0))[0]:      # k_single_factor
@@ -141,6 +150,7 @@ class Emulator:
 
     def update_finish(self):
         self._run(self.factor_launches, False, start=self._resume)
+        assert not self._upper_pending, "upper fronts without a WAIT_UPPER marker"
 
     def _run(self, launches, stop_at_marker=False, start=0):
         for li in range(start, len(launches)):
@@ -150,6 +160,12 @@ class Emulator:
                     return li + 1
                 continue
             if kind in (LK["SIDE_FORK"], LK["SIDE_JOIN"]):      # stream markers: no work
+                continue
+            if kind == LK["WAIT_UPPER"]:                         # `first` = stream group of the marker (-1: the fronts after the join)
+                for s_ in [q for q in self._upper_pending if first < 0 or self.front_group[q] == first]:
+                    assert s_ not in self._P, "an upper panel was touched before its WAIT_UPPER marker"
+                    vals, a = self._upper_pending.pop(s_), int(self.loff[s_])
+                    self.Lval[a: a + len(vals)] = vals
                 continue
             if kind == LK["POTRF_WIDE"]:
                 kind = LK["POTRF"]

@@ -89,12 +89,14 @@ __device__ __forceinline__ double asm_value(const i64 e, const i32 *__restrict__
     return s;
 }
 // target < 0: the entry belongs to a panel that k_front_assemble forms
+// upper != nullptr: only the entries with upper[e] == part (the fronts whose zero-fill + assembly run beside the leaf levels: symbolic.cpp step 13d)
 __global__ void k_assemble(i64 nent, const i64 *__restrict__ target, const i32 *__restrict__ diag_row,
                            const i64 *__restrict__ pptr, const double *__restrict__ pw,
                            const i32 *__restrict__ pj, const double *__restrict__ D,
-                           const double *__restrict__ regD, double *__restrict__ Lval) {
+                           const double *__restrict__ regD, double *__restrict__ Lval, const unsigned char *__restrict__ upper, int part) {
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nent) return;
+    if (upper && (int)upper[e] != part) return;
     const i64 tg = target[e];
     if (tg < 0) return;
     Lval[tg] = asm_value(e, diag_row, pptr, pw, pj, D, regD);
@@ -134,8 +136,12 @@ __global__ __launch_bounds__(256) void k_zero_panels(const i32 *__restrict__ tas
     const FrontDesc fd = c.fronts[s];
     const i32 lda = fd.lda, nc = min(NB_IN, fd.ns - c0), ld = pld(fd, c0);          // c0 = first column of a slice
     double *P = pcol(c, fd, c0);
+    // gridDim.y > 1: the slice's rows in gridDim.y pieces (multiples of 256 rows) -- short workgroups, so that the zero-fill of the upper fronts
+    // (symbolic.cpp step 13d) leaves slots to the leaf levels' launches that run beside it
+    const i32 rows = lda - c0, per = ((rows + (i32)gridDim.y - 1) / (i32)gridDim.y + 255) & ~255;
+    const i32 rb = c0 + (i32)blockIdx.y * per, re = min(lda, rb + per);
     for (i32 col = 0; col < nc; ++col)
-        for (i32 r = c0 + (i32)threadIdx.x; r < lda; r += 256) P[(i64)col * ld + r] = 0.0;
+        for (i32 r = rb + (i32)threadIdx.x; r < re; r += 256) P[(i64)col * ld + r] = 0.0;
 }
 
 __global__ __launch_bounds__(256) void k_zero_small(const i32 *__restrict__ fronts, i64 n, DevCtx c) {      // one wave per small front
@@ -2450,14 +2456,16 @@ static inline unsigned nblk(i64 n, int b) { return (unsigned)((n + b - 1) / b); 
 void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D) {
     if (n > 0) hipLaunchKernelGGL(k_compute_d, dim3(nblk(n, 256)), dim3(256), 0, st, n, theta, regP, D);
 }
-void launch_zero_panels(hipStream_t st, const DevArrays &a) {
-    if (a.n_zero_tasks > 0) hipLaunchKernelGGL(k_zero_panels, dim3((unsigned)a.n_zero_tasks), dim3(256), 0, st, a.zero_tasks, a.ctx);
-    if (a.n_zero_small > 0) hipLaunchKernelGGL(k_zero_small, dim3((unsigned)((a.n_zero_small + 3) / 4)), dim3(256), 0, st, a.zero_small, a.n_zero_small, a.ctx);
+void launch_zero_panels(hipStream_t st, const DevArrays &a, int part) {
+    const i64 first = (part == 1) ? a.n_zero_lower : 0, last = (part == 0) ? a.n_zero_lower : a.n_zero_tasks;
+    if (last > first) hipLaunchKernelGGL(k_zero_panels, dim3((unsigned)(last - first), part == 1 ? 8u : 1u), dim3(256), 0, st, a.zero_tasks + 2 * first, a.ctx);
+    if (part != 1 && a.n_zero_small > 0)     // the small panels are never `upper`
+        hipLaunchKernelGGL(k_zero_small, dim3((unsigned)((a.n_zero_small + 3) / 4)), dim3(256), 0, st, a.zero_small, a.n_zero_small, a.ctx);
 }
-void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD) {
+void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD, int part) {
     if (a.n_asm > 0)
         hipLaunchKernelGGL(k_assemble, dim3(nblk(a.n_asm, 256)), dim3(256), 0, st, a.n_asm, a.asm_target_small, a.asm_diag,
-                           a.asm_ptr, a.pair_w, a.pair_j, D, regD, a.ctx.Lval);
+                           a.asm_ptr, a.pair_w, a.pair_j, D, regD, a.ctx.Lval, part < 0 ? nullptr : a.asm_upper, part);
 }
 void launch_single_factor(hipStream_t st, const DevArrays &a) {
     if (a.n_single > 0)

@@ -1207,12 +1207,29 @@ static void build_schedule(Symbolic &S) {
     }
     // zero-fill of the panels before the assembly: per 64-column slice only the rows from the slice's first row down (the
     // blocks above the diagonal blocks are never read)
+    // Step 13d (round 4): UPPER fronts.  On a block-angular LP 97 % of the factor's bytes are the panels of the diagonal blocks' top fronts (depth 1) and
+    // the root, and nothing touches them before the extend-add of their level -- while the leaf levels below are a chain of short, latency-bound
+    // launches that leave HBM idle.  Their zero-fill (0.9 ms of the 52 ms step on config C4, 2.4 of 137 ms on the north-star LP) and assembly therefore
+    // run on a stream of their own beside the leaf levels; an LK_WAIT_UPPER marker makes a group's stream wait for them before its first launch
+    // of an upper level.  Only with stream groups (the single-stream modes and graph replay keep the one-stream order).  TLPK_DEFER_UPPER=0: off.
+    S.front_upper.assign(S.fronts.size(), 0);
+    {
+        static const bool defer = [] { const char *e = std::getenv("TLPK_DEFER_UPPER"); return !e || std::atoi(e) != 0; }();
+        if (defer && S.ngroups >= 2 && S.nlevels >= 3)
+            for (size_t s = 0; s < S.fronts.size(); ++s) {
+                const FrontDesc &w = S.fronts[s];
+                if (S.front_local[s] && !S.front_fa[s] && !S.front_single[s] && S.depth[s] <= 1 && (i64)w.lda * w.ns > 4096) S.front_upper[s] = 1;
+            }
+    }
     S.zero_tasks.clear(); S.zero_small.clear();
-    for (size_t s = 0; s < S.fronts.size(); ++s) {
-        if (!S.front_local[s] || S.front_fa[s]) continue;       // (panels formed by k_front_assemble are written whole)
-        const FrontDesc &w = S.fronts[s];
-        if ((i64)w.lda * w.ns <= 4096) { S.zero_small.push_back((i32)s); continue; }      // whole panel by one wave
-        for (i32 c0 = 0; c0 < w.ns; c0 += NB_IN) { S.zero_tasks.push_back((i32)s); S.zero_tasks.push_back(c0); }
+    for (int upper = 0; upper < 2; ++upper) {
+        for (size_t s = 0; s < S.fronts.size(); ++s) {
+            if (!S.front_local[s] || S.front_fa[s] || (int)S.front_upper[s] != upper) continue;       // (panels formed by k_front_assemble are written whole)
+            const FrontDesc &w = S.fronts[s];
+            if ((i64)w.lda * w.ns <= 4096) { S.zero_small.push_back((i32)s); continue; }      // whole panel by one wave
+            for (i32 c0 = 0; c0 < w.ns; c0 += NB_IN) { S.zero_tasks.push_back((i32)s); S.zero_tasks.push_back(c0); }
+        }
+        if (!upper) S.n_zero_lower = (i64)S.zero_tasks.size() / 2;
     }
     auto in_scope = [&](i32 s) { return S.front_local[s] && !S.front_single[s] && (cur_g < 0 || S.front_group[s] == cur_g); };
     // structural-zero flags of a 128-row operand window [r0, r0 + TILE) of front s, one byte per K slab (step 13c), built on first use
@@ -1241,6 +1258,11 @@ static void build_schedule(Symbolic &S) {
     auto factor_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
         const bool root_level = (d == 0 && S.root_front >= 0);
+        {
+            bool any_upper = false;
+            for (i32 t = t0; t < t1 && !any_upper; ++t) any_upper = in_scope(S.level_fronts[t]) && S.front_upper[(size_t)S.level_fronts[t]];
+            if (any_upper) S.factor_launches.push_back(Launch{LK_WAIT_UPPER, cur_g, (i64)cur_g, 0, 0, 0});      // step 13d (`first` repeats the group: the exported triples carry no group)
+        }
         // (a) extend-add, panel part: the children's update-matrix columns that land in the pivot
         // columns [0, ns) of their parent.  The U part [ns, f) is added AFTER the front's single
         // U update has written U (beta = 0), so U is never zero-filled nor read back by k_update.

@@ -176,11 +176,15 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
         hipStream_t st = (base && L[i].group < 0) ? base : h->stream;
         // profiling serialises everything on the main stream: per-launch HIP-event durations are
         // then the kernels' own durations, not time shared with other groups' kernels
-        const bool marker = (L[i].kind == LK_SIDE_FORK || L[i].kind == LK_SIDE_JOIN);
+        const bool marker = (L[i].kind == LK_SIDE_FORK || L[i].kind == LK_SIDE_JOIN || L[i].kind == LK_WAIT_UPPER);
         if (h->profile || h->serial) { if (marker) continue; }
         else {
             if (L[i].group >= 1) { fork_groups(h); st = h->gstream[L[i].group]; }
             else if (L[i].group == 0) fork_groups(h);      // group 0 runs on the main stream itself
+            if (L[i].kind == LK_WAIT_UPPER) {              // step 13d: the upper panels are zero-filled and assembled from here on
+                if (h->upper_split) hipStreamWaitEvent(st, h->ev_upper, 0);
+                continue;
+            }
             // side stream of the group (slot 0 also serves the depth-0 fronts, group -1)
             const int sg = std::max(L[i].group, 0);
             if (L[i].kind == LK_SIDE_FORK) {
@@ -271,6 +275,14 @@ int upload_all(tlpk_handle *h) {
             colptr[(size_t)S.m] = cnt;
             if (cnt != d.n_asm) { h->last_error = "assembly list: column pointers do not match the compacted entries"; return TLPK_INTERNAL; }
             UP(d.asm_colptr, colptr); UP(d.asm_target_small, tsmall);
+            // step 13d: which entries belong to an upper front (assembled on a stream of their own)
+            std::vector<unsigned char> up((size_t)d.n_asm, 0);
+            bool any = false;
+            if (!S.front_upper.empty())
+                for (i64 kk = 0; kk < S.m; ++kk)
+                    if (S.front_upper[(size_t)S.sn_of_col[(size_t)kk]]) { any = true; for (i64 q = colptr[(size_t)kk]; q < colptr[(size_t)kk + 1]; ++q) up[(size_t)q] = 1; }
+            d.has_upper = any;
+            if (any) UP(d.asm_upper, up);
         }
         // pairs of local entries are contiguous per entry; entries of non-local fronts have none,
         // so the pair arrays are already compact and in the same order.
@@ -294,7 +306,7 @@ int upload_all(tlpk_handle *h) {
     { i32 *p; UP(p, S.upd_seg); d.ctx.upd_seg = p; }
     d.n_single = (i64)S.single_col.size();
     UP(d.single_loff, S.single_loff); UP(d.single_dinvoff, S.single_dinvoff); UP(d.single_col, S.single_col);
-    UP(d.zero_tasks, S.zero_tasks); d.n_zero_tasks = (i64)S.zero_tasks.size() / 2;
+    UP(d.zero_tasks, S.zero_tasks); d.n_zero_tasks = (i64)S.zero_tasks.size() / 2; d.n_zero_lower = d.has_upper ? S.n_zero_lower : d.n_zero_tasks;
     UP(d.zero_small, S.zero_small); d.n_zero_small = (i64)S.zero_small.size();
     UP(d.fwd_gather_tasks, S.fwd_gather_tasks); UP(d.fwd_diag_tasks, S.fwd_diag_tasks);
     UP(d.fwd_update_tasks, S.fwd_update_tasks); UP(d.bwd_update_tasks, S.bwd_update_tasks);
@@ -509,6 +521,15 @@ static int create_device(tlpk_handle *h, const tlpk_options &def) {
         for (int g = 1; g < ng && e == hipSuccess; ++g) e = hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking);
         for (int g = 0; g < ng && e == hipSuccess; ++g) e = hipStreamCreateWithFlags(&h->sstream[g], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess && ng >= 2) {
+            // lowest priority: slots go to the leaf levels' launches first.  (A CU-masked stream -- 32 / 64 / 128 of the 256 CUs, to leave HBM bandwidth
+            // to the leaf levels -- measured no better: profiles/r04_defer_upper.txt.)
+            int least = 0, greatest = 0;
+            hipDeviceGetStreamPriorityRange(&least, &greatest);
+            e = hipStreamCreateWithPriority(&h->zstream, hipStreamNonBlocking, least);
+        }
+        if (e == hipSuccess && ng >= 2) e = hipEventCreateWithFlags(&h->ev_zfork, hipEventDisableTiming);
+        if (e == hipSuccess && ng >= 2) e = hipEventCreateWithFlags(&h->ev_upper, hipEventDisableTiming);
         for (int g = 1; g < ng && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming);
         for (int g = 0; g < ng && e == hipSuccess; ++g) e = hipEventCreateWithFlags(&h->ev_side[g], hipEventDisableTiming);
         if (e == hipSuccess && h->stagger) e = hipEventCreateWithFlags(&h->ev_stagger, hipEventDisableTiming);
@@ -611,6 +632,9 @@ void tlpk_destroy(tlpk_handle *h) {
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
         if (h->ev_fork) hipEventDestroy(h->ev_fork);
+        if (h->zstream) { hipStreamSynchronize(h->zstream); hipStreamDestroy(h->zstream); }
+        if (h->ev_zfork) hipEventDestroy(h->ev_zfork);
+        if (h->ev_upper) hipEventDestroy(h->ev_upper);
         if (h->rstream) { hipStreamSynchronize(h->rstream); hipStreamDestroy(h->rstream); }
         if (h->ev_blocks) hipEventDestroy(h->ev_blocks);
         if (h->ev_root) hipEventDestroy(h->ev_root);
@@ -639,7 +663,20 @@ static int enq_update_local(tlpk_handle *h) {
         if (S.system == 1) launch_k2_diag(h->stream, user_n(h), h->d_theta, h->d_regP, h->d_D);      // D2 = [theta + regP ; 1]  (sqd.jl:44-50)
         else launch_compute_d(h->stream, S.n, h->d_theta, h->d_regP, h->d_D);
     }
-    {
+    // step 13d: zero-fill + assembly of the upper fronts (97 % of the factor's bytes on a block-angular LP) on the last stream group's side stream,
+    // beside the latency-bound leaf levels; the groups wait for ev_upper at their LK_WAIT_UPPER marker.  One-stream order in the single-stream modes.
+    h->upper_split = h->d.has_upper && h->zstream && h->ev_upper && S.ngroups >= 2 && !h->profile && !h->serial && !graph_usable(h);
+    if (h->upper_split) {
+        hipStream_t zs = h->zstream;
+        HIPCHK(h, hipEventRecord(h->ev_zfork, h->stream));                 // D is computed, the previous factor is no longer read
+        launch_zero_panels(h->stream, h->d, 0);                            // the lower fronts first: their (short) workgroups take their slots before the long fill starts
+        launch_assemble(h->stream, h->d, h->d_D, h->d_regD, 0);
+        launch_single_factor(h->stream, h->d);
+        HIPCHK(h, hipStreamWaitEvent(zs, h->ev_zfork, 0));
+        launch_zero_panels(zs, h->d, 1);
+        launch_assemble(zs, h->d, h->d_D, h->d_regD, 1);
+        HIPCHK(h, hipEventRecord(h->ev_upper, zs));
+    } else {
         ProfScope ps(h, TLPK_KC_ASSEMBLE);
         launch_zero_panels(h->stream, h->d);
         launch_assemble(h->stream, h->d, h->d_D, h->d_regD);
@@ -1742,6 +1779,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "fa_tasks") { for (auto &t : S.fa_tasks) { tmp.push_back(t.front); tmp.push_back(t.bc); tmp.push_back(t.br0); tmp.push_back(t.br1); } }
     else if (w == "front_fa") tmp.assign(S.front_fa.begin(), S.front_fa.end());
+    else if (w == "front_upper") tmp.assign(S.front_upper.begin(), S.front_upper.end());
     else if (w == "ea_tasks") { for (auto &t : S.ea_tasks) { tmp.push_back(t.front); tmp.push_back(t.j0); tmp.push_back(t.j1); tmp.push_back(t.bidx); tmp.push_back(t.br0); tmp.push_back(t.br1); } }
     else if (w == "fwd_gather_tasks" || w == "fwd_diag_tasks" || w == "fwd_update_tasks" || w == "bwd_update_tasks" || w == "fwd_small_tasks" || w == "bwd_small_tasks" ||
              w == "fwd_sweep_tasks" || w == "bwd_sweep_tasks") {

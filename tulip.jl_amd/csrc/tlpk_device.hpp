@@ -47,6 +47,8 @@ struct DevArrays {
     i32 *perm = nullptr;
     double *rhs_w = nullptr;                  // D .* xi_d of the current solve (k_rhs_scale)
     i32 *zero_tasks = nullptr; i64 n_zero_tasks = 0;   // (front, c0) pairs of k_zero_panels
+    i64 n_zero_lower = 0;                              // the first n_zero_lower pairs: fronts that are not `upper` (symbolic.cpp step 13d)
+    unsigned char *asm_upper = nullptr; bool has_upper = false;   // per assembled entry: 1 = its front is upper
     i32 *zero_small = nullptr; i64 n_zero_small = 0;   // fronts zeroed whole, one wave each
     char *row_local = nullptr, *col_local = nullptr;
     // assembly lists (local entries only)
@@ -70,8 +72,9 @@ struct DevArrays {
 };
 
 void launch_compute_d(hipStream_t st, i64 n, const double *theta, const double *regP, double *D);
-void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD);
-void launch_zero_panels(hipStream_t st, const DevArrays &a);
+// part: -1 = everything, 0 = the lower fronts only, 1 = the upper fronts only (symbolic.cpp step 13d)
+void launch_assemble(hipStream_t st, const DevArrays &a, const double *D, const double *regD, int part = -1);
+void launch_zero_panels(hipStream_t st, const DevArrays &a, int part = -1);
 void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const SweepArgs *sw = nullptr, int nrhs = 1);
 void launch_single_factor(hipStream_t st, const DevArrays &a);
 void launch_single_solve(hipStream_t st, const DevArrays &a, int rhs = 0);

@@ -26,6 +26,9 @@ struct tlpk_handle {
     hipStream_t stream = nullptr;                 // main stream (= group 0)
     hipStream_t gstream[MAX_GROUPS] = {};         // gstream[0] == stream; others: concurrent subtree groups
     hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS] = {};
+    hipStream_t zstream = nullptr;        // lowest priority: the upper fronts' zero-fill + assembly must not take slots from the leaf levels' launches
+    hipEvent_t ev_zfork = nullptr, ev_upper = nullptr;   // zero-fill + assembly of the upper fronts beside the leaf levels (symbolic.cpp step 13d)
+    bool upper_split = false;             // this update runs them on the last group's side stream (set per call: not in the single-stream modes / graphs)
     hipStream_t sstream[MAX_GROUPS] = {};         // side stream of each group: diagonal-block chains overlap the bulk update
     hipEvent_t ev_side[MAX_GROUPS] = {};
     bool forked = false;

@@ -102,7 +102,8 @@ enum LaunchKind : i32 {
     LK_POTRF_SMALL,     // pivot blocks of fronts with <= SMALL_NS pivot columns: one wave per front
     LK_FWD_SWEEP,       // whole forward substitution of every (non-small) front of a level in ONE launch: workgroups
     LK_BWD_SWEEP,       // own row chunks / column blocks and hand solved blocks over through flags (k_fwd_sweep / k_bwd_sweep)
-    LK_FRONT_ASSEMBLE   // panels of the large fronts of a level formed tile by tile: S entries + children (k_front_assemble)
+    LK_FRONT_ASSEMBLE,  // panels of the large fronts of a level formed tile by tile: S entries + children (k_front_assemble)
+    LK_WAIT_UPPER       // marker: from here on the group's stream touches panels of the UPPER fronts (front_upper): wait for their zero-fill + assembly
 };
 struct Launch { i32 kind; i32 group; i64 first; i64 count; i32 side = 0; i32 pad = 0; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
 
@@ -148,6 +149,8 @@ struct Symbolic {
     std::vector<i64> single_loff, single_dinvoff; std::vector<i32> single_col;   // the local ones, for the device
     std::vector<i32> zero_tasks;           // (front, first column) of every 64-column slice of a local panel: k_zero_panels
     std::vector<i32> zero_small;           // local fronts whose whole panel (<= 4096 entries) one wave zeroes
+    std::vector<char> front_upper;         // 1 = big front of the top levels: its zero-fill + assembly run on a stream of their own beside the leaf levels (step 13d)
+    i64 n_zero_lower = 0;                  // zero_tasks: the first n_zero_lower (front, c0) pairs belong to the other ("lower") fronts
     std::vector<char> col_local;           // column of A handled by this rank
     std::vector<char> row_local;           // 0 = other rank's block row, 1 = local block row, 2 = linking row
     i32 root_front = -1;                   // the replicated linking front (or -1)
