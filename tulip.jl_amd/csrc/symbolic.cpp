@@ -1234,14 +1234,18 @@ static void build_schedule(Symbolic &S) {
     auto in_scope = [&](i32 s) { return S.front_local[s] && !S.front_single[s] && (cur_g < 0 || S.front_group[s] == cur_g); };
     // structural-zero flags of a 128-row operand window [r0, r0 + TILE) of front s, one byte per K slab (step 13c), built on first use
     std::vector<std::vector<std::pair<i32, std::vector<char>>>> win_cache(S.fronts.size());
+    // TLPK_SKIP_WIN (experiment): the window of rows a skip decision looks at, 128 (a tile's own rows) | 256 | 512: with a coarser window the tiles of a
+    // super-tile skip the SAME slabs and keep walking K side by side (their operand loads meet in L2), at the price of fewer skipped slabs
+    static const i32 skip_win = [] { const char *e = std::getenv("TLPK_SKIP_WIN"); const int v = e ? std::atoi(e) : TILE; return (v == 256 || v == 512) ? v : TILE; }();
     auto window_flags = [&](i32 s, i32 r0) -> const char * {
+        r0 = r0 / skip_win * skip_win;
         auto &lst = win_cache[(size_t)s];
         for (auto &e : lst) if (e.first == r0) return e.second.data();
         const FrontDesc &w = S.fronts[s];
         const i64 nsl = (w.ns + 15) / 16, W = ((w.f + 15) / 16 + 63) / 64;
         const uint64_t *bits = S.skip_bits.data() + S.skip_off[(size_t)s];
         std::vector<char> fl((size_t)nsl, 0);
-        const i32 g0 = r0 / 16, g1 = (std::min(r0 + TILE, w.f) - 1) / 16;
+        const i32 g0 = r0 / 16, g1 = (std::min(r0 + skip_win, w.f) - 1) / 16;
         for (i64 k = 0; k < nsl; ++k) {
             const uint64_t *b = bits + k * W;
             char any = 0;
