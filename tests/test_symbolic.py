@@ -383,6 +383,42 @@ def test_packed_panels_of_fronts_with_several_slices(kind):
     assert np.abs(Ls - Lo).max() <= 1e-10 * np.abs(Lo).max() and np.abs(Le - Lo).max() <= 1e-10 * np.abs(Lo).max()
 
 
+def _check_skip_decisions(kkt):
+    """Every K slab an update tile leaves out -- by a segment list, or because the whole tile was dropped from its launch -- is structurally zero for the
+    tile's OWN operand rows [i0, i0 + 128) or [j0, j0 + 128), recomputed here from the exported bits.  (Tiles of U start at row ns, not on a multiple
+    of 128: a window rounded down to one once made the GPU suite fail while the emulated factorisations of the small CPU shapes still passed.)
+    Returns the number of tiles with a list."""
+    ut = kkt.symbolic("update_tasks").reshape(-1, 10)
+    seg = kkt.symbolic("upd_seg")
+    so = kkt.symbolic("skip_off"); sb = kkt.symbolic("skip_bits").view(np.uint64)
+    f_f, f_ns = kkt.symbolic("front_f"), kkt.symbolic("front_ns")
+    cache = {}
+
+    def flags(sf, r0):
+        f, ns = int(f_f[sf]), int(f_ns[sf])
+        nsl, ng = (ns + 15) // 16, (f + 15) // 16
+        if sf not in cache:
+            W = (ng + 63) // 64
+            b = sb[so[sf]: so[sf] + nsl * W].reshape(nsl, W)
+            words = np.repeat(b, 64, axis=1)[:, :ng]
+            cache[sf] = ((words >> (np.arange(ng, dtype=np.uint64) & np.uint64(63))) & np.uint64(1)).astype(bool)
+        g0, g1 = r0 // 16, (min(r0 + 128, f) - 1) // 16
+        return cache[sf][:, g0:g1 + 1].any(axis=1)
+
+    n = 0
+    for t in ut[ut[:, 8] > 0]:
+        sf, k0, kw, i0, j0 = (int(v) for v in t[:5])
+        need = flags(sf, i0) & flags(sf, j0)
+        nseg = seg[t[8] - 1]
+        listed = np.zeros(len(need), dtype=bool)
+        for a, cnt in zip(seg[t[8]: t[8] + 2 * nseg: 2], seg[t[8] + 1: t[8] + 2 * nseg: 2]):
+            listed[a // 16: a // 16 + cnt] = True
+        rng = np.zeros(len(need), dtype=bool); rng[k0 // 16: k0 // 16 + kw // 16] = True
+        assert not (need & rng & ~listed).any(), ("a needed slab is skipped", sf, i0, j0)
+        n += 1
+    return n
+
+
 def test_skip_lists_of_structural_zeros(monkeypatch):
     """Update tiles skip the K slabs in which one of their operand row ranges holds only amalgamation padding (analyse step 13c).
     The emulator multiplies exactly the listed slabs: a slab wrongly declared zero would show in L.  Also: the flags are the true
@@ -433,3 +469,9 @@ def test_skip_lists_of_structural_zeros(monkeypatch):
             assert (lib[g0:] == truth[g0:]).all(), (s, k)
             checked += ng - g0
     assert checked > 1000
+    _check_skip_decisions(kkt)
+    # the bench workload's family at 8 blocks, default settings: ~3000 tiles with lists, among them tiles of the top fronts' U parts, which start at
+    # row ns = 3525 -- off a multiple of 128 (analyse only, no emulation; this is the shape on which the rounded window produced wrong lists)
+    monkeypatch.delenv("TLPK_SKIP_MIN_F"); monkeypatch.delenv("TLPK_SPLITK_TILES"); monkeypatch.delenv("TLPK_SKIP")
+    A2, rb2 = block_angular_lp(nblocks=8)
+    assert _check_skip_decisions(analyse_only(A2, row_block=rb2)) >= 1000

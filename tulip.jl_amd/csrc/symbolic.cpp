@@ -1237,15 +1237,17 @@ static void build_schedule(Symbolic &S) {
     // TLPK_SKIP_WIN (experiment): the window of rows a skip decision looks at, 128 (a tile's own rows) | 256 | 512: with a coarser window the tiles of a
     // super-tile skip the SAME slabs and keep walking K side by side (their operand loads meet in L2), at the price of fewer skipped slabs
     static const i32 skip_win = [] { const char *e = std::getenv("TLPK_SKIP_WIN"); const int v = e ? std::atoi(e) : TILE; return (v == 256 || v == 512) ? v : TILE; }();
-    auto window_flags = [&](i32 s, i32 r0) -> const char * {
-        r0 = r0 / skip_win * skip_win;
+    auto window_flags = [&](i32 s, i32 r0) -> const char * {            // r0 = first row of a tile (NOT always a multiple of TILE: the tiles of U start at row ns)
         auto &lst = win_cache[(size_t)s];
         for (auto &e : lst) if (e.first == r0) return e.second.data();
         const FrontDesc &w = S.fronts[s];
         const i64 nsl = (w.ns + 15) / 16, W = ((w.f + 15) / 16 + 63) / 64;
         const uint64_t *bits = S.skip_bits.data() + S.skip_off[(size_t)s];
         std::vector<char> fl((size_t)nsl, 0);
-        const i32 g0 = r0 / 16, g1 = (std::min(r0 + skip_win, w.f) - 1) / 16;
+        // rows looked at: the tile's own [r0, r0 + TILE), widened to whole skip_win-row windows when skip_win > TILE
+        const i32 lo = (skip_win > TILE) ? r0 / skip_win * skip_win : r0;
+        const i32 hi = (skip_win > TILE) ? (r0 + TILE + skip_win - 1) / skip_win * skip_win : r0 + TILE;
+        const i32 g0 = lo / 16, g1 = (std::min(hi, w.f) - 1) / 16;
         for (i64 k = 0; k < nsl; ++k) {
             const uint64_t *b = bits + k * W;
             char any = 0;
