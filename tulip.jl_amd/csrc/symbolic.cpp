@@ -122,7 +122,10 @@ static void build_schedule(Symbolic &S);
 static unsigned host_threads(i64 n) {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     // up to a quarter of the hardware threads, at most 64 (env TLPK_HOST_THREADS overrides): the per-front / per-block phases
-    // of a block-angular LP with 64 diagonal blocks were 3-4 rounds deep with the old cap of 16 on a 256-thread host
+    // of a block-angular LP with 64 diagonal blocks were 3-4 rounds deep with the old cap of 16 on a 256-thread host.  NOT capped by the
+    // container's CPU quota (16 CPUs on the GPU boxes): the phases are bursts of well under the 100-ms accounting period, 64 threads are the
+    // fastest setting there (C4 281 ms against 347 with 16; north-star LP 1093 against 1258: tools/analyse_threads_probe.py) -- unlike the
+    // seconds-long OpenMP teams of the CPU comparator, which the quota throttles
     static const i64 cap = [] { const char *e = std::getenv("TLPK_HOST_THREADS"); return e ? std::max<i64>(1, std::atoll(e)) : (i64)64; }();
     const i64 mine = std::getenv("TLPK_HOST_THREADS") ? cap : std::min<i64>(cap, std::max<i64>(16, hw / 4));
     return (unsigned)std::max<i64>(1, std::min<i64>({(i64)hw, mine, n}));
