@@ -571,18 +571,34 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
     if (opt.relax && ns_total > 1) {
         double GAMMA = 25.0;
         if (const char *e = std::getenv("TLPK_RELAX_GAMMA")) GAMMA = std::atof(e);    // tuning knob
+        double GAMMA_TALL = 400.0, TALL_RATIO = 0.5;                                  // (read once: two getenv calls per candidate were a fifth of this phase)
+        if (const char *e = std::getenv("TLPK_RELAX_GAMMA_TALL")) GAMMA_TALL = std::atof(e);
+        if (const char *e = std::getenv("TLPK_RELAX_TALL_RATIO")) TALL_RATIO = std::atof(e);
         const i32 forced_root = nlink ? ns_total - 1 : -1;
         std::vector<i32> into(ns_total, -1);
         std::vector<double> cns(ns_total), cf(ns_total), cz(ns_total, 0.0);
-        std::vector<std::vector<i32>> kids(ns_total);
+        // children lists as flat arrays (400 000 fronts on the north-star LP: a vector per front was a third of this phase): the initial lists in
+        // `kid0` (children in ascending order), the list a processed front KEEPS appended to `kept`; kid_list(x) = whichever is current
+        std::vector<i32> kid0_ptr((size_t)ns_total + 1, 0), kid0((size_t)ns_total), kept, kept_ptr((size_t)ns_total, -1), kept_cnt((size_t)ns_total, 0);
         for (i32 s = 0; s < ns_total; ++s) {
             cns[s] = S.fronts[s].ns; cf[s] = S.fronts[s].f;
-            if (sparent[s] != -1) kids[sparent[s]].push_back(s);
+            if (sparent[s] != -1) kid0_ptr[(size_t)sparent[s] + 1]++;
         }
+        for (i32 s = 0; s < ns_total; ++s) kid0_ptr[(size_t)s + 1] += kid0_ptr[(size_t)s];
+        {
+            std::vector<i32> fill(kid0_ptr.begin(), kid0_ptr.end() - 1);
+            for (i32 s = 0; s < ns_total; ++s) if (sparent[s] != -1) kid0[(size_t)fill[(size_t)sparent[s]]++] = s;
+        }
+        kept.reserve((size_t)ns_total);
+        auto kid_list = [&](i32 x, const i32 *&first, i32 &count) {
+            if (kept_ptr[(size_t)x] >= 0) { first = kept.data() + kept_ptr[(size_t)x]; count = kept_cnt[(size_t)x]; }
+            else { first = kid0.data() + kid0_ptr[(size_t)x]; count = kid0_ptr[(size_t)x + 1] - kid0_ptr[(size_t)x]; }
+        };
+        std::vector<i32> cand, keep;
         bool any_merge = false;
         for (i32 p = 0; p < ns_total; ++p) {
-            if (p == forced_root || kids[p].empty()) continue;
-            std::vector<i32> cand = kids[p], keep;
+            if (p == forced_root || kid0_ptr[(size_t)p + 1] == kid0_ptr[(size_t)p]) continue;
+            cand.assign(kid0.begin() + kid0_ptr[(size_t)p], kid0.begin() + kid0_ptr[(size_t)p + 1]); keep.clear();
             std::sort(cand.begin(), cand.end(), [&](i32 a, i32 b) { return (cf[a] - cns[a]) > (cf[b] - cns[b]); });
             for (size_t idx = 0; idx < cand.size(); ++idx) {
                 const i32 c = cand[idx];
@@ -606,23 +622,30 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
                 // update matrix of ~fp^2 entries for a handful of columns: merging pads little
                 // (measured: C4 63.7 -> 62.2 ms/step, headline instance 182 -> 172 ms/step, extend-add 30 -> 11 ms;
                 // saturates above ~400)
-                double GAMMA_TALL = 400.0, TALL_RATIO = 0.5;
-                if (const char *e = std::getenv("TLPK_RELAX_GAMMA_TALL")) GAMMA_TALL = std::atof(e);
-                if (const char *e = std::getenv("TLPK_RELAX_TALL_RATIO")) TALL_RATIO = std::atof(e);
                 const bool rule_c = rsc >= TALL_RATIO * fp && extra_flops < GAMMA_TALL * rsc * rsc && extra_zeros < 0.5 * rsc * rsc;
                 if (rule_a || rule_b || rule_c) {
                     into[c] = p; cns[p] += nc; cf[p] = fnew; cz[p] = newz; any_merge = true;
-                    for (i32 g : kids[c]) cand.push_back(g);      // grandchildren now hang off p
+                    const i32 *gf; i32 gc;
+                    kid_list(c, gf, gc);
+                    cand.insert(cand.end(), gf, gf + gc);          // grandchildren now hang off p
                 } else {
                     keep.push_back(c);
                 }
             }
-            kids[p].swap(keep);
+            kept_ptr[(size_t)p] = (i32)kept.size(); kept_cnt[(size_t)p] = (i32)keep.size();
+            kept.insert(kept.end(), keep.begin(), keep.end());
         }
+        pt.mark("amalgamation: re-order");
         if (any_merge) {
             auto root_of = [&](i32 s) { while (into[s] != -1) s = into[s]; return s; };
-            std::vector<std::vector<i32>> members(ns_total);
-            for (i32 s = 0; s < ns_total; ++s) members[root_of(s)].push_back(s);
+            // members of every group (ascending), flat
+            std::vector<i32> grp((size_t)ns_total), mem_ptr((size_t)ns_total + 1, 0), mem((size_t)ns_total);
+            for (i32 s = 0; s < ns_total; ++s) { grp[(size_t)s] = root_of(s); mem_ptr[(size_t)grp[(size_t)s] + 1]++; }
+            for (i32 s = 0; s < ns_total; ++s) mem_ptr[(size_t)s + 1] += mem_ptr[(size_t)s];
+            {
+                std::vector<i32> fill(mem_ptr.begin(), mem_ptr.end() - 1);
+                for (i32 s = 0; s < ns_total; ++s) mem[(size_t)fill[(size_t)grp[(size_t)s]]++] = s;
+            }
             // post-order over the group tree (children groups before the group's own columns)
             std::vector<i32> newpos(m, -1), new_start;
             i32 counter = 0;
@@ -633,10 +656,14 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
                 while (!stack.empty()) {
                     auto &top = stack.back();
                     const i32 g = top.first;
-                    if (top.second < kids[g].size()) { const i32 ch = kids[g][top.second++]; stack.emplace_back(ch, 0); continue; }
+                    const i32 *kf; i32 kc;
+                    kid_list(g, kf, kc);
+                    if (top.second < (size_t)kc) { const i32 ch = kf[top.second++]; stack.emplace_back(ch, 0); continue; }
                     new_start.push_back(counter);
-                    for (i32 mem : members[g])
-                        for (i32 j = sn_start[mem]; j < sn_start[mem + 1]; ++j) newpos[j] = counter++;
+                    for (i32 q = mem_ptr[(size_t)g]; q < mem_ptr[(size_t)g + 1]; ++q) {
+                        const i32 mm = mem[(size_t)q];
+                        for (i32 j = sn_start[mm]; j < sn_start[mm + 1]; ++j) newpos[j] = counter++;
+                    }
                     stack.pop_back();
                 }
             }
@@ -653,8 +680,10 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
             for (i32 k = 0; k < m; ++k) if (S.parent[k] != -1 && S.parent[k] <= k) return fail(S, TLPK_INTERNAL, "re-ordered etree not topological");
             if (nlink) for (i32 k = first_link; k < m; ++k) if (!is_link[S.perm[k]]) return fail(S, TLPK_INTERNAL, "linking rows moved");
             sn_start.swap(new_start);
+            pt.mark("amalgamation: pattern");
             build_pattern();
         }
+        pt.mark("amalgamation: fronts");
         const int rc = build_fronts(true);
         if (rc != TLPK_OK) return rc;
     }
