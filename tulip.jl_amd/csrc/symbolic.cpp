@@ -1221,6 +1221,7 @@ int analyse_k2(Symbolic &S, i64 m, i64 n, const i64 *colptr, const i64 *rowval, 
 // replays them once per update! (factor) and 2..6 times per Newton step (solves).
 // ---------------------------------------------------------------------------------------------
 static void build_schedule(Symbolic &S) {
+    PhaseTimer spt; spt.mark("schedule: prologue");
     // Scope of the level body being generated: stream group `cur_g` (fronts at depth >= 1 of that
     // group) or -1 = the depth-0 fronts, which run on the main stream after all groups joined.
     int cur_g = -1, cur_side = 0;
@@ -1292,6 +1293,7 @@ static void build_schedule(Symbolic &S) {
     auto push_launch = [&](std::vector<Launch> &L, i32 kind, i64 first, i64 count) {
         if (count > 0) L.push_back(Launch{kind, cur_g, first, count, cur_side, 0});
     };
+    spt.mark("schedule: factor");
     // ---------------- factorisation ----------------
     auto factor_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
@@ -1677,6 +1679,7 @@ static void build_schedule(Symbolic &S) {
             }
         }
     }
+    spt.mark("schedule: fwd");
     // ---------------- forward solve: deepest level first ----------------
     // (thin but TALL fronts keep the workgroup-per-row-chunk kernels: one wave walking 1000 rows is slower)
     auto is_small = [&](i32 s) { return S.fronts[s].ns <= SMALL_NS && S.fronts[s].f - S.fronts[s].ns <= SMALL_ROWS && s != S.root_front; };
@@ -1787,6 +1790,7 @@ static void build_schedule(Symbolic &S) {
         for (i32 d = S.nlevels - 1; d >= 1; --d) fwd_level(d);
     cur_g = -1;
     if (S.nlevels > 0) fwd_level(0);
+    spt.mark("schedule: bwd");
     // ---------------- backward solve: root level first ----------------
     // Column-oriented: launch 0 of a level removes the rows below the pivot block (known from the
     // ancestors) from every column block of every front and solves each front's last block; launch
@@ -1852,6 +1856,7 @@ static void build_schedule(Symbolic &S) {
     if (S.nlevels > 0) bwd_level(0);
     for (cur_g = 0; cur_g < S.ngroups; ++cur_g)
         for (i32 d = 1; d < S.nlevels; ++d) bwd_level(d);
+    spt.mark(nullptr);
 }
 
 }  // namespace tlpk
