@@ -75,7 +75,12 @@ def parse():
                          "factorisation overlaps the first solve's block-level sweeps; measured slower, profiles/r03_async_update.txt)")
     ap.add_argument("--no-small-lp", action="store_true", help="skip the latency-bound legs (25fv47-class and pds-20-class LPs)")
     ap.add_argument("--no-c3", action="store_true", help="skip the general sparse leg (BASELINE configs[2] shape at --c3-rows rows; N=1, workload c4 only)")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the timed region (exactly --steps Newton steps between two barriers) is run this many times back to back; `ms_per_step` / "
+                         "`value` are the MEDIAN run, all runs are listed in `ms_per_step_runs` (round-4 review: the box-to-box spread of the "
+                         "pool, +-0.7 ms, exceeded what a round gained)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--no-third-party", action="store_true", help="skip the SciPy splu point (BASELINE.md B2) of the cpu_baseline leg")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child-process mode of the cpu_baseline leg
     ap.add_argument("--force-collectives", action="store_true",
                     help="N = 1 only: run the multi-GPU code path (process group on backend nccl = RCCL, split-phase calls, all-reduce of "
@@ -247,8 +252,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(workload, steps, warmup, roofline):
-        """Times `steps` Newton steps of `workload`; returns (result dict, A, row_block)."""
+    def run(workload, steps, warmup, roofline, repeats=1):
+        """Times `steps` Newton steps of `workload` (`repeats` times: the median run is reported); returns (result dict, A, row_block)."""
         A, row_block, text = build_workload(args, workload)
         m, n = A.shape
         kkt = tk.setup(A, tk.K1(), tk.Backend(device=local_rank, row_block=row_block, rank=rank, nranks=world))
@@ -328,17 +333,20 @@ def main():
 
         for _ in range(warmup):
             newton_step(kkt)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            newton_step(kkt)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        ms_per_step = 1e3 * elapsed / steps
+        runs = []
+        for _rep in range(max(1, repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                newton_step(kkt)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            if dist is not None:
+                tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                elapsed = float(tt.item())
+            runs.append(1e3 * elapsed / steps)
+        ms_per_step = float(np.median(runs))
 
         # sanity: the residual identities of the reference's conformance test on the last step
         dx, dy = d_dx.cpu().numpy(), d_dy.cpu().numpy()
@@ -352,7 +360,7 @@ def main():
         r_p = float(np.abs(A @ dx + rd * dy - xp).max())
         r_d = float(np.abs(-dx * (th + rp) + A.T @ dy - xd).max())
 
-        out = {"ms_per_step": ms_per_step, "value": 1e3 / ms_per_step,
+        out = {"ms_per_step": ms_per_step, "value": 1e3 / ms_per_step, "ms_per_step_runs": [round(r, 4) for r in runs],
                "config": {"workload": text, "solves_per_step": args.solves, "regime": args.regime,
                           "solve_schedule": ("1 pair (two right-hand sides in one pass over the factor: HSD's h-system + predictor) + %d single" % (args.solves - 2))
                                             if pair else "%d single" % args.solves,
@@ -446,14 +454,16 @@ def main():
                 for _ in range(args.solves):
                     tk.solve(dxh, dyh, kkt, xp, xd)
             host_step()
-            hs = max(2, min(steps, 5))
+            hs = max(2, min(steps, 20))
             t0 = time.perf_counter()
             for _ in range(hs):
                 host_step()
             t_host = (time.perf_counter() - t0) / hs
             out["host_abi"] = {"ms_per_step": 1e3 * t_host, "value": 1.0 / t_host, "unit": "iter/s", "steps": hs,
                                "pcie_bytes_per_step": 8 * (2 * n + m) + args.solves * 16 * (m + n),
-                               "note": "tlpk_update + %d x tlpk_solve with pageable host vectors through pinned staging; "
+                               "copy_threads": tk._lib.lib().tlpk_host_copy_threads(),
+                               "note": "tlpk_update + %d x tlpk_solve with pageable host vectors through pinned staging (pieces of <= 512 KB handled by "
+                                       "a pool of host threads, every piece on the link as soon as it is staged); "
                                        "PCIe-inclusive, never reported as `value`" % args.solves}
         if pair and world == 1 and not split:
             # the same step with every right-hand side solved on its own (the round-2 definition of the step), for comparison
@@ -476,17 +486,20 @@ def main():
 
     # The roofline leg (a second, single-stream-group handle in profile mode) is measured at N = 1 only: with ranks it would run
     # collectives on a handle the timed loop never used, and a rank failing there would leave the others waiting in an all-reduce.
-    res, A, row_block = run(args.workload, args.steps, args.warmup, (not args.no_roofline) and not split)
+    res, A, row_block = run(args.workload, args.steps, args.warmup, (not args.no_roofline) and not split, args.repeats)
     out = {
         "metric": "IPM Newton-step rate: KKT.update! (A*D*A'+Rd, supernodal Cholesky) + %d KKT.solve!" % args.solves,
         "value": res["value"], "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": res["ms_per_step"], "ms_per_step_runs": res["ms_per_step_runs"],
+        "ms_per_step_min": min(res["ms_per_step_runs"]), "ms_per_step_max": max(res["ms_per_step_runs"]),
+        "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": res["config"],
     }
     # definition of the timed step, spelled out (round-3 advisor finding: the default changed from four single solves to a pair + two in round 3)
     out["value_definition"] = ("1 KKT.update! + %d right-hand sides per step; since round 3 the first two are solved as ONE pair (HSD's h-system + predictor, "
                                "one pass over the factor) -- `unpaired_ms_per_step` is the same step with %d single solves (the round-1/2 definition), "
-                               "`host_abi.ms_per_step` the drop-in path with host vectors over PCIe" % (args.solves, args.solves)) if not args.unpaired else \
+                               "`host_abi.ms_per_step` the drop-in path with host vectors over PCIe; the timed region (exactly `steps` steps between two barriers) is run "
+                               "%d times, `ms_per_step` / `value` are the median run, `ms_per_step_runs` lists all" % (args.solves, args.solves, max(1, args.repeats))) if not args.unpaired else \
                               ("1 KKT.update! + %d single KKT.solve! per step (the round-1/2 definition)" % args.solves)
     out["config"]["configs_untested_by_name"] = ("Netlib 25fv47 / pds-20 .mps are not in the image; generated equivalents of both classes "
                                                  "run end-to-end (HSD + MPC, HIP vs oracle vs HiGHS) in tests/test_lp_configs.py")
@@ -504,12 +517,12 @@ def main():
         out["collectives"] = "forced at N = 1: process group on backend nccl (RCCL), split-phase update / solve with all-reduce of the root panel and the root rhs"
     if rank == 0 and world == 1 and not split and args.workload == "c4" and not args.no_headline:
         try:
-            hres, _, _ = run("headline", max(2, min(args.steps, 5)), 1, not args.no_roofline)
-            out["headline"] = {"ms_per_step": hres["ms_per_step"], "value": hres["value"], "unit": "iter/s",
+            hres, _, _ = run("headline", max(2, min(args.steps, 5)), 1, not args.no_roofline, min(3, max(1, args.repeats)))
+            out["headline"] = {"ms_per_step": hres["ms_per_step"], "ms_per_step_runs": hres["ms_per_step_runs"], "value": hres["value"], "unit": "iter/s",
                                "workload": hres["config"]["workload"], "nnzL": hres["config"]["nnzL"],
                                "flops_chol": hres["config"]["flops_chol"], "frac_step": hres["frac_step"],
                                "residual_inf": hres["config"]["residual_inf"], "ms_analyse": hres["config"]["ms_analyse"]}
-            for k in ("roofline", "solve_roofline", "kernel_ms", "host_abi"):
+            for k in ("roofline", "solve_roofline", "kernel_ms", "host_abi", "unpaired_ms_per_step"):
                 if k in hres:
                     out["headline"][k] = hres[k]
             out["headline"]["stored_over_nnzL"] = hres["config"]["stored_over_nnzL"]

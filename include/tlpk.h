@@ -100,6 +100,8 @@ typedef struct tlpk_stats {
                                   true column counts l_j (no amalgamation zeros); <= flops_chol, <= flops_update */
     double  ms_enqueue_update; /* multi-device handles: host time from the entry of the last tlpk_update until the work of EVERY shard
                                   (root fronts included) was enqueued; ms_last_update is then the wall time of the whole call */
+    int64_t refine_rejected;   /* refine_steps > 0: refinement steps of the last completed solve that did NOT shrink max(|r1|inf, |r2|inf) and were
+                                  discarded (a rejected step ends the refinement of that solve); valid after tlpk_sync / a blocking solve */
 } tlpk_stats;
 
 /* per-kernel-class timing, filled when options.profile = 1 */
@@ -294,6 +296,9 @@ const char *tlpk_backend_name(void);         /* "HIP (gfx950)" */
 const char *tlpk_system_name(void);          /* "Normal equations (K1)" */
 const char *tlpk_linear_system(const tlpk_handle *h);   /* KKT.linear_system of this handle: "... (K1)" | "Augmented system (K2)" */
 int tlpk_device_count(void);
+/* host threads (pool workers + the caller) that stage the vectors of the host-pointer calls tlpk_update / tlpk_solve through pinned memory;
+ * TLPK_COPY_THREADS = number of workers (default 4, 0 = the caller copies alone), read when the pool is first used */
+int tlpk_host_copy_threads(void);
 
 #ifdef __cplusplus
 }

@@ -923,3 +923,85 @@ def test_eight_shards_enqueue_time_with_one_host_thread_per_shard(threads, monke
     r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
     assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp).max(), np.abs(xd).max()))
     kkt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", ["4", "0"])
+def test_host_pointer_calls_equal_device_pointer_calls_bitwise(threads, monkeypatch):
+    """The drop-in path (tlpk_update / tlpk_solve with host vectors, KKT.jl:83,100) moves the vectors through pinned staging in pieces
+    handled by a pool of host threads (round 5, csrc/hostcopy.cpp); the arithmetic is that of the device-pointer calls, so factor and
+    solutions must agree BIT FOR BIT -- on an LP whose vectors span several pieces (> 512 KB each), with host arrays at odd offsets, and
+    repeatedly (the staging area and the per-piece events are reused)."""
+    from helpers import DevBuf
+    monkeypatch.setenv("TLPK_COPY_THREADS", threads)      # (read when the pool is created: the first variant decides in a shared process; both paths are valid)
+    A, rb = block_angular(nblocks=6, mk=3000, nk=40000, m0=60, nnz_in=3, link_prob=0.5, seed=77)
+    m, n = A.shape
+    assert 8 * n > 3 * 512 * 1024
+    kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb))
+    th, rp, rd, xp, xd = ipm_like_data(m, n, 5)
+    # device-pointer path
+    d = [DevBuf(v) for v in (th, rp, rd, xp, xd)]
+    o_dx, o_dy = DevBuf(n), DevBuf(m)
+    kkt.update_device(d[0].ptr, d[1].ptr, d[2].ptr)
+    kkt.solve_device(o_dx.ptr, o_dy.ptr, d[3].ptr, d[4].ptr)
+    L_dev = kkt.factor_panels().copy()
+    dx_dev, dy_dev = o_dx.get(), o_dy.get()
+    # host-pointer path, arrays carved out of a larger buffer at an 8-byte (not 16-byte) offset
+    def odd(v):
+        buf = np.empty(v.size + 3)
+        w = buf[1:1 + v.size] if (buf.ctypes.data % 16 == 0) else buf[2:2 + v.size]
+        w[:] = v
+        return w
+    for rep in range(3):
+        tk.update(kkt, odd(th), odd(rp), odd(rd))
+        dx, dy = odd(np.full(n, np.nan)), odd(np.full(m, np.nan))
+        tk.solve(dx, dy, kkt, odd(xp), odd(xd))
+        assert np.array_equal(kkt.factor_panels(), L_dev), rep
+        assert np.array_equal(dx, dx_dev) and np.array_equal(dy, dy_dev), rep
+    kkt.close()
+
+
+@pytest.mark.gpu
+def test_guarded_refinement_never_increases_the_residual():
+    """Round 5: a refinement step is kept only if it shrinks max(|r1|inf, |r2|inf) of the augmented system (decided on the device; the
+    reference has no refinement, spd.jl:68).  Invariant on data far beyond what an interior-point run produces (theta over 30 decades,
+    regularisations at 1e-10: factors that are nearly useless as preconditioners): with any number of steps the residual norm is never
+    above the unrefined one, tlpk_stats.refine_rejected counts the discarded steps (at most one per solve: a rejection ends the
+    refinement), and a multi-device handle obeys the same rule."""
+    A, rb = block_angular(nblocks=4, mk=500, nk=1100, m0=50, nnz_in=3, link_prob=0.5, seed=91)
+    m, n = A.shape
+    rng = np.random.default_rng(4)
+    seen_reject = False
+    for trial, span in enumerate((8, 12, 15)):
+        th = 10.0 ** rng.uniform(-span, span, n); th[rng.random(n) < 0.05] = 0.0
+        rp = np.full(n, 1e-10); rd = np.full(m, 1e-10)
+        xp, xd = rng.standard_normal(m), rng.standard_normal(n)
+        norms = {}
+        for steps in (0, 1, 4):
+            for multi in ((False, True) if steps in (0, 4) else (False,)):
+                kw = dict(ngpus=2, devices=[0, 0]) if multi else {}
+                kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb, refine=steps, **kw))
+                try:
+                    tk.update(kkt, th, rp, rd)
+                except tk.PosDefException:
+                    kkt.close(); norms = None; break
+                dx = np.zeros(n); dy = np.zeros(m)
+                tk.solve(dx, dy, kkt, xp, xd)
+                rej = kkt.stats()["refine_rejected"]
+                assert 0 <= rej <= (1 if steps else 0), (steps, rej)
+                seen_reject |= rej > 0
+                norms[(steps, multi)] = max(kkt_residuals(A, th, rp, rd, xp, xd, dx, dy))
+                kkt.close()
+            if norms is None:
+                break
+        if norms is None:
+            continue
+        print("guarded refinement, theta over 10^+-%d: residual max-norms %s" % (span, {k: float("%.2e" % v) for k, v in norms.items()}))
+        for multi in (False, True):
+            base = norms[(0, multi)]
+            for (steps, mm), v in norms.items():
+                if mm == multi and steps > 0:
+                    # (the host evaluates the residuals in another summation order than the device kernels: with theta * dx terms of 1e15 the
+                    # two evaluations of a residual at rounding level differ by a factor of order one -- the guard is against growth by decades)
+                    assert v <= 2.0 * base or not np.isfinite(base), (span, steps, multi, v, base)
+    print("guarded refinement: a step was rejected in at least one trial:", seen_reject)

@@ -39,7 +39,7 @@ class Stats(C.Structure):
                 ("fail_col", C.c_int64), ("ms_analyse", C.c_double), ("ms_last_update", C.c_double),
                 ("ms_last_solve", C.c_double), ("n_local_blocks", C.c_int32), ("n_blocks", C.c_int32),
                 ("root_panel_len", C.c_int64), ("flops_update", C.c_double),
-                ("flops_update_alg", C.c_double), ("ms_enqueue_update", C.c_double)]
+                ("flops_update_alg", C.c_double), ("ms_enqueue_update", C.c_double), ("refine_rejected", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -66,6 +66,7 @@ EXPORTS = [
     "tlpk_mpc_start", "tlpk_mpc_newton", "tlpk_mpc_gap", "tlpk_mpc_targets", "tlpk_mpc_advance",
     "tlpk_detect_blocks", "tlpk_solve2_device", "tlpk_ipm_hsolve_newton", "tlpk_update_device_async", "tlpk_ipm_factor_hsolve_newton",
     "tlpk_refine_local", "tlpk_refine_finish", "tlpk_solve2_local", "tlpk_root_rhs2", "tlpk_solve2_finish", "tlpk_last_create_error",
+    "tlpk_host_copy_threads",
 ]
 
 
@@ -137,6 +138,7 @@ def lib():
     L.tlpk_linear_system.argtypes = [vp]
     L.tlpk_linear_system.restype = C.c_char_p
     L.tlpk_device_count.restype = C.c_int
+    L.tlpk_host_copy_threads.restype = C.c_int
     L.tlpk_detect_blocks.argtypes = [C.c_int64, C.c_int64, p64, p64, C.c_int, C.c_int64, p64, p64, p64]
     L.tlpk_detect_blocks.restype = C.c_int
     L.tlpk_ipm_load.argtypes = [vp, pd, pd, pd, pd]

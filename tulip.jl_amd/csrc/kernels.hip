@@ -2396,6 +2396,52 @@ __global__ void k_axpy2(i64 n, double *__restrict__ x, const double *__restrict_
     if (i < m) y[i] += dyc[i];
 }
 
+// Guarded refinement (round 5).  A refinement step is kept only if it shrinks max(|r1|inf, |r2|inf): the candidate x + c is formed beside x,
+// its residuals are computed (they are the next step's right-hand side if the step is kept), the two norms are compared ON THE DEVICE
+// (no host synchronisation inside a solve) and x is overwritten only then; after the first rejected step the remaining steps are no-ops.
+// ref[0], ref[1] = bit patterns of the current / candidate norm (non-negative doubles order like their bit patterns; a NaN anywhere
+// gives a pattern above +inf, i.e. "worse"), ref[2] = {rejected steps, stop}, ref[3] = {accept, -}.
+__global__ __launch_bounds__(256) void k_absmax2(i64 m, const double *__restrict__ r1, const char *__restrict__ row_mask, i64 n, const double *__restrict__ r2,
+                                                 const char *__restrict__ col_mask, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[4];
+    unsigned long long v = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m + n; i += (i64)gridDim.x * blockDim.x) {
+        const bool row = i < m;
+        if (row ? (row_mask && row_mask[i] != 1) : (col_mask && !col_mask[i - m])) continue;      // sharded: owned rows / columns only
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(row ? r1[i] : r2[i - m]));
+        v = b > v ? b : v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o); v = w > v ? w : v; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) v = red[w] > v ? red[w] : v;
+        atomicMax(out, v);                           // a maximum: the order of the blocks does not matter
+    }
+}
+__global__ void k_refine_decide(unsigned long long *ref) {
+    int *st = reinterpret_cast<int *>(ref + 2);
+    const bool accept = !st[1] && ref[1] < ref[0];
+    st[2] = accept ? 1 : 0;
+    if (accept) ref[0] = ref[1];
+    else if (!st[1]) { st[0] += 1; st[1] = 1; }
+    ref[1] = 0;
+}
+// candidate <- x + correction (kept beside x until the verdict)
+__global__ void k_candidate(i64 n, const double *__restrict__ x, double *__restrict__ cx, i64 m, const double *__restrict__ y, double *__restrict__ cy) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cx[i] = x[i] + cx[i];
+    if (i < m) cy[i] = y[i] + cy[i];
+}
+__global__ void k_refine_commit(i64 n, double *__restrict__ x, const double *__restrict__ cx, i64 m, double *__restrict__ y, const double *__restrict__ cy,
+                                const unsigned long long *__restrict__ ref) {
+    if (!reinterpret_cast<const int *>(ref + 2)[2]) return;
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = cx[i];
+    if (i < m) y[i] = cy[i];
+}
+
 // out = own + src[0] + src[1] + ... (fixed order): the root-panel / root-rhs reduction of the multi-device mode.
 // NOT in place: the ranks copy the result out of `out` at their own pace while the lead already factorises / solves
 // its own copy.
@@ -2593,6 +2639,20 @@ void launch_publish(hipStream_t st, const DevArrays &a, const double *dx, double
 void launch_axpy2(hipStream_t st, i64 n, double *x, const double *dxc, i64 m, double *y, const double *dyc) {
     const i64 len = std::max(n, m);
     if (len > 0) hipLaunchKernelGGL(k_axpy2, dim3(nblk(len, 256)), dim3(256), 0, st, n, x, dxc, m, y, dyc);
+}
+void launch_absmax2(hipStream_t st, const DevArrays &a, const double *r1, const double *r2, unsigned long long *out, int owned_only) {
+    const i64 len = a.m + a.n;
+    if (len > 0) hipLaunchKernelGGL(k_absmax2, dim3((unsigned)std::min<i64>(nblk(len, 256), 1024)), dim3(256), 0, st, a.m, r1, owned_only ? a.row_local : nullptr,
+                                    a.n, r2, owned_only ? a.col_local : nullptr, out);
+}
+void launch_refine_decide(hipStream_t st, unsigned long long *ref) { hipLaunchKernelGGL(k_refine_decide, dim3(1), dim3(1), 0, st, ref); }
+void launch_candidate(hipStream_t st, i64 n, const double *x, double *cx, i64 m, const double *y, double *cy) {
+    const i64 len = std::max(n, m);
+    if (len > 0) hipLaunchKernelGGL(k_candidate, dim3(nblk(len, 256)), dim3(256), 0, st, n, x, cx, m, y, cy);
+}
+void launch_refine_commit(hipStream_t st, i64 n, double *x, const double *cx, i64 m, double *y, const double *cy, const unsigned long long *ref) {
+    const i64 len = std::max(n, m);
+    if (len > 0) hipLaunchKernelGGL(k_refine_commit, dim3(nblk(len, 256)), dim3(256), 0, st, n, x, cx, m, y, cy, ref);
 }
 void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx, int local_only) {
     if (a.n > 0) hipLaunchKernelGGL(k_dx, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, D, dy, xi_d, a.col_local, dx, local_only);

@@ -1266,13 +1266,14 @@ static void build_schedule(Symbolic &S) {
     }
     auto in_scope = [&](i32 s) { return S.front_local[s] && !S.front_single[s] && (cur_g < 0 || S.front_group[s] == cur_g); };
     // structural-zero flags of a 128-row operand window [r0, r0 + TILE) of front s, one byte per K slab (step 13c), built on first use
-    std::vector<std::vector<std::pair<i32, std::vector<char>>>> win_cache(S.fronts.size());
+    // (node-based map: the address of a flag vector stays valid while others are added -- a tile looks up two windows and keeps both pointers)
+    std::vector<std::unordered_map<i32, std::vector<char>>> win_cache(S.fronts.size());
     // TLPK_SKIP_WIN (experiment): the window of rows a skip decision looks at, 128 (a tile's own rows) | 256 | 512: with a coarser window the tiles of a
     // super-tile skip the SAME slabs and keep walking K side by side (their operand loads meet in L2), at the price of fewer skipped slabs
     static const i32 skip_win = [] { const char *e = std::getenv("TLPK_SKIP_WIN"); const int v = e ? std::atoi(e) : TILE; return (v == 256 || v == 512) ? v : TILE; }();
     auto window_flags = [&](i32 s, i32 r0) -> const char * {            // r0 = first row of a tile (NOT always a multiple of TILE: the tiles of U start at row ns)
         auto &lst = win_cache[(size_t)s];
-        for (auto &e : lst) if (e.first == r0) return e.second.data();
+        { const auto it = lst.find(r0); if (it != lst.end()) return it->second.data(); }
         const FrontDesc &w = S.fronts[s];
         const i64 nsl = (w.ns + 15) / 16, W = ((w.f + 15) / 16 + 63) / 64;
         const uint64_t *bits = S.skip_bits.data() + S.skip_off[(size_t)s];
@@ -1287,8 +1288,7 @@ static void build_schedule(Symbolic &S) {
             for (i32 g = g0; g <= g1 && !any; ++g) any = (char)((b[g >> 6] >> (g & 63)) & 1);
             fl[(size_t)k] = any;
         }
-        lst.emplace_back(r0, std::move(fl));
-        return lst.back().second.data();
+        return lst.emplace(r0, std::move(fl)).first->second.data();
     };
     auto push_launch = [&](std::vector<Launch> &L, i32 kind, i64 first, i64 count) {
         if (count > 0) L.push_back(Launch{kind, cur_g, first, count, cur_side, 0});

@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cstdio>
@@ -25,6 +26,7 @@
 #include "../../include/tlpk.h"
 #include "tlpk_device.hpp"
 #include "tlpk_handle.hpp"
+#include "hostcopy.hpp"
 
 using namespace tlpk;
 
@@ -274,7 +276,9 @@ int upload_all(tlpk_handle *h) {
             }
             colptr[(size_t)S.m] = cnt;
             if (cnt != d.n_asm) { h->last_error = "assembly list: column pointers do not match the compacted entries"; return TLPK_INTERNAL; }
-            UP(d.asm_colptr, colptr); UP(d.asm_target_small, tsmall);
+            bool any_fa = false;
+            for (char f : S.front_fa) any_fa |= (f != 0);
+            if (any_fa) { UP(d.asm_colptr, colptr); UP(d.asm_target_small, tsmall); }      // k_front_assemble is off by default: no second copy of the target list then
             // step 13d: which entries belong to an upper front (assembled on a stream of their own)
             std::vector<unsigned char> up((size_t)d.n_asm, 0);
             bool any = false;
@@ -288,6 +292,7 @@ int upload_all(tlpk_handle *h) {
         // so the pair arrays are already compact and in the same order.
         (void)all_local;
         UP(d.asm_target, tgt); UP(d.asm_diag, diag); UP(d.asm_ptr, ptr);
+        if (!d.asm_target_small) d.asm_target_small = d.asm_target;
         UP(d.pair_w, S.pair_w); UP(d.pair_j, S.pair_j);
         if (np != (i64)S.pair_w.size()) { h->last_error = "assembly list compaction mismatch"; return TLPK_INTERNAL; }
     }
@@ -328,7 +333,7 @@ int upload_all(tlpk_handle *h) {
     // that reaches a result, but never uninitialised either)
     HIPCHK(h, hipMemset(h->d_theta, 0, (size_t)nn * 8)); HIPCHK(h, hipMemset(h->d_regP, 0, (size_t)nn * 8)); HIPCHK(h, hipMemset(h->d_xid, 0, (size_t)nn * 8));
     HIPCHK(h, hipMemset(h->d_regD, 0, (size_t)std::max<i64>(S.m, 1) * 8)); HIPCHK(h, hipMemset(h->d_xip, 0, (size_t)std::max<i64>(S.m, 1) * 8));
-    if (h->refine_steps > 0) { AL(h->d_r1, S.m); AL(h->d_r2, nn); AL(h->d_cx, nn); AL(h->d_cy, S.m); }
+    if (h->refine_steps > 0) { AL(h->d_r1, S.m); AL(h->d_r2, nn); AL(h->d_cx, nn); AL(h->d_cy, S.m); AL(h->d_ref, 4); }
     d.ctx.csign = nullptr;
     d.ctx.small_full = std::getenv("TLPK_SMALL_FULL") ? std::atoi(std::getenv("TLPK_SMALL_FULL")) : 0;
     d.ctx.upd_remap = 2;
@@ -448,6 +453,8 @@ int tlpk_device_count(void) {
     return n;
 }
 
+int tlpk_host_copy_threads(void) { return host_copy_threads(); }
+
 // tlpk_create in two steps (tlpk_create_multi runs the first one once for all shards and the second per device):
 //   create_host   : options -> handle, block detection, host analyse (or: copy of an analysed Symbolic + this rank's part)
 //   create_device : streams / events, memory gate, upload
@@ -549,8 +556,11 @@ static int create_device(tlpk_handle *h, const tlpk_options &def) {
             const double need = 8.0 * ((double)h->S.lval_len + (double)h->S.ubuf_len[0] + (double)h->S.ubuf_len[1] +
                                        (double)h->S.spart_len + (double)h->S.dinv_len + (double)h->S.uc_len +
                                        (double)h->S.gth_ptr.size() + (double)h->S.gth_src.size()) +
-                                12.0 * (double)h->S.pair_w.size() + 20.0 * (double)h->S.nnzS + 40.0 * (double)h->S.nnzA +
-                                8.0 * (double)h->S.rowidx.size();
+                                12.0 * (double)h->S.pair_w.size() + 21.0 * (double)h->S.nnzS + 40.0 * (double)h->S.nnzA +
+                                8.0 * (double)h->S.rowidx.size() +
+                                (double)sizeof(UpdateTask) * (double)(h->S.update_tasks.size() + h->S.reduce_tasks.size()) +
+                                (double)sizeof(EaTask) * (double)h->S.ea_tasks.size() + (double)sizeof(TrsmTask) * (double)h->S.trsm_tasks.size() +
+                                4.0 * (double)h->S.upd_seg.size() + 32.0 * (double)h->S.m;
             if (need > budget) {
                 h->last_error = "factor needs " + std::to_string(need / 1e9) + " GB, budget " + std::to_string(budget / 1e9) + " GB";
                 if (h->S.system == 0 && !h->S.Ap.empty()) {
@@ -628,6 +638,7 @@ void tlpk_destroy(tlpk_handle *h) {
         if (h->h_info) hipHostFree(h->h_info);
         if (h->pin_in) hipHostFree(h->pin_in);
         if (h->pin_out) hipHostFree(h->pin_out);
+        for (hipEvent_t e : h->io_events) hipEventDestroy(e);
         for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
@@ -840,10 +851,10 @@ int tlpk_update_device(tlpk_handle *h, const double *d_theta, const double *d_re
     return update_finish_wait(h);
 }
 
-// Host-pointer entry points: the caller's vectors are ordinary pageable memory (Julia arrays).  They go
-// through pinned staging buffers owned by the handle: vector k+1 is copied into the staging area by the
-// CPU while vector k travels over PCIe (hipMemcpyAsync from pageable memory is synchronous and runs at
-// a fraction of the link rate).  Nothing of the caller's is referenced after the call returns.
+// Host-pointer entry points: the caller's vectors are ordinary pageable memory (Julia arrays, KKT.jl:83,100).  They go through pinned
+// staging buffers owned by the handle, in pieces handled by a small pool of host threads (hostcopy.hpp): a piece is copied into the staging
+// area and its hipMemcpyAsync issued by the same thread, so the link works from the first piece on (round 4: one thread, whole vectors,
+// 13 - 19 GB/s end to end).  Nothing of the caller's is referenced after the call returns.
 static int ensure_pinned(tlpk_handle *h) {
     if (h->pin_in) return TLPK_OK;
     const size_t nin = (size_t)std::max<i64>(2 * user_n(h) + user_m(h), 1), nout = (size_t)std::max<i64>(user_n(h) + user_m(h), 1);
@@ -851,6 +862,72 @@ static int ensure_pinned(tlpk_handle *h) {
     HIPCHK(h, hipHostMalloc((void **)&h->pin_out, nout * 8, hipHostMallocDefault));
     return TLPK_OK;
 }
+
+namespace {
+struct HostVec { double *dev; double *host; i64 count; };        // one vector of a host-pointer call (host: source or destination)
+struct IoPiece { double *dev, *pin, *host; i64 cnt; };
+// pieces of <= ~512 KB, at most ~32 per call (a piece costs one hipMemcpyAsync and, on the way out, one event)
+void io_pieces(double *pin, const HostVec *v, int nv, std::vector<IoPiece> &out) {
+    i64 total = 0;
+    for (int k = 0; k < nv; ++k) total += v[k].count;
+    const i64 piece = std::max<i64>(65536, ((total + 31) / 32 + 8191) / 8192 * 8192);
+    out.clear();
+    i64 off = 0;
+    for (int k = 0; k < nv; ++k) {
+        for (i64 o = 0; o < v[k].count; o += piece) out.push_back(IoPiece{v[k].dev + o, pin + off + o, v[k].host + o, std::min(piece, v[k].count - o)});
+        off += v[k].count;
+    }
+}
+// host -> staging -> device, all vectors of a call; returns when every copy has been ENQUEUED on the handle's stream
+int stage_in(tlpk_handle *h, const HostVec *v, int nv) {
+    std::vector<IoPiece> pcs; io_pieces(h->pin_in, v, nv, pcs);
+    std::atomic<int> err{(int)hipSuccess};
+    const int dev = h->device; hipStream_t st = h->stream;
+    host_parallel_for((int)pcs.size(), [&](int i) {
+        const IoPiece &p = pcs[(size_t)i];
+        copy_to_staging(p.pin, p.host, (size_t)p.cnt * 8);
+        hipError_t e = hipSetDevice(dev);                        // (per thread; a no-op after the first piece)
+        if (e == hipSuccess) e = hipMemcpyAsync(p.dev, p.pin, (size_t)p.cnt * 8, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) err.store((int)e);
+    });
+    if (err.load() != (int)hipSuccess) return hip_fail(h, (hipError_t)err.load(), "staged host-to-device copy");
+    return TLPK_OK;
+}
+// device -> staging -> host: every piece's copy is followed by an event; the pool copies a piece out as soon as its event has fired,
+// while the later pieces are still on the link
+int stage_out(tlpk_handle *h, const HostVec *v, int nv) {
+    std::vector<IoPiece> pcs; io_pieces(h->pin_out, v, nv, pcs);
+    while (h->io_events.size() < pcs.size()) {
+        hipEvent_t e = nullptr;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->io_events.push_back(e);
+    }
+    for (size_t i = 0; i < pcs.size(); ++i) {
+        HIPCHK(h, hipMemcpyAsync(pcs[i].pin, pcs[i].dev, (size_t)pcs[i].cnt * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipEventRecord(h->io_events[i], h->stream));
+    }
+    std::atomic<int> err{(int)hipSuccess};
+    const int dev = h->device;
+    host_parallel_for((int)pcs.size(), [&](int i) {
+        const IoPiece &p = pcs[(size_t)i];
+        hipError_t e = hipSetDevice(dev);
+        if (e == hipSuccess) e = hipEventSynchronize(h->io_events[(size_t)i]);
+        if (e != hipSuccess) { err.store((int)e); return; }
+        std::memcpy(p.host, p.pin, (size_t)p.cnt * 8);
+    });
+    if (err.load() != (int)hipSuccess) return hip_fail(h, (hipError_t)err.load(), "staged device-to-host copy");
+    return TLPK_OK;
+}
+// blocking parallel copy between two host buffers (multi-device mode: the job-wide vectors into / out of the lead's staging area)
+void host_copy(double *dst, const double *src, i64 count, bool to_staging) {
+    const i64 piece = std::max<i64>(65536, ((count + 31) / 32 + 8191) / 8192 * 8192);
+    const int np = (int)((count + piece - 1) / piece);
+    host_parallel_for(np, [&](int i) {
+        const i64 o = (i64)i * piece, c = std::min(piece, count - o);
+        if (to_staging) copy_to_staging(dst + o, src + o, (size_t)c * 8); else std::memcpy(dst + o, src + o, (size_t)c * 8);
+    });
+}
+}  // namespace
 
 int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
     if (!h || !theta || !regP || !regD) return TLPK_BADARG;
@@ -861,13 +938,8 @@ int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const d
     if (int rc = ensure_pinned(h)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));          // the staging area may still feed an earlier call's copies
     const i64 un = user_n(h), um = user_m(h);
-    double *p0 = h->pin_in, *p1 = p0 + un, *p2 = p1 + un;
-    std::memcpy(p0, theta, (size_t)un * 8);
-    HIPCHK(h, hipMemcpyAsync(h->d_theta, p0, (size_t)un * 8, hipMemcpyHostToDevice, h->stream));
-    std::memcpy(p1, regP, (size_t)un * 8);
-    HIPCHK(h, hipMemcpyAsync(h->d_regP, p1, (size_t)un * 8, hipMemcpyHostToDevice, h->stream));
-    std::memcpy(p2, regD, (size_t)um * 8);
-    HIPCHK(h, hipMemcpyAsync(h->d_regD, p2, (size_t)um * 8, hipMemcpyHostToDevice, h->stream));
+    const HostVec in[3] = {{h->d_theta, const_cast<double *>(theta), un}, {h->d_regP, const_cast<double *>(regP), un}, {h->d_regD, const_cast<double *>(regD), um}};
+    if (int rc = stage_in(h, in, 3)) return rc;
     return tlpk_update_device(h, h->d_theta, h->d_regP, h->d_regD);
 }
 
@@ -967,14 +1039,29 @@ int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     if (rc != TLPK_OK) return rc;
     if (!whole) rc = tlpk_solve_finish(h, d_dx, d_dy, d_xid);
     // optional iterative refinement on the residuals of the augmented system (KKT.jl:70-75): each step is one more solve with
-    // (r1, r2) as right-hand side, its result added to (dx, dy).  Off by default = the reference (spd.jl:68).
-    for (int it = 0; it < h->refine_steps && rc == TLPK_OK; ++it) {
+    // (r1, r2) as right-hand side.  Off by default = the reference (spd.jl:68).  GUARDED (round 5): the candidate x + c is kept only if
+    // max(|r1|inf, |r2|inf) shrinks -- decided on the device, no host synchronisation; a rejected step ends the refinement of this solve
+    // (tlpk_stats.refine_rejected).  On the north-star LP's late iterations an unguarded second step grew the dual residual from 2e-8 to 0.6
+    // (profiles/r04_mpc_levers.txt): an option that exists must not make a solve worse.
+    if (h->refine_steps > 0 && rc == TLPK_OK) {
+        HIPCHK(h, hipMemsetAsync(h->d_ref, 0, 4 * sizeof(unsigned long long), h->stream));
         launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, d_dx, d_dy, h->d_r1, h->d_r2, 0);
+        launch_absmax2(h->stream, h->d, h->d_r1, h->d_r2, h->d_ref + 0);
+    }
+    for (int it = 0; it < h->refine_steps && rc == TLPK_OK; ++it) {
         rc = whole ? solve_whole(h, h->d_cx, h->d_cy, h->d_r1, h->d_r2) : tlpk_solve_local(h, h->d_r1, h->d_r2);
         if (rc == TLPK_OK && !whole) rc = tlpk_solve_finish(h, h->d_cx, h->d_cy, h->d_r2);
-        if (rc == TLPK_OK) launch_axpy2(h->stream, h->S.n, d_dx, h->d_cx, h->S.m, d_dy, h->d_cy);
+        if (rc != TLPK_OK) break;
+        launch_candidate(h->stream, h->S.n, d_dx, h->d_cx, h->S.m, d_dy, h->d_cy);
+        // residuals of the candidate: the next step's right-hand side if the candidate is kept (after a rejection nothing is kept any more)
+        launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, h->d_cx, h->d_cy, h->d_r1, h->d_r2, 0);
+        launch_absmax2(h->stream, h->d, h->d_r1, h->d_r2, h->d_ref + 1);
+        launch_refine_decide(h->stream, h->d_ref);
+        launch_refine_commit(h->stream, h->S.n, d_dx, h->d_cx, h->S.m, d_dy, h->d_cy, h->d_ref);
         HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     }
+    if (h->refine_steps > 0 && rc == TLPK_OK)
+        HIPCHK(h, hipMemcpyAsync(h->h_info + 2, reinterpret_cast<int *>(h->d_ref + 2), sizeof(int), hipMemcpyDeviceToHost, h->stream));
     return rc;
 }
 
@@ -991,6 +1078,7 @@ static int refine_buffers(tlpk_handle *h) {
     if ((rc = dev_alloc(h, &h->d_r1, mm)) != TLPK_OK) return rc;
     if ((rc = dev_alloc(h, &h->d_r2, nn)) != TLPK_OK) return rc;
     if ((rc = dev_alloc(h, &h->d_cx, nn)) != TLPK_OK) return rc;
+    if ((rc = dev_alloc(h, &h->d_ref, 4)) != TLPK_OK) return rc;
     return dev_alloc(h, &h->d_cy, mm);
 }
 int tlpk_refine_local(tlpk_handle *h, const double *d_dx, const double *d_dy, const double *d_xip, const double *d_xid) {
@@ -1159,6 +1247,7 @@ int tlpk_sync(tlpk_handle *h) {
     }
     (void)hipGetLastError();
     prof_collect(h);
+    if (h->refine_steps > 0) h->refine_rejected = h->h_info[2];
     if (h->h_info[1] != 0) {
         h->last_error = "a solve sweep gave up waiting for a block hand-over (internal scheduling error); results are invalid";
         return TLPK_INTERNAL;
@@ -1178,21 +1267,15 @@ int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const
     if (int rc = ensure_pinned(h)) return rc;
     const i64 un = user_n(h), um = user_m(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    double *pi0 = h->pin_in, *pi1 = pi0 + um;
-    std::memcpy(pi0, xi_p, (size_t)um * 8);
-    HIPCHK(h, hipMemcpyAsync(h->d_xip, pi0, (size_t)um * 8, hipMemcpyHostToDevice, h->stream));
-    std::memcpy(pi1, xi_d, (size_t)un * 8);
-    HIPCHK(h, hipMemcpyAsync(h->d_xid, pi1, (size_t)un * 8, hipMemcpyHostToDevice, h->stream));
+    const HostVec in[2] = {{h->d_xip, const_cast<double *>(xi_p), um}, {h->d_xid, const_cast<double *>(xi_d), un}};
+    if (int rc = stage_in(h, in, 2)) return rc;
     int rc = tlpk_solve_device(h, h->d_dx, h->d_dy, h->d_xip, h->d_xid);
     if (rc != TLPK_OK) return rc;
-    double *po0 = h->pin_out, *po1 = po0 + um;
-    HIPCHK(h, hipMemcpyAsync(po0, h->d_dy, (size_t)um * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(po1, h->d_dx, (size_t)un * 8, hipMemcpyDeviceToHost, h->stream));
-    rc = tlpk_sync(h);
-    if (rc != TLPK_OK) return rc;
-    std::memcpy(dy, po0, (size_t)um * 8);
-    std::memcpy(dx, po1, (size_t)un * 8);
-    return TLPK_OK;
+    // dy is final before k_dx starts: its pieces go first
+    const HostVec out[2] = {{h->d_dy, dy, um}, {h->d_dx, dx, un}};
+    rc = stage_out(h, out, 2);
+    const int src = tlpk_sync(h);                          // status words (a sweep that gave up waiting), timers; the stream is idle by now
+    return rc != TLPK_OK ? rc : src;
 }
 
 // ---- single-process multi-device mode (block-angular LPs; SURVEY.md 8e "one-process-8-devices") ----
@@ -1271,7 +1354,8 @@ int multi_allreduce_rs(tlpk_handle *h, int which) {
         if (r == 0) cnt = cr; else if (cr != cnt) { h->last_error = "root buffers of the ranks differ"; return TLPK_INTERNAL; }
     }
     if (cnt == 0) return TLPK_OK;
-    const i64 sl = std::min<i64>(h->rs_slice, ((cnt + N - 1) / N + 15) / 16 * 16);      // slice length: multiples of 16 doubles
+    const i64 sl = ((cnt + N - 1) / N + 15) / 16 * 16;                                   // slice length: multiples of 16 doubles
+    if (sl > h->rs_slice) { h->last_error = "reduce-scatter: buffer larger than the staging slices sized at create"; return TLPK_INTERNAL; }
     auto lo = [&](int r) { return std::min<i64>(cnt, (i64)r * sl); };
     auto len = [&](int r) { return std::min<i64>(cnt, (i64)(r + 1) * sl) - lo(r); };
     for (int s_ = 0; s_ < N; ++s_) {                    // scatter: shard s sends slice r of its buffer to shard r
@@ -1341,6 +1425,73 @@ int multi_allreduce(tlpk_handle *h, int which) {
     return TLPK_OK;
 }
 
+
+// Guarded refinement on a multi-device handle (round 5).  max(|r1|inf, |r2|inf) of the augmented system's residuals for shard-resident
+// solutions: every shard forms the residuals of the rows / columns it owns and its PARTIAL sums on the linking rows (same convention as the
+// right-hand side of the solve: `all_ranks` = every shard's xi_p counts there, otherwise rank 0's only); the owned maxima are reduced on the
+// devices, the linking rows are summed on the host in shard order.  Host-synchronised: refinement is an off-by-default option.
+int refine_buffers_multi(tlpk_handle *c) {
+    if (int rc = refine_buffers(c)) return rc;
+    if (c->d_bx) return TLPK_OK;
+    if (int rc = dev_alloc(c, &c->d_bx, std::max<i64>(c->S.n, 1))) return rc;
+    return dev_alloc(c, &c->d_by, std::max<i64>(c->S.m, 1));
+}
+int multi_resid_norm(tlpk_handle *h, double *const *dx, double *const *dy, const double *const *xip, const double *const *xid, bool all_ranks, double *out) {
+    const int N = (int)h->sub.size();
+    for (int r = 0; r < N; ++r) {
+        tlpk_handle *c = h->sub[(size_t)r];
+        HIPCHK(h, hipSetDevice(c->device));
+        if (int rc = refine_buffers_multi(c)) { h->last_error = c->last_error; return rc; }
+        HIPCHK(h, hipMemsetAsync(c->d_ref, 0, 4 * sizeof(unsigned long long), c->stream));
+        launch_residuals(c->stream, c->d, xip[r], xid[r], c->d_theta, c->d_regP, c->d_regD, dx[r], dy[r], c->d_r1, c->d_r2, all_ranks ? 0 : c->opt.rank);
+        launch_absmax2(c->stream, c->d, c->d_r1, c->d_r2, c->d_ref, 1);
+    }
+    double nrm = 0.0;
+    std::vector<double> link, part;
+    for (int r = 0; r < N; ++r) {
+        tlpk_handle *c = h->sub[(size_t)r];
+        HIPCHK(h, hipSetDevice(c->device));
+        HIPCHK(h, hipStreamSynchronize(c->stream));
+        unsigned long long bits = 0;
+        HIPCHK(h, hipMemcpy(&bits, c->d_ref, sizeof(bits), hipMemcpyDeviceToHost));
+        double v; std::memcpy(&v, &bits, sizeof(v));
+        if (!(v <= nrm)) nrm = v;                                  // (a NaN pattern propagates)
+        const i64 span = c->link_hi - c->link_lo;
+        if (span > 0) {
+            part.resize((size_t)span);
+            HIPCHK(h, hipMemcpy(part.data(), c->d_r1 + c->link_lo, (size_t)span * 8, hipMemcpyDeviceToHost));
+            if (link.empty()) link.assign((size_t)span, 0.0);
+            for (i64 i = 0; i < span; ++i) if (c->S.row_local[(size_t)(c->link_lo + i)] == 2) link[(size_t)i] += part[(size_t)i];
+        }
+    }
+    for (double v : link) { const double a = std::fabs(v); if (!(a <= nrm)) nrm = a; }
+    HIPCHK(h, hipSetDevice(h->sub[0]->device));
+    *out = nrm;
+    return TLPK_OK;
+}
+// one guarded step: backup, step(), verdict; *stop = the step was rejected (the iterate is restored)
+int multi_guarded_step(tlpk_handle *h, double *const *dx, double *const *dy, const double *const *xip, const double *const *xid, bool all_ranks,
+                       double *norm, bool *stop, const std::function<int()> &step) {
+    for (size_t r = 0; r < h->sub.size(); ++r) {
+        tlpk_handle *c = h->sub[r];
+        HIPCHK(h, hipSetDevice(c->device));
+        HIPCHK(h, hipMemcpyAsync(c->d_bx, dx[r], (size_t)c->S.n * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(h, hipMemcpyAsync(c->d_by, dy[r], (size_t)c->S.m * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (int rc = step()) return rc;
+    double after = 0.0;
+    if (int rc = multi_resid_norm(h, dx, dy, xip, xid, all_ranks, &after)) return rc;
+    if (after < *norm) { *norm = after; *stop = false; return TLPK_OK; }
+    for (size_t r = 0; r < h->sub.size(); ++r) {
+        tlpk_handle *c = h->sub[r];
+        HIPCHK(h, hipSetDevice(c->device));
+        HIPCHK(h, hipMemcpyAsync(dx[r], c->d_bx, (size_t)c->S.n * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(h, hipMemcpyAsync(dy[r], c->d_by, (size_t)c->S.m * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    h->refine_rejected += 1; *stop = true;
+    return TLPK_OK;
+}
+
 // host -> device copy of the entries [lo, hi) of a pinned full-length vector (device arrays are full length too)
 inline hipError_t upload_range(double *dst, const double *src, i64 lo, i64 hi, hipStream_t st) {
     return hi > lo ? hipMemcpyAsync(dst + lo, src + lo, (size_t)(hi - lo) * 8, hipMemcpyHostToDevice, st) : hipSuccess;
@@ -1374,7 +1525,7 @@ int multi_update(tlpk_handle *h, const double *theta, const double *regP, const 
     if (int rc = ensure_pinned(lead)) { h->last_error = lead->last_error; return rc; }
     for (tlpk_handle *c : h->sub) { HIPCHK(h, hipSetDevice(c->device)); HIPCHK(h, hipStreamSynchronize(c->stream)); }   // staging area free again
     double *p0 = lead->pin_in, *p1 = p0 + n, *p2 = p1 + n;
-    std::memcpy(p0, theta, (size_t)n * 8); std::memcpy(p1, regP, (size_t)n * 8); std::memcpy(p2, regD, (size_t)m * 8);
+    host_copy(p0, theta, n, true); host_copy(p1, regP, n, true); host_copy(p2, regD, m, true);
     if (int rc = for_shards(h, [&](tlpk_handle *c, int) -> int {
             // only what this shard reads: its columns of theta / regP, its block rows and the linking rows of regD
             HIPCHK(c, upload_range(c->d_theta, p0, c->col_lo, c->col_hi, c->stream));
@@ -1394,7 +1545,7 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
     if (int rc = ensure_pinned(lead)) { h->last_error = lead->last_error; return rc; }
     for (tlpk_handle *c : h->sub) { HIPCHK(h, hipSetDevice(c->device)); HIPCHK(h, hipStreamSynchronize(c->stream)); }
     double *pi0 = lead->pin_in, *pi1 = pi0 + m;
-    std::memcpy(pi0, xi_p, (size_t)m * 8); std::memcpy(pi1, xi_d, (size_t)n * 8);
+    host_copy(pi0, xi_p, m, true); host_copy(pi1, xi_d, n, true);
     if (int rc = for_shards(h, [&](tlpk_handle *c, int) -> int {
             HIPCHK(c, upload_range(c->d_xip, pi0, c->row_lo, c->row_hi, c->stream));
             HIPCHK(c, upload_range(c->d_xip, pi0, c->link_lo, c->link_hi, c->stream));
@@ -1411,15 +1562,26 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
             const int rc = tlpk_solve_finish(c, c->d_dx, c->d_dy, c->d_xid);
             if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
         }
-        for (int it = 0; it < h->refine_steps; ++it) {
-            for (tlpk_handle *c : h->sub) {
-                const int rc = tlpk_refine_local(c, c->d_dx, c->d_dy, c->d_xip, c->d_xid);
-                if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
-            }
-            if (int rc = multi_allreduce(h, 1)) return rc;
-            for (tlpk_handle *c : h->sub) {
-                const int rc = tlpk_refine_finish(c, c->d_dx, c->d_dy);
-                if (rc != TLPK_OK) { h->last_error = c->last_error; return rc; }
+        {
+            const int N = (int)h->sub.size();
+            double *dxs[MAX_DEVICES], *dys[MAX_DEVICES]; const double *xps[MAX_DEVICES], *xds[MAX_DEVICES];
+            for (int r = 0; r < N; ++r) { tlpk_handle *c = h->sub[(size_t)r]; dxs[r] = c->d_dx; dys[r] = c->d_dy; xps[r] = c->d_xip; xds[r] = c->d_xid; }
+            double norm = 0.0; bool stop = false;
+            h->refine_rejected = 0;
+            if (int rc = multi_resid_norm(h, dxs, dys, xps, xds, false, &norm)) return rc;
+            for (int it = 0; it < h->refine_steps && !stop; ++it) {
+                if (int rc = multi_guarded_step(h, dxs, dys, xps, xds, false, &norm, &stop, [&]() -> int {
+                        for (tlpk_handle *c : h->sub) {
+                            const int q = tlpk_refine_local(c, c->d_dx, c->d_dy, c->d_xip, c->d_xid);
+                            if (q != TLPK_OK) { h->last_error = c->last_error; return q; }
+                        }
+                        if (int q = multi_allreduce(h, 1)) return q;
+                        for (tlpk_handle *c : h->sub) {
+                            const int q = tlpk_refine_finish(c, c->d_dx, c->d_dy);
+                            if (q != TLPK_OK) { h->last_error = c->last_error; return q; }
+                        }
+                        return TLPK_OK;
+                    })) return rc;
             }
         }
         // the lead's own last kernels still read-modify-write ITS rank-local dx / dy (= the job-wide vectors): peers publish after them
@@ -1448,7 +1610,7 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
     int worst = TLPK_OK;
     for (tlpk_handle *c : h->sub) { const int rc = tlpk_sync(c); if (rc != TLPK_OK) { h->last_error = c->last_error; worst = rc; } }
     if (worst != TLPK_OK) return worst;
-    std::memcpy(dy, po0, (size_t)m * 8); std::memcpy(dx, po1, (size_t)n * 8);
+    host_copy(dy, po0, m, false); host_copy(dx, po1, n, false);
     return TLPK_OK;
 }
 
@@ -1505,15 +1667,22 @@ int multi_solve_resident(tlpk_handle *h, double *const *dx, double *const *dy, c
     // iterative refinement (Backend(ngpus = N, refine = k) under the device-resident loops; round-3 advisor finding: only the host-pointer
     // tlpk_solve refined): one more split solve per step on the residuals every shard forms for the rows / columns it owns -- with the SAME
     // convention as the solve above, every shard's xi_p counting on the linking rows
-    for (int it = 0; it < h->refine_steps; ++it) {
-        if (int rc = for_shards(h, [&](tlpk_handle *c, int r) {
-                c->rhs_all_ranks = true;
-                const int q = tlpk_refine_local(c, dx[r], dy[r], xip[r], xid[r]);
-                c->rhs_all_ranks = false;
-                return q;
-            })) return rc;
-        if (int rc = multi_allreduce(h, 1)) return rc;
-        if (int rc = for_shards(h, [&](tlpk_handle *c, int r) { return tlpk_refine_finish(c, dx[r], dy[r]); })) return rc;
+    if (h->refine_steps > 0) {
+        double norm = 0.0; bool stop = false;
+        h->refine_rejected = 0;
+        if (int rc = multi_resid_norm(h, dx, dy, xip, xid, true, &norm)) return rc;
+        for (int it = 0; it < h->refine_steps && !stop; ++it) {
+            if (int rc = multi_guarded_step(h, dx, dy, xip, xid, true, &norm, &stop, [&]() -> int {
+                    if (int q = for_shards(h, [&](tlpk_handle *c, int r) {
+                            c->rhs_all_ranks = true;
+                            const int q2 = tlpk_refine_local(c, dx[r], dy[r], xip[r], xid[r]);
+                            c->rhs_all_ranks = false;
+                            return q2;
+                        })) return q;
+                    if (int q = multi_allreduce(h, 1)) return q;
+                    return for_shards(h, [&](tlpk_handle *c, int r) { return tlpk_refine_finish(c, dx[r], dy[r]); });
+                })) return rc;
+        }
     }
     return TLPK_OK;
 }
@@ -1632,11 +1801,15 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
                 e = hipMalloc(&q, (size_t)std::max<i64>((i64)(ngpus - 1) * h->rs_slice, 1) * 8);
                 if (e == hipSuccess) { h->sub[r]->rs_stage = (double *)q; h->sub[r]->allocs.push_back(q); }
             }
-            for (int t = 0; t < ngpus && e == hipSuccess; ++t)                     // every shard stores into every other shard's buffers
+            // reduce-scatter + all-gather: every shard copies into every other shard's staging / root buffers.  hipMemcpyPeerAsync needs no peer
+            // mapping, but a mapped peer lets the copy engine go straight over the link; a pair that cannot be mapped (a node without full
+            // connectivity) is NOT an error: the reduction falls back to gather-to-lead, which only needs the rank-to-lead mappings checked
+            // below (round-4 advisor finding: the all-pairs requirement made creates fail that worked in round 3).
+            for (int t = 0; t < ngpus && e == hipSuccess && h->multi_mode == 1; ++t)
                 if (h->sub[t]->device != h->sub[r]->device) {
                     const hipError_t pe = hipDeviceEnablePeerAccess(h->sub[t]->device, 0);
-                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) e = pe;
                     (void)hipGetLastError();
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) h->multi_mode = 0;
                 }
         }
         for (int r = 1; r < ngpus && e == hipSuccess; ++r) {
@@ -1685,6 +1858,7 @@ int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
         for (const tlpk_handle *c : h->sub) { bytes += c->device_bytes; nloc += c->S.n_local_blocks; }
         out->device_bytes = bytes; out->n_local_blocks = nloc;
         out->ms_analyse = h->ms_analyse; out->ms_last_update = h->ms_update; out->ms_enqueue_update = h->ms_enqueue_update;
+        out->refine_rejected = h->refine_rejected;
         return rc;
     }
     const Symbolic &S = h->S;
@@ -1703,6 +1877,7 @@ int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
     out->n_local_blocks = S.n_local_blocks; out->n_blocks = S.nblocks;
     out->flops_update = S.flops_update;
     out->flops_update_alg = S.flops_update_alg;
+    out->refine_rejected = h->refine_rejected;
     out->root_panel_len = (S.root_front >= 0) ? pk_len(S.fronts[S.root_front].lda, S.fronts[S.root_front].ns) : 0;
     return TLPK_OK;
 }

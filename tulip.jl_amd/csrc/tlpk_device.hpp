@@ -84,6 +84,11 @@ void launch_residuals(hipStream_t st, const DevArrays &a, const double *xi_p, co
                       const double *regD, const double *dx, const double *dy, double *r1, double *r2, int rank);
 void launch_publish(hipStream_t st, const DevArrays &a, const double *dx, double *dx_job, const double *dy, double *dy_job);
 void launch_axpy2(hipStream_t st, i64 n, double *x, const double *dxc, i64 m, double *y, const double *dyc);
+// guarded refinement (kernels.hip: k_absmax2 ...): max-norm of (r1, r2) into *out (bit pattern, atomicMax: zero it first), verdict, candidate, commit
+void launch_absmax2(hipStream_t st, const DevArrays &a, const double *r1, const double *r2, unsigned long long *out, int owned_only = 0);
+void launch_refine_decide(hipStream_t st, unsigned long long *ref);
+void launch_candidate(hipStream_t st, i64 n, const double *x, double *cx, i64 m, const double *y, double *cy);
+void launch_refine_commit(hipStream_t st, i64 n, double *x, const double *cx, i64 m, double *y, const double *cy, const unsigned long long *ref);
 void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx, int local_only = 0);
 void launch_sum_to(hipStream_t st, i64 len, double *out, const double *own, const double *src, int nsrc, i64 stride);
 void launch_sum_ranked(hipStream_t st, i64 len, double *inout, const double *stage, int nranks, int own_rank, i64 stride);

@@ -47,8 +47,12 @@ struct tlpk_handle {
     double *d_xip = nullptr, *d_xid = nullptr, *d_dx = nullptr, *d_dy = nullptr;
     int refine_steps = 0;                         // tlpk_options.refine_steps
     double *d_r1 = nullptr, *d_r2 = nullptr, *d_cx = nullptr, *d_cy = nullptr;   // refinement: residuals and correction
+    unsigned long long *d_ref = nullptr;          // guarded refinement: norms and verdict words (kernels.hip: k_refine_decide)
+    i64 refine_rejected = 0;                      // refinement steps of the last solve that did not shrink the residual and were discarded
+    double *d_bx = nullptr, *d_by = nullptr;      // multi-device refinement: the iterate before a step (restored if the step is rejected)
     int *h_info = nullptr;
     double *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-pointer entry points (lazily allocated)
+    std::vector<hipEvent_t> io_events;              // one per device-to-host piece of tlpk_solve (tlpk_api.cpp: stage_out)
     bool factored = false, local_done = false, solve_local_done = false, solve_timed = false, refine_pending = false, pair_pending = false;
     i64 fail_col = -1;
     double ms_analyse = 0, ms_update = 0, ms_solve = 0;
