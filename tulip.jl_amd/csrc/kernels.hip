@@ -1506,14 +1506,16 @@ __global__ __launch_bounds__(256) void k_rhs(i64 m, const i32 *__restrict__ perm
                       const char *__restrict__ col_local, int rank, double *__restrict__ xw) {
     // 8 lanes per row (LP rows are short: a wave per row left 7/8 of the lanes idle; a long linking
     // row just takes more trips); fixed shuffle-tree reduction inside the 8-lane group
+    // Tp / Tj / Tx: the CSR copy with rows in PERMUTED order (tlpk_api.cpp: upload_all) -- row ii is contiguous with row ii + 1
     const i64 ii = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     const int lane = threadIdx.x & 7;
     const bool live = ii < m;
+    const i64 q0 = live ? Tp[ii] : 0, q1 = live ? Tp[ii + 1] : 0;
     const i32 i = live ? perm[ii] : 0;
     const char rl = live ? row_local[i] : 0;
     double s = 0.0;
     if (rl != 0) {
-        for (i64 q = Tp[i] + lane; q < Tp[i + 1]; q += 8) s += Tx[q] * D[Tj[q]];      // D = the pre-scaled vector w (k_rhs_scale)
+        for (i64 q = q0 + lane; q < q1; q += 8) s += Tx[q] * D[Tj[q]];      // D = the pre-scaled vector w (k_rhs_scale)
     }
 #pragma unroll
     for (int off = 4; off > 0; off >>= 1) s += __shfl_down(s, off, 8);
@@ -2605,7 +2607,7 @@ void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const doubl
     {
         double *w = a.rhs_w + (rhs ? a.n : 0);
         if (a.n > 0) hipLaunchKernelGGL(k_rhs_scale, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, D, xi_d, a.col_local, w);
-        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Tp, a.Tj, a.Tx, w, xi_p, xi_d,
+        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Pp, a.Pj, a.Px, w, xi_p, xi_d,
                            a.row_local, a.col_local, rank, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
     }
 }

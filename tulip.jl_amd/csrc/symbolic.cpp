@@ -1572,7 +1572,21 @@ static void build_schedule(Symbolic &S) {
         // MEASURED (profiles/r04_lookahead.txt) and OFF by default (TLPK_LOOKAHEAD=1 turns it on): pds-class LP 18.86 -> 18.5 ms per step -- split-K had already
         // cut the long-K diagonal update to ~0.1 ms and the chain is the potrf kernel itself (7.8 of 13.8 ms) --, C4 / north-star LP unchanged, and the C3
         // shape LOSES 11 % (675 -> 750 ms: inside its 16-wide macro columns the look-ahead tiles are a second long-K tail in every rows-below launch).
-        static const bool lookahead = [] { const char *e = std::getenv("TLPK_LOOKAHEAD"); return e && std::atoi(e) != 0; }();
+        // Round 5: AUTO (TLPK_LOOKAHEAD unset) turns it on for the levels it was measured to help -- at most 16 of this rank's fronts have more than
+        // one block column and none has more than 12 288 pivot columns (a pds-class top front, the root front, the few blocks of a rank of an
+        // 8-GPU job; not the C3 shape's 48 000-column front, not the 32 blocks per stream group of config C4 at N = 1, whose diagonal-block chains
+        // are hidden behind the bulk updates anyway).  The rule looks at the rank's fronts of the level only, never at the stream groups.
+        const int la_env = [] { const char *e = std::getenv("TLPK_LOOKAHEAD"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
+        bool lookahead = la_env == 1;
+        if (la_env < 0) {
+            i32 nbig = 0, ns_max = 0;
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 sf = S.level_fronts[t];
+                if (!S.front_local[sf] || S.front_single[sf]) continue;
+                if (S.fronts[sf].ns > NB_OUT) { ++nbig; ns_max = std::max(ns_max, S.fronts[sf].ns); }
+            }
+            lookahead = nbig >= 1 && nbig <= 16 && ns_max <= 12288;
+        }
         for (i32 io = 0; io <= nouter; ++io) {
             const i32 ko = io * NB_OUT;
             const i32 io_macro = mac_first[(size_t)io], G = mac_G[(size_t)io];
@@ -1786,7 +1800,14 @@ static void build_schedule(Symbolic &S) {
             push_launch(S.fwd_launches, LK_FWD_UPDATE, f_upd, (i64)S.fwd_update_tasks.size() - f_upd);
         }
     };
-    for (cur_g = 0; cur_g < S.ngroups; ++cur_g)
+    // One solve schedule for all stream groups (round 5, default; TLPK_SOLVE_ONE_GROUP=0 restores one schedule per group).  The stream groups exist
+    // for the factorisation, whose launches leave tails that a second group fills.  The solve's big launches are the persistent, ticketed sweeps:
+    // one of them fills the chip, and a second group's leaf-level launches then crawl beside the first group's sweep -- in the paired solve the two
+    // groups' forward sweeps ran one after the other (629 + 650 us, profiles/r04_solve_timeline.txt).  With scope -1 a level's launch holds the
+    // fronts of every group and runs on the main stream; per-item arithmetic is unchanged (bit-identical results).
+    const bool solve_one_group = [&] { const char *e = std::getenv("TLPK_SOLVE_ONE_GROUP"); return S.ngroups >= 2 && (!e || std::atoi(e) != 0); }();
+    cur_g = solve_one_group ? -1 : 0;
+    for (; cur_g < (solve_one_group ? 0 : S.ngroups); ++cur_g)
         for (i32 d = S.nlevels - 1; d >= 1; --d) fwd_level(d);
     cur_g = -1;
     if (S.nlevels > 0) fwd_level(0);
@@ -1854,7 +1875,8 @@ static void build_schedule(Symbolic &S) {
     };
     cur_g = -1;
     if (S.nlevels > 0) bwd_level(0);
-    for (cur_g = 0; cur_g < S.ngroups; ++cur_g)
+    cur_g = solve_one_group ? -1 : 0;
+    for (; cur_g < (solve_one_group ? 0 : S.ngroups); ++cur_g)
         for (i32 d = 1; d < S.nlevels; ++d) bwd_level(d);
     spt.mark(nullptr);
 }

@@ -45,6 +45,7 @@ struct DevArrays {
     i64 *Ap = nullptr; i32 *Ai = nullptr; double *Ax = nullptr;
     i64 *Tp = nullptr; i32 *Tj = nullptr; double *Tx = nullptr;
     i32 *perm = nullptr;
+    i64 *Pp = nullptr; i32 *Pj = nullptr; double *Px = nullptr;   // K1: CSR of A with the rows in permuted order (k_rhs)
     double *rhs_w = nullptr;                  // D .* xi_d of the current solve (k_rhs_scale)
     i32 *zero_tasks = nullptr; i64 n_zero_tasks = 0;   // (front, c0) pairs of k_zero_panels
     i64 n_zero_lower = 0;                              // the first n_zero_lower pairs: fronts that are not `upper` (symbolic.cpp step 13d)
