@@ -101,6 +101,70 @@ def host_info():
     return os.cpu_count() or 1, model
 
 
+def scipy_splu_block(args, A, row_block, th, rp, rd, xp):
+    """an independent third-party sparse direct solver on ONE diagonal block of the LP -- SciPy's SuperLU,
+    `splu(S_k, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0, options={"SymmetricMode": True})` + `lu.solve`, one thread (SuperLU is
+    sequential) -- as a cross-check of fill (lu.L.nnz against nnz(L) of the same block under this library's AMD ordering) and of time."""
+    try:
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+        import tulip_jl_amd as tk
+        rows = np.nonzero(row_block == 0)[0]
+        Ak = A.tocsr()[rows].tocsc()
+        used = np.nonzero(np.diff(Ak.indptr) > 0)[0]
+        Ak = Ak[:, used].tocsc(); Ak.sort_indices()
+        D = 1.0 / (th[used] + rp[used])
+        S = (Ak @ sp.diags(D) @ Ak.T + sp.diags(rd[rows])).tocsc()
+        t0 = time.perf_counter()
+        lu = spla.splu(S, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options={"SymmetricMode": True})
+        t_f = time.perf_counter() - t0
+        b = xp[rows]
+        t0 = time.perf_counter()
+        for _ in range(args.solves):
+            y = lu.solve(b)
+        t_s = time.perf_counter() - t0
+        mine = tk.setup(Ak, tk.K1(), tk.Backend(device=-1)).stats()
+        nb = int(row_block.max()) + 1
+        return {"solver": "scipy.sparse.linalg.splu (SuperLU, MMD_AT_PLUS_A, SymmetricMode, diag_pivot_thresh=0), 1 thread",
+                "sample": "diagonal block 0 of %d: %d rows x %d columns" % (nb, Ak.shape[0], Ak.shape[1]),
+                "nnzL_superlu": int(lu.L.nnz), "nnzL_this_library_amd": int(mine["nnzL"]),
+                "fill_ratio_superlu_over_this": float(lu.L.nnz) / max(mine["nnzL"], 1),
+                "seconds_factor": t_f, "seconds_solves": t_s, "ms_per_step_one_block": 1e3 * (t_f + t_s),
+                "ms_per_step_all_blocks_extrapolated": 1e3 * (t_f + t_s) * nb,
+                "residual_inf": float(np.abs(S @ y - b).max())}
+    except Exception as e:       # the third-party point must never cost the comparator
+        return {"error": repr(e)}
+
+
+def reference_probe(args, A, th, rp, rd, xp, xd):
+    """BASELINE.md B4 / SURVEY.md 8(d): the real reference (Tulip.jl + CHOLMOD) if a `julia` with Tulip.jl installed is on the PATH
+    (tools/reference_cpu_bench.jl on the dumped matrices); otherwise the line says why it was not run."""
+    import shutil
+    import subprocess
+    import tempfile
+    jl = shutil.which("julia")
+    if not jl:
+        return "not run: julia absent (no `julia` on PATH in this image; Tulip's CHOLMOD path cannot be timed here, BASELINE.md section 2)"
+    try:
+        r = subprocess.run([jl, "-e", "import Tulip"], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return "not run: julia present (%s) but Tulip.jl is not installed and there is no network" % jl
+        with tempfile.TemporaryDirectory() as d:
+            m, n = A.shape
+            np.array([m, n, A.nnz], dtype=np.int64).tofile(os.path.join(d, "dims.i64"))
+            (A.indptr.astype(np.int64) + 1).tofile(os.path.join(d, "colptr.i64"))
+            (A.indices.astype(np.int64) + 1).tofile(os.path.join(d, "rowval.i64"))
+            A.data.astype(np.float64).tofile(os.path.join(d, "nzval.f64"))
+            for name, v in (("theta", th), ("regP", rp), ("regD", rd), ("xip", xp), ("xid", xd)):
+                np.ascontiguousarray(v, dtype=np.float64).tofile(os.path.join(d, name + ".f64"))
+            r = subprocess.run([jl, "-t", "auto", os.path.join(ROOT, "tools", "reference_cpu_bench.jl"), d, str(args.solves)],
+                               capture_output=True, text=True, timeout=1800)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            return json.loads(lines[-1]) if (r.returncode == 0 and lines) else "julia run failed: " + (r.stderr or "")[-300:]
+    except Exception as e:
+        return "julia probe failed: " + repr(e)
+
+
 def cpu_baseline(args, A, row_block, nblocks_total):
     """CHOLMOD-class CPU path on the host cores of this box: supernodal multifrontal Cholesky on
     OpenBLAS, OpenMP over the elimination tree (oracle/k1_supernodal.c, all cores), same ordering and
@@ -141,6 +205,14 @@ def cpu_baseline(args, A, row_block, nblocks_total):
     r_p = float(np.abs(A @ dx + rd * dy - xp).max()); r_d = float(np.abs(-dx * (th + rp) + A.T @ dy - xd).max())
     t = (t_upd + t_sol) / frac
     st = full.stats()
+    third = None
+    if row_block is not None and not args.no_third_party:
+        third = scipy_splu_block(args, A, row_block, th, rp, rd, xp)
+    ref = reference_probe(args, A, th, rp, rd, xp, xd)
+    return {"third_party": third, "reference_cpu": ref, **_cpu_dict(args, t, t_upd, t_sol, frac, st, sn, cores, model, r_p, r_d)}
+
+
+def _cpu_dict(args, t, t_upd, t_sol, frac, st, sn, cores, model, r_p, r_d):
     return {"value": 1.0 / t, "unit": "iter/s", "cores": sn.threads, "kind": "port",
             "sample": ("whole LP" if frac == 1.0 else f"leading diagonal blocks + linking rows = {frac:.3f} of the LP's factor flops, time scaled by 1/{frac:.3f}")
                       + f": 1 update {t_upd:.2f} s + {args.solves} solves {t_sol:.2f} s on {sn.threads} threads "
@@ -194,6 +266,8 @@ def cpu_baseline_subprocess(args, workload=None):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload or args.workload,
            "--solves", str(args.solves), "--blocks", str(args.blocks), "--mk", str(args.mk), "--nk", str(args.nk),
            "--m0", str(args.m0), "--nnz-col", str(args.nnz_col), "--regime", args.regime, "--cpu-seconds", str(args.cpu_seconds)]
+    if args.no_third_party or (workload or args.workload) != "c4":
+        cmd.append("--no-third-party")
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -27,6 +27,10 @@ def test_bench_line_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the timed region is run `--repeats` (3) times: ms_per_step is the median run, all runs are in the line
+    runs = d["ms_per_step_runs"]
+    assert len(runs) == 3 and min(runs) == d["ms_per_step_min"] and max(runs) == d["ms_per_step_max"] and sorted(runs)[1] == pytest.approx(d["ms_per_step"], rel=1e-3)
+    assert d["host_abi"]["copy_threads"] >= 1 and d["host_abi"]["steps"] >= 2
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-9 * d["value"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -46,6 +50,11 @@ def test_bench_cpu_baseline_leg():
         assert k in c, (k, c)
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"] and c["value"] > 0
     assert max(c["residual_inf"]) <= 1e-6                                  # the comparator solved the same system
+    # BASELINE.md B2 (SciPy splu on one diagonal block: fill within a few per cent of this library's AMD ordering) and the B4 probe
+    t = c["third_party"]
+    assert "error" not in t, t
+    assert 0.7 < t["fill_ratio_superlu_over_this"] < 1.4 and t["seconds_factor"] > 0 and t["residual_inf"] <= 1e-6
+    assert isinstance(c["reference_cpu"], (str, dict)) and (isinstance(c["reference_cpu"], dict) or "julia" in c["reference_cpu"])
 
 
 @pytest.mark.gpu

@@ -1,14 +1,15 @@
 // potrf_wave_bench.hip -- the 64 x 64 diagonal-block factorisations of kernels.hip in isolation: NF independent dense fronts of order 64 (k_potrf) or 256
-// (k_potrf_wide), potrf_block (256 threads, one barrier per column) against potrf_block_wave (one wave, readlane broadcasts); -DPOTRF_TRACE adds
+// (k_potrf_wide), potrf_block (256 threads, one barrier per column) against potrf_block_wave (one wave, readlane broadcasts) and potrf_block_pair (round 5: one barrier per two columns, bit-identical to potrf_block); -DPOTRF_TRACE adds
 // 100 MHz phase stamps of the wave version.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPOTRF_TRACE -I tulip.jl_amd/csrc tools/potrf_wave_bench.hip -o tools/potrf_wave_bench
 #include "../tulip.jl_amd/csrc/kernels.hip"
 #include <cstdio>
 #include <cmath>
+#include <cstring>
 #include <vector>
 using namespace tlpk;
 
-template <bool WAVE>
+template <int MODE>
 static double run(int nf, int n, const std::vector<double> &A0, std::vector<double> &Lout, std::vector<unsigned long long> *stamps) {
     std::vector<FrontDesc> fr(nf);
     i64 loff = 0, doff = 0;
@@ -36,8 +37,8 @@ static double run(int nf, int n, const std::vector<double> &A0, std::vector<doub
         hipMemcpy(L, host.data(), 8 * loff, hipMemcpyHostToDevice);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        if (n <= 64) hipLaunchKernelGGL((k_potrf<false, WAVE>), dim3(nf), dim3(256), 0, 0, dt, c);
-        else hipLaunchKernelGGL((k_potrf_wide<false, WAVE>), dim3(nf), dim3(256), 0, 0, dt, c);
+        if (n <= 64) hipLaunchKernelGGL((k_potrf<false, MODE>), dim3(nf), dim3(256), 0, 0, dt, c);
+        else hipLaunchKernelGGL((k_potrf_wide<false, MODE>), dim3(nf), dim3(256), 0, 0, dt, c);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
     }
@@ -52,11 +53,12 @@ int main(int argc, char **argv) {
     std::vector<double> B((size_t)n * n), A((size_t)n * n);
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) B[i + (size_t)j * n] = std::sin(0.37 * i + 1.3 * j) + 0.01 * i - 0.02 * j;
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += B[i + (size_t)k * n] * B[j + (size_t)k * n]; A[i + (size_t)j * n] = s + (i == j ? n : 0.0); }
-    std::vector<double> L0, L1; std::vector<unsigned long long> st;
-    const double t0 = run<false>(nf, n, A, L0, nullptr), t1 = run<true>(nf, n, A, L1, &st);
-    double err = 0, mx = 0;
-    for (size_t i = 0; i < L0.size(); ++i) { err = std::fmax(err, std::fabs(L0[i] - L1[i])); mx = std::fmax(mx, std::fabs(L0[i])); }
-    printf("%d fronts of order %d: potrf_block %.1f us, potrf_block_wave %.1f us per launch; max |L0 - L1| = %.2e (max |L| %.2e)\n", nf, n, t0, t1, err, mx);
+    std::vector<double> L0, L1, L2; std::vector<unsigned long long> st;
+    const double t0 = run<0>(nf, n, A, L0, nullptr), t1 = run<1>(nf, n, A, L1, &st), t2 = run<2>(nf, n, A, L2, nullptr);
+    double err = 0, mx = 0; size_t ndiff = 0;
+    for (size_t i = 0; i < L0.size(); ++i) { err = std::fmax(err, std::fabs(L0[i] - L1[i])); mx = std::fmax(mx, std::fabs(L0[i])); ndiff += (std::memcmp(&L0[i], &L2[i], 8) != 0); }
+    printf("%d fronts of order %d: potrf_block %.1f us, potrf_block_wave %.1f us, potrf_block_pair %.1f us per launch; max |L0 - L_wave| = %.2e (max |L| %.2e); "
+           "entries of L_pair that differ from L0 in any bit: %zu of %zu\n", nf, n, t0, t1, t2, err, mx, ndiff, L0.size());
     printf("wave stamps (10 ns units, differences):");
     for (int i = 1; i < 32 && st[i]; ++i) printf(" %llu", st[i] - st[i - 1]);
     printf("\n");

@@ -493,6 +493,180 @@ __device__ __forceinline__ void potrf_block(const DevCtx &c, const FrontDesc &fd
 }
 
 // ------------------------------------------------------------------------------------------
+// potrf_block with ONE barrier per TWO columns (round 5).  profiles/r03_potrf_phases.txt: of the ~1050 cycles a column step of potrf_block
+// costs, ~485 are the LDS hand-over of the pivot column (write -> barrier -> read).  Here the owners publish the columns j and j + 1 (and the
+// rows j, j + 1 of the inverse) AS THEY ARE BEFORE STEP j, and every thread redoes locally what step j would have done to the entries of column
+// j + 1 it needs: its own row's A'[r][j+1] = fma(-l_rj, A[j+1][j], A[r][j+1]), the pivot A'[j+1][j+1], the multipliers' column
+// A'[col][j+1] for the columns it owns, and row j + 1 of the inverse -- exactly the expressions the owning threads evaluate in potrf_block,
+// on the same operands, so the factor and the inverse are BIT-IDENTICAL to potrf_block's (tools/potrf_wave_bench.hip asserts it; the numpy
+// model of the pair step: tools/potrf_pair_model.py).  The two broadcast columns are interleaved in LDS ({C0[i], C1[i]} adjacent: one
+// 16-byte read fetches a column entry of both), so a pair step issues no more LDS reads than two single steps.  An odd last column
+// (j + 1 == nb) runs the same code with the second step masked off.
+// ------------------------------------------------------------------------------------------
+constexpr int POTRF_PAIR_SCRATCH = NB_IN * (NB_IN + 1) + 8 * NB_IN + NB_IN;   // Ds | CB[2][64][2] | RB[2][64][2] | dg   (Ds starts 16-byte aligned, NB_IN (NB_IN + 1) is even)
+
+template <bool SIGNED = false>
+__device__ __forceinline__ void potrf_block_pair(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb,
+                                                 const i32 kprev, double *scratch) {
+    const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
+    double *Ds = scratch;                                   // NB_IN x (NB_IN + 1)
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    v2 (*CB)[NB_IN] = reinterpret_cast<v2 (*)[NB_IN]>(scratch + NB_IN * (NB_IN + 1));        // CB[pb][i] = {A[i][j], A[i][j+1]} before step j
+    v2 (*RB)[NB_IN] = CB + 2;                                                                   // RB[pb][col] = {W[j][col], W[j+1][col]}
+    double *dg = scratch + NB_IN * (NB_IN + 1) + 8 * NB_IN;
+    const i32 lda = pld(fd, bk0);
+    double *P = pcol(c, fd, bk0) + bk0;             // origin (bk0, bk0)
+    const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
+    const bool rok = r < nb;
+    double av[16], wv[16];
+    // left-looking prologue inside the block column: identical to potrf_block's
+    const i32 Kp = bk0 - kprev;
+    if (Kp > 0) {
+        const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+        v4f64 dacc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) dacc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        const i32 rrow = 16 * cg + lr;
+        const i32 rr_c = min(rrow, nb - 1);
+        i32 cr_c[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cr_c[a] = min(16 * a + lr, nb - 1);
+        for (i32 ks = 0; ks < Kp; ks += 16) {
+            double bq[4], aq[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double *Xc = pcol(c, fd, kprev + ks + 4 * u + lk) + bk0;
+                bq[u] = Xc[rr_c];
+                if (SIGNED) bq[u] *= sg[kprev + ks + 4 * u + lk];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) aq[u][a] = Xc[cr_c[a]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    dacc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[u][a], bq[u], dacc[a], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ds[(16 * a + lk + 4 * q) * (NB_IN + 1) + rrow] = dacc[a][q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const i32 col = cg + 4 * q;
+        const bool mine = rok && col < nb && r >= col;
+        const double pv = P[(i64)min(r, nb - 1) + (i64)min(col, nb - 1) * lda];
+        const double dv = (Kp > 0) ? Ds[col * (NB_IN + 1) + r] : 0.0;
+        av[q] = mine ? (pv - dv) : 0.0;
+        wv[q] = (r == col) ? 1.0 : 0.0;
+    }
+    // pivot of one column from its diagonal entry d (sign s): 1 / (signed pivot), column scale, sqrt|d| -- potrf_block's arithmetic
+    auto pivot = [&](double d, const double sj, const i32 j, double &inv2, double &isq, double &sq) {
+        if (!(sj * d > 0.0)) {
+            if (tid == 0) atomicMin(c.info, fd.col0 + bk0 + j);
+            d = sj;
+        }
+        if (SIGNED) d = fabs(d);
+        isq = __builtin_amdgcn_rsq(d);
+        isq = isq * (1.5 - 0.5 * d * isq * isq);
+        isq = isq * (1.5 - 0.5 * d * isq * isq);
+        sq = d * isq;
+        sq = fma(0.5 * isq, fma(-sq, sq, d), sq);
+        inv2 = SIGNED ? isq * isq * sj : isq * isq;
+        if (SIGNED) isq *= sj;
+    };
+#pragma unroll
+    for (int jq = 0; jq < 16; ++jq) {
+#pragma unroll 1
+        for (int jp = 0; jp < 2; ++jp) {
+            const int jj = 2 * jp;
+            const i32 j = 4 * jq + jj;
+            if (j >= nb) break;                                  // workgroup-uniform
+            const bool two = j + 1 < nb;                         // workgroup-uniform: the pair is complete
+            const int pb = jp;                                   // consecutive pair steps alternate between the two buffers
+            if (cg == jj) CB[pb][r].x = av[jq];                  // A[r][j]
+            if (cg == jj + 1) CB[pb][r].y = av[jq];              // A[r][j + 1], not yet updated by column j
+            if (r == j) {
+#pragma unroll
+                for (int q = 0; q <= jq; ++q) RB[pb][cg + 4 * q].x = wv[q];   // W[j][0 .. j]
+            }
+            if (r == j + 1) {
+#pragma unroll
+                for (int q = 0; q <= jq; ++q) RB[pb][cg + 4 * q].y = wv[q];   // W[j + 1][0 .. j + 1], not yet updated by step j
+            }
+            __syncthreads();
+            // every LDS read of the pair is issued here, before the pivot arithmetic
+            const v2 pj = CB[pb][j], pj1 = CB[pb][j + 1], pr = CB[pb][r];
+            v2 cv[16], rv[16];
+#pragma unroll
+            for (int q = jq; q < 16; ++q) cv[q] = CB[pb][cg + 4 * q];
+#pragma unroll
+            for (int q = 0; q <= jq; ++q) rv[q] = RB[pb][cg + 4 * q];
+            // ---- step j ----
+            double inv2_0, isq_0, sq_0;
+            pivot(pj.x, SIGNED ? sg[bk0 + j] : 1.0, j, inv2_0, isq_0, sq_0);
+            const double arj0 = (rok && r > j) ? pr.x * inv2_0 : 0.0;              // multiplier L~[r][j]
+            const double a10 = pj1.x;                                              // A[j + 1][j]
+            const double a0_j1 = two ? a10 * inv2_0 : 0.0;                         // multiplier of row j + 1 (row j + 1 < nb iff `two`)
+            // ---- what step j does to column j + 1 and to row j + 1 of the inverse, redone locally ----
+            const double d1 = fma(-a0_j1, a10, pj1.y);                             // A'[j + 1][j + 1]
+            const double c1r = fma(-arj0, a10, pr.y);                              // A'[r][j + 1] of this thread's row
+            // ---- step j + 1 ----
+            double inv2_1 = 0.0, isq_1 = 0.0, sq_1 = 0.0;
+            if (two) pivot(d1, SIGNED ? sg[bk0 + j + 1] : 1.0, j + 1, inv2_1, isq_1, sq_1);
+            const double arj1 = (two && rok && r > j + 1) ? c1r * inv2_1 : 0.0;    // multiplier L~[r][j + 1]
+            // A[r][col] -= l_rj A[col][j] + l_r,j+1 A'[col][j+1]   (col > j + 1), in potrf_block's order: step j first
+#pragma unroll
+            for (int q = jq + 1; q < 16; ++q) {
+                const i32 col = cg + 4 * q;
+                const double a0c = (col < nb) ? cv[q].x * inv2_0 : 0.0;            // multiplier of row `col` at step j (col > j here)
+                const double c1c = fma(-a0c, a10, cv[q].y);                        // A'[col][j + 1]
+                av[q] = fma(-arj1, c1c, fma(-arj0, cv[q].x, av[q]));
+            }
+            {
+                // register jq: columns 4 jq + cg.  cg <= jj: columns <= j, final or being finished (multipliers masked to 0, as in potrf_block);
+                // cg == jj + 1: column j + 1 itself receives step j; cg > jj + 1: both steps
+                const i32 col = cg + 4 * jq;
+                const double a0c = (col < nb && col > j) ? cv[jq].x * inv2_0 : 0.0;
+                const double c1c = fma(-a0c, a10, cv[jq].y);
+                av[jq] = fma(-((cg > jj) ? arj0 : 0.0), cv[jq].x, av[jq]);
+                av[jq] = fma(-((cg > jj + 1) ? arj1 : 0.0), c1c, av[jq]);
+            }
+            // W[r][c] -= l_rj W[j][c] + l_r,j+1 W'[j+1][c]
+#pragma unroll
+            for (int q = 0; q <= jq; ++q) {
+                const double r1c = fma(-a0_j1, rv[q].x, rv[q].y);                  // W'[j + 1][c]: row j + 1 after step j
+                wv[q] = fma(-arj1, r1c, fma(-arj0, rv[q].x, wv[q]));
+            }
+            if (cg == jj) av[jq] = (r == j) ? sq_0 : ((r > j) ? av[jq] * isq_0 : av[jq]);                       // finish column j
+            if (two && cg == jj + 1) av[jq] = (r == j + 1) ? sq_1 : ((r > j + 1) ? av[jq] * isq_1 : av[jq]);    // finish column j + 1
+        }
+    }
+    // diagonal of L for the row scaling of the inverse
+    if (rok && cg == (r & 3)) {
+        double v = 1.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v = (q == (r >> 2)) ? av[q] : v;
+        dg[r] = v;
+    }
+    __syncthreads();
+    double *W = front_dinv(c, fd, bk0);
+    if (rok) {
+        const double idg = 1.0 / dg[r];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const i32 col = cg + 4 * q;
+            if (col < nb) {
+                if (r >= col) P[(i64)r + (i64)col * lda] = av[q];
+                W[(i64)r + (i64)col * nb] = (r >= col) ? wv[q] * idg : 0.0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // potrf_block without a barrier per column (round 4; tools/potrf64_probe.hip, profiles/r03_potrf_phases.txt): the 64-column loop of potrf_block
 // costs ~1050 cycles per column, of which ~485 are the LDS hand-over of the pivot column (write -> barrier -> read) and ~280 the LDS
 // bandwidth of four waves' broadcast reads.  Here ONE wave factors the block: lane r owns row r, the block is walked in four 16-column
@@ -718,7 +892,7 @@ __device__ __forceinline__ void potrf_block_wave(const DevCtx &c, const FrontDes
 // through LDS.
 // ------------------------------------------------------------------------------------------
 constexpr int LDW = NB_IN + 16;                 // == 16 mod 32: conflict-free ds_read_b64
-static_assert(NB_IN * LDW >= POTRF_SCRATCH, "the trsm LDS block doubles as the potrf scratch");
+static_assert(NB_IN * LDW >= POTRF_SCRATCH && NB_IN * LDW >= POTRF_PAIR_SCRATCH, "the trsm LDS block doubles as the potrf scratch");
 
 // Pivot block of a small front (ns <= SMALL_NS), one WAVE per front, four fronts per workgroup: lane i
 // holds row i of the lower triangle and row i of an identity block in registers, pivots and pivot
@@ -909,30 +1083,34 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 // WAVE: the 64 x 64 diagonal blocks by potrf_block_wave (one wave, no barrier per column) instead of potrf_block (TLPK_POTRF_WAVE=0: the
 // round-1..3 kernels)
 static_assert(LDW_ == LDW, "potrf_block_wave: LDS stride");
-template <bool SIGNED, bool WAVE>
+// MODE: 0 = potrf_block (one barrier per column), 1 = potrf_block_wave, 2 = potrf_block_pair (one barrier per two columns; the default since round 5)
+template <bool SIGNED, int MODE>
+__device__ __forceinline__ void potrf_block_any(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb, const i32 kprev, double *scratch) {
+    if (MODE == 1) potrf_block_wave<SIGNED>(c, fd, bk0, nb, kprev, scratch);
+    else if (MODE == 2) potrf_block_pair<SIGNED>(c, fd, bk0, nb, kprev, scratch);
+    else potrf_block<SIGNED>(c, fd, bk0, nb, kprev, scratch);
+}
+template <bool SIGNED, int MODE>
 __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {      // t.nb <= NB_IN
-    __shared__ double scratch[WAVE ? POTRF_WAVE_LDS : POTRF_SCRATCH];
+    __shared__ __attribute__((aligned(16))) double scratch[MODE == 1 ? POTRF_WAVE_LDS : (MODE == 2 ? POTRF_PAIR_SCRATCH : POTRF_SCRATCH)];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    if (WAVE) potrf_block_wave<SIGNED>(c, fd, t.k0, t.nb, t.k0, scratch);
-    else potrf_block<SIGNED>(c, fd, t.k0, t.nb, t.k0, scratch);
+    potrf_block_any<SIGNED, MODE>(c, fd, t.k0, t.nb, t.k0, scratch);
 }
-template <bool SIGNED, bool WAVE>
+template <bool SIGNED, int MODE>
 __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restrict__ tasks, DevCtx c) {
-    __shared__ double Ws[WAVE ? POTRF_WAVE_LDS : NB_IN * LDW];
+    __shared__ __attribute__((aligned(16))) double Ws[MODE == 1 ? POTRF_WAVE_LDS : NB_IN * LDW];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
-    if (WAVE) potrf_block_wave<SIGNED>(c, fd, k0, min(w, NB_IN), k0, Ws);
-    else potrf_block<SIGNED>(c, fd, k0, min(w, NB_IN), k0, Ws);
+    potrf_block_any<SIGNED, MODE>(c, fd, k0, min(w, NB_IN), k0, Ws);
     for (i32 ks = k0; ks + NB_IN < kend; ks += NB_IN) {          // step ks is factored: rows below, next diagonal block
         for (i32 r0 = ks + NB_IN; r0 < kend; r0 += NB_IN) {
             __syncthreads();                                     // own global stores visible, Ws free
             trsm_rows<SIGNED>(c, fd, ks, NB_IN, r0, kend, k0, Ws);
         }
         __syncthreads();
-        if (WAVE) potrf_block_wave<SIGNED>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
-        else potrf_block<SIGNED>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
+        potrf_block_any<SIGNED, MODE>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
     }
 }
 
@@ -2554,12 +2732,18 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
                            a.pair_w, a.pair_j, a.asm_D, a.asm_regD);
         break;
     case LK_POTRF: case LK_POTRF_WIDE: {
-        static const bool wv = [] { const char *e = std::getenv("TLPK_POTRF_WAVE"); return e && std::atoi(e) != 0; }();     // off: measured slower, see potrf_block_wave
-#define TLPK_LAUNCH_P(KERNEL) do { if (sgn) { if (wv) hipLaunchKernelGGL((KERNEL<true, true>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
-                                              else hipLaunchKernelGGL((KERNEL<true, false>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); } \
-                                    else { if (wv) hipLaunchKernelGGL((KERNEL<false, true>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
-                                           else hipLaunchKernelGGL((KERNEL<false, false>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); } } while (0)
+        // 64 x 64 diagonal-block kernel: 2 = potrf_block_pair (one barrier per two columns; bit-identical to 0, the default since round 5),
+        // 0 = potrf_block (TLPK_POTRF_PAIR=0), 1 = potrf_block_wave (TLPK_POTRF_WAVE=1; measured slower, see there)
+        static const int pm = [] {
+            const char *w = std::getenv("TLPK_POTRF_WAVE"); if (w && std::atoi(w) != 0) return 1;
+            const char *e = std::getenv("TLPK_POTRF_PAIR"); return (e && std::atoi(e) == 0) ? 0 : 2;
+        }();
+#define TLPK_LAUNCH_PM(KERNEL, SG) do { if (pm == 1) hipLaunchKernelGGL((KERNEL<SG, 1>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
+                                        else if (pm == 2) hipLaunchKernelGGL((KERNEL<SG, 2>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
+                                        else hipLaunchKernelGGL((KERNEL<SG, 0>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); } while (0)
+#define TLPK_LAUNCH_P(KERNEL) do { if (sgn) TLPK_LAUNCH_PM(KERNEL, true); else TLPK_LAUNCH_PM(KERNEL, false); } while (0)
         if (L.kind == LK_POTRF) TLPK_LAUNCH_P(k_potrf); else TLPK_LAUNCH_P(k_potrf_wide);
+#undef TLPK_LAUNCH_PM
 #undef TLPK_LAUNCH_P
         break;
     }
