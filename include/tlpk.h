@@ -100,8 +100,8 @@ typedef struct tlpk_stats {
                                   true column counts l_j (no amalgamation zeros); <= flops_chol, <= flops_update */
     double  ms_enqueue_update; /* multi-device handles: host time from the entry of the last tlpk_update until the work of EVERY shard
                                   (root fronts included) was enqueued; ms_last_update is then the wall time of the whole call */
-    int64_t refine_rejected;   /* refine_steps > 0: refinement steps of the last completed solve that did NOT shrink max(|r1|inf, |r2|inf) and were
-                                  discarded (a rejected step ends the refinement of that solve); valid after tlpk_sync / a blocking solve */
+    int64_t refine_rejected;   /* refine_steps > 0: refinement steps of the last completed solve that did NOT shrink |r1|inf, or lifted |r2|inf beyond 16 x its
+                                  value after the unrefined solve, and were discarded (a rejected step ends the refinement of that solve); valid after tlpk_sync / a blocking solve */
 } tlpk_stats;
 
 /* per-kernel-class timing, filled when options.profile = 1 */

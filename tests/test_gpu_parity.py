@@ -963,8 +963,8 @@ def test_host_pointer_calls_equal_device_pointer_calls_bitwise(threads, monkeypa
 
 @pytest.mark.gpu
 def test_guarded_refinement_never_increases_the_residual():
-    """Round 5: a refinement step is kept only if it shrinks max(|r1|inf, |r2|inf) of the augmented system (decided on the device; the
-    reference has no refinement, spd.jl:68).  Invariant on data far beyond what an interior-point run produces (theta over 30 decades,
+    """Round 5: a refinement step is kept only if it shrinks |r1|inf and leaves |r2|inf within 16 x of the unrefined solve's (decided on the
+    device; the reference has no refinement, spd.jl:68).  Invariant on data far beyond what an interior-point run produces (theta over 30 decades,
     regularisations at 1e-10: factors that are nearly useless as preconditioners): with any number of steps the residual norm is never
     above the unrefined one, tlpk_stats.refine_rejected counts the discarded steps (at most one per solve: a rejection ends the
     refinement), and a multi-device handle obeys the same rule."""
@@ -990,18 +990,18 @@ def test_guarded_refinement_never_increases_the_residual():
                 rej = kkt.stats()["refine_rejected"]
                 assert 0 <= rej <= (1 if steps else 0), (steps, rej)
                 seen_reject |= rej > 0
-                norms[(steps, multi)] = max(kkt_residuals(A, th, rp, rd, xp, xd, dx, dy))
+                norms[(steps, multi)] = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
                 kkt.close()
             if norms is None:
                 break
         if norms is None:
             continue
-        print("guarded refinement, theta over 10^+-%d: residual max-norms %s" % (span, {k: float("%.2e" % v) for k, v in norms.items()}))
+        print("guarded refinement, theta over 10^+-%d: (|r1|, |r2|) %s" % (span, {k: tuple(float("%.2e" % x) for x in v) for k, v in norms.items()}))
         for multi in (False, True):
             base = norms[(0, multi)]
             for (steps, mm), v in norms.items():
                 if mm == multi and steps > 0:
                     # (the host evaluates the residuals in another summation order than the device kernels: with theta * dx terms of 1e15 the
                     # two evaluations of a residual at rounding level differ by a factor of order one -- the guard is against growth by decades)
-                    assert v <= 2.0 * base or not np.isfinite(base), (span, steps, multi, v, base)
+                    assert not np.isfinite(base[0]) or (v[0] <= 2.0 * base[0] and v[1] <= 64.0 * max(base[1], 1e-300)), (span, steps, multi, v, base)
     print("guarded refinement: a step was rejected in at least one trial:", seen_reject)

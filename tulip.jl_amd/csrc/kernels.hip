@@ -2576,37 +2576,46 @@ __global__ void k_axpy2(i64 n, double *__restrict__ x, const double *__restrict_
     if (i < m) y[i] += dyc[i];
 }
 
-// Guarded refinement (round 5).  A refinement step is kept only if it shrinks max(|r1|inf, |r2|inf): the candidate x + c is formed beside x,
-// its residuals are computed (they are the next step's right-hand side if the step is kept), the two norms are compared ON THE DEVICE
-// (no host synchronisation inside a solve) and x is overwritten only then; after the first rejected step the remaining steps are no-ops.
-// ref[0], ref[1] = bit patterns of the current / candidate norm (non-negative doubles order like their bit patterns; a NaN anywhere
-// gives a pattern above +inf, i.e. "worse"), ref[2] = {rejected steps, stop}, ref[3] = {accept, -}.
+// Guarded refinement (round 5).  The unrefined normal-equations solve leaves r2 = xi_d + (theta + Rp) dx - A' dy at ROUNDING level by construction
+// (dx is computed from dy) and all of its error in r1 = xi_p - A dx - Rd dy; the interior-point loops rely on that structure (a dual residual
+// that a solve introduces is never removed again).  A refinement step is therefore kept only if it SHRINKS |r1|inf and leaves |r2|inf within
+// 16 x of the unrefined solve's: the candidate x + c is formed beside x, its residuals are computed (they are the next step's right-hand side
+// if the step is kept), the verdict is reached ON THE DEVICE (no host synchronisation inside a solve) and x is overwritten only then; after
+// the first rejected step the remaining steps of the solve are no-ops.  (First version of the guard, same round: "max(|r1|, |r2|) must shrink"
+// -- MPC on the north-star LP still ended with a dual residual of 0.2: steps that traded r1 for r2 passed.  gpurun_out session A.)
+// ref[0] = |r1| of the current iterate, ref[1] = |r2| of the UNREFINED solve, ref[2], ref[3] = |r1|, |r2| of the candidate -- bit patterns of
+// non-negative doubles (they order like the doubles; a NaN anywhere gives a pattern above +inf, i.e. "worse"); ref[4] = {rejected steps, stop},
+// ref[5] = {accept, -}.
 __global__ __launch_bounds__(256) void k_absmax2(i64 m, const double *__restrict__ r1, const char *__restrict__ row_mask, i64 n, const double *__restrict__ r2,
                                                  const char *__restrict__ col_mask, unsigned long long *__restrict__ out) {
-    __shared__ unsigned long long red[4];
-    unsigned long long v = 0;
+    __shared__ unsigned long long red[2][4];
+    unsigned long long v1 = 0, v2 = 0;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < m + n; i += (i64)gridDim.x * blockDim.x) {
         const bool row = i < m;
         if (row ? (row_mask && row_mask[i] != 1) : (col_mask && !col_mask[i - m])) continue;      // sharded: owned rows / columns only
         const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(row ? r1[i] : r2[i - m]));
-        v = b > v ? b : v;
+        if (row) v1 = b > v1 ? b : v1; else v2 = b > v2 ? b : v2;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o); v = w > v ? w : v; }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long w1 = __shfl_xor(v1, o), w2 = __shfl_xor(v2, o);
+        v1 = w1 > v1 ? w1 : v1; v2 = w2 > v2 ? w2 : v2;
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = v1; red[1][threadIdx.x >> 6] = v2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) v = red[w] > v ? red[w] : v;
-        atomicMax(out, v);                           // a maximum: the order of the blocks does not matter
+        for (int w = 1; w < 4; ++w) { v1 = red[0][w] > v1 ? red[0][w] : v1; v2 = red[1][w] > v2 ? red[1][w] : v2; }
+        atomicMax(out, v1); atomicMax(out + 1, v2);       // maxima: the order of the blocks does not matter
     }
 }
 __global__ void k_refine_decide(unsigned long long *ref) {
-    int *st = reinterpret_cast<int *>(ref + 2);
-    const bool accept = !st[1] && ref[1] < ref[0];
+    int *st = reinterpret_cast<int *>(ref + 4);
+    const double r2_ref = __longlong_as_double((long long)ref[1]), r2_new = __longlong_as_double((long long)ref[3]);
+    const bool accept = !st[1] && ref[2] < ref[0] && r2_new <= 16.0 * r2_ref;
     st[2] = accept ? 1 : 0;
-    if (accept) ref[0] = ref[1];
+    if (accept) ref[0] = ref[2];
     else if (!st[1]) { st[0] += 1; st[1] = 1; }
-    ref[1] = 0;
+    ref[2] = 0; ref[3] = 0;
 }
 // candidate <- x + correction (kept beside x until the verdict)
 __global__ void k_candidate(i64 n, const double *__restrict__ x, double *__restrict__ cx, i64 m, const double *__restrict__ y, double *__restrict__ cy) {
@@ -2616,7 +2625,7 @@ __global__ void k_candidate(i64 n, const double *__restrict__ x, double *__restr
 }
 __global__ void k_refine_commit(i64 n, double *__restrict__ x, const double *__restrict__ cx, i64 m, double *__restrict__ y, const double *__restrict__ cy,
                                 const unsigned long long *__restrict__ ref) {
-    if (!reinterpret_cast<const int *>(ref + 2)[2]) return;
+    if (!reinterpret_cast<const int *>(ref + 4)[2]) return;
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = cx[i];
     if (i < m) y[i] = cy[i];

@@ -347,7 +347,7 @@ int upload_all(tlpk_handle *h) {
     // that reaches a result, but never uninitialised either)
     HIPCHK(h, hipMemset(h->d_theta, 0, (size_t)nn * 8)); HIPCHK(h, hipMemset(h->d_regP, 0, (size_t)nn * 8)); HIPCHK(h, hipMemset(h->d_xid, 0, (size_t)nn * 8));
     HIPCHK(h, hipMemset(h->d_regD, 0, (size_t)std::max<i64>(S.m, 1) * 8)); HIPCHK(h, hipMemset(h->d_xip, 0, (size_t)std::max<i64>(S.m, 1) * 8));
-    if (h->refine_steps > 0) { AL(h->d_r1, S.m); AL(h->d_r2, nn); AL(h->d_cx, nn); AL(h->d_cy, S.m); AL(h->d_ref, 4); }
+    if (h->refine_steps > 0) { AL(h->d_r1, S.m); AL(h->d_r2, nn); AL(h->d_cx, nn); AL(h->d_cy, S.m); AL(h->d_ref, 8); }
     d.ctx.csign = nullptr;
     d.ctx.small_full = std::getenv("TLPK_SMALL_FULL") ? std::atoi(std::getenv("TLPK_SMALL_FULL")) : 0;
     d.ctx.upd_remap = 2;
@@ -878,6 +878,7 @@ static int ensure_pinned(tlpk_handle *h) {
 }
 
 namespace {
+double now_ms();
 struct HostVec { double *dev; double *host; i64 count; };        // one vector of a host-pointer call (host: source or destination)
 struct IoPiece { double *dev, *pin, *host; i64 cnt; };
 // pieces of <= ~512 KB, at most ~32 per call (a piece costs one hipMemcpyAsync and, on the way out, one event)
@@ -953,8 +954,14 @@ int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const d
     HIPCHK(h, hipStreamSynchronize(h->stream));          // the staging area may still feed an earlier call's copies
     const i64 un = user_n(h), um = user_m(h);
     const HostVec in[3] = {{h->d_theta, const_cast<double *>(theta), un}, {h->d_regP, const_cast<double *>(regP), un}, {h->d_regD, const_cast<double *>(regD), um}};
+    static const bool timing = [] { const char *e = std::getenv("TLPK_HOSTIO_TIMING"); return e && std::atoi(e) != 0; }();
+    const double t0 = timing ? now_ms() : 0.0;
     if (int rc = stage_in(h, in, 3)) return rc;
-    return tlpk_update_device(h, h->d_theta, h->d_regP, h->d_regD);
+    const double t1 = timing ? now_ms() : 0.0;
+    const int rc = tlpk_update_device(h, h->d_theta, h->d_regP, h->d_regD);
+    if (timing) std::fprintf(stderr, "tlpk_update host path: stage in + H2D issued %.3f ms | factorisation (enqueue + wait) %.3f ms | device update (events) %.3f ms\n",
+                             t1 - t0, now_ms() - t1, h->ms_update);
+    return rc;
 }
 
 // ---- solve ----
@@ -1054,13 +1061,13 @@ int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *
     if (!whole) rc = tlpk_solve_finish(h, d_dx, d_dy, d_xid);
     // optional iterative refinement on the residuals of the augmented system (KKT.jl:70-75): each step is one more solve with
     // (r1, r2) as right-hand side.  Off by default = the reference (spd.jl:68).  GUARDED (round 5): the candidate x + c is kept only if
-    // max(|r1|inf, |r2|inf) shrinks -- decided on the device, no host synchronisation; a rejected step ends the refinement of this solve
+    // |r1|inf shrinks and |r2|inf stays within 16 x of the unrefined solve's (kernels.hip: k_refine_decide) -- decided on the device, no host synchronisation; a rejected step ends the refinement of this solve
     // (tlpk_stats.refine_rejected).  On the north-star LP's late iterations an unguarded second step grew the dual residual from 2e-8 to 0.6
     // (profiles/r04_mpc_levers.txt): an option that exists must not make a solve worse.
     if (h->refine_steps > 0 && rc == TLPK_OK) {
-        HIPCHK(h, hipMemsetAsync(h->d_ref, 0, 4 * sizeof(unsigned long long), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_ref, 0, 8 * sizeof(unsigned long long), h->stream));
         launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, d_dx, d_dy, h->d_r1, h->d_r2, 0);
-        launch_absmax2(h->stream, h->d, h->d_r1, h->d_r2, h->d_ref + 0);
+        launch_absmax2(h->stream, h->d, h->d_r1, h->d_r2, h->d_ref + 0);      // |r1| current, |r2| of the unrefined solve
     }
     for (int it = 0; it < h->refine_steps && rc == TLPK_OK; ++it) {
         rc = whole ? solve_whole(h, h->d_cx, h->d_cy, h->d_r1, h->d_r2) : tlpk_solve_local(h, h->d_r1, h->d_r2);
@@ -1069,13 +1076,13 @@ int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *
         launch_candidate(h->stream, h->S.n, d_dx, h->d_cx, h->S.m, d_dy, h->d_cy);
         // residuals of the candidate: the next step's right-hand side if the candidate is kept (after a rejection nothing is kept any more)
         launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, h->d_cx, h->d_cy, h->d_r1, h->d_r2, 0);
-        launch_absmax2(h->stream, h->d, h->d_r1, h->d_r2, h->d_ref + 1);
+        launch_absmax2(h->stream, h->d, h->d_r1, h->d_r2, h->d_ref + 2);
         launch_refine_decide(h->stream, h->d_ref);
         launch_refine_commit(h->stream, h->S.n, d_dx, h->d_cx, h->S.m, d_dy, h->d_cy, h->d_ref);
         HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     }
     if (h->refine_steps > 0 && rc == TLPK_OK)
-        HIPCHK(h, hipMemcpyAsync(h->h_info + 2, reinterpret_cast<int *>(h->d_ref + 2), sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_info + 2, reinterpret_cast<int *>(h->d_ref + 4), sizeof(int), hipMemcpyDeviceToHost, h->stream));
     return rc;
 }
 
@@ -1092,7 +1099,7 @@ static int refine_buffers(tlpk_handle *h) {
     if ((rc = dev_alloc(h, &h->d_r1, mm)) != TLPK_OK) return rc;
     if ((rc = dev_alloc(h, &h->d_r2, nn)) != TLPK_OK) return rc;
     if ((rc = dev_alloc(h, &h->d_cx, nn)) != TLPK_OK) return rc;
-    if ((rc = dev_alloc(h, &h->d_ref, 4)) != TLPK_OK) return rc;
+    if ((rc = dev_alloc(h, &h->d_ref, 8)) != TLPK_OK) return rc;
     return dev_alloc(h, &h->d_cy, mm);
 }
 int tlpk_refine_local(tlpk_handle *h, const double *d_dx, const double *d_dy, const double *d_xip, const double *d_xid) {
@@ -1281,14 +1288,20 @@ int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const
     if (int rc = ensure_pinned(h)) return rc;
     const i64 un = user_n(h), um = user_m(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    static const bool timing = [] { const char *e = std::getenv("TLPK_HOSTIO_TIMING"); return e && std::atoi(e) != 0; }();
+    const double t0 = timing ? now_ms() : 0.0;
     const HostVec in[2] = {{h->d_xip, const_cast<double *>(xi_p), um}, {h->d_xid, const_cast<double *>(xi_d), un}};
     if (int rc = stage_in(h, in, 2)) return rc;
+    const double t1 = timing ? now_ms() : 0.0;
     int rc = tlpk_solve_device(h, h->d_dx, h->d_dy, h->d_xip, h->d_xid);
     if (rc != TLPK_OK) return rc;
+    const double t2 = timing ? now_ms() : 0.0;
     // dy is final before k_dx starts: its pieces go first
     const HostVec out[2] = {{h->d_dy, dy, um}, {h->d_dx, dx, un}};
     rc = stage_out(h, out, 2);
     const int src = tlpk_sync(h);                          // status words (a sweep that gave up waiting), timers; the stream is idle by now
+    if (timing) std::fprintf(stderr, "tlpk_solve host path: stage in + H2D issued %.3f ms | kernels enqueued %.3f ms | wait + D2H + stage out %.3f ms | device solve (events) %.3f ms | total %.3f ms\n",
+                             t1 - t0, t2 - t1, now_ms() - t2, h->ms_solve, now_ms() - t0);
     return rc != TLPK_OK ? rc : src;
 }
 
@@ -1440,8 +1453,8 @@ int multi_allreduce(tlpk_handle *h, int which) {
 }
 
 
-// Guarded refinement on a multi-device handle (round 5).  max(|r1|inf, |r2|inf) of the augmented system's residuals for shard-resident
-// solutions: every shard forms the residuals of the rows / columns it owns and its PARTIAL sums on the linking rows (same convention as the
+// Guarded refinement on a multi-device handle (round 5).  |r1|inf and |r2|inf of the augmented system's residuals for shard-resident
+// solutions (the rule of kernels.hip: k_refine_decide, evaluated on the host): every shard forms the residuals of the rows / columns it owns and its PARTIAL sums on the linking rows (same convention as the
 // right-hand side of the solve: `all_ranks` = every shard's xi_p counts there, otherwise rank 0's only); the owned maxima are reduced on the
 // devices, the linking rows are summed on the host in shard order.  Host-synchronised: refinement is an off-by-default option.
 int refine_buffers_multi(tlpk_handle *c) {
@@ -1450,26 +1463,27 @@ int refine_buffers_multi(tlpk_handle *c) {
     if (int rc = dev_alloc(c, &c->d_bx, std::max<i64>(c->S.n, 1))) return rc;
     return dev_alloc(c, &c->d_by, std::max<i64>(c->S.m, 1));
 }
-int multi_resid_norm(tlpk_handle *h, double *const *dx, double *const *dy, const double *const *xip, const double *const *xid, bool all_ranks, double *out) {
+int multi_resid_norm(tlpk_handle *h, double *const *dx, double *const *dy, const double *const *xip, const double *const *xid, bool all_ranks, double *out /* |r1|, |r2| */) {
     const int N = (int)h->sub.size();
     for (int r = 0; r < N; ++r) {
         tlpk_handle *c = h->sub[(size_t)r];
         HIPCHK(h, hipSetDevice(c->device));
         if (int rc = refine_buffers_multi(c)) { h->last_error = c->last_error; return rc; }
-        HIPCHK(h, hipMemsetAsync(c->d_ref, 0, 4 * sizeof(unsigned long long), c->stream));
+        HIPCHK(h, hipMemsetAsync(c->d_ref, 0, 8 * sizeof(unsigned long long), c->stream));
         launch_residuals(c->stream, c->d, xip[r], xid[r], c->d_theta, c->d_regP, c->d_regD, dx[r], dy[r], c->d_r1, c->d_r2, all_ranks ? 0 : c->opt.rank);
         launch_absmax2(c->stream, c->d, c->d_r1, c->d_r2, c->d_ref, 1);
     }
-    double nrm = 0.0;
+    double n1 = 0.0, n2 = 0.0;
     std::vector<double> link, part;
     for (int r = 0; r < N; ++r) {
         tlpk_handle *c = h->sub[(size_t)r];
         HIPCHK(h, hipSetDevice(c->device));
         HIPCHK(h, hipStreamSynchronize(c->stream));
-        unsigned long long bits = 0;
-        HIPCHK(h, hipMemcpy(&bits, c->d_ref, sizeof(bits), hipMemcpyDeviceToHost));
-        double v; std::memcpy(&v, &bits, sizeof(v));
-        if (!(v <= nrm)) nrm = v;                                  // (a NaN pattern propagates)
+        unsigned long long bits[2] = {0, 0};
+        HIPCHK(h, hipMemcpy(bits, c->d_ref, sizeof(bits), hipMemcpyDeviceToHost));
+        double v1, v2; std::memcpy(&v1, &bits[0], 8); std::memcpy(&v2, &bits[1], 8);
+        if (!(v1 <= n1)) n1 = v1;                                  // (a NaN pattern propagates)
+        if (!(v2 <= n2)) n2 = v2;
         const i64 span = c->link_hi - c->link_lo;
         if (span > 0) {
             part.resize((size_t)span);
@@ -1478,9 +1492,9 @@ int multi_resid_norm(tlpk_handle *h, double *const *dx, double *const *dy, const
             for (i64 i = 0; i < span; ++i) if (c->S.row_local[(size_t)(c->link_lo + i)] == 2) link[(size_t)i] += part[(size_t)i];
         }
     }
-    for (double v : link) { const double a = std::fabs(v); if (!(a <= nrm)) nrm = a; }
+    for (double v : link) { const double a = std::fabs(v); if (!(a <= n1)) n1 = a; }
     HIPCHK(h, hipSetDevice(h->sub[0]->device));
-    *out = nrm;
+    out[0] = n1; out[1] = n2;
     return TLPK_OK;
 }
 // one guarded step: backup, step(), verdict; *stop = the step was rejected (the iterate is restored)
@@ -1493,9 +1507,9 @@ int multi_guarded_step(tlpk_handle *h, double *const *dx, double *const *dy, con
         HIPCHK(h, hipMemcpyAsync(c->d_by, dy[r], (size_t)c->S.m * 8, hipMemcpyDeviceToDevice, c->stream));
     }
     if (int rc = step()) return rc;
-    double after = 0.0;
-    if (int rc = multi_resid_norm(h, dx, dy, xip, xid, all_ranks, &after)) return rc;
-    if (after < *norm) { *norm = after; *stop = false; return TLPK_OK; }
+    double after[2] = {0.0, 0.0};
+    if (int rc = multi_resid_norm(h, dx, dy, xip, xid, all_ranks, after)) return rc;
+    if (after[0] < norm[0] && after[1] <= 16.0 * norm[1]) { norm[0] = after[0]; *stop = false; return TLPK_OK; }      // the rule of k_refine_decide
     for (size_t r = 0; r < h->sub.size(); ++r) {
         tlpk_handle *c = h->sub[r];
         HIPCHK(h, hipSetDevice(c->device));
@@ -1580,11 +1594,11 @@ int multi_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, cons
             const int N = (int)h->sub.size();
             double *dxs[MAX_DEVICES], *dys[MAX_DEVICES]; const double *xps[MAX_DEVICES], *xds[MAX_DEVICES];
             for (int r = 0; r < N; ++r) { tlpk_handle *c = h->sub[(size_t)r]; dxs[r] = c->d_dx; dys[r] = c->d_dy; xps[r] = c->d_xip; xds[r] = c->d_xid; }
-            double norm = 0.0; bool stop = false;
+            double norm[2] = {0.0, 0.0}; bool stop = false;      // |r1| of the current iterate, |r2| of the unrefined solve
             h->refine_rejected = 0;
-            if (int rc = multi_resid_norm(h, dxs, dys, xps, xds, false, &norm)) return rc;
+            if (int rc = multi_resid_norm(h, dxs, dys, xps, xds, false, norm)) return rc;
             for (int it = 0; it < h->refine_steps && !stop; ++it) {
-                if (int rc = multi_guarded_step(h, dxs, dys, xps, xds, false, &norm, &stop, [&]() -> int {
+                if (int rc = multi_guarded_step(h, dxs, dys, xps, xds, false, norm, &stop, [&]() -> int {
                         for (tlpk_handle *c : h->sub) {
                             const int q = tlpk_refine_local(c, c->d_dx, c->d_dy, c->d_xip, c->d_xid);
                             if (q != TLPK_OK) { h->last_error = c->last_error; return q; }
@@ -1682,11 +1696,11 @@ int multi_solve_resident(tlpk_handle *h, double *const *dx, double *const *dy, c
     // tlpk_solve refined): one more split solve per step on the residuals every shard forms for the rows / columns it owns -- with the SAME
     // convention as the solve above, every shard's xi_p counting on the linking rows
     if (h->refine_steps > 0) {
-        double norm = 0.0; bool stop = false;
+        double norm[2] = {0.0, 0.0}; bool stop = false;
         h->refine_rejected = 0;
-        if (int rc = multi_resid_norm(h, dx, dy, xip, xid, true, &norm)) return rc;
+        if (int rc = multi_resid_norm(h, dx, dy, xip, xid, true, norm)) return rc;
         for (int it = 0; it < h->refine_steps && !stop; ++it) {
-            if (int rc = multi_guarded_step(h, dx, dy, xip, xid, true, &norm, &stop, [&]() -> int {
+            if (int rc = multi_guarded_step(h, dx, dy, xip, xid, true, norm, &stop, [&]() -> int {
                     if (int q = for_shards(h, [&](tlpk_handle *c, int r) {
                             c->rhs_all_ranks = true;
                             const int q2 = tlpk_refine_local(c, dx[r], dy[r], xip[r], xid[r]);
