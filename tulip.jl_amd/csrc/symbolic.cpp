@@ -1806,6 +1806,7 @@ static void build_schedule(Symbolic &S) {
     // groups' forward sweeps ran one after the other (629 + 650 us, profiles/r04_solve_timeline.txt).  With scope -1 a level's launch holds the
     // fronts of every group and runs on the main stream; per-item arithmetic is unchanged (bit-identical results).
     const bool solve_one_group = [&] { const char *e = std::getenv("TLPK_SOLVE_ONE_GROUP"); return S.ngroups >= 2 && (!e || std::atoi(e) != 0); }();
+    S.solve_single_stream = solve_one_group || S.ngroups <= 1;
     cur_g = solve_one_group ? -1 : 0;
     for (; cur_g < (solve_one_group ? 0 : S.ngroups); ++cur_g)
         for (i32 d = S.nlevels - 1; d >= 1; --d) fwd_level(d);

@@ -403,9 +403,19 @@ inline bool graph_usable(const tlpk_handle *h) {
     return h->use_graph && !h->profile && !h->serial && (h->S.ngroups <= 1 || h->force_graph);
 }
 
+// Solves: since round 5 the solve schedule of a block-angular LP is ONE schedule on the main stream (symbolic.cpp: solve_one_group), so a solve can be
+// captured whatever the number of stream groups the factorisation uses.  What it buys there is host time: the blocking host-pointer solve
+// (tlpk_solve) starts with ~25 short launches that the GPU executes faster than the host enqueues them.  Not while an asynchronous update's root
+// front is pending (the solve then waits for an event recorded outside the capture).  TLPK_GRAPH_SOLVE=0: only where updates are captured too.
+inline bool graph_usable_solve(const tlpk_handle *h) {
+    static const bool on = [] { const char *e = std::getenv("TLPK_GRAPH_SOLVE"); return !e || std::atoi(e) != 0; }();
+    if (graph_usable(h)) return true;
+    return on && h->use_graph && !h->profile && !h->serial && h->S.solve_single_stream && !h->root_pending && h->opt.nranks == 1;
+}
+
 template <class F>
-int graph_or_direct(tlpk_handle *h, const GraphKey &key, F &&body) {
-    if (!graph_usable(h)) return body();
+int graph_or_direct(tlpk_handle *h, const GraphKey &key, F &&body, bool usable) {
+    if (!usable) return body();
     for (size_t i = 0; i < h->graph_keys.size(); ++i)
         if (*reinterpret_cast<const GraphKey *>(h->graph_keys[i].data()) == key) {
             HIPCHK(h, hipGraphLaunch(h->graph_execs[i], h->stream));
@@ -858,7 +868,7 @@ int tlpk_update_device(tlpk_handle *h, const double *d_theta, const double *d_re
     h->update_whole = false;
     if (rc != TLPK_OK) return rc;
     const GraphKey key{1, {}};
-    rc = graph_or_direct(h, key, [&]() { const int q = enq_update_local(h); return q != TLPK_OK ? q : enq_update_finish(h); });
+    rc = graph_or_direct(h, key, [&]() { const int q = enq_update_local(h); return q != TLPK_OK ? q : enq_update_finish(h); }, graph_usable(h));
     if (rc != TLPK_OK) return rc;
     h->local_done = true;
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
@@ -880,55 +890,73 @@ static int ensure_pinned(tlpk_handle *h) {
 namespace {
 double now_ms();
 struct HostVec { double *dev; double *host; i64 count; };        // one vector of a host-pointer call (host: source or destination)
-struct IoPiece { double *dev, *pin, *host; i64 cnt; };
-// pieces of <= ~512 KB, at most ~32 per call (a piece costs one hipMemcpyAsync and, on the way out, one event)
-void io_pieces(double *pin, const HostVec *v, int nv, std::vector<IoPiece> &out) {
+// A vector crosses the link in DMA GROUPS of ~2 MB (one hipMemcpyAsync each; on the way out one event each) and is copied into / out of the staging
+// area in CHUNKS of <= 512 KB by the pool's threads (several chunks per group).  First version of round 5: one 512 KB copy + event per piece -- the
+// 15 device-to-host copies of a config-C4 solve took 0.4 ms for 7.7 MB (19 GB/s, gpurun_out session B: TLPK_HOSTIO_TIMING); the link wants few, large copies,
+// the host copy wants many, small ones.
+struct IoGroup { double *dev, *pin; i64 cnt; std::atomic<int> left{0}; IoGroup() = default; IoGroup(const IoGroup &o) : dev(o.dev), pin(o.pin), cnt(o.cnt), left(o.left.load()) {} };
+struct IoChunk { double *pin, *host; i64 cnt; int group; };
+void io_plan(double *pin, const HostVec *v, int nv, std::vector<IoGroup> &groups, std::vector<IoChunk> &chunks) {
     i64 total = 0;
     for (int k = 0; k < nv; ++k) total += v[k].count;
-    const i64 piece = std::max<i64>(65536, ((total + 31) / 32 + 8191) / 8192 * 8192);
-    out.clear();
+    const i64 gsz = std::max<i64>(262144, ((total + 15) / 16 + 65535) / 65536 * 65536);      // >= 2 MB, at most ~16 groups per call
+    const i64 csz = 65536;                                                                  // 512 KB
+    groups.clear(); chunks.clear();
     i64 off = 0;
     for (int k = 0; k < nv; ++k) {
-        for (i64 o = 0; o < v[k].count; o += piece) out.push_back(IoPiece{v[k].dev + o, pin + off + o, v[k].host + o, std::min(piece, v[k].count - o)});
+        for (i64 o = 0; o < v[k].count; o += gsz) {
+            IoGroup g; g.dev = v[k].dev + o; g.pin = pin + off + o; g.cnt = std::min(gsz, v[k].count - o);
+            int nch = 0;
+            for (i64 c = 0; c < g.cnt; c += csz, ++nch) chunks.push_back(IoChunk{g.pin + c, v[k].host + o + c, std::min(csz, g.cnt - c), (int)groups.size()});
+            g.left.store(nch);
+            groups.push_back(g);
+        }
         off += v[k].count;
     }
 }
-// host -> staging -> device, all vectors of a call; returns when every copy has been ENQUEUED on the handle's stream
+// host -> staging -> device, all vectors of a call; returns when every copy has been ENQUEUED on the handle's stream.  The thread that stages the
+// last chunk of a group issues the group's copy: the link works while the other groups are still being staged.
 int stage_in(tlpk_handle *h, const HostVec *v, int nv) {
-    std::vector<IoPiece> pcs; io_pieces(h->pin_in, v, nv, pcs);
+    std::vector<IoGroup> groups; std::vector<IoChunk> chunks;
+    io_plan(h->pin_in, v, nv, groups, chunks);
     std::atomic<int> err{(int)hipSuccess};
     const int dev = h->device; hipStream_t st = h->stream;
-    host_parallel_for((int)pcs.size(), [&](int i) {
-        const IoPiece &p = pcs[(size_t)i];
-        copy_to_staging(p.pin, p.host, (size_t)p.cnt * 8);
-        hipError_t e = hipSetDevice(dev);                        // (per thread; a no-op after the first piece)
-        if (e == hipSuccess) e = hipMemcpyAsync(p.dev, p.pin, (size_t)p.cnt * 8, hipMemcpyHostToDevice, st);
+    host_parallel_for((int)chunks.size(), [&](int i) {
+        const IoChunk &c = chunks[(size_t)i];
+        copy_to_staging(c.pin, c.host, (size_t)c.cnt * 8);
+        IoGroup &g = groups[(size_t)c.group];
+        if (g.left.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+        hipError_t e = hipSetDevice(dev);                        // (per thread; a no-op after the first time)
+        if (e == hipSuccess) e = hipMemcpyAsync(g.dev, g.pin, (size_t)g.cnt * 8, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) err.store((int)e);
     });
     if (err.load() != (int)hipSuccess) return hip_fail(h, (hipError_t)err.load(), "staged host-to-device copy");
     return TLPK_OK;
 }
-// device -> staging -> host: every piece's copy is followed by an event; the pool copies a piece out as soon as its event has fired,
-// while the later pieces are still on the link
+// device -> staging -> host: every group's copy is followed by an event; the pool copies a chunk out as soon as its group's event has fired,
+// while the later groups are still on the link
 int stage_out(tlpk_handle *h, const HostVec *v, int nv) {
-    std::vector<IoPiece> pcs; io_pieces(h->pin_out, v, nv, pcs);
-    while (h->io_events.size() < pcs.size()) {
+    std::vector<IoGroup> groups; std::vector<IoChunk> chunks;
+    io_plan(h->pin_out, v, nv, groups, chunks);
+    while (h->io_events.size() < groups.size()) {
         hipEvent_t e = nullptr;
         HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         h->io_events.push_back(e);
     }
-    for (size_t i = 0; i < pcs.size(); ++i) {
-        HIPCHK(h, hipMemcpyAsync(pcs[i].pin, pcs[i].dev, (size_t)pcs[i].cnt * 8, hipMemcpyDeviceToHost, h->stream));
+    for (size_t i = 0; i < groups.size(); ++i) {
+        HIPCHK(h, hipMemcpyAsync(groups[i].pin, groups[i].dev, (size_t)groups[i].cnt * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipEventRecord(h->io_events[i], h->stream));
     }
     std::atomic<int> err{(int)hipSuccess};
     const int dev = h->device;
-    host_parallel_for((int)pcs.size(), [&](int i) {
-        const IoPiece &p = pcs[(size_t)i];
+    h->io_t_first = h->io_t_last = 0.0;
+    host_parallel_for((int)chunks.size(), [&](int i) {
+        const IoChunk &c = chunks[(size_t)i];
         hipError_t e = hipSetDevice(dev);
-        if (e == hipSuccess) e = hipEventSynchronize(h->io_events[(size_t)i]);
+        if (e == hipSuccess) e = hipEventSynchronize(h->io_events[(size_t)c.group]);
         if (e != hipSuccess) { err.store((int)e); return; }
-        std::memcpy(p.host, p.pin, (size_t)p.cnt * 8);
+        if (h->io_timing) { const double t = now_ms(); if (c.group == 0 && c.pin == groups[0].pin) h->io_t_first = t; if (c.group + 1 == (int)groups.size()) h->io_t_last = t; }
+        std::memcpy(c.host, c.pin, (size_t)c.cnt * 8);
     });
     if (err.load() != (int)hipSuccess) return hip_fail(h, (hipError_t)err.load(), "staged device-to-host copy");
     return TLPK_OK;
@@ -1045,7 +1073,7 @@ static int solve_whole(tlpk_handle *h, double *d_dx, double *d_dy, const double 
     h->solve_whole = false;
     if (rc != TLPK_OK) return rc;
     const GraphKey key{2, {d_dx, d_dy, d_xip, d_xid}};
-    rc = graph_or_direct(h, key, [&]() { const int q = enq_solve_local(h, d_xip, d_xid); return q != TLPK_OK ? q : enq_solve_finish(h, d_dx, d_dy, d_xid); });
+    rc = graph_or_direct(h, key, [&]() { const int q = enq_solve_local(h, d_xip, d_xid); return q != TLPK_OK ? q : enq_solve_finish(h, d_dx, d_dy, d_xid); }, graph_usable_solve(h));
     if (rc != TLPK_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
@@ -1055,7 +1083,7 @@ static int solve_whole(tlpk_handle *h, double *d_dx, double *d_dy, const double 
 
 int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *d_xip, const double *d_xid) {
     if (int g = sharded_needs_split(h, "tlpk_solve_device")) return g;
-    const bool whole = h && h->sub.empty() && h->has_device && graph_usable(h);
+    const bool whole = h && h->sub.empty() && h->has_device && graph_usable_solve(h);
     int rc = whole ? solve_whole(h, d_dx, d_dy, d_xip, d_xid) : tlpk_solve_local(h, d_xip, d_xid);
     if (rc != TLPK_OK) return rc;
     if (!whole) rc = tlpk_solve_finish(h, d_dx, d_dy, d_xid);
@@ -1201,7 +1229,7 @@ int tlpk_solve2_device(tlpk_handle *h, double *d_dx0, double *d_dy0, const doubl
     const int grc = graph_or_direct(h, key, [&]() -> int {
         const int q = enq_solve2_local(h, xip, xid, -1);
         return q != TLPK_OK ? q : enq_solve2_finish(h, dx, dy, xid);
-    });
+    }, graph_usable_solve(h));
     if (grc != TLPK_OK) return grc;
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipGetLastError());
@@ -1289,6 +1317,7 @@ int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const
     const i64 un = user_n(h), um = user_m(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     static const bool timing = [] { const char *e = std::getenv("TLPK_HOSTIO_TIMING"); return e && std::atoi(e) != 0; }();
+    h->io_timing = timing;
     const double t0 = timing ? now_ms() : 0.0;
     const HostVec in[2] = {{h->d_xip, const_cast<double *>(xi_p), um}, {h->d_xid, const_cast<double *>(xi_d), un}};
     if (int rc = stage_in(h, in, 2)) return rc;
@@ -1300,8 +1329,9 @@ int tlpk_solve(tlpk_handle *h, double *dx, double *dy, const double *xi_p, const
     const HostVec out[2] = {{h->d_dy, dy, um}, {h->d_dx, dx, un}};
     rc = stage_out(h, out, 2);
     const int src = tlpk_sync(h);                          // status words (a sweep that gave up waiting), timers; the stream is idle by now
-    if (timing) std::fprintf(stderr, "tlpk_solve host path: stage in + H2D issued %.3f ms | kernels enqueued %.3f ms | wait + D2H + stage out %.3f ms | device solve (events) %.3f ms | total %.3f ms\n",
-                             t1 - t0, t2 - t1, now_ms() - t2, h->ms_solve, now_ms() - t0);
+    if (timing) std::fprintf(stderr, "tlpk_solve host path: stage in + H2D issued %.3f ms | kernels enqueued %.3f ms | first D2H group landed +%.3f ms | last D2H group landed +%.3f ms | "
+                             "copied out +%.3f ms | device solve (events) %.3f ms | total %.3f ms\n",
+                             t1 - t0, t2 - t1, h->io_t_first - t2, h->io_t_last - h->io_t_first, now_ms() - h->io_t_last, h->ms_solve, now_ms() - t0);
     return rc != TLPK_OK ? rc : src;
 }
 

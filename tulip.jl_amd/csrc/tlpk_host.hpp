@@ -182,6 +182,7 @@ struct Symbolic {
     std::vector<SolveTask> fwd_sweep_tasks, bwd_sweep_tasks;
     i64 n_sweep_flags = 0;                 // number of fronts handled by the sweep kernels
     bool sweep = true;                     // persistent sweep kernels (TLPK_SWEEP=0: one launch per 128-column block step)
+    bool solve_single_stream = true;       // every launch of the solve schedules runs on the handle's main stream (one stream group, or solve_one_group)
     std::vector<Launch> factor_launches, fwd_launches, bwd_launches;
     // state handed from analyse_common to analyse_rank (rank-independent)
     std::vector<i32> row_block_v, col_block_v;   // block of each row / column of A (-1: linking), empty = general sparse
