@@ -405,7 +405,7 @@ inline bool graph_usable(const tlpk_handle *h) {
 
 // Solves: since round 5 the solve schedule of a block-angular LP is ONE schedule on the main stream (symbolic.cpp: solve_one_group), so a solve can be
 // captured whatever the number of stream groups the factorisation uses.  What it buys there is host time: the blocking host-pointer solve
-// (tlpk_solve) starts with ~25 short launches.  MEASURED (gpurun_out session C) and OFF by default: config C4 52.85 vs 52.66 ms per step, north-star LP
+// (tlpk_solve) starts with ~25 short launches.  MEASURED (profiles/r05_host_path.txt) and OFF by default: config C4 52.85 vs 52.66 ms per step, north-star LP
 // 139.0 vs 139.9, host-pointer path 157.3 vs 155.4 -- the host enqueues a solve in 20 - 70 us, there is nothing to hide.  TLPK_GRAPH_SOLVE=1 turns it on; never
 // while an asynchronous update's root front is pending (the solve then waits for an event recorded outside the capture).
 inline bool graph_usable_solve(const tlpk_handle *h) {
@@ -664,8 +664,6 @@ void tlpk_destroy(tlpk_handle *h) {
         if (h->pin_in) hipHostFree(h->pin_in);
         if (h->pin_out) hipHostFree(h->pin_out);
         for (hipEvent_t e : h->io_events) hipEventDestroy(e);
-        for (int k = 0; k < 2; ++k) { if (h->cstream[k]) { hipStreamSynchronize(h->cstream[k]); hipStreamDestroy(h->cstream[k]); } if (h->ev_c[k]) hipEventDestroy(h->ev_c[k]); }
-        if (h->ev_cmain) hipEventDestroy(h->ev_cmain);
         for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
@@ -887,17 +885,6 @@ static int ensure_pinned(tlpk_handle *h) {
     const size_t nin = (size_t)std::max<i64>(2 * user_n(h) + user_m(h), 1), nout = (size_t)std::max<i64>(user_n(h) + user_m(h), 1);
     HIPCHK(h, hipHostMalloc((void **)&h->pin_in, nin * 8, hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc((void **)&h->pin_out, nout * 8, hipHostMallocDefault));
-    // two copy streams: the DMA groups of a call alternate between them, i.e. between two copy engines (one engine moved 36 GB/s in 2 MB groups,
-    // gpurun_out session C); ordered with the handle's stream by events.  TLPK_COPY_STREAMS=1: everything on the handle's stream (the first version).
-    const char *e = std::getenv("TLPK_COPY_STREAMS");
-    const int ncs = e ? std::atoi(e) : 2;
-    if (ncs >= 2) {
-        for (int k = 0; k < 2; ++k) {
-            HIPCHK(h, hipStreamCreateWithFlags(&h->cstream[k], hipStreamNonBlocking));
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_c[k], hipEventDisableTiming));
-        }
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_cmain, hipEventDisableTiming));
-    }
     return TLPK_OK;
 }
 
@@ -907,7 +894,9 @@ struct HostVec { double *dev; double *host; i64 count; };        // one vector o
 // A vector crosses the link in DMA GROUPS of ~2 MB (one hipMemcpyAsync each; on the way out one event each) and is copied into / out of the staging
 // area in CHUNKS of <= 512 KB by the pool's threads (several chunks per group).  First version of round 5: one 512 KB copy + event per piece -- the
 // 15 device-to-host copies of a config-C4 solve took 0.4 ms for 7.7 MB (19 GB/s, gpurun_out session B: TLPK_HOSTIO_TIMING); the link wants few, large copies,
-// the host copy wants many, small ones.
+// the host copy wants many, small ones.  Also measured, and removed: the groups alternating between two extra copy streams (two copy engines) -- the device
+// time of a solve rose from 2.45 to 3.3 ms with the two extra streams alive (more streams than hardware queues: the handle's main stream then shares one),
+// host-pointer step 60.3 vs 56.2 ms (profiles/r05_host_path.txt).
 struct IoGroup { double *dev, *pin; i64 cnt; std::atomic<int> left{0}; IoGroup() = default; IoGroup(const IoGroup &o) : dev(o.dev), pin(o.pin), cnt(o.cnt), left(o.left.load()) {} };
 struct IoChunk { double *pin, *host; i64 cnt; int group; };
 void io_plan(double *pin, const HostVec *v, int nv, std::vector<IoGroup> &groups, std::vector<IoChunk> &chunks) {
@@ -934,20 +923,17 @@ int stage_in(tlpk_handle *h, const HostVec *v, int nv) {
     std::vector<IoGroup> groups; std::vector<IoChunk> chunks;
     io_plan(h->pin_in, v, nv, groups, chunks);
     std::atomic<int> err{(int)hipSuccess};
-    const int dev = h->device;
-    const bool two = h->cstream[0] != nullptr;                   // (the handle's stream is idle: the callers synchronise it before they touch the staging area)
+    const int dev = h->device; hipStream_t st = h->stream;
     host_parallel_for((int)chunks.size(), [&](int i) {
         const IoChunk &c = chunks[(size_t)i];
         copy_to_staging(c.pin, c.host, (size_t)c.cnt * 8);
         IoGroup &g = groups[(size_t)c.group];
         if (g.left.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
         hipError_t e = hipSetDevice(dev);                        // (per thread; a no-op after the first time)
-        if (e == hipSuccess) e = hipMemcpyAsync(g.dev, g.pin, (size_t)g.cnt * 8, hipMemcpyHostToDevice, two ? h->cstream[c.group & 1] : h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(g.dev, g.pin, (size_t)g.cnt * 8, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) err.store((int)e);
     });
     if (err.load() != (int)hipSuccess) return hip_fail(h, (hipError_t)err.load(), "staged host-to-device copy");
-    if (two)
-        for (int k = 0; k < 2; ++k) { HIPCHK(h, hipEventRecord(h->ev_c[k], h->cstream[k])); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_c[k], 0)); }
     return TLPK_OK;
 }
 // device -> staging -> host: every group's copy is followed by an event; the pool copies a chunk out as soon as its group's event has fired,
@@ -960,15 +946,9 @@ int stage_out(tlpk_handle *h, const HostVec *v, int nv) {
         HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         h->io_events.push_back(e);
     }
-    const bool two = h->cstream[0] != nullptr;
-    if (two) {
-        HIPCHK(h, hipEventRecord(h->ev_cmain, h->stream));
-        for (int k = 0; k < 2; ++k) HIPCHK(h, hipStreamWaitEvent(h->cstream[k], h->ev_cmain, 0));
-    }
     for (size_t i = 0; i < groups.size(); ++i) {
-        hipStream_t st = two ? h->cstream[i & 1] : h->stream;
-        HIPCHK(h, hipMemcpyAsync(groups[i].pin, groups[i].dev, (size_t)groups[i].cnt * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipEventRecord(h->io_events[i], st));
+        HIPCHK(h, hipMemcpyAsync(groups[i].pin, groups[i].dev, (size_t)groups[i].cnt * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipEventRecord(h->io_events[i], h->stream));
     }
     std::atomic<int> err{(int)hipSuccess};
     const int dev = h->device;

@@ -52,7 +52,6 @@ struct tlpk_handle {
     double *d_bx = nullptr, *d_by = nullptr;      // multi-device refinement: the iterate before a step (restored if the step is rejected)
     int *h_info = nullptr;
     double *pin_in = nullptr, *pin_out = nullptr;   // pinned staging of the host-pointer entry points (lazily allocated)
-    hipStream_t cstream[2] = {nullptr, nullptr}; hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_cmain = nullptr;   // copy streams of the host-pointer calls (tlpk_api.cpp: ensure_pinned)
     bool io_timing = false; double io_t_first = 0, io_t_last = 0;   // TLPK_HOSTIO_TIMING: when the first / last device-to-host group had landed
     std::vector<hipEvent_t> io_events;              // one per device-to-host piece of tlpk_solve (tlpk_api.cpp: stage_out)
     bool factored = false, local_done = false, solve_local_done = false, solve_timed = false, refine_pending = false, pair_pending = false;
