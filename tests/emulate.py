@@ -227,7 +227,7 @@ class Emulator:
                         Up[tr - ns, tc - ns] += src
 
     def _k20(self, T):     # front assembly: tile = S entries + children (child order), written whole
-        FA_CW = 16
+        FA_CW = 4
         fa_e = np.nonzero(self.fa_entry & (self.s_target >= 0))[0]
         fa_c = self.col_of_entry[fa_e]
         for front, bc, br0, br1 in T:
@@ -238,7 +238,7 @@ class Emulator:
                 return k * FA_CW if k < npan else min(f, ns + (k - npan) * FA_CW)
             j0, j1 = bc * FA_CW, min(bc * FA_CW + FA_CW, ns)
             i0, i1 = bound(br0), bound(br1)
-            assert 0 < i1 - i0 <= 256 and j0 < ns
+            assert 0 < i1 - i0 <= 576 * FA_CW and j0 < ns          # FA_RB * FA_CW rows (tlpk_host.hpp)
             tile = np.zeros((i1 - i0, j1 - j0))
             loff, lda = int(self.loff[front]), int(self.lda[front])
             for q in np.nonzero((fa_c >= col0 + j0) & (fa_c < col0 + j1))[0]:      # entries of S in the tile

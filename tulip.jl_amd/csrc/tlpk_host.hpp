@@ -79,8 +79,8 @@ struct alignas(16) UpdateTask { i32 front, k0, kw, i0, j0, jlim, beta0, pad1, se
 // front assembly (k_front_assemble): the tile [rows of boundaries br0 .. br1) x [columns of boundary bc, bc + 1) of the panel of a large front is
 // FORMED in LDS -- entries of S, then the children's update matrices in child order -- and written once (no zero-fill, no read-modify-write)
 struct FaTask    { i32 front, bc, br0, br1; };
-constexpr int FA_CW = 16;      // parent columns per tile = the extend-add column range of the large fronts
-constexpr int FA_RB = 16;      // row boundaries per tile: <= FA_RB * FA_CW = 256 rows
+constexpr int FA_CW = 4;       // parent columns per tile = the extend-add column range of the large fronts (round 5: 4 x 2304 tall tiles; round 4: 16 x 256)
+constexpr int FA_RB = 576;     // row boundaries per tile: <= FA_RB * FA_CW = 2304 rows (73.7 KB of LDS per tile: two workgroups per CU)
 struct EaTask    { i32 front, j0, j1, bidx, br0, br1, pad0, pad1; };   // rows of the boundaries [br0, br1) only (br1 = 0: all rows): row bands shrink a workgroup's working set of parent lines (TLPK_EA_BANDS)                       // parent columns [j0, j1) = boundaries bidx, bidx + 1 of the front's extend-add ranges
 struct SolveTask { i32 front, k0, nb, row0, slot, nslot, pad0, pad1; };
 // sweep items (LK_FWD_SWEEP): k0/nb = first row / rows of the chunk (<= SWEEP_NB pivot rows or <= SOLVE_NB rows below),
