@@ -127,3 +127,17 @@ class DevBuf:
                 self.hip().hipFree(self.ptr); self.ptr = None
         except Exception:
             pass
+
+
+def check_retry_run(timers, status, z, zopt):
+    """Outcome of an IPM run on the LP engineered to fail numerically (lp_generators.bump_lp).  WHICH pivot fails, and in which iteration, is
+    decided by rounding, and the iterates after a bump depend on it: the same run with another 64 x 64 block kernel (round 5) fails in the same
+    matrices (checked matrix by matrix, profiles/r05_bump_trajectories.txt) but walks another trajectory.  Invariant: the retry loop fired, and
+    the run ended Trm_Optimal at the HiGHS optimum -- or, the reference's own rule (HSD/step.jl:51, MPC/step.jl:56), Trm_NumericalProblem in a
+    step that needed three bumps, by then within 1e-3 of the optimum."""
+    assert timers["n_bump"] > 0
+    if status == "Trm_Optimal":
+        assert abs(z - zopt) <= 1e-6 * (1 + abs(zopt))
+    else:
+        assert status == "Trm_NumericalProblem" and timers["max_bumps_in_a_step"] >= 3, (status, dict(timers))
+        assert abs(z - zopt) <= 1e-3 * (1 + abs(zopt))

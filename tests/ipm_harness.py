@@ -267,6 +267,7 @@ class HSD:
                 self.regD *= 100; self.regP *= 100; self.regG *= 100
                 nbump += 1
                 self.timers["n_bump"] += 1
+        self.timers["max_bumps_in_a_step"] = max(self.timers.get("max_bumps_in_a_step", 0), nbump)
         if not nbump < 3:                              # step.jl:51 (the reference's off-by-one is kept)
             raise PosDef("factorization could not be saved")
         D, Dc = Point(pt.m, pt.n, pt.p), Point(pt.m, pt.n, pt.p)
@@ -495,6 +496,7 @@ class MPC:
                 self.regD *= 100; self.regP *= 100
                 nbump += 1
                 self.timers["n_bump"] += 1
+        self.timers["max_bumps_in_a_step"] = max(self.timers.get("max_bumps_in_a_step", 0), nbump)
         if not nbump < 3:                              # step.jl:51
             raise PosDef("factorization could not be saved")
         D, Dc = Point(pt.m, pt.n, pt.p), Point(pt.m, pt.n, pt.p)

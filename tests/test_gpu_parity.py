@@ -592,15 +592,25 @@ def test_iterative_refinement_split_calls_and_multi_device():
         o = (DevBuf(n), DevBuf(m))
         kkt.solve_device(P(o[0]), P(o[1]), P(d_xp), P(d_xd)); kkt.sync()
         if steps == 0:
+            after = [(o[0].get(), o[1].get())]                           # the solution after 0, 1, 2 unguarded split steps
             for _ in range(2):
                 kkt.refine_local(P(o[0]), P(o[1]), P(d_xp), P(d_xd))
                 kkt.refine_finish(P(o[0]), P(o[1]))
-            kkt.sync()
+                kkt.sync()
+                after.append((o[0].get(), o[1].get()))
             with pytest.raises(tk.DimensionMismatch):
                 kkt.refine_finish(P(o[0]), P(o[1]))                      # no refine_local before it
+        else:
+            rejected = kkt.stats()["refine_rejected"]
         ref[steps] = (o[0].get(), o[1].get())
         kkt.close()
-    assert np.array_equal(ref[0][0], ref[2][0]) and np.array_equal(ref[0][1], ref[2][1])
+    # refine_steps is guarded (round 5: a step that does not shrink |r1| ends the refinement of the solve), the split calls are not: with no
+    # rejection the two compose bit for bit; after a rejection the guarded solve holds the solution of the accepted steps
+    same = lambda a, b: np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])      # noqa: E731
+    if rejected == 0:
+        assert same(after[2], ref[2])
+    else:
+        assert rejected == 1 and (same(after[0], ref[2]) or same(after[1], ref[2]))
     res = {}
     for steps in (0, 2):
         kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb, ngpus=3, devices=[0, 0, 0], refine=steps))

@@ -883,6 +883,404 @@ __device__ __forceinline__ void potrf_block_wave(const DevCtx &c, const FrontDes
 }
 
 // ------------------------------------------------------------------------------------------
+// potrf_block on DPP broadcasts (round 5).  The 64 x 64 block is walked in four 16-column panels as in potrf_block_wave, but the 16 column
+// steps of a panel run in the layout  lane (g, cc) = column cc of the panel, registers = rows:  d[k] = A[16 p + k][16 p + cc] (the 16 x 16
+// diagonal block, held FULL -- both triangles -- by each of the wave's four rows of 16 lanes) and b[k] = a row of the panel below the diagonal
+// block (the 16 (3 - p) rows are dealt to the four rows of lanes: 4 (3 - p) registers).  In that layout the entry A[k][j] of the pivot column
+// that every lane needs in step j is lane j's register k -- a `row_newbcast:j` DPP operand (CDNA's DPP form for 64-bit operations) -- and the
+// second factor of the elimination
+//     A[k][c] -= A[k][j] A[c][j] / d_j
+// is the lane's OWN register j (A[j][c] = A[c][j]: the two triangles of the diagonal block are kept bit-identical, see dpp_steps).  A step is
+// one DPP move + multiply + multiply-add per register of the diagonal block and ONE v_fmac_f64_dpp per register of the rows below it: no
+// v_readlane -> scalar register -> multiply-add round trips (potrf_block_wave: 456 cycles per column), no LDS hand-over and no barrier
+// (potrf_block: ~1050 cycles).  The serial chain of a step is the broadcast of the next pivot, a reciprocal (hardware estimate + 2 Newton
+// steps), two multiplies and the multiply-add of the next pivot; the products of the step are formed while the reciprocal is under way.
+// Column scaling is deferred: the registers keep the unscaled Schur state, every lane remembers ITS column's pivot and scales its column once
+// after the 16 steps.
+// The DPP instructions are inline assembly (the compiler splits a 64-bit DPP move off every multiply-add and then waits a cycle for its own
+// temporary): the statements keep the two-instruction distance the hardware requires between a write of a register and a DPP read of it (the
+// compiler's hazard recogniser does not look inside inline assembly) by an explicit s_nop in front.
+// Between panels the trailing 16 x 16 tiles are updated right-looking on the matrix cores (K = 16): the tiles the next panel reads by waves
+// 1..3 between two barriers; the other tiles, the inverse W_pp of the diagonal block (forward substitution in the same DPP layout) and the
+// stores of the finished panel by waves 1..3 WHILE wave 0 runs the next panel.  The off-diagonal blocks of the inverse follow by block
+// distance as in potrf_block_wave.  LDS: Mt as in potrf_block_wave (the part of the block not yet factored in place of L), leading dimension
+// PD_LD = 82 (lane stride 164 dwords = 36 mod 64 banks: the 16-byte accesses of wave 0, one column per lane, are conflict-free).
+// A pivot of the wrong sign is reported as in potrf_block; the panel that holds it and the panels after it become columns of the identity
+// (nothing non-finite is stored).  Partial blocks (nb < 64): rows / columns >= nb are rows of the identity.
+// ------------------------------------------------------------------------------------------
+constexpr int PD_LD = NB_IN + 18;                  // leading dimension of Mt in potrf_block_dpp
+constexpr int PD_LP = PW_W * PW_W;                 // L_pp, column-major, for the forward substitution and the stores
+constexpr int POTRF_DPP_LDS = NB_IN * PD_LD + 4 * PW_W * PW_LDT + 4 * PW_W * PW_LDT + 2 * PD_LP + NB_IN;  // doubles: Mt | Wd[4] | Ts[4] | Lp[2] | Sg
+
+template <int J>
+__device__ __forceinline__ double bc16(const double x) {         // lane J of the caller's row of 16 lanes
+    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + J, 0xf, 0xf, true);
+}
+
+#define TLPK_DPP_FMAC(i) "v_fmac_f64_dpp %" #i ", %" #i ", %[nm] row_newbcast:%c[j] row_mask:0xf bank_mask:0xf\n"
+#define TLPK_DPP_FMK(i) "v_fmac_f64_dpp %" #i ", %[w], %[v] row_newbcast:" #i " row_mask:0xf bank_mask:0xf\n"
+#define TLPK_DPP_EARLY(i) ".if (" #i " > %c[j]) && (" #i " <= %c[j] + 3)\n" TLPK_DPP_FMK(i) ".endif\n"
+#define TLPK_DPP_LATE(i) ".if " #i " > %c[j] + 3\n" TLPK_DPP_FMK(i) ".endif\n"
+#define TLPK_DPP_NEXT(i) ".if " #i " == %c[j] + 1\nv_mov_b64_dpp %0, %" #i " row_newbcast:" #i " row_mask:0xf bank_mask:0xf\n.endif\n"
+#define TLPK_DPP_ALL15(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+// step J on the diagonal block: d[k] += w(lane k) * v for the registers k = J + 1 .. 15 -- entry (k, c) of the block, held by the lane of column c,
+// takes -A[j][k] / d_j from lane k (w, read through `row_newbcast:k`) and A[j][c] from its own register j (v) -- and dn = lane J + 1's d[J + 1],
+// the next pivot, two instructions after that register was written.  (s_nop 1: w was written by the instruction in front of the statement.)
+template <int J>
+__device__ __forceinline__ void dpp_dblock(double (&d)[PW_W], const double w, const double v, double &dn) {
+    static_assert(J < PW_W - 1, "the last step has no trailing part");
+    asm("s_nop 1\n"
+        TLPK_DPP_ALL15(TLPK_DPP_EARLY)
+        ".if %c[j] == 13\ns_nop 0\n.endif\n.if %c[j] == 14\ns_nop 1\n.endif\n"
+        TLPK_DPP_ALL15(TLPK_DPP_NEXT)
+        TLPK_DPP_ALL15(TLPK_DPP_LATE)
+        : "=&v"(dn), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]), "+v"(d[10]),
+          "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15])
+        : [w] "v"(w), [v] "v"(v), [j] "n"(J));
+}
+#undef TLPK_DPP_ALL15
+#undef TLPK_DPP_NEXT
+#undef TLPK_DPP_LATE
+#undef TLPK_DPP_EARLY
+#undef TLPK_DPP_FMK
+// four rows below the diagonal block: b += bcast_J(b) * nm (the s_nop: the registers were written by the previous step's block, which the
+// compiler may have placed right in front of this one)
+template <int J>
+__device__ __forceinline__ void dpp_bchunk(double &b0, double &b1, double &b2, double &b3, const double nm) {
+    asm("s_nop 1\n" TLPK_DPP_FMAC(0) TLPK_DPP_FMAC(1) TLPK_DPP_FMAC(2) TLPK_DPP_FMAC(3)
+        : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : [nm] "v"(nm), [j] "n"(J));
+}
+// the two Newton steps of step J's reciprocal (x = rcp(dj) on entry) with the multiply-adds of step JP = J - 1 on the NBR rows below the diagonal
+// block (multiplier nmp) in the issue slots behind each dependent operation.  (s_nop 1: the trans -> VALU distance of x, and the DPP distance of b.)
+#define TLPK_DPP_BIF(i, n) ".if %c[nbr] > " #n "\n" TLPK_DPP_FMAC(i) ".endif\n"
+template <int JP, int NBR>
+__device__ __forceinline__ void dpp_newton_b(double &x, const double dj, double (&b)[12], const double nmp) {
+    double e;
+    asm("s_nop 1\n"
+        "v_fma_f64 %[e], -%[dj], %[x], 1.0\n" TLPK_DPP_BIF(0, 0)
+        "v_fmac_f64_e32 %[x], %[x], %[e]\n" TLPK_DPP_BIF(1, 1) TLPK_DPP_BIF(2, 2)
+        "v_fma_f64 %[e], -%[dj], %[x], 1.0\n" TLPK_DPP_BIF(3, 3) TLPK_DPP_BIF(4, 4)
+        "v_fmac_f64_e32 %[x], %[x], %[e]\n" TLPK_DPP_BIF(5, 5) TLPK_DPP_BIF(6, 6) TLPK_DPP_BIF(7, 7) TLPK_DPP_BIF(8, 8) TLPK_DPP_BIF(9, 9)
+        TLPK_DPP_BIF(10, 10) TLPK_DPP_BIF(11, 11)
+        : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]),
+          [x] "+v"(x), [e] "=&v"(e)
+        : [dj] "v"(dj), [nm] "v"(nmp), [j] "n"(JP), [nbr] "n"(NBR));
+}
+#undef TLPK_DPP_BIF
+#undef TLPK_DPP_FMAC
+
+// column steps J .. 15 of one panel (template recursion: the DPP lane selects are immediates).  dj = the pivot of step J (same in every lane).
+// Diagonal block: the lane of column c works on the entries (k, c) with k < c -- its registers k < c; the registers behind them are never read --
+// so the multipliers of step j are ROW j of that triangle: A[j][c] is the lane's own register j, A[j][k] is lane k's register j, and the factor
+// column j is what the lanes k > j hold in register j.  Every entry is updated from those numbers only: the standard elimination on one triangle
+// (a first version kept both triangles and took one factor from each: the two copies differ in the last bit, and on the quasi-definite system,
+// whose multipliers reach 1e8, the device-resident loops then needed 11 - 19 iterations instead of 8 - 14).
+// The rows below the diagonal block take the multiplier form with lane j's registers as the pivot column, and lag one step behind: their
+// multiply-adds of step J - 1 (multiplier nmp) stand between the dependent operations of step J's reciprocal, where the wave would otherwise wait.
+template <int NBR, int J>
+__device__ __forceinline__ void dpp_steps(double (&d)[PW_W], double (&b)[12], const double dj, const double nmp, const double (&gt)[PW_W], const int cc,
+                                          double &pv_own) {
+    double x = __builtin_amdgcn_rcp(dj);                            // 1 / (signed pivot)
+    const double dm = d[J] * gt[J];                                 // A[j][c] in the lanes of the columns c > j, 0 in the finished ones
+    if constexpr (J > 0 && NBR > 0) dpp_newton_b<J - 1, NBR>(x, dj, b, nmp);
+    else {
+        double e = fma(-dj, x, 1.0);
+        x = fma(x, e, x);
+        e = fma(-dj, x, 1.0);
+        x = fma(x, e, x);
+    }
+    const double nm = -(dm * x);                                    // -A[j][c] / d_j
+    int cj = cc;
+    asm volatile("" : "+v"(cj));                                    // keeps the lane masks of a panel's 16 steps out of the scalar registers
+    pv_own = (cj == J) ? dj : pv_own;
+    if constexpr (J + 1 < PW_W) {
+        double dn;
+        dpp_dblock<J>(d, nm, d[J], dn);
+        dpp_steps<NBR, J + 1>(d, b, dn, nm, gt, cc, pv_own);
+    } else {
+        if constexpr (NBR >= 4) dpp_bchunk<J>(b[0], b[1], b[2], b[3], nm);
+        if constexpr (NBR >= 8) dpp_bchunk<J>(b[4], b[5], b[6], b[7], nm);
+        if constexpr (NBR >= 12) dpp_bchunk<J>(b[8], b[9], b[10], b[11], nm);
+    }
+}
+
+// d[j] *= (the scale of column j, held by lane j), j = J .. 15
+template <int J>
+__device__ __forceinline__ void dpp_scale_rows(double (&d)[PW_W], const double isq) {
+    d[J] *= bc16<J>(isq);
+    if constexpr (J + 1 < PW_W) dpp_scale_rows<J + 1>(d, isq);
+}
+
+// panel P of the block (wave 0): 16 column steps on the registers, then the scaled columns go to LDS (Lp: the diagonal block, Mt: the rows below)
+template <bool SIGNED, int P>
+__device__ __forceinline__ void dpp_panel(double *Mt, double *Lp, const double *Sg, const int lane_, i32 &failcol) {
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    constexpr int NBR = 4 * (3 - P);                                // registers of rows below the diagonal block per lane
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));                                  // (nothing derived from the lane index is hoisted out of the panel loop: register pressure of the other waves' code)
+    const int g = lane >> 4, cc = lane & 15;
+    double d[PW_W], b[12], gt[PW_W];                                // gt[j] = 1 in the lanes whose column lies behind column j of the panel
+#pragma unroll
+    for (int j = 0; j < PW_W; ++j) gt[j] = (cc > j) ? 1.0 : 0.0;
+    double *Cd = Mt + (PW_W * P + cc) * PD_LD;                      // column 16 P + cc of the block
+#pragma unroll
+    for (int k = 0; k < PW_W; k += 2) {
+        const v2f64 t = *reinterpret_cast<const v2f64 *>(Cd + PW_W * P + k);
+        d[k] = t.x; d[k + 1] = t.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k += 2) {
+        if (k < NBR) {
+            const v2f64 t = *reinterpret_cast<const v2f64 *>(Cd + PW_W * (P + 1) + g * NBR + k);
+            b[k] = t.x; b[k + 1] = t.y;
+        } else { b[k] = 0.0; b[k + 1] = 0.0; }
+    }
+    double pv_own = 1.0;
+    dpp_steps<NBR, 0>(d, b, bc16<0>(d[0]), 0.0, gt, cc, pv_own);
+    const double sgl = SIGNED ? Sg[PW_W * P + cc] : 1.0;
+    const unsigned long long badm = __builtin_amdgcn_ballot_w64(!(sgl * pv_own > 0.0)) & 0xffffull;      // (every row of lanes holds the same pivots)
+    if (badm && failcol == NB_IN) failcol = PW_W * P + __builtin_ctzll(badm);
+    if (failcol < NB_IN) {                                          // (wave-uniform) this panel or an earlier one failed: columns of the identity
+#pragma unroll
+        for (int k = 0; k < PW_W; ++k) d[k] = (k == cc) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) b[k] = 0.0;
+    } else {
+        const double ad = SIGNED ? fabs(pv_own) : pv_own;
+        double isq = __builtin_amdgcn_rsq(ad);
+        isq = isq * (1.5 - 0.5 * ad * isq * isq);
+        isq = isq * (1.5 - 0.5 * ad * isq * isq);
+        if (SIGNED) isq *= sgl;                                     // column scale s_j / sqrt|d|; the diagonal entry d * s / sqrt|d| = sqrt|d|
+        dpp_scale_rows<0>(d, isq);                                  // lane r, register j <= r: L[r][j] = A[r][j] * (scale of column j)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) b[k] *= isq;
+    }
+    if (g == 0) {                                                   // lane r holds ROW r of the diagonal block (the registers behind the diagonal: never read)
+#pragma unroll
+        for (int j = 0; j < PW_W; ++j) Lp[(P & 1) * PD_LP + j * PW_W + cc] = d[j];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k += 2)
+        if (k < NBR) *reinterpret_cast<v2f64 *>(Cd + PW_W * (P + 1) + g * NBR + k) = (v2f64){b[k], b[k + 1]};
+}
+
+// x = L_pp^-1 e_cc for the lane's column cc, from l[k] = L_pp[k][cc]: steps J .. 15 of the forward substitution
+template <int J>
+__device__ __forceinline__ void dpp_inv_steps(const double (&l)[PW_W], double (&x)[PW_W], const double il) {
+    x[J] *= bc16<J>(il);
+#pragma unroll
+    for (int k = J + 1; k < PW_W; ++k) x[k] = fma(-bc16<J>(l[k]), x[J], x[k]);
+    if constexpr (J + 1 < PW_W) dpp_inv_steps<J + 1>(l, x, il);
+}
+
+template <bool SIGNED = false>
+__device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb,
+                                                const i32 kprev, double *scratch) {
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
+    double *Mt = scratch;                                        // NB_IN x PD_LD
+    double *Wd = scratch + NB_IN * PD_LD;                        // Wd[p][t * PW_LDT + r] = W_pp[r][t]
+    double *Ts = Wd + 4 * PW_W * PW_LDT;                         // one PW_W x PW_LDT transposition piece per wave
+    double *Lp = Ts + 4 * PW_W * PW_LDT;                         // Lp[p & 1][t * PW_W + r] = L_pp[r][t] (two buffers: waves 1..3 read panel p - 1's while wave 0 writes panel p's)
+    double *Sg = Lp + 2 * PD_LP;                                 // column signs of the block (SIGNED)
+    double *Ds = scratch;
+    const i32 lda = pld(fd, bk0);
+    double *P = pcol(c, fd, bk0) + bk0;                          // origin (bk0, bk0)
+    double *W = front_dinv(c, fd, bk0);                          // column-major nb x nb, ld = nb, upper part zero
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int r = lane;
+    const bool rok = r < nb;
+    const bool wfull = nb == NB_IN && !((size_t)W & 15);         // (workgroup-uniform) 16-byte stores of the inverse
+#ifdef POTRF_TRACE   /* tools/potrf_wave_bench.hip: 100 MHz stamps of the phases, one row of 32 per workgroup in c.spart */
+    unsigned long long *ptr_ = (unsigned long long *)c.spart + (size_t)blockIdx.x * 32;
+    int pti_ = 0;
+#endif
+    PT_STAMP();
+    double pv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pv[q] = P[(i64)min(r, nb - 1) + (i64)min(wave + 4 * q, nb - 1) * lda];
+    if (SIGNED && tid < NB_IN) Sg[tid] = (tid < nb) ? sg[bk0 + tid] : 1.0;
+    // left-looking over the already factored 64-wide steps of this block column (all four waves; as in potrf_block)
+    const i32 Kp = bk0 - kprev;
+    if (Kp > 0) {
+        v4f64 dacc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) dacc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        const i32 rrow = 16 * wave + lr;
+        const i32 rr_c = min(rrow, nb - 1);
+        i32 cr_c[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cr_c[a] = min(16 * a + lr, nb - 1);
+        for (i32 ks = 0; ks < Kp; ks += 16) {
+            double bq[4], aq[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double *Xc = pcol(c, fd, kprev + ks + 4 * u + lk) + bk0;
+                bq[u] = Xc[rr_c];
+                if (SIGNED) bq[u] *= sg[kprev + ks + 4 * u + lk];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) aq[u][a] = Xc[cr_c[a]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    dacc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[u][a], bq[u], dacc[a], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ds[(16 * a + lk + 4 * q) * PD_LD + rrow] = dacc[a][q];
+        __syncthreads();
+    }
+    // As = block - Ds in place of Ds: the blocks below the diagonal blocks + FULL (symmetric) diagonal 16 x 16 blocks; rows / columns beyond nb: identity
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int col = wave + 4 * q;
+        const double dv = (Kp > 0) ? Ds[col * PD_LD + r] : 0.0;
+        const double v = (rok && col < nb) ? (pv[q] - dv) : ((r == col) ? 1.0 : 0.0);
+        if (r >= col) {
+            Mt[col * PD_LD + r] = v;
+            if (r > col && (r >> 4) == (col >> 4)) Mt[r * PD_LD + col] = v;
+        }
+    }
+    __syncthreads();
+    PT_STAMP();
+    i32 failcol = NB_IN;                                         // first pivot of the wrong sign (wave 0; wave-uniform)
+    // one 16 x 16 tile of the part not yet factored: T(g, q) -= L_gp S L_qp'
+    auto tile_update = [&](const int g, const int q, const int p) {
+        v4f64 acc;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) acc[qq] = Mt[(PW_W * q + lk + 4 * qq) * PD_LD + PW_W * g + lr];
+#pragma unroll
+        for (int k4 = 0; k4 < PW_W; k4 += 4) {
+            const int kk = PW_W * p + k4 + lk;
+            double x = -Mt[kk * PD_LD + PW_W * q + lr];
+            if (SIGNED) x *= Sg[kk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, Mt[kk * PD_LD + PW_W * g + lr], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) Mt[(PW_W * q + lk + 4 * qq) * PD_LD + PW_W * g + lr] = acc[qq];
+    };
+    // columns [c0, c1) of the finished panel pp to the packed panel in global memory (lane = row: one 512-byte segment per column)
+    auto store_panel = [&](const int pp, const int c0, const int c1) {
+        const double *Lq = Lp + (pp & 1) * PD_LP;
+        int r = lane;
+        asm volatile("" : "+v"(r));
+        const bool rok = r < nb;
+        const int rd = min(max(r - PW_W * pp, 0), PW_W - 1);
+#pragma unroll 4
+        for (int cc = c0; cc < c1; ++cc) {
+            const i32 col = PW_W * pp + cc;
+            const double vb = Mt[col * PD_LD + r], vd = Lq[cc * PW_W + rd];
+            if (r >= col && rok && col < nb) P[(i64)r + (i64)col * lda] = (r < PW_W * (pp + 1)) ? vd : vb;
+        }
+    };
+    // inverse of the diagonal block pp (one wave; every row of 16 lanes computes it, row g stores its share)
+    auto inv_diag = [&](const int pp) {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const int g = lo >> 4, cc = lo & 15;
+        double l[PW_W], x[PW_W];
+#pragma unroll
+        for (int k = 0; k < PW_W; k += 2) {
+            const v2f64 t = *reinterpret_cast<const v2f64 *>(Lp + (pp & 1) * PD_LP + cc * PW_W + k);
+            l[k] = t.x; l[k + 1] = t.y;
+        }
+        double lcc = 1.0;
+#pragma unroll
+        for (int k = 0; k < PW_W; ++k) { lcc = (k == cc) ? l[k] : lcc; x[k] = (k == cc) ? 1.0 : 0.0; }
+        const double il = 1.0 / lcc;
+        dpp_inv_steps<0>(l, x, il);
+        const i32 col = PW_W * pp + cc;
+        if (g == pp) {
+#pragma unroll
+            for (int k = 0; k < PW_W; ++k) {
+                Mt[(PW_W * pp + k) * PD_LD + col] = x[k];                          // W row-major in the diagonal block
+                Wd[pp * PW_W * PW_LDT + cc * PW_LDT + k] = x[k];
+            }
+        }
+        if (g <= pp) {                                                            // rows of block g of column `col`: zeros above the diagonal block
+            if (wfull) {
+#pragma unroll
+                for (int k = 0; k < PW_W; k += 2)
+                    *reinterpret_cast<v2f64 *>(W + (i64)col * NB_IN + PW_W * g + k) = (g == pp) ? (v2f64){x[k], x[k + 1]} : (v2f64){0.0, 0.0};
+            } else if (col < nb) {
+#pragma unroll
+                for (int k = 0; k < PW_W; ++k)
+                    if (PW_W * g + k < nb) W[(i64)col * nb + PW_W * g + k] = (g == pp) ? x[k] : 0.0;
+            }
+        }
+    };
+    // what is left of panel pp once the next panel has what it reads: the inverse of its diagonal block, its stores, the other tiles
+    auto lazy = [&](const int pp) {
+        if (wave == 1) inv_diag(pp);
+        else {
+            int idx = 0;
+            for (int q = pp + 2; q < 4; ++q)
+                for (int g = q; g < 4; ++g, ++idx)
+                    if ((idx & 1) == (wave & 1)) tile_update(g, q, pp);
+            store_panel(pp, wave == 2 ? 0 : PW_W / 2, wave == 2 ? PW_W / 2 : PW_W);
+        }
+    };
+#pragma unroll 1
+    for (int p = 0; p < 4; ++p) {
+        if (wave == 0) {
+            switch (p) {
+            case 0: dpp_panel<SIGNED, 0>(Mt, Lp, Sg, lane, failcol); break;
+            case 1: dpp_panel<SIGNED, 1>(Mt, Lp, Sg, lane, failcol); break;
+            case 2: dpp_panel<SIGNED, 2>(Mt, Lp, Sg, lane, failcol); break;
+            default: dpp_panel<SIGNED, 3>(Mt, Lp, Sg, lane, failcol); break;
+            }
+        } else if (p > 0) lazy(p - 1);                           // beside wave 0's panel p
+        PT_STAMP();
+        __syncthreads();                                         // panel p of L is in Mt / Lp; the lazy work of panel p - 1 is done
+        PT_STAMP();
+        if (p < 3) {
+            if (wave >= 1 && p + wave <= 3) tile_update(p + wave, p + 1, p);      // what panel p + 1 reads
+            __syncthreads();
+            PT_STAMP();
+        }
+    }
+    if (wave == 0) { if (failcol < NB_IN && lane == 0) atomicMin(c.info, fd.col0 + bk0 + failcol); }
+    else lazy(3);
+    PT_STAMP();
+    // off-diagonal blocks of the inverse, by block distance: W_ij = -W_ii (sum_{k=j}^{i-1} L_ik W_kj); the blocks of one distance are independent:
+    // one wave each, a barrier between the distances (as in potrf_block_wave)
+#pragma unroll 1
+    for (int dist = 1; dist < 4; ++dist) {
+        __syncthreads();
+        const int i = dist + wave, j = wave;
+        if (i < 4) {                                            // (wave-uniform)
+            double *Tw = Ts + wave * (PW_W * PW_LDT);
+            v4f64 gq = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int k = j; k < i; ++k) {
+#pragma unroll
+                for (int k4 = 0; k4 < PW_W; k4 += 4)
+                    gq = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[(PW_W * k + k4 + lk) * PD_LD + PW_W * j + lr], Mt[(PW_W * k + k4 + lk) * PD_LD + PW_W * i + lr], gq, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Tw[lr * PW_LDT + lk + 4 * q] = gq[q];
+            TLPK_LDS_FENCE();
+            v4f64 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k4 = 0; k4 < PW_W; k4 += 4)
+                h = __builtin_amdgcn_mfma_f64_16x16x4f64(Tw[(k4 + lk) * PW_LDT + lr], Wd[i * PW_W * PW_LDT + (k4 + lk) * PW_LDT + lr], h, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = PW_W * i + lr, cq = PW_W * j + lk + 4 * q;
+                Mt[rr * PD_LD + cq] = -h[q];
+                if (rr < nb && cq < nb) W[(i64)rr + (i64)cq * nb] = -h[q];
+            }
+        }
+    }
+    PT_STAMP();
+}
+
+// ------------------------------------------------------------------------------------------
 // trsm on the matrix cores: X = B * L11^{-T} as the product with the inverted diagonal block,
 // computed transposed (D[c][r] = sum_k Linv[c][k] * B[r][k]) so that consecutive lanes write
 // consecutive panel rows.  The operand fragments of a 16-row strip stay in registers: each
@@ -892,7 +1290,7 @@ __device__ __forceinline__ void potrf_block_wave(const DevCtx &c, const FrontDes
 // through LDS.
 // ------------------------------------------------------------------------------------------
 constexpr int LDW = NB_IN + 16;                 // == 16 mod 32: conflict-free ds_read_b64
-static_assert(NB_IN * LDW >= POTRF_SCRATCH && NB_IN * LDW >= POTRF_PAIR_SCRATCH, "the trsm LDS block doubles as the potrf scratch");
+static_assert(NB_IN * LDW >= POTRF_SCRATCH && NB_IN * LDW >= POTRF_PAIR_SCRATCH && POTRF_DPP_LDS >= POTRF_WAVE_LDS, "the trsm LDS block doubles as the potrf scratch");
 
 // Pivot block of a small front (ns <= SMALL_NS), one WAVE per front, four fronts per workgroup: lane i
 // holds row i of the lower triangle and row i of an identity block in registers, pivots and pivot
@@ -964,11 +1362,13 @@ __global__ __launch_bounds__(256) void k_potrf_small(const PotrfTask *__restrict
     }
 }
 
-// Rows [row0, min(row0 + 64, rowlim)) of the 64-wide step k0 (width nb), inside the diagonal
+// Rows [row0, min(row0 + 64 NBR, rowlim)) of the 64-wide step k0 (width nb), inside the diagonal
 // block of a block column: B -= X_prev * L[k0.., kprev..k0)' first (left-looking), then the
-// solve.  One wave = 16 rows (keeps the kernel within 256 registers: its workgroup must fit
-// next to a k_update workgroup on the same CU).  In place: a wave only overwrites its own rows, after all of its loads.
-template <bool SIGNED = false>
+// solve.  One wave = 16 rows of each 64-row block (wave w: rows row0 + 16 w + 64 b, b < NBR).  In place: a wave only overwrites its own rows, after
+// all of its loads.  NBR = 3 (round 5): ALL the rows below the step inside a 256-wide block column in one call -- the staged blocks (L of the
+// earlier steps, the inverted diagonal block) are shared by the row blocks, a block column costs 3 calls instead of 6 (every row is computed
+// exactly as by the one-block calls: same sums, same order).
+template <bool SIGNED = false, int NBR = 1>
 __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, const i32 k0, const i32 nb,
                                           const i32 row0, const i32 rowlim, const i32 kprev, double *Ws) {
     const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
@@ -980,24 +1380,25 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
-    constexpr int NBR = 1;                          // 16-row blocks per wave
-    const i32 rbase = row0 + wave * 16 * NBR;
-    const bool active = rbase < rowlim;
+    const i32 rbase = row0 + wave * 16;
+    const int nact = (rbase < rowlim) ? min(NBR, (rowlim - rbase + NB_IN - 1) / NB_IN) : 0;      // (wave-uniform) 16-row groups of this wave
     // rows are clamped instead of guarded (per-lane guards turn every load into its own
     // exec-masked branch with its own wait; a clamped row only produces entries the stores skip)
     double bf[NBR][16];
     i32 rowc[NBR];
 #pragma unroll
-    for (int b = 0; b < NBR; ++b) rowc[b] = min(rbase + b * 16 + lr, rowlim - 1);
+    for (int b = 0; b < NBR; ++b) rowc[b] = min(rbase + b * NB_IN + lr, rowlim - 1);
 #pragma unroll
     for (int b = 0; b < NBR; ++b)
+        if (b < nact) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const i32 k = 4 * ks + lk;
-            const double v = P0[(i64)rowc[b] + (i64)min(k, nb - 1) * ld0];      // clamped, not guarded
-            bf[b][ks] = (k < nb) ? v : 0.0;
+            for (int ks = 0; ks < 16; ++ks) {
+                const i32 k = 4 * ks + lk;
+                const double v = P0[(i64)rowc[b] + (i64)min(k, nb - 1) * ld0];      // clamped, not guarded
+                bf[b][ks] = (k < nb) ? v : 0.0;
+            }
         }
-    v4f64 acc[4][NBR];
+    v4f64 acc[4];
     const i32 Kp = k0 - kprev;
     for (i32 c0 = 0; c0 < Kp; c0 += NB_IN) {
         __syncthreads();
@@ -1009,34 +1410,26 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
             Ws[k * LDW + cc] = (cc < nb) ? v : 0.0;
         }
         __syncthreads();
-        if (active) {
-            double xf[NBR][16];
 #pragma unroll
-            for (int b = 0; b < NBR; ++b)
+        for (int b = 0; b < NBR; ++b)
+            if (b < nact) {
+                double xf[16];
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
-                    xf[b][ks] = Pc[(i64)rowc[b] + (i64)(4 * ks + lk) * ldc] * (SIGNED ? sg[kprev + c0 + 4 * ks + lk] : 1.0);
+                    xf[ks] = Pc[(i64)rowc[b] + (i64)(4 * ks + lk) * ldc] * (SIGNED ? sg[kprev + c0 + 4 * ks + lk] : 1.0);
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int b = 0; b < NBR; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+                for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const double wv = Ws[(4 * ks + lk) * LDW + a * 16 + lr];
-#pragma unroll
-                    for (int b = 0; b < NBR; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, xf[b][ks], acc[a][b], 0, 0, 0);
+                    for (int a = 0; a < 4; ++a)
+                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[(4 * ks + lk) * LDW + a * 16 + lr], xf[ks], acc[a], 0, 0, 0);
                 }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bf[b][4 * a + q] -= acc[a][q];
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < NBR; ++b)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) bf[b][4 * a + q] -= acc[a][b][q];
-        }
     }
     __syncthreads();
     for (int idx = tid; idx < NB_IN * NB_IN; idx += 256) {
@@ -1045,35 +1438,29 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
         Ws[k * LDW + cc] = (cc < nb && k < nb) ? v : 0.0;
     }
     __syncthreads();
-    if (active) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < NBR; ++b)
+        if (b < nact) {
 #pragma unroll
-            for (int b = 0; b < NBR; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
+            for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (4 * ks > 16 * a + 15) continue;       // Linv[c][k] = 0 for k > c: whole block is zero
-                const double wv = Ws[(4 * ks + lk) * LDW + a * 16 + lr];
-#pragma unroll
-                for (int b = 0; b < NBR; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, bf[b][ks], acc[a][b], 0, 0, 0);
+                for (int a = 0; a < 4; ++a) {
+                    if (4 * ks > 16 * a + 15) continue;       // Linv[c][k] = 0 for k > c: whole block is zero
+                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[(4 * ks + lk) * LDW + a * 16 + lr], bf[b][ks], acc[a], 0, 0, 0);
+                }
             }
-        }
-        // D[i][j] (reg q: i = lk + 4q -> column c = 16a + i ; j = lr -> row)
+            // D[i][j] (reg q: i = lk + 4q -> column c = 16a + i ; j = lr -> row)
+            const i32 row = rbase + b * NB_IN + lr;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < NBR; ++b) {
-                const i32 row = rbase + b * 16 + lr;
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const i32 cc = a * 16 + lk + 4 * q;
-                    if (row < rowlim && cc < nb) P0[(i64)row + (i64)cc * ld0] = SIGNED ? acc[a][b][q] * sg[k0 + cc] : acc[a][b][q];
+                    if (row < rowlim && cc < nb) P0[(i64)row + (i64)cc * ld0] = SIGNED ? acc[a][q] * sg[k0 + cc] : acc[a][q];
                 }
-            }
-    }
+        }
 }
 
 // Diagonal block of one block column (t.nb <= NB_OUT columns from t.k0; the columns before k0 have
@@ -1083,31 +1470,38 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
 // WAVE: the 64 x 64 diagonal blocks by potrf_block_wave (one wave, no barrier per column) instead of potrf_block (TLPK_POTRF_WAVE=0: the
 // round-1..3 kernels)
 static_assert(LDW_ == LDW, "potrf_block_wave: LDS stride");
-// MODE: 0 = potrf_block (one barrier per column), 1 = potrf_block_wave, 2 = potrf_block_pair (one barrier per two columns; the default since round 5)
+// MODE: 0 = potrf_block (one barrier per column), 1 = potrf_block_wave, 2 = potrf_block_pair (one barrier per two columns), 3 = potrf_block_dpp (round 5; with ONE
+// trsm_rows call per 64-wide step inside k_potrf_wide: 115 against 123 us per 256-wide block, same bits)
 template <bool SIGNED, int MODE>
 __device__ __forceinline__ void potrf_block_any(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb, const i32 kprev, double *scratch) {
-    if (MODE == 1) potrf_block_wave<SIGNED>(c, fd, bk0, nb, kprev, scratch);
+    if (MODE == 3) potrf_block_dpp<SIGNED>(c, fd, bk0, nb, kprev, scratch);
+    else if (MODE == 1) potrf_block_wave<SIGNED>(c, fd, bk0, nb, kprev, scratch);
     else if (MODE == 2) potrf_block_pair<SIGNED>(c, fd, bk0, nb, kprev, scratch);
     else potrf_block<SIGNED>(c, fd, bk0, nb, kprev, scratch);
 }
 template <bool SIGNED, int MODE>
 __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tasks, DevCtx c) {      // t.nb <= NB_IN
-    __shared__ __attribute__((aligned(16))) double scratch[MODE == 1 ? POTRF_WAVE_LDS : (MODE == 2 ? POTRF_PAIR_SCRATCH : POTRF_SCRATCH)];
+    __shared__ __attribute__((aligned(16))) double scratch[MODE == 3 ? POTRF_DPP_LDS : (MODE == 1 ? POTRF_WAVE_LDS : (MODE == 2 ? POTRF_PAIR_SCRATCH : POTRF_SCRATCH))];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     potrf_block_any<SIGNED, MODE>(c, fd, t.k0, t.nb, t.k0, scratch);
 }
 template <bool SIGNED, int MODE>
 __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restrict__ tasks, DevCtx c) {
-    __shared__ __attribute__((aligned(16))) double Ws[MODE == 1 ? POTRF_WAVE_LDS : NB_IN * LDW];
+    __shared__ __attribute__((aligned(16))) double Ws[MODE == 3 ? POTRF_DPP_LDS : (MODE == 1 ? POTRF_WAVE_LDS : NB_IN * LDW)];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
     potrf_block_any<SIGNED, MODE>(c, fd, k0, min(w, NB_IN), k0, Ws);
     for (i32 ks = k0; ks + NB_IN < kend; ks += NB_IN) {          // step ks is factored: rows below, next diagonal block
-        for (i32 r0 = ks + NB_IN; r0 < kend; r0 += NB_IN) {
+        if constexpr (MODE == 3) {
             __syncthreads();                                     // own global stores visible, Ws free
-            trsm_rows<SIGNED>(c, fd, ks, NB_IN, r0, kend, k0, Ws);
+            trsm_rows<SIGNED, (NB_OUT - NB_IN) / NB_IN>(c, fd, ks, NB_IN, ks + NB_IN, kend, k0, Ws);      // all the rows below the step inside the block column
+        } else {                                                 // (the older block kernels keep their one-block calls: next to them three row blocks in registers spill)
+            for (i32 r0 = ks + NB_IN; r0 < kend; r0 += NB_IN) {
+                __syncthreads();
+                trsm_rows<SIGNED>(c, fd, ks, NB_IN, r0, kend, k0, Ws);
+            }
         }
         __syncthreads();
         potrf_block_any<SIGNED, MODE>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
@@ -2741,13 +3135,20 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
                            a.pair_w, a.pair_j, a.asm_D, a.asm_regD);
         break;
     case LK_POTRF: case LK_POTRF_WIDE: {
-        // 64 x 64 diagonal-block kernel: 2 = potrf_block_pair (one barrier per two columns; bit-identical to 0, the default since round 5),
-        // 0 = potrf_block (TLPK_POTRF_PAIR=0), 1 = potrf_block_wave (TLPK_POTRF_WAVE=1; measured slower, see there)
-        static const int pm = [] {
+        // 64 x 64 diagonal-block kernel (TLPK_POTRF_MODE): 3 = potrf_block_dpp (DPP broadcasts, one wave per panel chain; the default since round 5:
+        // 16.7 us per block against 32.9), 2 = potrf_block_pair (one barrier per two columns; bit-identical to 0), 0 = potrf_block (one barrier per
+        // column, rounds 1..4), 1 = potrf_block_wave (readlane broadcasts; measured slower, see there).  TLPK_POTRF_WAVE / TLPK_POTRF_PAIR: the older switches.
+        auto mode = [] {
+            const char *m = std::getenv("TLPK_POTRF_MODE"); if (m) return std::atoi(m) & 3;
             const char *w = std::getenv("TLPK_POTRF_WAVE"); if (w && std::atoi(w) != 0) return 1;
-            const char *e = std::getenv("TLPK_POTRF_PAIR"); return (e && std::atoi(e) == 0) ? 0 : 2;
-        }();
-#define TLPK_LAUNCH_PM(KERNEL, SG) do { if (pm == 1) hipLaunchKernelGGL((KERNEL<SG, 1>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
+            const char *e = std::getenv("TLPK_POTRF_PAIR"); if (e) return std::atoi(e) == 0 ? 0 : 2;
+            return 3;
+        };
+        static const bool dyn = std::getenv("TLPK_POTRF_DYN") != nullptr;      // (diagnostics: the mode is re-read at every launch)
+        static const int pm0 = mode();
+        const int pm = dyn ? mode() : pm0;
+#define TLPK_LAUNCH_PM(KERNEL, SG) do { if (pm == 3) hipLaunchKernelGGL((KERNEL<SG, 3>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
+                                        else if (pm == 1) hipLaunchKernelGGL((KERNEL<SG, 1>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
                                         else if (pm == 2) hipLaunchKernelGGL((KERNEL<SG, 2>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
                                         else hipLaunchKernelGGL((KERNEL<SG, 0>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); } while (0)
 #define TLPK_LAUNCH_P(KERNEL) do { if (sgn) TLPK_LAUNCH_PM(KERNEL, true); else TLPK_LAUNCH_PM(KERNEL, false); } while (0)

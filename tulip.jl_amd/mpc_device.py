@@ -84,6 +84,7 @@ class DeviceMPC(DeviceHSD):
                 self.regD *= 100; self.regP *= 100
                 nbump += 1
                 self.timers["n_bump"] += 1
+        self.timers["max_bumps_in_a_step"] = max(self.timers.get("max_bumps_in_a_step", 0), nbump)
         if not nbump < 3:                                                     # step.jl:51 (the reference's off-by-one is kept)
             raise PosDefException(0)
         out = self._out
