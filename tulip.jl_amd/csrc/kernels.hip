@@ -1064,14 +1064,24 @@ __device__ __forceinline__ void dpp_panel(double *Mt, double *Lp, const double *
         if (k < NBR) *reinterpret_cast<v2f64 *>(Cd + PW_W * (P + 1) + g * NBR + k) = (v2f64){b[k], b[k + 1]};
 }
 
-// x = L_pp^-1 e_cc for the lane's column cc, from l[k] = L_pp[k][cc]: steps J .. 15 of the forward substitution
+// x = L_pp^-1 e_cc for the lane's column cc, from l[k] = L_pp[k][cc]: steps J .. 15 of the forward substitution, x[k] -= L[k][J] x[J] with
+// L[k][J] = lane J's l[k] (one v_fmac_f64_dpp each; l is never written here, the s_nop covers whatever the compiler did to it before)
+#define TLPK_DPP_XK(i) ".if " #i " > %c[j]\nv_fmac_f64_dpp %[x" #i "], %[l" #i "], %[nx] row_newbcast:%c[j] row_mask:0xf bank_mask:0xf\n.endif\n"
 template <int J>
 __device__ __forceinline__ void dpp_inv_steps(const double (&l)[PW_W], double (&x)[PW_W], const double il) {
     x[J] *= bc16<J>(il);
-#pragma unroll
-    for (int k = J + 1; k < PW_W; ++k) x[k] = fma(-bc16<J>(l[k]), x[J], x[k]);
-    if constexpr (J + 1 < PW_W) dpp_inv_steps<J + 1>(l, x, il);
+    if constexpr (J + 1 < PW_W) {
+        const double nx = -x[J];
+        asm("s_nop 1\n" TLPK_DPP_XK(1) TLPK_DPP_XK(2) TLPK_DPP_XK(3) TLPK_DPP_XK(4) TLPK_DPP_XK(5) TLPK_DPP_XK(6) TLPK_DPP_XK(7) TLPK_DPP_XK(8)
+            : [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]), [x6] "+v"(x[6]), [x7] "+v"(x[7]), [x8] "+v"(x[8])
+            : [l1] "v"(l[1]), [l2] "v"(l[2]), [l3] "v"(l[3]), [l4] "v"(l[4]), [l5] "v"(l[5]), [l6] "v"(l[6]), [l7] "v"(l[7]), [l8] "v"(l[8]), [nx] "v"(nx), [j] "n"(J));
+        asm("s_nop 1\n" TLPK_DPP_XK(9) TLPK_DPP_XK(10) TLPK_DPP_XK(11) TLPK_DPP_XK(12) TLPK_DPP_XK(13) TLPK_DPP_XK(14) TLPK_DPP_XK(15)
+            : [x9] "+v"(x[9]), [x10] "+v"(x[10]), [x11] "+v"(x[11]), [x12] "+v"(x[12]), [x13] "+v"(x[13]), [x14] "+v"(x[14]), [x15] "+v"(x[15])
+            : [l9] "v"(l[9]), [l10] "v"(l[10]), [l11] "v"(l[11]), [l12] "v"(l[12]), [l13] "v"(l[13]), [l14] "v"(l[14]), [l15] "v"(l[15]), [nx] "v"(nx), [j] "n"(J));
+        dpp_inv_steps<J + 1>(l, x, il);
+    }
 }
+#undef TLPK_DPP_XK
 
 template <bool SIGNED = false>
 __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb,
@@ -1214,7 +1224,41 @@ __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc
             }
         }
     };
-    // what is left of panel pp once the next panel has what it reads: the inverse of its diagonal block, its stores, the other tiles
+    // Off-diagonal blocks of the inverse: W_ij = -W_ii G_ij, G_ij = sum_{k=j}^{i-1} L_ik W_kj (needs the blocks W_kj of the row blocks above i).
+    // inv_gpart adds the terms k0 <= k < k1 to an accumulator (matrix-core layout), inv_finish multiplies by -W_ii through the wave's transposition piece.
+    auto inv_gpart = [&](v4f64 gq, const int i, const int j, const int k0, const int k1) {
+#pragma unroll 1
+        for (int k = k0; k < k1; ++k) {
+#pragma unroll
+            for (int k4 = 0; k4 < PW_W; k4 += 4)
+                gq = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[(PW_W * k + k4 + lk) * PD_LD + PW_W * j + lr], Mt[(PW_W * k + k4 + lk) * PD_LD + PW_W * i + lr], gq, 0, 0, 0);
+        }
+        return gq;
+    };
+    auto inv_finish = [&](const v4f64 gq, const int i, const int j) {
+        double *Tw = Ts + wave * (PW_W * PW_LDT);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Tw[lr * PW_LDT + lk + 4 * q] = gq[q];
+        TLPK_LDS_FENCE();
+        v4f64 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k4 = 0; k4 < PW_W; k4 += 4)
+            h = __builtin_amdgcn_mfma_f64_16x16x4f64(Tw[(k4 + lk) * PW_LDT + lr], Wd[i * PW_W * PW_LDT + (k4 + lk) * PW_LDT + lr], h, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = PW_W * i + lr, cq = PW_W * j + lk + 4 * q;
+            Mt[rr * PD_LD + cq] = -h[q];
+            if (rr < nb && cq < nb) W[(i64)rr + (i64)cq * nb] = -h[q];
+        }
+        TLPK_LDS_FENCE();
+    };
+    const v4f64 zero4 = {0.0, 0.0, 0.0, 0.0};
+    v4f64 ga = zero4, gb = zero4;                                // sums G_ij of waves 0, 2, 3, kept in registers from the slot that forms them to the phase that finishes them
+    // What is left of panel pp (pp < 3) once the next panel has what it reads -- beside wave 0's panel pp + 1:
+    //   wave 1: the inverse W_pp of the diagonal block (a serial chain of its own: ~1 us);
+    //   waves 2, 3: the tiles panel pp + 1 does not read, the stores of panel pp, and every sum G_ij whose terms are older than the last barrier.
+    // The products -W_ii G_ij follow in the next phase in which W_ii is visible and a wave is idle (W_10: wave 3 beside the tile of panel 3;
+    // W_20, W_21: waves 2, 3 beside W_33; W_3j: after one more barrier).
     auto lazy = [&](const int pp) {
         if (wave == 1) inv_diag(pp);
         else {
@@ -1223,6 +1267,11 @@ __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc
                 for (int g = q; g < 4; ++g, ++idx)
                     if ((idx & 1) == (wave & 1)) tile_update(g, q, pp);
             store_panel(pp, wave == 2 ? 0 : PW_W / 2, wave == 2 ? PW_W / 2 : PW_W);
+            if (pp == 1 && wave == 3) ga = inv_gpart(zero4, 1, 0, 0, 1);           // G_10 = L_10 W_00
+            if (pp == 2) {
+                ga = inv_gpart(zero4, 2, wave - 2, wave - 2, 2);                   // G_20 = L_20 W_00 + L_21 W_10 (wave 2), G_21 = L_21 W_11 (wave 3)
+                gb = inv_gpart(zero4, 3, wave - 2, wave - 2, 2);                   // the terms k < 2 of G_30 (wave 2), G_31 (wave 3)
+            }
         }
     };
 #pragma unroll 1
@@ -1240,43 +1289,25 @@ __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc
         PT_STAMP();
         if (p < 3) {
             if (wave >= 1 && p + wave <= 3) tile_update(p + wave, p + 1, p);      // what panel p + 1 reads
+            if (p == 2 && wave == 3) inv_finish(ga, 1, 0);                        // W_10 = -W_11 G_10 (W_11: beside panel 2)
             __syncthreads();
             PT_STAMP();
         }
     }
-    if (wave == 0) { if (failcol < NB_IN && lane == 0) atomicMin(c.info, fd.col0 + bk0 + failcol); }
-    else lazy(3);
-    PT_STAMP();
-    // off-diagonal blocks of the inverse, by block distance: W_ij = -W_ii (sum_{k=j}^{i-1} L_ik W_kj); the blocks of one distance are independent:
-    // one wave each, a barrier between the distances (as in potrf_block_wave)
-#pragma unroll 1
-    for (int dist = 1; dist < 4; ++dist) {
-        __syncthreads();
-        const int i = dist + wave, j = wave;
-        if (i < 4) {                                            // (wave-uniform)
-            double *Tw = Ts + wave * (PW_W * PW_LDT);
-            v4f64 gq = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-            for (int k = j; k < i; ++k) {
-#pragma unroll
-                for (int k4 = 0; k4 < PW_W; k4 += 4)
-                    gq = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[(PW_W * k + k4 + lk) * PD_LD + PW_W * j + lr], Mt[(PW_W * k + k4 + lk) * PD_LD + PW_W * i + lr], gq, 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Tw[lr * PW_LDT + lk + 4 * q] = gq[q];
-            TLPK_LDS_FENCE();
-            v4f64 h = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k4 = 0; k4 < PW_W; k4 += 4)
-                h = __builtin_amdgcn_mfma_f64_16x16x4f64(Tw[(k4 + lk) * PW_LDT + lr], Wd[i * PW_W * PW_LDT + (k4 + lk) * PW_LDT + lr], h, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rr = PW_W * i + lr, cq = PW_W * j + lk + 4 * q;
-                Mt[rr * PD_LD + cq] = -h[q];
-                if (rr < nb && cq < nb) W[(i64)rr + (i64)cq * nb] = -h[q];
-            }
-        }
+    // the end: W_33 by wave 1; beside it waves 2, 3 finish W_20, W_21 (W_22: beside panel 3) and add their term to G_30, G_31, wave 0 forms G_32 and
+    // stores panel 3; after one more barrier W_3j = -W_33 G_3j
+    if (wave == 1) inv_diag(3);
+    else if (wave == 0) {
+        if (failcol < NB_IN && lane == 0) atomicMin(c.info, fd.col0 + bk0 + failcol);
+        gb = inv_gpart(zero4, 3, 2, 2, 3);
+        store_panel(3, 0, PW_W);
+    } else {
+        inv_finish(ga, 2, wave - 2);
+        gb = inv_gpart(gb, 3, wave - 2, 2, 3);
     }
+    PT_STAMP();
+    __syncthreads();
+    if (wave != 1) inv_finish(gb, 3, wave == 0 ? 2 : wave - 2);
     PT_STAMP();
 }
 
