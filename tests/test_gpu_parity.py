@@ -1015,3 +1015,48 @@ def test_guarded_refinement_never_increases_the_residual():
                     # two evaluations of a residual at rounding level differ by a factor of order one -- the guard is against growth by decades)
                     assert not np.isfinite(base[0]) or (v[0] <= 2.0 * base[0] and v[1] <= 64.0 * max(base[1], 1e-300)), (span, steps, multi, v, base)
     print("guarded refinement: a step was rejected in at least one trial:", seen_reject)
+
+
+@pytest.mark.parametrize("system", ["K1", "K2"])
+def test_diagonal_block_kernels_agree(system, monkeypatch):
+    """Round 5: potrf_block_dpp (TLPK_POTRF_MODE=3, the default: column steps on DPP row broadcasts, multipliers from one triangle of the diagonal
+    block) against potrf_block_pair / potrf_block (2 / 0: one LDS hand-over per column) on the SAME handle (TLPK_POTRF_DYN re-reads the mode at every
+    launch): fronts with whole and partial 64-wide blocks, 256-wide block columns (one trsm call per step against one per 64 rows), late-IPM
+    scaling, the signed factorisation of the augmented system; a failing pivot is reported by every kernel, the handle stays usable."""
+    monkeypatch.setenv("TLPK_POTRF_DYN", "1")
+    A, rb = block_angular(nblocks=3, mk=700, nk=1100, m0=90, nnz_in=5, link_prob=0.6, seed=123)
+    m, n = A.shape
+    kkt = tk.setup(A, tk.K1() if system == "K1" else tk.K2(), tk.Backend(device=0, row_block=rb))
+    assert kkt.stats()["max_front"] > 300
+    for regime in ("mid", "late"):
+        th, rp, rd, xp, xd = ipm_like_data(m, n, 17, regime)
+        res = {}
+        for mode in ("3", "2", "0"):
+            monkeypatch.setenv("TLPK_POTRF_MODE", mode)
+            tk.update(kkt, th, rp, rd)
+            dx = np.zeros(n); dy = np.zeros(m)
+            tk.solve(dx, dy, kkt, xp, xd)
+            res[mode] = (kkt.factor_panels().copy(), dx, dy, max(kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)))
+        assert np.array_equal(res["2"][0], res["0"][0])                          # potrf_block_pair is bit-identical to potrf_block
+        L3, L2 = res["3"][0], res["2"][0]
+        scale = np.abs(L2).max()
+        # mid: the factors agree entry by entry (measured 1e-14 for K1, 3e-11 for K2).  late (theta_inv in 10^[-8, 8], regularisations sqrt(eps)): K1 still
+        # agrees to 2e-10, the quasi-definite factor is no longer determined entry by entry (the two kernels' L differ by 1e-2 of max|L| = 3e4) --
+        # what both must deliver there is an equally good solution of the KKT system, asserted below
+        ltol = {("K1", "mid"): 1e-11, ("K1", "late"): 1e-7, ("K2", "mid"): 1e-9, ("K2", "late"): np.inf}[(system, regime)]
+        assert np.abs(L3 - L2).max() <= ltol * scale, (regime, np.abs(L3 - L2).max() / scale)
+        if regime == "mid":
+            for k in (1, 2):
+                assert np.abs(res["3"][k] - res["2"][k]).max() <= 1e-9 * max(1.0, np.abs(res["2"][k]).max())
+        assert res["3"][3] <= 10 * res["2"][3] + 1e-12                           # the new kernel's solve is as good a solution of the KKT system
+        print(system, regime, "max |L3 - L2| / max|L| = %.2e, residuals %.2e (dpp) %.2e (pair)" % (np.abs(L3 - L2).max() / scale, res["3"][3], res["2"][3]))
+    bad = rd.copy(); bad[m // 2] = -1e9
+    for mode in ("3", "2"):
+        monkeypatch.setenv("TLPK_POTRF_MODE", mode)
+        with pytest.raises(tk.PosDefException):
+            tk.update(kkt, th, rp, bad)
+        tk.update(kkt, th, rp, rd)                                               # the handle is usable after the failure
+        dx = np.zeros(n); dy = np.zeros(m)
+        tk.solve(dx, dy, kkt, xp, xd)
+        assert np.isfinite(dx).all() and np.isfinite(dy).all()
+    kkt.close()

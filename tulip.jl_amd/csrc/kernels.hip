@@ -3175,7 +3175,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
             const char *e = std::getenv("TLPK_POTRF_PAIR"); if (e) return std::atoi(e) == 0 ? 0 : 2;
             return 3;
         };
-        static const bool dyn = std::getenv("TLPK_POTRF_DYN") != nullptr;      // (diagnostics: the mode is re-read at every launch)
+        const bool dyn = std::getenv("TLPK_POTRF_DYN") != nullptr;             // (diagnostics / the kernel-agreement test: the mode is re-read at every launch)
         static const int pm0 = mode();
         const int pm = dyn ? mode() : pm0;
 #define TLPK_LAUNCH_PM(KERNEL, SG) do { if (pm == 3) hipLaunchKernelGGL((KERNEL<SG, 3>), g, dim3(256), 0, st, a.potrf_tasks + L.first, a.ctx); \
