@@ -761,6 +761,10 @@ int analyse_rank(Symbolic &S, const Options &opt) {
         // 2 groups x (stream + side stream) = 4 streams = the runtime's default number of hardware
         // queues; more streams share queues and serialise (measured: 2 -> 69.5, 3 -> 75.5, 4 -> 74.3 ms/step on C4)
         S.ngroups = std::min(2, nblocks);
+        // a rank of a sharded / multi-device handle that owns few blocks: every launch of a group holds one tile set per block, two groups halve it for
+        // nothing to overlap with (round 5, rank-local step of C4 / north-star shape: 8 blocks 12.5 vs 13.0 ms, 12 blocks 25.7 vs 25.7, 16 blocks 18.8 vs
+        // 18.9, 25 blocks 42.6 vs 42.0, 32 blocks 30.4 vs 30.1 with one / two groups; results do not depend on the number of groups)
+        if (opt.nranks > 1 && S.n_local_blocks <= 8) S.ngroups = 1;
         if (opt.streams > 0) S.ngroups = std::min({opt.streams, MAX_GROUPS, nblocks});
         else if (const char *e = std::getenv("TLPK_STREAMS")) S.ngroups = std::max(1, std::min({std::atoi(e), MAX_GROUPS, nblocks}));
     }
