@@ -1523,6 +1523,9 @@ __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restri
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
+    // the chain's four waves are served before the update tiles' waves that share their SIMDs (beside k_update the chain runs on the side stream: its end is what the
+    // group's stream waits for at the join): C4 51.0 -> 50.8 ms, pds-class 15.79 -> 15.68 ms (profiles/r05_chain_overlap.txt)
+    if (MODE == 3) __builtin_amdgcn_s_setprio(3);
     potrf_block_any<SIGNED, MODE>(c, fd, k0, min(w, NB_IN), k0, Ws);
     for (i32 ks = k0; ks + NB_IN < kend; ks += NB_IN) {          // step ks is factored: rows below, next diagonal block
         if constexpr (MODE == 3) {
