@@ -54,16 +54,24 @@ __device__ __forceinline__ double blk_min(double v, double *sh) {
     return r;
 }
 
-// partials[block][slot]; slots [0, nsum) are sums, [nsum, nsum + nmax) maxima, the rest minima
-__global__ void k_ipm_finalize(int nblocks, int nsum, int nmax, int nmin, const double *__restrict__ partials, double *__restrict__ out) {
-    const int k = threadIdx.x;
-    if (k >= nsum + nmax + nmin) return;
-    double r = partials[k];
-    for (int b = 1; b < nblocks; ++b) {
+// partials[block][slot]; slots [0, nsum) are sums, [nsum, nsum + nmax) maxima, the rest minima.  One wave per slot: lane l combines the blocks l, l + 64, ... in
+// that order, then a fixed butterfly over the 64 lanes -- the same order in every run (bitwise deterministic), whatever the number of blocks.  (Until round 5 one
+// THREAD per slot walked the 1024 blocks one dependent load at a time: 363 us per call, ten calls per interior-point iteration.)
+__global__ __launch_bounds__(64 * IPM_SLOTS) void k_ipm_finalize(int nblocks, int nsum, int nmax, int nmin, const double *__restrict__ partials, double *__restrict__ out) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (k >= nsum + nmax + nmin) return;                                     // (wave-uniform)
+    const int op = (k < nsum) ? 0 : (k < nsum + nmax ? 1 : 2);
+    double r = (op == 0) ? 0.0 : (op == 1 ? -INFINITY : INFINITY);
+    for (int b = lane; b < nblocks; b += 64) {
         const double v = partials[(size_t)b * IPM_SLOTS + k];
-        r = (k < nsum) ? r + v : (k < nsum + nmax ? fmax(r, v) : fmin(r, v));
+        r = (op == 0) ? r + v : (op == 1 ? fmax(r, v) : fmin(r, v));
     }
-    out[k] = r;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double v = __shfl_xor(r, off, 64);
+        r = (op == 0) ? r + v : (op == 1 ? fmax(r, v) : fmin(r, v));
+    }
+    if (lane == 0) out[k] = r;
 }
 
 __global__ void k_ipm_init(IpmVecs v) {                                     // HSD.jl:238-247
@@ -103,12 +111,20 @@ __global__ __launch_bounds__(IPM_T) void k_ipm_res_cols(IpmVecs v, double tau, d
 }
 // rows: rp + sum {b'y} + maxima {|rp|, |A x|}
 __global__ __launch_bounds__(IPM_T) void k_ipm_res_rows(IpmVecs v, double tau, double *__restrict__ partials) {
+    // 8 lanes per row, fixed shuffle tree inside the group (as k_rhs: one thread per row walked its ~9 entries one dependent gather at a time, 441 us on config C4)
     __shared__ double sh[IPM_T];
     double s0 = 0, m0 = 0, m1 = 0;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < v.m; i += stride) {
+    const int lane = threadIdx.x & 7;
+    const i64 stride = ((i64)gridDim.x * blockDim.x) >> 3;
+    const i64 mround = (v.m + stride - 1) / stride * stride;                 // every group runs the same number of trips: the shuffles stay convergent
+    for (i64 i = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < mround; i += stride) {
+        const bool live = i < v.m;
         double ax = 0.0;
-        for (i64 q = v.Tp[i]; q < v.Tp[i + 1]; ++q) ax += v.Tx[q] * v.x[v.Tj[q]];
+        if (live)
+            for (i64 q = v.Tp[i] + lane; q < v.Tp[i + 1]; q += 8) ax += v.Tx[q] * v.x[v.Tj[q]];
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) ax += __shfl_down(ax, off, 8);
+        if (!live || lane != 0) continue;
         const double rp = tau * v.b[i] - ax;
         v.rp[i] = rp;
         s0 += v.b[i] * v.y[i];
@@ -349,7 +365,7 @@ static inline int ipm_blocks(i64 len) { return (int)std::max<i64>(1, std::min<i6
 
 void ipm_launch_init(hipStream_t st, const IpmVecs &v) { hipLaunchKernelGGL(k_ipm_init, dim3(ipm_blocks(std::max(v.n, v.m))), dim3(IPM_T), 0, st, v); }
 void ipm_launch_finalize(hipStream_t st, int nblocks, int nsum, int nmax, int nmin, const double *partials, double *out) {
-    hipLaunchKernelGGL(k_ipm_finalize, dim3(1), dim3(64), 0, st, nblocks, nsum, nmax, nmin, partials, out);
+    hipLaunchKernelGGL(k_ipm_finalize, dim3(1), dim3(64 * (nsum + nmax + nmin)), 0, st, nblocks, nsum, nmax, nmin, partials, out);
 }
 int ipm_launch_res_cols(hipStream_t st, const IpmVecs &v, double tau, double *partials) { const int nb = ipm_blocks(v.n); hipLaunchKernelGGL(k_ipm_res_cols, dim3(nb), dim3(IPM_T), 0, st, v, tau, partials); return nb; }
 int ipm_launch_res_rows(hipStream_t st, const IpmVecs &v, double tau, double *partials) { const int nb = ipm_blocks(v.m); hipLaunchKernelGGL(k_ipm_res_rows, dim3(nb), dim3(IPM_T), 0, st, v, tau, partials); return nb; }
