@@ -883,28 +883,28 @@ __device__ __forceinline__ void potrf_block_wave(const DevCtx &c, const FrontDes
 }
 
 // ------------------------------------------------------------------------------------------
-// potrf_block on DPP broadcasts (round 5).  The 64 x 64 block is walked in four 16-column panels as in potrf_block_wave, but the 16 column
-// steps of a panel run in the layout  lane (g, cc) = column cc of the panel, registers = rows:  d[k] = A[16 p + k][16 p + cc] (the 16 x 16
-// diagonal block, held FULL -- both triangles -- by each of the wave's four rows of 16 lanes) and b[k] = a row of the panel below the diagonal
-// block (the 16 (3 - p) rows are dealt to the four rows of lanes: 4 (3 - p) registers).  In that layout the entry A[k][j] of the pivot column
-// that every lane needs in step j is lane j's register k -- a `row_newbcast:j` DPP operand (CDNA's DPP form for 64-bit operations) -- and the
-// second factor of the elimination
-//     A[k][c] -= A[k][j] A[c][j] / d_j
-// is the lane's OWN register j (A[j][c] = A[c][j]: the two triangles of the diagonal block are kept bit-identical, see dpp_steps).  A step is
-// one DPP move + multiply + multiply-add per register of the diagonal block and ONE v_fmac_f64_dpp per register of the rows below it: no
-// v_readlane -> scalar register -> multiply-add round trips (potrf_block_wave: 456 cycles per column), no LDS hand-over and no barrier
-// (potrf_block: ~1050 cycles).  The serial chain of a step is the broadcast of the next pivot, a reciprocal (hardware estimate + 2 Newton
-// steps), two multiplies and the multiply-add of the next pivot; the products of the step are formed while the reciprocal is under way.
-// Column scaling is deferred: the registers keep the unscaled Schur state, every lane remembers ITS column's pivot and scales its column once
-// after the 16 steps.
+// potrf_block on DPP broadcasts (round 5).  The 64 x 64 block is walked in four 16-column panels as in potrf_block_wave, but the
+// 16 column steps of a panel run in the layout  lane (g, cc) = column cc of the panel, registers = rows:  d[k] = A[16 p + k][16 p + cc] (the 16 x 16
+// diagonal block, replicated in the wave's four rows of 16 lanes; the lane of column c WORKS on the entries (k, c), k < c -- what its registers hold
+// behind the diagonal is never read) and b[k] = a row of the panel below the diagonal block (the 16 (3 - p) rows are dealt to the four rows of lanes:
+// 4 (3 - p) registers).  The multipliers of step j are ROW j of the triangle: A[j][c] is the lane's own register j, A[j][k] is lane k's register j, so
+// with w = -A[j][c] / d_j formed once per lane an entry is updated by ONE instruction,
+//     v_fmac_f64_dpp d[k], w, d[j] row_newbcast:k      (A[k][c] += w(lane k) * A[j][c])         diagonal block
+//     v_fmac_f64_dpp b[k], b[k], w row_newbcast:j      (A[r][c] += A[r][j](lane j) * w)          rows below
+// -- `row_newbcast` (lane j of each row of 16 lanes) is the DPP form CDNA has for 64-bit operands (v_fmac_f64, v_mov_b64 only).  No v_readlane -> scalar
+// register -> multiply-add round trips (potrf_block_wave: 456 cycles per column), no LDS hand-over and no barrier (potrf_block: ~1050 cycles); the
+// serial chain of a step is the broadcast of the next pivot, a reciprocal (hardware estimate + 2 Newton steps), the multiplier and the multiply-add of
+// the next pivot: 85 - 125 ns per column.  Column scaling is deferred: the registers keep the unscaled Schur state, every lane remembers ITS column's
+// pivot and scales once after the 16 steps.  (Two earlier versions kept both triangles of the diagonal block: see dpp_steps.)
 // The DPP instructions are inline assembly (the compiler splits a 64-bit DPP move off every multiply-add and then waits a cycle for its own
-// temporary): the statements keep the two-instruction distance the hardware requires between a write of a register and a DPP read of it (the
-// compiler's hazard recogniser does not look inside inline assembly) by an explicit s_nop in front.
-// Between panels the trailing 16 x 16 tiles are updated right-looking on the matrix cores (K = 16): the tiles the next panel reads by waves
-// 1..3 between two barriers; the other tiles, the inverse W_pp of the diagonal block (forward substitution in the same DPP layout) and the
-// stores of the finished panel by waves 1..3 WHILE wave 0 runs the next panel.  The off-diagonal blocks of the inverse follow by block
-// distance as in potrf_block_wave.  LDS: Mt as in potrf_block_wave (the part of the block not yet factored in place of L), leading dimension
-// PD_LD = 82 (lane stride 164 dwords = 36 mod 64 banks: the 16-byte accesses of wave 0, one column per lane, are conflict-free).
+// temporary); the statements keep the two-instruction distance the hardware requires between a write of a register and a DPP read of it (the compiler's
+// hazard recogniser does not look inside inline assembly): an s_nop in front, or the order of the instructions inside the statement.
+// Between panels the trailing 16 x 16 tiles are updated right-looking on the matrix cores (K = 16): the tiles the next panel reads by waves 1..3
+// between two barriers.  WHILE wave 0 runs the next panel, wave 1 inverts the finished diagonal block (forward substitution in the same DPP layout),
+// waves 2, 3 update the other tiles, store the finished panel and form the sums G_ij = sum_k L_ik W_kj of the inverse's off-diagonal blocks whose
+// operands are older than the last barrier; W_ij = -W_ii G_ij follows in the next phase that has W_ii (one barrier is left after W_33).
+// LDS: Mt as in potrf_block_wave (the part of the block not yet factored in place of L), leading dimension PD_LD = 82 (lane stride 164 dwords = 36 mod
+// 64 banks: the 16-byte accesses of wave 0, one column per lane, are conflict-free).
 // A pivot of the wrong sign is reported as in potrf_block; the panel that holds it and the panels after it become columns of the identity
 // (nothing non-finite is stored).  Partial blocks (nb < 64): rows / columns >= nb are rows of the identity.
 // ------------------------------------------------------------------------------------------
