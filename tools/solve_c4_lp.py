@@ -22,7 +22,10 @@ ys = rng.standard_normal(m)
 zs = rng.uniform(0.0, 1.0, n) * (xs == 0.0)                    # complementary slack
 c = A.T @ ys + zs
 l = np.zeros(n); u = np.full(n, np.inf)
+ALGS = os.environ.get("ALGS", "HSD,MPC").split(",")
 for name, cls in (("HSD", DeviceHSD), ("MPC", DeviceMPC)):
+    if name not in ALGS:
+        continue
     t0 = time.perf_counter()
     opt = cls(A, b, c, l, u, device=0, row_block=row_block, **MULTI)
     t_setup = time.perf_counter() - t0
