@@ -198,23 +198,45 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
         S.Ap[j] = colptr[j] - base;
         if (S.Ap[j] < 0 || S.Ap[j] > nnz || (j > 0 && S.Ap[j] < S.Ap[j - 1])) return fail(S, TLPK_BADARG, "colptr not monotone");
     }
+    // (round 5: on the host threads.  The copy by chunks of columns; the transposition by ranges of ROWS: every thread scans the row indices of the whole matrix -- a
+    // sequential read of 4 nnz bytes -- and places the entries of its own rows, in column order: the same CSR arrays as the serial loop, without a shared cursor.)
+    {
+        constexpr i64 CH = 8192;
+        const i64 nch = ((i64)n + CH - 1) / CH;
+        std::atomic<int> bad{0};
+        if (!parallel_for(nch, host_threads(nch), [&](unsigned, i64 ch) {
+                const i32 j1 = (i32)std::min<i64>(n, (ch + 1) * CH);
+                for (i32 j = (i32)(ch * CH); j < j1; ++j)
+                    for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
+                        const i64 r = rowval[p] - base;
+                        if (r < 0 || r >= m) { bad = 1; continue; }
+                        S.Ai[p] = (i32)r; S.Ax[p] = nzval[p]; S.Acol[p] = j;
+                    }
+            })) return fail(S, TLPK_OOM, "out of memory in the analyse phase");
+        if (bad) return fail(S, TLPK_BADARG, "row index out of range");
+    }
     S.Tp.assign((size_t)m + 1, 0);
-    for (i32 j = 0; j < n; ++j)
-        for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
-            const i64 r = rowval[p] - base;
-            if (r < 0 || r >= m) return fail(S, TLPK_BADARG, "row index out of range");
-            S.Ai[p] = (i32)r; S.Ax[p] = nzval[p]; S.Acol[p] = j;
-            S.Tp[r + 1]++;
-        }
-    for (i32 i = 0; i < m; ++i) S.Tp[i + 1] += S.Tp[i];
     S.Tj.resize((size_t)nnz); S.Tpos.resize((size_t)nnz);
     {
-        std::vector<i64> cur(S.Tp.begin(), S.Tp.end() - 1);
-        for (i32 j = 0; j < n; ++j)
-            for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
-                const i64 q = cur[S.Ai[p]]++;
-                S.Tj[q] = j; S.Tpos[q] = (i32)p;
-            }
+        const unsigned nt = host_threads(std::max<i64>(1, nnz / 200000));          // row ranges, one per thread
+        const i64 rstep = ((i64)m + nt - 1) / nt;
+        if (!parallel_for(nt, nt, [&](unsigned, i64 t) {                             // counts of the thread's rows
+                const i64 r0 = t * rstep, r1 = std::min<i64>(m, r0 + rstep);
+                if (r0 >= r1) return;
+                for (i64 p = 0; p < nnz; ++p) { const i64 r = S.Ai[p]; if (r >= r0 && r < r1) S.Tp[r + 1]++; }
+            })) return fail(S, TLPK_OOM, "out of memory in the analyse phase");
+        for (i32 i = 0; i < m; ++i) S.Tp[i + 1] += S.Tp[i];
+        if (!parallel_for(nt, nt, [&](unsigned, i64 t) {
+                const i64 r0 = t * rstep, r1 = std::min<i64>(m, r0 + rstep);
+                if (r0 >= r1) return;
+                std::vector<i64> cur(S.Tp.begin() + r0, S.Tp.begin() + r1);
+                for (i64 p = 0; p < nnz; ++p) {
+                    const i64 r = S.Ai[p];
+                    if (r < r0 || r >= r1) continue;
+                    const i64 q = cur[(size_t)(r - r0)]++;
+                    S.Tj[q] = S.Acol[p]; S.Tpos[q] = (i32)p;
+                }
+            })) return fail(S, TLPK_OOM, "out of memory in the analyse phase");
     }
 
     pt.mark("block structure");
@@ -1050,10 +1072,17 @@ int analyse_rank(Symbolic &S, const Options &opt) {
     pt.mark("assembly lists");
     // ---- 14. assembly lists: S[ii,kk] = sum_j A[i,j] D_j A[k,j] (+ regD on the diagonal) ----
     {
-        S.s_target.assign((size_t)S.nnzS, -1);
-        S.s_diag_row.assign((size_t)S.nnzS, -1);
-        S.s_local.assign((size_t)S.nnzS, 0);
-        S.pair_ptr.assign((size_t)S.nnzS + 1, 0);
+        // (uvec: no zero-fill by resize; the defaults are written by the host threads, chunk by chunk)
+        S.s_target.resize((size_t)S.nnzS); S.s_diag_row.resize((size_t)S.nnzS); S.s_local.resize((size_t)S.nnzS); S.pair_ptr.resize((size_t)S.nnzS + 1);
+        {
+            constexpr i64 CH = (i64)1 << 16;
+            const i64 nch = (S.nnzS + CH) / CH;                  // covers pair_ptr[nnzS]
+            if (!parallel_for(nch, host_threads(nch), [&](unsigned, i64 ch) {
+                    const i64 e0 = ch * CH, e1 = std::min(S.nnzS, e0 + CH);
+                    for (i64 e = e0; e < e1; ++e) { S.s_target[(size_t)e] = -1; S.s_diag_row[(size_t)e] = -1; S.s_local[(size_t)e] = 0; S.pair_ptr[(size_t)e] = 0; }
+                    if (e1 == S.nnzS) S.pair_ptr[(size_t)S.nnzS] = 0;
+                })) return fail(S, TLPK_OOM, "out of memory while building the assembly lists");
+        }
         auto col_is_mine = [&](i32 j) -> bool {
             if (opt.nranks == 1 || !have_blocks) return true;
             const i32 b = col_block[j];
@@ -1065,12 +1094,18 @@ int analyse_rank(Symbolic &S, const Options &opt) {
         const unsigned nthreads = host_threads(ns_total);
         std::vector<std::vector<i32>> t_pos(nthreads);
         std::vector<std::vector<i64>> t_epos(nthreads);
-        std::vector<i64> cursor;
+        uvec<i64> cursor;
         for (int pass = 0; pass < 2; ++pass) {
             if (pass) {
                 for (i64 e = 0; e < S.nnzS; ++e) S.pair_ptr[e + 1] += S.pair_ptr[e];
-                S.pair_w.resize((size_t)S.pair_ptr[S.nnzS]); S.pair_j.resize((size_t)S.pair_ptr[S.nnzS]);
-                cursor.assign(S.pair_ptr.begin(), S.pair_ptr.end() - 1);
+                S.pair_w.resize((size_t)S.pair_ptr[S.nnzS]); S.pair_j.resize((size_t)S.pair_ptr[S.nnzS]);      // (first touched by the threads that fill them)
+                cursor.resize((size_t)S.nnzS);
+                constexpr i64 CH = (i64)1 << 16;
+                const i64 nch = (S.nnzS + CH - 1) / CH;
+                if (!parallel_for(nch, host_threads(nch), [&](unsigned, i64 ch) {
+                        const i64 e0 = ch * CH, e1 = std::min(S.nnzS, e0 + CH);
+                        std::copy(S.pair_ptr.begin() + e0, S.pair_ptr.begin() + e1, cursor.begin() + e0);
+                    })) return fail(S, TLPK_OOM, "out of memory while building the assembly lists");
             }
             const bool ok = parallel_for(ns_total, nthreads, [&](unsigned tid, i64 s64) {
                 const i32 s = (i32)s64;

@@ -264,48 +264,64 @@ int upload_all(tlpk_handle *h) {
     }
     UP(d.row_local, S.row_local); UP(d.col_local, S.col_local);
     {
-        // compact the assembly lists to the entries this rank owns
+        // compact the assembly lists to the entries this rank owns.  One rank (every entry local): the lists of the analyse phase ARE the compact ones -- no copies
+        // (round 5: the element-by-element compaction of 5 - 30 million entries and an unconditional second copy of the target list were ~70 ms of KKT.setup on C4)
+        bool every = true;
+        for (i64 e = 0; e < S.nnzS && every; ++e) every = S.s_local[(size_t)e] != 0;
         std::vector<i64> tgt, ptr; std::vector<i32> diag;
-        tgt.reserve((size_t)S.nnzS); diag.reserve((size_t)S.nnzS); ptr.reserve((size_t)S.nnzS + 1);
-        std::vector<double> pw; std::vector<i32> pj;
-        const bool all_local = (S.pair_ptr[(size_t)S.nnzS] == (i64)S.pair_w.size());
         i64 np = 0;
-        ptr.push_back(0);
-        for (i64 e = 0; e < S.nnzS; ++e) {
-            if (!S.s_local[e]) continue;
-            tgt.push_back(S.s_target[e]); diag.push_back(S.s_diag_row[e]);
-            np += S.pair_ptr[e + 1] - S.pair_ptr[e];
-            ptr.push_back(np);
+        if (every) { d.n_asm = S.nnzS; np = S.pair_ptr[(size_t)S.nnzS]; }
+        else {
+            tgt.reserve((size_t)S.nnzS); diag.reserve((size_t)S.nnzS); ptr.reserve((size_t)S.nnzS + 1);
+            ptr.push_back(0);
+            for (i64 e = 0; e < S.nnzS; ++e) {
+                if (!S.s_local[e]) continue;
+                tgt.push_back(S.s_target[e]); diag.push_back(S.s_diag_row[e]);
+                np += S.pair_ptr[e + 1] - S.pair_ptr[e];
+                ptr.push_back(np);
+            }
+            d.n_asm = (i64)tgt.size();
         }
-        d.n_asm = (i64)tgt.size();
         {
             // per permuted column: its first entry in the compacted list (entries are in column order); and the target list of
             // k_assemble: -1 for the entries of the fronts whose panels k_front_assemble forms
-            std::vector<i64> colptr((size_t)S.m + 1, 0), tsmall(tgt);
-            i64 cnt = 0;
-            for (i64 kk = 0; kk < S.m; ++kk) {
-                colptr[(size_t)kk] = cnt;
-                const bool fa = !S.front_fa.empty() && S.front_fa[(size_t)S.sn_of_col[(size_t)kk]];
-                for (i64 e = S.Sp[(size_t)kk]; e < S.Sp[(size_t)kk + 1]; ++e) if (S.s_local[(size_t)e]) { if (fa) tsmall[(size_t)cnt] = -1; ++cnt; }
-            }
-            colptr[(size_t)S.m] = cnt;
-            if (cnt != d.n_asm) { h->last_error = "assembly list: column pointers do not match the compacted entries"; return TLPK_INTERNAL; }
             bool any_fa = false;
             for (char f : S.front_fa) any_fa |= (f != 0);
-            if (any_fa) { UP(d.asm_colptr, colptr); UP(d.asm_target_small, tsmall); }      // k_front_assemble is off by default: no second copy of the target list then
-            // step 13d: which entries belong to an upper front (assembled on a stream of their own)
-            std::vector<unsigned char> up((size_t)d.n_asm, 0);
-            bool any = false;
-            if (!S.front_upper.empty())
+            std::vector<i64> colptr_c;
+            if (!every) {
+                colptr_c.assign((size_t)S.m + 1, 0);
+                i64 cnt = 0;
+                for (i64 kk = 0; kk < S.m; ++kk) {
+                    colptr_c[(size_t)kk] = cnt;
+                    for (i64 e = S.Sp[(size_t)kk]; e < S.Sp[(size_t)kk + 1]; ++e) cnt += (S.s_local[(size_t)e] != 0);
+                }
+                colptr_c[(size_t)S.m] = cnt;
+                if (cnt != d.n_asm) { h->last_error = "assembly list: column pointers do not match the compacted entries"; return TLPK_INTERNAL; }
+            }
+            const std::vector<i64> &colptr = every ? S.Sp : colptr_c;
+            if (any_fa) {      // k_front_assemble is off by default: no second copy of the target list then
+                std::vector<i64> tsmall;
+                if (every) tsmall.assign(S.s_target.begin(), S.s_target.end()); else tsmall = tgt;
                 for (i64 kk = 0; kk < S.m; ++kk)
-                    if (S.front_upper[(size_t)S.sn_of_col[(size_t)kk]]) { any = true; for (i64 q = colptr[(size_t)kk]; q < colptr[(size_t)kk + 1]; ++q) up[(size_t)q] = 1; }
+                    if (S.front_fa[(size_t)S.sn_of_col[(size_t)kk]])
+                        for (i64 q = colptr[(size_t)kk]; q < colptr[(size_t)kk + 1]; ++q) tsmall[(size_t)q] = -1;
+                UP(d.asm_colptr, colptr); UP(d.asm_target_small, tsmall);
+            }
+            // step 13d: which entries belong to an upper front (assembled on a stream of their own)
+            bool any = false;
+            for (char f : S.front_upper) any |= (f != 0);
             d.has_upper = any;
-            if (any) UP(d.asm_upper, up);
+            if (any) {
+                std::vector<unsigned char> up((size_t)d.n_asm, 0);
+                for (i64 kk = 0; kk < S.m; ++kk)
+                    if (S.front_upper[(size_t)S.sn_of_col[(size_t)kk]]) std::fill(up.begin() + colptr[(size_t)kk], up.begin() + colptr[(size_t)kk + 1], (unsigned char)1);
+                UP(d.asm_upper, up);
+            }
         }
         // pairs of local entries are contiguous per entry; entries of non-local fronts have none,
         // so the pair arrays are already compact and in the same order.
-        (void)all_local;
-        UP(d.asm_target, tgt); UP(d.asm_diag, diag); UP(d.asm_ptr, ptr);
+        if (every) { UP(d.asm_target, S.s_target); UP(d.asm_diag, S.s_diag_row); UP(d.asm_ptr, S.pair_ptr); }
+        else { UP(d.asm_target, tgt); UP(d.asm_diag, diag); UP(d.asm_ptr, ptr); }
         if (!d.asm_target_small) d.asm_target_small = d.asm_target;
         UP(d.pair_w, S.pair_w); UP(d.pair_j, S.pair_j);
         if (np != (i64)S.pair_w.size()) { h->last_error = "assembly list compaction mismatch"; return TLPK_INTERNAL; }
@@ -371,7 +387,7 @@ int upload_all(tlpk_handle *h) {
     HIPCHK(h, hipHostMalloc((void **)&h->h_info, 4 * sizeof(int), hipHostMallocDefault));
     h->h_info[0] = h->h_info[1] = h->h_info[2] = h->h_info[3] = 0;
     // free host-side copies that are only needed on the device
-    std::vector<double>().swap(S.pair_w); std::vector<i32>().swap(S.pair_j);
+    uvec<double>().swap(S.pair_w); uvec<i32>().swap(S.pair_j);
     return TLPK_OK;
 }
 
@@ -1970,16 +1986,16 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     const Symbolic &S = h->S;
     std::vector<i64> tmp;
     const std::string w(what);
-    auto from32 = [&](const std::vector<i32> &v) { tmp.assign(v.begin(), v.end()); };
+    auto from32 = [&](const auto &v) { tmp.assign(v.begin(), v.end()); };
     auto field = [&](auto getter) { tmp.resize(S.fronts.size()); for (size_t s = 0; s < S.fronts.size(); ++s) tmp[s] = (i64)getter(S.fronts[s]); };
     if (w == "perm") from32(S.perm);
     else if (w == "etree") from32(S.parent);
     else if (w == "colcount") from32(S.colcount);
     else if (w == "s_colptr") tmp = S.Sp;
     else if (w == "s_rowidx") from32(S.Si);
-    else if (w == "s_target") tmp = S.s_target;
+    else if (w == "s_target") from32(S.s_target);
     else if (w == "s_diag_row") from32(S.s_diag_row);
-    else if (w == "pair_ptr") tmp = S.pair_ptr;
+    else if (w == "pair_ptr") from32(S.pair_ptr);
     else if (w == "pair_j") from32(S.pair_j);
     else if (w == "rowidx") from32(S.rowidx);
     else if (w == "rel") from32(S.rel);
@@ -2044,11 +2060,10 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
 int64_t tlpk_symbolic_get_f64(const tlpk_handle *h, const char *what, double *buf, int64_t cap) {
     if (!h || !what) return -1;
     const std::string w(what);
-    const std::vector<double> *v = nullptr;
-    if (w == "pair_w") v = &h->S.pair_w;
-    else return -1;
-    const i64 len = (i64)v->size();
-    if (buf) std::copy(v->begin(), v->begin() + std::min(len, cap), buf);
+    if (w != "pair_w") return -1;
+    const auto &v = h->S.pair_w;
+    const i64 len = (i64)v.size();
+    if (buf) std::copy(v.begin(), v.begin() + std::min(len, cap), buf);
     return len;
 }
 

@@ -125,8 +125,8 @@ inline int dev_alloc(tlpk_handle *h, T **out, i64 count) {
     *out = (T *)p;
     return TLPK_OK;
 }
-template <class T>
-inline int dev_upload(tlpk_handle *h, T **out, const std::vector<T> &v) {
+template <class T, class A>
+inline int dev_upload(tlpk_handle *h, T **out, const std::vector<T, A> &v) {
     int rc = dev_alloc(h, out, (i64)v.size());
     if (rc != TLPK_OK) return rc;
     if (!v.empty()) HIPCHK(h, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));

@@ -115,6 +115,19 @@ struct Options {
     const i64 *row_block = nullptr;
 };
 
+// std::vector without the value-initialisation of resize(n): the large arrays of the analyse phase are written exactly once, by the host threads that own their
+// parts -- a serial zero-fill in front of that costs a page fault per 4 KB on one thread (round 5: a third of the "assembly lists" phase).
+template <class T>
+struct NoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInit<U>; };
+    NoInit() = default;
+    template <class U> NoInit(const NoInit<U> &) {}
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new (static_cast<void *>(p)) U; else ::new (static_cast<void *>(p)) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using uvec = std::vector<T, NoInit<T>>;
+
 struct Symbolic {
     i64 m = 0, n = 0, nnzA = 0;          // K2: m = order of the augmented matrix (n_var + m_con), n / nnzA those of the incidence matrix below
     i32 system = 0; i64 k2_n = 0, k2_m = 0;   // K2: user dimensions (variables, constraints)
@@ -158,12 +171,12 @@ struct Symbolic {
     std::vector<i32> front_group;          // group of each front (fronts at depth 0 run after the join)
     i32 n_local_blocks = 0;
     // assembly of S = A*D*A' + Rd into the panels
-    std::vector<i64> s_target;             // per S entry: position in Lval
-    std::vector<i32> s_diag_row;           // per S entry: original row index if diagonal, else -1
-    std::vector<i64> pair_ptr;             // per S entry: range of products
-    std::vector<double> pair_w;            // A[i,j]*A[k,j]
-    std::vector<i32> pair_j;               // j
-    std::vector<char> s_local;             // entry assembled by this rank
+    uvec<i64> s_target;                    // per S entry: position in Lval
+    uvec<i32> s_diag_row;                  // per S entry: original row index if diagonal, else -1
+    uvec<i64> pair_ptr;                    // per S entry: range of products
+    uvec<double> pair_w;                   // A[i,j]*A[k,j]
+    uvec<i32> pair_j;                      // j
+    uvec<char> s_local;                    // entry assembled by this rank
     // sizes
     i64 nnzS = 0, nnzL = 0, lval_len = 0, ubuf_len[2] = {0, 0}, uc_len = 0, max_front = 0, dinv_len = 0;
     double flops_chol = 0, flops_panel = 0, flops_update = 0, flops_update_alg = 0;
