@@ -102,6 +102,9 @@ typedef struct tlpk_stats {
                                   (root fronts included) was enqueued; ms_last_update is then the wall time of the whole call */
     int64_t refine_rejected;   /* refine_steps > 0: refinement steps of the last completed solve that did NOT shrink |r1|inf, or lifted |r2|inf beyond 16 x its
                                   value after the unrefined solve, and were discarded (a rejected step ends the refinement of that solve); valid after tlpk_sync / a blocking solve */
+    double  flops_update_chain;     /* round 6: the share of flops_update / flops_update_alg whose tiles run as items of the dependency-driven launches */
+    double  flops_update_alg_chain; /* (k_chain: fronts with more than one block column on levels with few such fronts) instead of in k_update launches */
+    int64_t chain_launches, chain_items;   /* number of those launches per factorisation and the items (update tiles, diagonal blocks, solve strips, reductions) they hold */
 } tlpk_stats;
 
 /* per-kernel-class timing, filled when options.profile = 1 */
@@ -114,7 +117,8 @@ typedef struct tlpk_stats {
 #define TLPK_KC_SOLVE_BWD 6
 #define TLPK_KC_SPMV 7
 #define TLPK_KC_UPDATE_REDUCE 8   /* split-K: ordered sum of partial tiles + application to the targets */
-#define TLPK_KC_COUNT 9
+#define TLPK_KC_CHAIN 9           /* round 6: dependency-driven launches (k_chain): update tiles + diagonal blocks + triangular solves of a level's multi-block-column fronts */
+#define TLPK_KC_COUNT 10
 typedef struct tlpk_kernel_times {
     double  ms[TLPK_KC_COUNT];       /* summed duration of the class in the last update+solve */
     int64_t launches[TLPK_KC_COUNT];

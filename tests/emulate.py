@@ -8,7 +8,7 @@ import numpy as np
 
 LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
           BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12,
-          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17, FWD_SWEEP=18, BWD_SWEEP=19, FRONT_ASSEMBLE=20, WAIT_UPPER=21)
+          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17, FWD_SWEEP=18, BWD_SWEEP=19, FRONT_ASSEMBLE=20, WAIT_UPPER=21, CHAIN=22)
 
 
 class Emulator:
@@ -60,6 +60,8 @@ class Emulator:
             LK["FWD_SWEEP"]: g("fwd_sweep_tasks").reshape(-1, 6),
             LK["BWD_SWEEP"]: g("bwd_sweep_tasks").reshape(-1, 6),
         }
+        self.chain_items = g("chain_items").reshape(-1, 12)      # items of the dependency-driven launches (LK_CHAIN): role, task, sub, three waits, signal
+        self.chain_cnt = np.zeros(int(g("chain_counters")[0]) + 1, dtype=np.int64)
         self.upd_seg = g("upd_seg")     # K-segment lists of the update tasks that skip structurally zero slabs
         self.flagoff = g("front_flagoff")
         self.factor_launches = g("factor_launches").reshape(-1, 3)
@@ -129,6 +131,7 @@ class Emulator:
             self.Lval[a:b] = np.nan
         self.U = {}
         self.fail_col = None
+        self.chain_cnt[:] = 0                  # one memset per update! zeroes the tickets and completion counters
         for s_ in np.nonzero(self.single & (self.local != 0))[0]:      # k_single_factor
             d = self.Lval[self.loff[s_]]
             sj = self.sign[self.col0[s_]] if self.k2 else 1.0
@@ -167,6 +170,9 @@ class Emulator:
                     vals, a = self._upper_pending.pop(s_), int(self.loff[s_])
                     self.Lval[a: a + len(vals)] = vals
                 continue
+            if kind == LK["CHAIN"]:
+                self._chain(self.chain_items[first: first + count])
+                continue
             if kind == LK["POTRF_WIDE"]:
                 kind = LK["POTRF"]
             if kind == LK["POTRF_SMALL"]:                        # count = workgroups of 4 fronts (list padded with -1)
@@ -195,6 +201,46 @@ class Emulator:
             T = self.tasks[kind][first: first + count]
             getattr(self, "_k%d" % kind)(T)
         return len(launches)
+
+    def _chain(self, items):
+        """k_chain: the items of one dependency-driven launch, executed in TICKET order.  Every wait must already be satisfied when its item's turn comes:
+        an item may only depend on items with smaller tickets -- the property that makes the device kernel deadlock-free under any scheduling."""
+        cnt = self.chain_cnt
+        items = [tuple(int(v) for v in it) for it in items]
+
+        def ready(it):
+            _r, _t, _s, w0, n0, need0, w1, n1, need1, w2, need2, _sig = it
+            return all(cnt[w0 + q] >= need0 for q in range(n0)) and all(cnt[w1 + q] >= need1 for q in range(n1)) and (w2 < 0 or cnt[w2] >= need2)
+        rng = getattr(self, "chain_rng", None)
+        if rng is not None:
+            # adversarial schedule: any item whose counters have arrived may run next (what the device may do with many workgroups in flight).  The
+            # result must not depend on it: the waits alone order every pair of items that touch the same data.
+            pending, order = list(range(len(items))), []
+            while pending:
+                cand = [q for q in pending[:64] if ready(items[q])]      # (a window of tickets: workgroups draw them in order)
+                assert cand, "no runnable chain item"
+                q = cand[int(rng.integers(len(cand)))]
+                pending.remove(q); order.append(q)
+                self._chain_run(items[q])
+            return
+        for it in items:
+            assert ready(it), "chain item waits for an item with a larger ticket"
+            self._chain_run(it)
+
+    def _chain_run(self, it):
+        cnt = self.chain_cnt
+        for role, task, sub, w0, n0, need0, w1, n1, need1, w2, need2, sig in (it,):
+            if role == 0:
+                self._k3(self.tasks[LK["UPDATE"]][task: task + 1])
+            elif role == 1:
+                self._k1(self.tasks[LK["POTRF"]][task: task + 1])
+            elif role == 2:
+                self._k2(self.tasks[LK["TRSM"]][task: task + 1])
+            else:
+                assert role == 3 and 0 <= sub < 8
+                self._k13(self.tasks[LK["UPDATE_REDUCE"]][task: task + 1], sub=sub)
+            if sig >= 0:
+                cnt[sig] += 1
 
     def _k0(self, T):      # extend-add
         # group tasks by front: emulation processes whole columns ranges, children in order
@@ -332,16 +378,17 @@ class Emulator:
                         self.U[front][rsel - ns, c - ns] -= G[rsel - i0, c - j0]
             del mask
 
-    def _k13(self, T):     # split-K reduce: parts of a tile summed in slot order, then applied like _k3
-        TILE = 128
+    def _k13(self, T, sub=None):     # split-K reduce: parts of a tile summed in slot order, then applied like _k3
+        TILE = 128                   # sub = one eighth of the tile's columns (a chain item); None = the whole tile (a launch: eight workgroups)
         for front, slot0, parts, i0, j0, jlim, beta0, _ in T:
             f, ns = int(self.f[front]), int(self.ns[front])
             i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)
-            G = self.spart.pop(int(slot0))          # pop: a slot may be reused by a later launch of the stream
+            take = (lambda q: self.spart.pop(q)) if sub is None else (lambda q: self.spart[q])     # pop: a slot may be reused by a later launch of the stream (never inside a chain launch)
+            G = take(int(slot0))
             for sp in range(1, int(parts)):
-                G = G + self.spart.pop(int(slot0) + sp)
+                G = G + take(int(slot0) + sp)
             P = self.panel(front)
-            for c in range(j0, j1):
+            for c in (range(j0, j1) if sub is None else range(j0 + 16 * sub, min(j0 + 16 * sub + 16, j1))):
                 rsel = np.arange(max(i0, c), i1)
                 if rsel.size == 0:
                     continue

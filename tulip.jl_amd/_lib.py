@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("TLPK_LIB") or os.path.join(HERE, "libtlpk.so")      #
 OK, NOT_POSDEF, BADARG, OOM, HIPERR, NO_DEVICE, TOO_LARGE, NOT_FACTORED, INTERNAL = range(9)
 ORDER_AMD, ORDER_NATURAL, ORDER_USER = 0, 1, 2
 SYSTEM_K1, SYSTEM_K2 = 0, 1
-KC_NAMES = ["assemble", "extend_add", "potrf", "trsm", "update", "solve_fwd", "solve_bwd", "spmv", "update_reduce"]
+KC_NAMES = ["assemble", "extend_add", "potrf", "trsm", "update", "solve_fwd", "solve_bwd", "spmv", "update_reduce", "chain"]
 
 p64 = C.POINTER(C.c_int64)
 pd = C.POINTER(C.c_double)
@@ -39,7 +39,8 @@ class Stats(C.Structure):
                 ("fail_col", C.c_int64), ("ms_analyse", C.c_double), ("ms_last_update", C.c_double),
                 ("ms_last_solve", C.c_double), ("n_local_blocks", C.c_int32), ("n_blocks", C.c_int32),
                 ("root_panel_len", C.c_int64), ("flops_update", C.c_double),
-                ("flops_update_alg", C.c_double), ("ms_enqueue_update", C.c_double), ("refine_rejected", C.c_int64)]
+                ("flops_update_alg", C.c_double), ("ms_enqueue_update", C.c_double), ("refine_rejected", C.c_int64),
+                ("flops_update_chain", C.c_double), ("flops_update_alg_chain", C.c_double), ("chain_launches", C.c_int64), ("chain_items", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

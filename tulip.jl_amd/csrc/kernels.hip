@@ -1518,10 +1518,7 @@ __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tas
     potrf_block_any<SIGNED, MODE>(c, fd, t.k0, t.nb, t.k0, scratch);
 }
 template <bool SIGNED, int MODE>
-__global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restrict__ tasks, DevCtx c) {
-    __shared__ __attribute__((aligned(16))) double Ws[MODE == 3 ? POTRF_DPP_LDS : (MODE == 1 ? POTRF_WAVE_LDS : NB_IN * LDW)];
-    const PotrfTask t = tasks[blockIdx.x];
-    const FrontDesc fd = c.fronts[t.front];
+__device__ __forceinline__ void potrf_wide_task(const PotrfTask t, const FrontDesc &fd, const DevCtx &c, double *Ws) {
     const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
     // the chain's four waves are served before the update tiles' waves that share their SIMDs (beside k_update the chain runs on the side stream: its end is what the
     // group's stream waits for at the join): C4 51.0 -> 50.8 ms, pds-class 15.79 -> 15.68 ms (profiles/r05_chain_overlap.txt)
@@ -1541,6 +1538,13 @@ __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restri
         potrf_block_any<SIGNED, MODE>(c, fd, ks + NB_IN, min(NB_IN, kend - (ks + NB_IN)), k0, Ws);
     }
 }
+template <bool SIGNED, int MODE>
+__global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restrict__ tasks, DevCtx c) {
+    __shared__ __attribute__((aligned(16))) double Ws[MODE == 3 ? POTRF_DPP_LDS : (MODE == 1 ? POTRF_WAVE_LDS : NB_IN * LDW)];
+    const PotrfTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    potrf_wide_task<SIGNED, MODE>(t, fd, c, Ws);
+}
 
 // Rows below the diagonal block of a block column: X = B * L11^{-T} for the whole (<= 256 wide)
 // block column in ONE pass: a wave keeps its 16 rows x 256 columns in registers, and walks the
@@ -1550,13 +1554,10 @@ __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restri
 // SIGNED: the registers keep B Linv' = X S (what the later steps of the block column need: B_i -= sum_j X_j S_j L_ij');
 // the stored factor block X gets its column signs only at the final store.
 template <bool SIGNED>
-__global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
+__device__ __forceinline__ void trsm_task(const TrsmTask t, const FrontDesc &fd, const DevCtx &c, double (*Wb)[NB_IN * LDW]) {
     // two operand buffers: the block staged for step n + 1 never overwrites what slower waves still read for step n, so a
     // step needs ONE barrier (after its stores) instead of two
-    __shared__ double Wb[2][NB_IN * LDW];           // staged operand: Wb[.][k*LDW + c]
     int wsel = 0;
-    const TrsmTask t = tasks[blockIdx.x];
-    const FrontDesc fd = c.fronts[t.front];
     const i32 k0 = t.k0, w = t.nb;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1674,6 +1675,13 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
             }
         }
     }
+}
+template <bool SIGNED>
+__global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double Wb[2][NB_IN * LDW];           // staged operand: Wb[.][k*LDW + c]
+    const TrsmTask t = tasks[blockIdx.x];
+    const FrontDesc fd = c.fronts[t.front];
+    trsm_task<SIGNED>(t, fd, c, Wb);
 }
 
 // Thin block columns (w <= TRSM_THIN_W: the small fronts of the leaf levels): X = B * L11^{-T} with
@@ -2070,11 +2078,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_update(const Updat
 // and applies the sum to the tile's targets with the masks of the ordinary epilogue.
 // RED_SPLIT workgroups per tile (TILE / RED_SPLIT columns each): a launch that needed split-K has few tiles by
 // definition, one workgroup per tile pulled parts x 128 KB through ONE CU (105 us per launch on a 7 900-row front).
-constexpr int RED_SPLIT = 8;
-__global__ __launch_bounds__(256) void k_update_reduce(const UpdateTask *__restrict__ tasks, DevCtx c) {
-    const UpdateTask t = tasks[blockIdx.x / RED_SPLIT];
-    const int part = blockIdx.x % RED_SPLIT;
-    const FrontDesc fd = c.fronts[t.front];
+__device__ __forceinline__ void reduce_part(const UpdateTask t, const int part, const FrontDesc &fd, const DevCtx &c) {
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
     const double *Sp = c.spart + (i64)t.k0 * (TILE * TILE);
@@ -2091,6 +2095,165 @@ __global__ __launch_bounds__(256) void k_update_reduce(const UpdateTask *__restr
             double *dst = Uw + (i64)(row - ns) + (i64)(col - ns) * rs;
             *dst = t.beta0 ? -sum : (*dst - sum);
         }
+    }
+}
+__global__ __launch_bounds__(256) void k_update_reduce(const UpdateTask *__restrict__ tasks, DevCtx c) {
+    const UpdateTask t = tasks[blockIdx.x / RED_SPLIT];
+    const FrontDesc fd = c.fronts[t.front];
+    reduce_part(t, (int)(blockIdx.x % RED_SPLIT), fd, c);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_chain (round 6): the blocked factorisation of a level's multi-block-column fronts as ONE persistent, dependency-driven launch.
+// symbolic.cpp (build_schedule: build_chain) turns the tasks of the launches above -- update tiles, diagonal blocks, 64-row strips of the
+// triangular solves, eighths of split-K reductions -- into ITEMS.  A workgroup draws the next item from the launch's ticket counter, waits until
+// the completion counters the item names have reached their values, runs the task's ordinary device function (update_tile, potrf_wide_task,
+// trsm_task, reduce_part: the arithmetic of the launch form, bit for bit) and raises the item's counter.
+//   * visibility (cdna_hip_programming.md, Guideline 16, counter form): the per-die L2s and the per-CU L1s are not coherent for ordinary stores
+//     inside a launch.  Producer: every wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane: agent-scope release fence (L2
+//     write-back) -> wait -> relaxed agent-scope add on the counter.  Consumer: ONE wave polls its counters with relaxed agent-scope loads, ONE
+//     agent-scope acquire fence after the match (drops the stale lines of this CU's L1 / this die's L2), workgroup barrier, then plain loads.
+//     The update tiles' fire-and-forget L2 adds are covered by the same release; adders of one target tile are ordered through its counter.
+//   * no deadlock by construction: every wait names counters raised by items with SMALLER tickets, whose holders already run; nothing depends
+//     on residency, dispatch order or placement (a profiler that serialises dispatches changes nothing: it is one launch).
+//   * every spin is bounded (~2 s): the wave that gives up sets info[1], everybody stops waiting and skips the work, the host reports
+//     TLPK_INTERNAL.  Counters and tickets are zeroed by one hipMemsetAsync at the start of every update! (no state survives a launch).
+// 256 threads, two workgroups per CU (the strips' two staging blocks fill half the LDS): the diagonal block of a front shares its CU with ONE
+// other workgroup instead of the four waves per SIMD of the k_update launches it used to run beside.
+// ------------------------------------------------------------------------------------------
+struct ChainArgs {
+    const ChainItem *items; i32 nitems;
+    unsigned *cnt; i32 ticket;                       // counters of all chain launches; index of this launch's ticket
+    const UpdateTask *upd, *red; const PotrfTask *potrf; const TrsmTask *trsm;
+    unsigned long long *trace;                       // TLPK_CHAIN_TRACE=1 (diagnostics): per item 4 words -- drawn, released by its counters, work done, published (100 MHz clock)
+};
+constexpr int CHAIN_LDS = 2 * NB_IN * LDW;           // doubles (81 920 bytes): the strips' two staging blocks >= the four K slabs of an update tile, >= the diagonal block's scratch
+static_assert(CHAIN_LDS >= 4 * UPD_KT * UPD_LD && CHAIN_LDS >= POTRF_DPP_LDS, "k_chain: one LDS block serves every role");
+
+// wave 0 of the workgroup: wait for the item's counters; returns false if somebody (maybe this wave) gave up
+__device__ __forceinline__ bool chain_wait(const ChainItem &it, const unsigned *cnt, int *info, const int lane) {
+    const int n01 = it.n0 + it.n1, ntot = n01 + (it.w2 >= 0 ? 1 : 0);
+    if (ntot == 0) return __hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    // lane l polls wait entry min(l, ntot - 1): every lane has a valid address (no guarded loads in the loop)
+    const int e = min(lane, ntot - 1);
+    const int idx = (e < it.n0) ? it.w0 + e : ((e < n01) ? it.w1 + (e - it.n0) : it.w2);
+    const unsigned need = (unsigned)((e < it.n0) ? it.need0 : ((e < n01) ? it.need1 : it.need2));
+    const unsigned *p = cnt + idx;
+    bool dead = false;
+    unsigned spins = 0;
+    unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (!dead && !__all(v >= need)) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((++spins & 127u) == 0u) {
+            if (__hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
+            else if (spins > (1u << 21)) { __hip_atomic_store(info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
+        }
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE acquire after the match: plain loads of the producers' data from here on
+    return !dead;
+}
+
+
+// Arguments of a non-kernel function arrive in VECTOR registers, uniform or not: without help every address computed from them is vector arithmetic and every
+// descriptor load a vector load (the stand-alone kernels get theirs from the kernel-argument segment, in scalar registers).  uni() / uni_ctx() tell the compiler
+// what it cannot see across the call: these values are wave-uniform.
+template <class T> __device__ __forceinline__ T *uni(T *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    // (through a GLOBAL-address-space pointer: a generic pointer that crossed a call is reached with flat_load / flat_store, which also tie up the LDS counter)
+    typedef __attribute__((address_space(1))) T gT;
+    return (T *)(gT *)(((unsigned long long)hi << 32) | lo);
+}
+// The LDS block travels as an LDS-address-space pointer (32 bits): as a generic pointer the callee would reach it with FLAT instructions -- behind the call the
+// compiler no longer knows that it is LDS --; the cast back to a generic pointer happens inside the callee, where address-space inference sees its origin.
+typedef __attribute__((address_space(3))) double lds_double;
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ double *uni_lds(lds_double *p) {
+    const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(lds_char *)p);
+    return (double *)(lds_double *)(lds_char *)(unsigned long long)v;
+}
+__device__ __forceinline__ DevCtx uni_ctx(const DevCtx &c) {
+    DevCtx u = c;
+    u.fronts = uni(c.fronts); u.Lval = uni(c.Lval); u.U0 = uni(c.U0); u.U1 = uni(c.U1); u.dinv = uni(c.dinv); u.spart = uni(c.spart); u.info = uni(c.info);
+    u.csign = uni(c.csign); u.upd_seg = uni(c.upd_seg);
+    return u;
+}
+
+template <bool SIGNED>
+__device__ __noinline__ void chain_role_update(const UpdateTask *tp_, const DevCtx &c_, lds_double *lds_) {
+    const UpdateTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); double *lds = uni_lds(lds_);
+    const UpdateTask t{tp->front, tp->k0, tp->kw, tp->i0, tp->j0, tp->jlim, tp->beta0, tp->pad1, tp->seg, tp->nsl, 0, 0};
+    const FrontDesc fd = c.fronts[t.front];
+    double (*As)[UPD_KT * UPD_LD] = reinterpret_cast<double (*)[UPD_KT * UPD_LD]>(lds);
+    const bool full = (t.i0 + TILE <= fd.f) && (t.j0 + TILE <= t.jlim) && (t.i0 >= t.j0 + TILE);
+    if (full) update_tile<true, SIGNED, 4>(t, fd, c, As, As + 2);
+    else update_tile<false, SIGNED, 4>(t, fd, c, As, As + 2);
+}
+template <bool SIGNED>
+__device__ __noinline__ void chain_role_potrf(const PotrfTask *tp_, const DevCtx &c_, lds_double *lds_) {
+    const PotrfTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); double *lds = uni_lds(lds_);
+    const PotrfTask t{tp->front, tp->k0, tp->nb, tp->kprev};
+    const FrontDesc fd = c.fronts[t.front];
+    potrf_wide_task<SIGNED, 3>(t, fd, c, lds);
+    __builtin_amdgcn_s_setprio(0);
+}
+template <bool SIGNED>
+__device__ __noinline__ void chain_role_trsm(const TrsmTask *tp_, const DevCtx &c_, lds_double *lds_) {
+    const TrsmTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); double *lds = uni_lds(lds_);
+    const TrsmTask t{tp->front, tp->k0, tp->nb, tp->row0, tp->kprev, tp->fuse_nb, tp->pad1, tp->pad2};
+    const FrontDesc fd = c.fronts[t.front];
+    trsm_task<SIGNED>(t, fd, c, reinterpret_cast<double (*)[NB_IN * LDW]>(lds));
+}
+__device__ __noinline__ void chain_role_reduce(const UpdateTask *tp_, const int sub_, const DevCtx &c_) {
+    const UpdateTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); const int sub = __builtin_amdgcn_readfirstlane(sub_);
+    const UpdateTask t{tp->front, tp->k0, tp->kw, tp->i0, tp->j0, tp->jlim, tp->beta0, tp->pad1, tp->seg, tp->nsl, 0, 0};
+    const FrontDesc fd = c.fronts[t.front];
+    reduce_part(t, sub, fd, c);
+}
+
+template <bool SIGNED>
+__global__ __launch_bounds__(256, 2) void k_chain(const ChainArgs a, DevCtx c) {
+    __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS];
+    unsigned *ctl = reinterpret_cast<unsigned *>(lds);        // ctl[0] = the drawn ticket, ctl[1] = 1: skip the work (somebody gave up waiting); in the role's own LDS, between its uses
+    const int tid = threadIdx.x;
+    for (;;) {
+        __syncthreads();                                       // the previous item no longer reads its LDS
+        if (tid == 0) ctl[0] = __hip_atomic_fetch_add(a.cnt + a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl[0]);
+        if (slot >= (unsigned)a.nitems) return;
+        const ChainItem *ip = a.items + slot;
+        const ChainItem it{ip->role, ip->task, ip->sub, ip->w0, ip->n0, ip->need0, ip->w1, ip->n1, ip->need1, ip->w2, ip->need2, ip->sig};
+        unsigned long long *tr = a.trace ? a.trace + 4 * (size_t)slot : nullptr;
+        if (tr && tid == 0) tr[0] = wall_clock64();
+        if (tid < 64) {
+            const bool ok = chain_wait(it, a.cnt, c.info, tid);
+            if (tid == 0) ctl[1] = ok ? 0u : 1u;
+        }
+        __syncthreads();
+        const bool skip = __builtin_amdgcn_readfirstlane((int)ctl[1]) != 0;
+        __syncthreads();                                       // ctl is read: the role may overwrite it
+        if (tr && tid == 0) tr[1] = wall_clock64();
+        if (!skip) {
+            // (the roles are separate functions, not inlined: each gets the register allocation of the stand-alone kernel it comes from -- inlined into
+            // one loop body the strips' 256-register working set pushed 125 registers of the other roles' live ranges into scratch)
+            if (it.role == CR_UPDATE) chain_role_update<SIGNED>(a.upd + it.task, c, (lds_double *)lds);
+            else if (it.role == CR_POTRF) chain_role_potrf<SIGNED>(a.potrf + it.task, c, (lds_double *)lds);
+            else if (it.role == CR_TRSM) chain_role_trsm<SIGNED>(a.trsm + it.task, c, (lds_double *)lds);
+            else chain_role_reduce(a.red + it.task, it.sub, c);
+        }
+        // publish: every wave's stores (and L2 adds) have left the CU, then ONE lane writes the die's L2 back and raises the counter
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tr && tid == 0) tr[2] = wall_clock64();
+        if (tid == 0 && it.sig >= 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(a.cnt + it.sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tr && tid == 0) tr[3] = wall_clock64();
     }
 }
 
@@ -3203,6 +3366,21 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
             if (sgn) hipLaunchKernelGGL((k_update<true, 8>), g, dim3(512), 0, st, a.update_tasks + L.first, a.ctx);
             else hipLaunchKernelGGL((k_update<false, 8>), g, dim3(512), 0, st, a.update_tasks + L.first, a.ctx);
         } else TLPK_LAUNCH_S(k_update, a.update_tasks);
+        break;
+    }
+    case LK_CHAIN: {
+        // Persistent: min(items, grid) workgroups loop over the launch's ticket counter.  ONE workgroup per CU by default (TLPK_CHAIN_DYNLDS = 70 000 bytes of
+        // dynamic LDS that nobody uses, on top of the 81 920 static ones: a second workgroup does not fit): every role has its CU to itself -- the diagonal
+        // block's serial chain runs 20 % slower beside another workgroup's matrix-core waves, an update tile nearly twice as fast alone -- measured on the
+        // pds-class LP: 15.08 ms per Newton step against 16.54 with two per CU and 15.76 with the launches (profiles/r06_chain_*.txt).
+        // TLPK_CHAIN_DYNLDS=0 TLPK_CHAIN_GRID=512: two per CU.  More workgroups than fit are harmless: one that starts late draws the next ticket.
+        const unsigned dyn = [] { const char *e = std::getenv("TLPK_CHAIN_DYNLDS"); return e ? (unsigned)std::max(0, std::atoi(e)) : 70000u; }();
+        const unsigned grid_max = [&] { const char *e = std::getenv("TLPK_CHAIN_GRID"); return e ? (unsigned)std::max(1, std::atoi(e)) : (dyn >= 70000u ? 256u : 512u); }();
+        const ChainArgs ca{a.chain_items + L.first, (i32)L.count, a.chain_cnt, L.pad, a.update_tasks, a.reduce_tasks, a.potrf_tasks, a.trsm_tasks,
+                           a.chain_trace ? a.chain_trace + 4 * L.first : nullptr};
+        const dim3 gc((unsigned)std::min<i64>(L.count, grid_max));
+        if (sgn) hipLaunchKernelGGL(k_chain<true>, gc, dim3(256), dyn, st, ca, a.ctx);
+        else hipLaunchKernelGGL(k_chain<false>, gc, dim3(256), dyn, st, ca, a.ctx);
         break;
     }
     case LK_UPDATE_REDUCE: hipLaunchKernelGGL(k_update_reduce, dim3((unsigned)L.count * RED_SPLIT), dim3(256), 0, st, a.reduce_tasks + L.first, a.ctx); break;

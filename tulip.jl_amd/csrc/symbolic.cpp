@@ -1172,7 +1172,9 @@ int analyse_rank(Symbolic &S, const Options &opt) {
         }
     }
     pt.mark("schedule");
+    S.error.clear();
     build_schedule(S);
+    if (!S.error.empty()) return TLPK_INTERNAL;
     // k_update walks its K range in slabs of 16 columns and relies on a slab lying inside ONE 64-column slice of the packed panel
     for (const UpdateTask &u : S.update_tasks)
         if ((u.k0 & 15) != 0) return fail(S, TLPK_INTERNAL, "update task: K range does not start on a multiple of 16 columns");
@@ -1410,6 +1412,20 @@ static void build_schedule(Symbolic &S) {
         std::vector<i64> task_canon;                      // canonical index of every task pushed by the current launch
         bool allow_skip = true;                           // off for split-K launches (few tiles: the parts are cut by K position)
         std::vector<char> need_tmp;
+        // Round 6: the fronts of the level with more than one block column may run as ONE dependency-driven launch (LK_CHAIN, below): pass 0 = every front
+        // through the launches; pass 1 = the other fronts through the launches, pass 2 = the chain fronts, their launches CAPTURED and turned into items.
+        // The decisions that look at the whole level (split-K, macro columns, look-ahead) see all of the rank's fronts in every pass: a tile is the same
+        // tile whichever way it is launched.
+        int pass = 0;
+        std::vector<char> chain_front(S.fronts.size(), 0);       // (only the entries of this level's fronts are ever set)
+        struct Cap { i32 kind; i64 first, count; };
+        std::vector<Cap> cap;
+        i64 chain_slot_base = 0;                                 // split-K scratch slots of a chain launch are never reused inside the launch
+        auto pass_ok = [&](i32 s) { return pass == 0 || ((bool)chain_front[(size_t)s] == (pass == 2)); };
+        auto emit = [&](i32 kind, i64 first, i64 count) {
+            if (count <= 0) return;
+            if (pass == 2) cap.push_back(Cap{kind, first, count}); else push_launch(S.factor_launches, kind, first, count);
+        };
         // entries of a tile that are targets: row >= column, row < f, column < c1
         auto tile_entries = [&](const FrontDesc &w, i32 i0, i32 j0, i32 c1) {
             double e = 0;
@@ -1462,6 +1478,7 @@ static void build_schedule(Symbolic &S) {
                             else {
                                 const double ent = tile_entries(w, i0, j0, c1);
                                 S.flops_update += 2.0 * kexec * ent; S.flops_update_skipped += 2.0 * (kw - kexec) * ent;
+                                if (pass == 2) S.flops_update_chain += 2.0 * kexec * ent;
                                 S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0, seg, nsl}); task_canon.push_back(canon_next[(size_t)s]++);
                             }
                         }
@@ -1469,7 +1486,7 @@ static void build_schedule(Symbolic &S) {
         auto for_fronts = [&](auto &&fn) {              // dry runs see all of the rank's fronts of the level
             for (i32 t = t0; t < t1; ++t) {
                 const i32 s = S.level_fronts[t];
-                if (dry ? (bool)S.front_local[s] : in_scope(s)) fn(s, S.fronts[s]);
+                if (dry ? (bool)S.front_local[s] : (in_scope(s) && pass_ok(s))) fn(s, S.fronts[s]);
             }
         };
         // One update launch: `gen` pushes its tiles.  Split-K: when the launch would leave most of the
@@ -1538,11 +1555,11 @@ static void build_schedule(Symbolic &S) {
                 if (t_level < UPD_SLOTS) nsplit = best_parts(t_level);                    // a single, partly filled wave: cut every tile
                 else if (r > 0) { tail_parts = best_parts(r); tail_from = t_level - r; }  // the last wave
             }
-            if (nsplit < 2 && tail_parts < 2) { push_launch(S.factor_launches, LK_UPDATE, f_upd, cnt); return; }
+            if (nsplit < 2 && tail_parts < 2) { emit(LK_UPDATE, f_upd, cnt); return; }
             std::vector<UpdateTask> orig(S.update_tasks.begin() + f_upd, S.update_tasks.end());
             S.update_tasks.resize(f_upd);
             const i64 f_red = (i64)S.reduce_tasks.size();
-            i32 slot = 0;
+            i32 slot = (pass == 2) ? (i32)chain_slot_base : 0;
             for (size_t q = 0; q < orig.size(); ++q) {
                 const UpdateTask &t = orig[q];
                 const i32 limit = (nsplit >= 2) ? nsplit : (task_canon[q] >= tail_from ? tail_parts : 1);
@@ -1562,8 +1579,9 @@ static void build_schedule(Symbolic &S) {
             const int region = (cur_g + 1) * 2 + cur_side;
             if ((int)region_slots.size() <= region) region_slots.resize(region + 1, 0);
             region_slots[region] = std::max<i64>(region_slots[region], slot);
-            push_launch(S.factor_launches, LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
-            push_launch(S.factor_launches, LK_UPDATE_REDUCE, f_red, (i64)S.reduce_tasks.size() - f_red);
+            if (pass == 2) chain_slot_base = slot;
+            emit(LK_UPDATE, f_upd, (i64)S.update_tasks.size() - f_upd);
+            emit(LK_UPDATE_REDUCE, f_red, (i64)S.reduce_tasks.size() - f_red);
         };
         // Macro columns: G consecutive block columns share ONE left-looking update with
         // K = [0, kM) (kM = first column of the macro column); inside the macro column a block
@@ -1626,6 +1644,11 @@ static void build_schedule(Symbolic &S) {
             }
             lookahead = nbig >= 1 && nbig <= 16 && ns_max <= 12288;
         }
+        auto block_columns = [&]() {
+        i32 pmax = 0;
+        for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t]) && pass_ok(S.level_fronts[t])) pmax = std::max(pmax, S.fronts[S.level_fronts[t]].ns);
+        if (pmax == 0 && pass != 0) return;
+        const i32 nouter = (pass == 0) ? (max_ns + NB_OUT - 1) / NB_OUT : (pmax + NB_OUT - 1) / NB_OUT;      // (shadows the level's: block columns of THIS pass's fronts)
         for (i32 io = 0; io <= nouter; ++io) {
             const i32 ko = io * NB_OUT;
             const i32 io_macro = mac_first[(size_t)io], G = mac_G[(size_t)io];
@@ -1638,8 +1661,8 @@ static void build_schedule(Symbolic &S) {
             // stream and hides them.  Only stream order and events: correct under any scheduling
             // (a profiler that serialises dispatches included).
             const bool overlap = io > 0 && io < nouter;
-            if (overlap) S.factor_launches.push_back(Launch{LK_SIDE_FORK, cur_g, 0, 0, 0, 0});
-            cur_side = overlap ? 1 : 0;
+            if (overlap && pass != 2) S.factor_launches.push_back(Launch{LK_SIDE_FORK, cur_g, 0, 0, 0, 0});
+            cur_side = (overlap && pass != 2) ? 1 : 0;
             if (overlap)
                 emit_update_launch([&]() {
                     for_fronts([&](i32 s, const FrontDesc &w) {
@@ -1660,9 +1683,9 @@ static void build_schedule(Symbolic &S) {
                     });
                     if (cls == 0) {
                         while (((i64)S.potrf_tasks.size() - f_potrf) % 4) S.potrf_tasks.push_back(PotrfTask{-1, 0, 0, 0});
-                        push_launch(S.factor_launches, LK_POTRF_SMALL, f_potrf, ((i64)S.potrf_tasks.size() - f_potrf) / 4);
+                        emit(LK_POTRF_SMALL, f_potrf, ((i64)S.potrf_tasks.size() - f_potrf) / 4);
                     } else
-                        push_launch(S.factor_launches, cls == 2 ? LK_POTRF_WIDE : LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
+                        emit(cls == 2 ? LK_POTRF_WIDE : LK_POTRF, f_potrf, (i64)S.potrf_tasks.size() - f_potrf);
                 }
             }
             cur_side = 0;
@@ -1686,7 +1709,7 @@ static void build_schedule(Symbolic &S) {
                     });
                 });
             }
-            if (overlap) S.factor_launches.push_back(Launch{LK_SIDE_JOIN, cur_g, 0, 0, 0, 0});
+            if (overlap && pass != 2) S.factor_launches.push_back(Launch{LK_SIDE_JOIN, cur_g, 0, 0, 0, 0});
             if (io == nouter) break;
             // k_trsm solves the rows below the diagonal block in one pass
             // (thin block columns -- the small fronts of the leaf levels -- take one thread per row instead
@@ -1696,7 +1719,7 @@ static void build_schedule(Symbolic &S) {
                 for_fronts([&](i32 s, const FrontDesc &w) {
                     if (ko >= w.ns) return;
                     const i32 no = std::min(NB_OUT, w.ns - ko);
-                    if ((no <= TRSM_THIN_W) != (thin == 1)) return;
+                    if ((no <= TRSM_THIN_W && pass != 2) != (thin == 1)) return;      // (chain items: 64-row strips for every width)
                     const i32 step = thin ? 256 : TRSM_WG_ROWS;
                     // row ranges END on multiples of `step` rows (16-row strips then sit on 128-byte lines of the
                     // line-aligned panel); pad1 = row limit of the task
@@ -1706,7 +1729,198 @@ static void build_schedule(Symbolic &S) {
                         r0 = r1;
                     }
                 });
-                push_launch(S.factor_launches, thin ? LK_TRSM_THIN : LK_TRSM, f_trsm, (i64)S.trsm_tasks.size() - f_trsm);
+                emit(thin ? LK_TRSM_THIN : LK_TRSM, f_trsm, (i64)S.trsm_tasks.size() - f_trsm);
+            }
+        }
+        };      // block_columns
+        // ---- round 6: the dependency-driven form (LK_CHAIN) --------------------------------------------------------------------------------
+        // The launches of a block column -- diagonal tiles -> diagonal block -> rows-below tiles -> triangular solve, with their stream forks and joins --
+        // are a lock-step over ALL fronts of the level and four or five launch gaps per 256 columns; where a level has few fronts (a pds-class top front,
+        // the root front, the blocks of one rank of an 8-GPU job) the chain potrf(io) -> trsm(io) -> diagonal update(io + 1) IS the level's time, and
+        // profiles/r05_chain_overlap.txt showed that it never runs beside the rows-below tiles it was forked to hide behind.  Here the SAME tasks (same
+        // tiles, same K ranges, same split-K parts: the captured launches of pass 2) become the items of one persistent launch: a workgroup draws an
+        // item, waits for the completion counters the item names, runs the task's ordinary device function and publishes its stores with one agent-scope
+        // release before it raises its counter (cdna_hip_programming.md, Guideline 16, counter form).  Ticket order = the order of the captured launches
+        // = block column major: diagonal tiles, diagonal block, rows-below tiles (+ look-ahead / macro-column tiles), strips of the triangular solve.
+        // Every wait names counters raised by EARLIER items only, so no schedule of the workgroups can deadlock (tests/emulate.py asserts it).
+        // Adders of one target tile (macro-column tile, look-ahead tile, the block column's own tile or its split-K reduction) are chained through the
+        // tile's counter in that order: exactly the order of the launches, so the factor is bit-identical to the launch form (TLPK_CHAIN=0).
+        auto build_chain = [&]() {
+            if (cap.empty()) return;
+            struct FC { i64 base; i32 nbc, ntr, nsl, stride; };
+            std::unordered_map<i32, FC> fc;
+            i64 ncnt = 0;
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 s = S.level_fronts[t];
+                if (!in_scope(s) || !chain_front[(size_t)s]) continue;
+                const FrontDesc &w = S.fronts[s];
+                FC c; c.base = ncnt; c.nbc = (w.ns + NB_OUT - 1) / NB_OUT; c.ntr = (w.f + TILE - 1) / TILE; c.nsl = (w.f + 63) / 64;
+                c.stride = 4 + 2 * c.ntr + c.nsl;
+                ncnt += (i64)c.nbc * c.stride;
+                fc[s] = c;
+            }
+            const i64 ticket_idx = S.chain_counters, cbase = S.chain_counters + 1;      // global index of local counter q: cbase + q
+            std::vector<i32> expect((size_t)ncnt, 0);                                   // signals handed out so far, per local counter
+            auto new_counter = [&]() { expect.push_back(0); return (i64)expect.size() - 1; };
+            auto c_dg = [&](const FC &c, i32 io, i32 pos) { return c.base + (i64)io * c.stride + pos; };                  // diagonal block of io: tiles (ko, ko) | (ko + 128, ko) | (ko + 128, ko + 128)
+            auto c_pf = [&](const FC &c, i32 io) { return c.base + (i64)io * c.stride + 3; };                             // the diagonal block is factored
+            auto c_tg = [&](const FC &c, i32 io, i32 tr, i32 cj) { return c.base + (i64)io * c.stride + 4 + 2 * tr + cj; };     // target tile (rows 128 tr .., column tile cj of block column io)
+            auto c_ts = [&](const FC &c, i32 io, i32 sl) { return c.base + (i64)io * c.stride + 4 + 2 * c.ntr + sl; };    // rows [64 sl, 64 sl + 64) are solved in block column io
+            const i64 first_item = (i64)S.chain_items.size();
+            bool bad = false;
+            auto G = [&](i64 q) { return (i32)(cbase + q); };
+            // the counter an adder of target tile (i0, j0) raises, or -1 (targets in the update matrix: read by the next level's extend-add launch)
+            auto target_counter = [&](const FC &c, const FrontDesc &w, i32 i0, i32 j0) -> i64 {
+                if (j0 >= w.ns) return -1;
+                const i32 io = j0 / NB_OUT, ko = io * NB_OUT;
+                if (i0 < ko + NB_OUT) return c_dg(c, io, (i0 == ko) ? 0 : 1 + (j0 - ko) / TILE);
+                return c_tg(c, io, i0 / TILE, (j0 - ko) / TILE);
+            };
+            // operand rows [r0, r0 + 128) of an update tile whose K range ends in block column io_k: hand-over flags of the strips that solved them
+            auto operand_wait = [&](const FC &c, const FrontDesc &w, i32 io_k, i32 r0, i32 &wq, i32 &nq) {
+                const i32 s0 = r0 / 64, s1 = (std::min(r0 + TILE, w.f) - 1) / 64;
+                for (i32 sl = s0; sl <= s1; ++sl) if (expect[(size_t)c_ts(c, io_k, sl)] != 1) bad = true;      // no strip (or two) for these rows: a bug
+                wq = G(c_ts(c, io_k, s0)); nq = s1 - s0 + 1;
+            };
+            for (size_t ci = 0; ci < cap.size() && !bad; ++ci) {
+                const Cap &L = cap[ci];
+                if (L.kind == LK_UPDATE) {
+                    // split-K parts of this launch: scratch slot -> the counter of the reduction that owns it
+                    std::unordered_map<i32, i64> slot_red;
+                    std::vector<i64> red_counter;
+                    if (ci + 1 < cap.size() && cap[ci + 1].kind == LK_UPDATE_REDUCE) {
+                        const Cap &R = cap[ci + 1];
+                        for (i64 q = R.first; q < R.first + R.count; ++q) {
+                            const UpdateTask &r = S.reduce_tasks[(size_t)q];
+                            const i64 rc = new_counter();
+                            red_counter.push_back(rc);
+                            for (i32 sp = 0; sp < r.kw; ++sp) slot_red[r.k0 + sp] = rc;
+                        }
+                    }
+                    for (i64 q = L.first; q < L.first + L.count; ++q) {
+                        const UpdateTask &u = S.update_tasks[(size_t)q];
+                        const FrontDesc &w = S.fronts[u.front];
+                        const FC &c = fc.at(u.front);
+                        ChainItem it{CR_UPDATE, (i32)q, 0, 0, 0, 0, 0, 0, 0, -1, 0, -1};
+                        const i32 io_k = (u.k0 + u.kw - 1) / NB_OUT;
+                        operand_wait(c, w, io_k, u.i0, it.w0, it.n0); it.need0 = 1;
+                        if (u.j0 != u.i0) { operand_wait(c, w, io_k, u.j0, it.w1, it.n1); it.need1 = 1; }
+                        if (u.pad1) {
+                            const auto f = slot_red.find(u.pad1 - 1);
+                            if (f == slot_red.end()) { bad = true; break; }
+                            it.sig = G(f->second); ++expect[(size_t)f->second];
+                        } else {
+                            const i64 tc = target_counter(c, w, u.i0, u.j0);
+                            if (tc >= 0) {
+                                if (expect[(size_t)tc] > 0) { it.w2 = G(tc); it.need2 = expect[(size_t)tc]; }     // the earlier adder(s) of this tile
+                                it.sig = G(tc); ++expect[(size_t)tc];
+                            }
+                        }
+                        S.chain_items.push_back(it);
+                    }
+                    if (!red_counter.empty()) {
+                        const Cap &R = cap[ci + 1];
+                        for (i64 q = R.first; q < R.first + R.count; ++q) {
+                            const UpdateTask &r = S.reduce_tasks[(size_t)q];
+                            const FrontDesc &w = S.fronts[r.front];
+                            const FC &c = fc.at(r.front);
+                            const i64 rc = red_counter[(size_t)(q - R.first)];
+                            if (expect[(size_t)rc] != r.kw) { bad = true; break; }
+                            const i64 tc = target_counter(c, w, r.i0, r.j0);
+                            for (i32 sub = 0; sub < RED_SPLIT; ++sub) {
+                                ChainItem it{CR_REDUCE, (i32)q, sub, G(rc), 1, r.kw, 0, 0, 0, -1, 0, -1};
+                                if (tc >= 0) {
+                                    if (expect[(size_t)tc] > 0) { it.w2 = G(tc); it.need2 = expect[(size_t)tc]; }
+                                    it.sig = G(tc);
+                                }
+                                S.chain_items.push_back(it);
+                            }
+                            if (tc >= 0) expect[(size_t)tc] += RED_SPLIT;
+                        }
+                        ++ci;                                            // the reduce launch is consumed
+                    }
+                } else if (L.kind == LK_POTRF || L.kind == LK_POTRF_WIDE) {
+                    for (i64 q = L.first; q < L.first + L.count; ++q) {
+                        const PotrfTask &pt = S.potrf_tasks[(size_t)q];
+                        const FC &c = fc.at(pt.front);
+                        const i32 io = pt.k0 / NB_OUT;
+                        ChainItem it{CR_POTRF, (i32)q, 0, 0, 0, 0, 0, 0, 0, -1, 0, G(c_pf(c, io))};
+                        const i64 d0 = c_dg(c, io, 0), d1 = c_dg(c, io, 1), d2 = c_dg(c, io, 2);
+                        if (expect[(size_t)d0] > 0) { it.w0 = G(d0); it.n0 = 1; it.need0 = expect[(size_t)d0]; }
+                        if (expect[(size_t)d1] > 0) { it.w1 = G(d1); it.n1 = 1; it.need1 = expect[(size_t)d1]; }
+                        if (expect[(size_t)d2] > 0) { it.w2 = G(d2); it.need2 = expect[(size_t)d2]; }
+                        ++expect[(size_t)c_pf(c, io)];
+                        S.chain_items.push_back(it);
+                    }
+                } else if (L.kind == LK_TRSM) {
+                    for (i64 q = L.first; q < L.first + L.count; ++q) {
+                        const TrsmTask &tt = S.trsm_tasks[(size_t)q];
+                        const FC &c = fc.at(tt.front);
+                        const i32 io = tt.k0 / NB_OUT, tr = tt.row0 / TILE;
+                        if (expect[(size_t)c_pf(c, io)] != 1 || tt.pad1 > (tt.row0 / 64 + 1) * 64) { bad = true; break; }
+                        ChainItem it{CR_TRSM, (i32)q, 0, 0, 0, 0, 0, 0, 0, G(c_pf(c, io)), 1, G(c_ts(c, io, tt.row0 / 64))};
+                        if (tr * TILE >= tt.k0 + NB_OUT) {              // (a strip inside the diagonal tiles' rows -- a narrow last block column -- is released by the diagonal block alone)
+                            const i64 g0 = c_tg(c, io, tr, 0), g1 = c_tg(c, io, tr, 1);
+                            if (expect[(size_t)g0] > 0) { it.w0 = G(g0); it.n0 = 1; it.need0 = expect[(size_t)g0]; }
+                            if (expect[(size_t)g1] > 0) { it.w1 = G(g1); it.n1 = 1; it.need1 = expect[(size_t)g1]; }
+                        }
+                        ++expect[(size_t)c_ts(c, io, tt.row0 / 64)];
+                        S.chain_items.push_back(it);
+                    }
+                } else bad = true;                                       // (no other kind is ever captured)
+            }
+            // the values the diagonal blocks and the strips wait for must be FINAL: nothing after them may add to their tiles
+            for (i64 q = first_item; q < (i64)S.chain_items.size() && !bad; ++q) {
+                const ChainItem &it = S.chain_items[(size_t)q];
+                if (it.role != CR_POTRF && it.role != CR_TRSM) continue;
+                if (it.n0 && expect[(size_t)(it.w0 - cbase)] != it.need0) bad = true;
+                if (it.n1 && expect[(size_t)(it.w1 - cbase)] != it.need1) bad = true;
+                if (it.role == CR_POTRF && it.w2 >= 0 && expect[(size_t)(it.w2 - cbase)] != it.need2) bad = true;
+            }
+            if (bad) { S.error = "internal: inconsistent chain schedule"; return; }
+            S.factor_launches.push_back(Launch{LK_CHAIN, cur_g, first_item, (i64)S.chain_items.size() - first_item, 0, (i32)ticket_idx});
+            S.chain_counters += 1 + (i64)expect.size();
+        };
+        {
+            // TLPK_CHAIN: 0 = off, 1 = every level that has a front with more than one block column, unset = auto: the levels the look-ahead rule above names
+            // (at most TLPK_CHAIN_MAX_FRONTS = 16 of this rank's fronts have more than one block column, none more than 12 288 pivot columns).  The chain's
+            // diagonal-block role is the round-5 DPP kernel: the older block kernels (TLPK_POTRF_MODE != 3, diagnostics) keep the launches.
+            const int chain_env = [] { const char *e = std::getenv("TLPK_CHAIN"); return e ? std::atoi(e) : -1; }();
+            const i32 chain_max = [] { const char *e = std::getenv("TLPK_CHAIN_MAX_FRONTS"); return e ? std::max(1, std::atoi(e)) : 16; }();
+            const bool potrf_default = [] {
+                const char *m = std::getenv("TLPK_POTRF_MODE");
+                return (!m || (std::atoi(m) & 3) == 3) && !std::getenv("TLPK_POTRF_WAVE") && !std::getenv("TLPK_POTRF_PAIR") && !std::getenv("TLPK_POTRF_DYN");
+            }();
+            i32 nbig = 0, ns_big = 0;
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 sf = S.level_fronts[t];
+                if (!S.front_local[sf] || S.front_single[sf]) continue;
+                if (S.fronts[sf].ns > NB_OUT) { ++nbig; ns_big = std::max(ns_big, S.fronts[sf].ns); }
+            }
+            // ... and the widest of them has at least TLPK_CHAIN_MIN_NS pivot columns: a front of two or three block columns has too few items for the hand-overs
+            // (a few microseconds each) to beat the launches it replaces (25fv47-class LPs; the lower levels of a pds-class LP)
+            const i32 chain_min_ns = [] { const char *e = std::getenv("TLPK_CHAIN_MIN_NS"); return e ? std::atoi(e) : 769; }();
+            const bool use_chain = chain_env != 0 && potrf_default && UPD_SLOTS == 0 && nbig >= 1 &&
+                                   (chain_env > 0 || (nbig <= chain_max && ns_big <= 12288 && ns_big >= chain_min_ns));
+            bool any = false;
+            if (use_chain)
+                for (i32 t = t0; t < t1; ++t) {
+                    const i32 sf = S.level_fronts[t];
+                    if (S.front_local[sf] && !S.front_single[sf] && S.fronts[sf].ns > NB_OUT) { chain_front[(size_t)sf] = 1; any = any || in_scope(sf); }
+                    if (chain_front[(size_t)sf] && in_scope(sf)) {       // the algorithmic update flops of its columns (the formula of step 12) now run inside k_chain
+                        const FrontDesc &w = S.fronts[sf];
+                        for (i32 c = 0; c < w.ns; ++c) {
+                            const double l = (double)S.colcount[w.col0 + c] - (double)(std::min((c / NB_OUT + 1) * NB_OUT, w.ns) - c);
+                            if (l > 0) S.flops_update_alg_chain += l * l;
+                        }
+                    }
+                }
+            if (!any) { pass = 0; block_columns(); }
+            else {
+                pass = 1; block_columns();
+                pass = 2; cap.clear(); chain_slot_base = 0; block_columns();
+                build_chain();
+                pass = 0;
             }
         }
         // (c) extend-add, U part (every U of this level has been written by now)
@@ -1729,6 +1943,16 @@ static void build_schedule(Symbolic &S) {
             for (i64 q = L.first; q < L.first + L.count; ++q) {
                 if (L.kind == LK_UPDATE) { if (S.update_tasks[q].pad1) S.update_tasks[q].pad1 += (i32)base[region]; }
                 else S.reduce_tasks[q].k0 += (i32)base[region];
+            }
+        }
+        for (const Launch &L : S.factor_launches) {              // the split-K tasks inside the chain launches (region of the group's main stream)
+            if (L.kind != LK_CHAIN) continue;
+            const size_t region = (size_t)((L.group + 1) * 2);
+            if (region >= region_slots.size() || base[region] == 0) continue;
+            for (i64 q = L.first; q < L.first + L.count; ++q) {
+                const ChainItem &it = S.chain_items[(size_t)q];
+                if (it.role == CR_UPDATE) { if (S.update_tasks[(size_t)it.task].pad1) S.update_tasks[(size_t)it.task].pad1 += (i32)base[region]; }
+                else if (it.role == CR_REDUCE && it.sub == 0) S.reduce_tasks[(size_t)it.task].k0 += (i32)base[region];
             }
         }
     }

@@ -106,6 +106,7 @@ int kind_class(i32 kind) {
     case LK_TRSM: case LK_TRSM_THIN: return TLPK_KC_TRSM;
     case LK_UPDATE: return TLPK_KC_UPDATE;
     case LK_UPDATE_REDUCE: return TLPK_KC_UPDATE_REDUCE;
+    case LK_CHAIN: return TLPK_KC_CHAIN;
     case LK_FWD_GATHER: case LK_FWD_DIAG: case LK_FWD_UPDATE: case LK_FWD_SMALL: case LK_FWD_SWEEP: return TLPK_KC_SOLVE_FWD;
     default: return TLPK_KC_SOLVE_BWD;
     }
@@ -338,6 +339,9 @@ int upload_all(tlpk_handle *h) {
     UP(d.fa_tasks, S.fa_tasks);
     UP(d.ea_tasks, S.ea_tasks); UP(d.potrf_tasks, S.potrf_tasks); UP(d.trsm_tasks, S.trsm_tasks);
     UP(d.update_tasks, S.update_tasks); UP(d.reduce_tasks, S.reduce_tasks);
+    UP(d.chain_items, S.chain_items); d.n_chain_cnt = S.chain_counters;
+    if (S.chain_counters > 0 && (rc = dev_alloc(h, &d.chain_cnt, S.chain_counters)) != TLPK_OK) return rc;
+    if (!S.chain_items.empty() && std::getenv("TLPK_CHAIN_TRACE") && (rc = dev_alloc(h, &d.chain_trace, 4 * (i64)S.chain_items.size())) != TLPK_OK) return rc;
     { i32 *p; UP(p, S.upd_seg); d.ctx.upd_seg = p; }
     d.n_single = (i64)S.single_col.size();
     UP(d.single_loff, S.single_loff); UP(d.single_dinvoff, S.single_dinvoff); UP(d.single_col, S.single_col);
@@ -710,6 +714,7 @@ static int update_async_wait(tlpk_handle *h);
 static int enq_update_local(tlpk_handle *h) {
     const Symbolic &S = h->S;
     HIPCHK(h, hipMemcpyAsync(h->d.ctx.info, h->h_info, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (h->d.n_chain_cnt > 0) HIPCHK(h, hipMemsetAsync(h->d.chain_cnt, 0, (size_t)h->d.n_chain_cnt * sizeof(unsigned), h->stream));     // tickets + completion counters of the chain launches
     {
         ProfScope ps(h, TLPK_KC_ASSEMBLE);
         if (S.system == 1) launch_k2_diag(h->stream, user_n(h), h->d_theta, h->d_regP, h->d_D);      // D2 = [theta + regP ; 1]  (sqd.jl:44-50)
@@ -742,7 +747,8 @@ static int enq_update_local(tlpk_handle *h) {
 static int enq_update_finish(tlpk_handle *h, hipStream_t root_stream = nullptr) {
     const Symbolic &S = h->S;
     run_launches(h, S.factor_launches, h->factor_marker, S.factor_launches.size(), -1, 1, root_stream);
-    HIPCHK(h, hipMemcpyAsync(h->h_info, h->d.ctx.info, sizeof(int), hipMemcpyDeviceToHost, root_stream ? root_stream : h->stream));
+    // (with chain launches also info[1]: a workgroup of k_chain gave up waiting -- the bounded spins of kernels.hip)
+    HIPCHK(h, hipMemcpyAsync(h->h_info, h->d.ctx.info, (h->d.n_chain_cnt > 0 ? 2 : 1) * sizeof(int), hipMemcpyDeviceToHost, root_stream ? root_stream : h->stream));
     return TLPK_OK;
 }
 
@@ -809,6 +815,7 @@ static int update_finish_wait(tlpk_handle *h) {
     float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->ms_update = ms;
     prof_collect(h);
     h->local_done = false;
+    if (h->d.n_chain_cnt > 0 && h->h_info[1] != 0) { h->last_error = "the dependency-driven factorisation gave up waiting for a completion counter (internal scheduling error); the factor is invalid"; return TLPK_INTERNAL; }
     if (h->h_info[0] != INT_MAX) { h->fail_col = h->h_info[0]; return TLPK_NOT_POSDEF; }
     h->factored = true;
     return TLPK_OK;
@@ -847,6 +854,7 @@ static int update_async_wait(tlpk_handle *h) {
     HIPCHK(h, hipGetLastError());
     float ms = 0.f; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->ms_update = ms;
     h->root_pending = false; h->local_done = false;
+    if (h->d.n_chain_cnt > 0 && h->h_info[1] != 0) { h->factored = false; h->last_error = "the dependency-driven factorisation gave up waiting for a completion counter (internal scheduling error); the factor is invalid"; return TLPK_INTERNAL; }
     if (h->h_info[0] != INT_MAX) { h->fail_col = h->h_info[0]; h->factored = false; return TLPK_NOT_POSDEF; }
     h->factored = true;
     return TLPK_OK;
@@ -1954,6 +1962,8 @@ int tlpk_info(const tlpk_handle *h, tlpk_stats *out) {
     out->n_local_blocks = S.n_local_blocks; out->n_blocks = S.nblocks;
     out->flops_update = S.flops_update;
     out->flops_update_alg = S.flops_update_alg;
+    out->flops_update_chain = S.flops_update_chain; out->flops_update_alg_chain = S.flops_update_alg_chain;
+    for (const Launch &L : S.factor_launches) if (L.kind == LK_CHAIN) { out->chain_launches++; out->chain_items += L.count; }
     out->refine_rejected = h->refine_rejected;
     out->root_panel_len = (S.root_front >= 0) ? pk_len(S.fronts[S.root_front].lda, S.fronts[S.root_front].ns) : 0;
     return TLPK_OK;
@@ -2029,6 +2039,13 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "skip_bits") { tmp.resize(S.skip_bits.size()); std::memcpy(tmp.data(), S.skip_bits.data(), S.skip_bits.size() * 8); }
     else if (w == "front_single") tmp.assign(S.front_single.begin(), S.front_single.end());
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
+    else if (w == "chain_items") { for (auto &t : S.chain_items) { for (i32 v : {t.role, t.task, t.sub, t.w0, t.n0, t.need0, t.w1, t.n1, t.need1, t.w2, t.need2, t.sig}) tmp.push_back(v); } }
+    else if (w == "chain_counters") tmp.assign(1, S.chain_counters);
+    else if (w == "chain_trace") {                               // diagnostics: the time stamps of the last update (the caller has synchronised)
+        if (!h->d.chain_trace) return -1;
+        tmp.resize(4 * S.chain_items.size());
+        if (hipMemcpy(tmp.data(), h->d.chain_trace, tmp.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
     else if (w == "fa_tasks") { for (auto &t : S.fa_tasks) { tmp.push_back(t.front); tmp.push_back(t.bc); tmp.push_back(t.br0); tmp.push_back(t.br1); } }
     else if (w == "front_fa") tmp.assign(S.front_fa.begin(), S.front_fa.end());
     else if (w == "front_upper") tmp.assign(S.front_upper.begin(), S.front_upper.end());

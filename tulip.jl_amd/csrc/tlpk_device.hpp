@@ -63,6 +63,9 @@ struct DevArrays {
     const double *asm_D = nullptr, *asm_regD = nullptr;   // handle-owned D = 1 / (theta + regP) (K2: D2) and regD, read by the assembly kernels
     EaTask *ea_tasks = nullptr; PotrfTask *potrf_tasks = nullptr; TrsmTask *trsm_tasks = nullptr;
     UpdateTask *update_tasks = nullptr, *reduce_tasks = nullptr;
+    ChainItem *chain_items = nullptr;                 // items of the LK_CHAIN launches (k_chain)
+    unsigned long long *chain_trace = nullptr;        // TLPK_CHAIN_TRACE=1: 4 time stamps per item (kernels.hip: k_chain), read back through tlpk_symbolic_get("chain_trace")
+    unsigned *chain_cnt = nullptr; i64 n_chain_cnt = 0;   // their tickets + completion counters, zeroed at the start of every update
     i64 n_single = 0; i64 *single_loff = nullptr, *single_dinvoff = nullptr; i32 *single_col = nullptr;   // isolated 1 x 1 fronts
     SolveTask *fwd_gather_tasks = nullptr, *fwd_diag_tasks = nullptr, *fwd_update_tasks = nullptr,
               *bwd_update_tasks = nullptr, *fwd_small_tasks = nullptr, *bwd_small_tasks = nullptr,

@@ -103,8 +103,21 @@ enum LaunchKind : i32 {
     LK_FWD_SWEEP,       // whole forward substitution of every (non-small) front of a level in ONE launch: workgroups
     LK_BWD_SWEEP,       // own row chunks / column blocks and hand solved blocks over through flags (k_fwd_sweep / k_bwd_sweep)
     LK_FRONT_ASSEMBLE,  // panels of the large fronts of a level formed tile by tile: S entries + children (k_front_assemble)
-    LK_WAIT_UPPER       // marker: from here on the group's stream touches panels of the UPPER fronts (front_upper): wait for their zero-fill + assembly
+    LK_WAIT_UPPER,      // marker: from here on the group's stream touches panels of the UPPER fronts (front_upper): wait for their zero-fill + assembly
+    LK_CHAIN            // round 6: the whole blocked factorisation of a level's multi-block-column fronts in ONE persistent launch (k_chain): update tiles,
+                        // diagonal blocks, triangular solves and split-K reductions are ITEMS drawn from a ticket counter, released by completion counters
 };
+// ---- dependency-driven factorisation (LK_CHAIN, symbolic.cpp: build_schedule / kernels.hip: k_chain) ----
+// An item is one task of the ordinary kernels (an update tile, the diagonal block of a block column, a 64-row strip of a triangular solve, one eighth of a
+// split-K reduction).  It starts when the counters it names have reached their values -- every one of them is raised by items with SMALLER tickets, so a
+// workgroup only ever waits for workgroups that already run -- and raises ONE counter when its stores are published (agent-scope release).
+//   wait 0 / wait 1: every counter of [w, w + n) >= need   (the hand-over flags of the two operand row ranges of an update tile; the target tiles of a
+//                    diagonal block / of a strip's tile row)
+//   wait 2:          counter w2 >= need2                   (the earlier adder of the same target tile; the diagonal block of a strip; the parts of a reduction)
+enum ChainRole : i32 { CR_UPDATE = 0, CR_POTRF = 1, CR_TRSM = 2, CR_REDUCE = 3 };
+struct alignas(16) ChainItem { i32 role, task, sub, w0, n0, need0, w1, n1, need1, w2, need2, sig; };     // sub: part of a reduction (0 .. RED_SPLIT - 1); sig < 0: none
+static_assert(sizeof(ChainItem) == 48, "ChainItem layout");
+constexpr int RED_SPLIT = 8;       // workgroups (items) per split-K reduction tile
 struct Launch { i32 kind; i32 group; i64 first; i64 count; i32 side = 0; i32 pad = 0; };   // tasks[first .. first+count); group: stream (-1 = after all groups joined)
 
 struct Options {
@@ -180,6 +193,7 @@ struct Symbolic {
     // sizes
     i64 nnzS = 0, nnzL = 0, lval_len = 0, ubuf_len[2] = {0, 0}, uc_len = 0, max_front = 0, dinv_len = 0;
     double flops_chol = 0, flops_panel = 0, flops_update = 0, flops_update_alg = 0;
+    double flops_update_chain = 0, flops_update_alg_chain = 0;   // the share of the two that runs inside the LK_CHAIN launches (k_chain), not in k_update
     // schedules
     std::vector<PotrfTask> potrf_tasks; std::vector<TrsmTask> trsm_tasks;
     std::vector<UpdateTask> update_tasks, reduce_tasks; std::vector<EaTask> ea_tasks;
@@ -197,6 +211,8 @@ struct Symbolic {
     bool sweep = true;                     // persistent sweep kernels (TLPK_SWEEP=0: one launch per 128-column block step)
     bool solve_single_stream = true;       // every launch of the solve schedules runs on the handle's main stream (one stream group, or solve_one_group)
     std::vector<Launch> factor_launches, fwd_launches, bwd_launches;
+    std::vector<ChainItem> chain_items;    // items of the LK_CHAIN launches (Launch.first / count index this list; Launch.pad = counter index of the launch's ticket)
+    i64 chain_counters = 0;                // completion counters + tickets of all LK_CHAIN launches (u32 each, zeroed at the start of every update!)
     // state handed from analyse_common to analyse_rank (rank-independent)
     std::vector<i32> row_block_v, col_block_v;   // block of each row / column of A (-1: linking), empty = general sparse
     std::vector<i32> sparent_v;                  // parent of each front
