@@ -474,7 +474,10 @@ def main():
                 if kkt1 is not kkt:
                     kkt1.close()
                 upd = kt["update"]
-                fl_alg, fl_exec = st["flops_update_alg"], st["flops_update"]
+                # (round 6: the tiles of the dependency-driven launches -- k_chain: the root front here -- are not k_update launches: their flops leave the numerator,
+                # their time is the `chain` class of kernel_ms)
+                st1 = kkt1.stats()
+                fl_alg, fl_exec = st1["flops_update_alg"] - st1["flops_update_alg_chain"], st1["flops_update"] - st1["flops_update_chain"]
                 sec = upd["ms"] * 1e-3
                 ach = fl_alg / sec / 1e12 if sec > 0 else 0.0
                 traffic, traffic_src = None, None
@@ -496,7 +499,8 @@ def main():
                                    "frac_executed": (fl_exec / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS) if sec > 0 else 0.0,
                                    "flops_executed_per_step": fl_exec,
                                    "frac_if_all_of_flops_chol_were_credited": (st["flops_chol"] / sec / 1e12 / FP64_MFMA_PEAK_TFLOPS) if sec > 0 else 0.0,
-                                   "frac_step": out["frac_step"], "peak_measured": 77.9, "measured_with_streams": 1}
+                                   "frac_step": out["frac_step"], "peak_measured": 77.9, "measured_with_streams": 1,
+                                   "flops_in_chain_launches": st1["flops_update_alg_chain"], "chain_launches": st1["chain_launches"], "chain_items": st1["chain_items"]}
                 solve_bytes = 2 * 8 * st["nnzL"] + 2 * 12 * A.nnz + 8 * (4 * n + 3 * m)
                 sol_ms = (kt["solve_fwd"]["ms"] + kt["solve_bwd"]["ms"] + kt["spmv"]["ms"]) / max(args.solves, 1)
                 out["kernel_ms"] = {k: round(v["ms"], 4) for k, v in kt.items()}
@@ -656,6 +660,45 @@ def main():
         out["cpu_baseline"] = cpu_baseline_subprocess(args)
         if "value" in out["cpu_baseline"]:
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    # The drop-in path (north_star: "Julia host code calls ... via ccall", src/IPM untouched: /root/reference/src/KKT/KKT.jl:83,100 -- one update! and
+    # `solves` SEPARATE solve! calls on host vectors) next to `value` at the top level, inside `config` (which the driver's record keeps whole) and in a
+    # compact `summary` object that is the LAST key of the line (the driver's record also keeps the tail of stdout).
+    drop_in = (out.get("host_abi") or {}).get("ms_per_step")
+    h = out.get("headline") or {}
+    summary = {"ms_per_step": out["ms_per_step"], "drop_in_ms_per_step": drop_in, "unpaired_ms_per_step": out.get("unpaired_ms_per_step"),
+               "headline_ms_per_step": h.get("ms_per_step"), "headline_drop_in_ms_per_step": (h.get("host_abi") or {}).get("ms_per_step"),
+               "headline_unpaired_ms_per_step": h.get("unpaired_ms_per_step"),
+               "roofline_frac": (out.get("roofline") or {}).get("frac"), "headline_roofline_frac": (h.get("roofline") or {}).get("frac"),
+               "solve_roofline_frac": (out.get("solve_roofline") or {}).get("frac"), "headline_solve_roofline_frac": (h.get("solve_roofline") or {}).get("frac"),
+               "pair_ms_over_single": ((out.get("solve_roofline") or {}).get("pair") or {}).get("ms_over_single"),
+               "headline_pair_ms_over_single": ((h.get("solve_roofline") or {}).get("pair") or {}).get("ms_over_single"),
+               "c3_ms_per_step": (out.get("c3") or {}).get("ms_per_step"),
+               "small_lp_ms_per_step": {k: v.get("ms_per_step") for k, v in (out.get("small_lp") or {}).items()},
+               "ms_analyse": out["config"].get("ms_analyse"), "headline_ms_analyse": h.get("ms_analyse"),
+               "gpu_over_cpu": (out.get("cpu_baseline") or {}).get("gpu_over_cpu"), "headline_gpu_over_cpu": (h.get("cpu_baseline") or {}).get("gpu_over_cpu")}
+    out["config"]["drop_in_ms_per_step"] = drop_in
+    out["config"]["headline_ms_per_step"] = h.get("ms_per_step")
+    out["config"]["headline_drop_in_ms_per_step"] = summary["headline_drop_in_ms_per_step"]
+    if world == 1 and not split:
+        try:        # multi-GPU: no node has been available to measure on; the committed projection (rank-local times measured on one GPU + modelled reductions), labelled as such
+            pj = json.load(open(os.path.join(ROOT, "profiles", "scale_projection.json")))
+            out["projected"] = pj
+            summary["projected_step_ms"] = {k: v.get("step_ms") for k, v in pj.get("workloads", {}).items()}
+        except Exception:
+            out["projected"] = None
+    ordered = {}
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step"):
+        ordered[k] = out[k]
+    ordered["drop_in_ms_per_step"] = drop_in
+    ordered["headline_ms_per_step"] = h.get("ms_per_step")
+    ordered["headline_drop_in_ms_per_step"] = summary["headline_drop_in_ms_per_step"]
+    if "host_abi" in out:
+        ordered["host_abi"] = out["host_abi"]
+    for k, v in out.items():
+        if k not in ordered:
+            ordered[k] = v
+    ordered["summary"] = summary
+    out = ordered
     if rank == 0:
         emit(json.dumps(out))
     if dist is not None:

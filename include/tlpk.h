@@ -101,7 +101,8 @@ typedef struct tlpk_stats {
     double  ms_enqueue_update; /* multi-device handles: host time from the entry of the last tlpk_update until the work of EVERY shard
                                   (root fronts included) was enqueued; ms_last_update is then the wall time of the whole call */
     int64_t refine_rejected;   /* refine_steps > 0: refinement steps of the last completed solve that did NOT shrink |r1|inf, or lifted |r2|inf beyond 16 x its
-                                  value after the unrefined solve, and were discarded (a rejected step ends the refinement of that solve); valid after tlpk_sync / a blocking solve */
+                                  value after the unrefined solve, and were discarded (a rejected step ends the refinement of that solve's RESULT; on one device the remaining steps are still enqueued -- solve, candidate, residuals, norms: the
+                                  verdict is taken on the device without a host round trip -- and only their commit is skipped: a rejected step does not make the call cheaper); valid after tlpk_sync / a blocking solve */
     double  flops_update_chain;     /* round 6: the share of flops_update / flops_update_alg whose tiles run as items of the dependency-driven launches */
     double  flops_update_alg_chain; /* (k_chain: fronts with more than one block column on levels with few such fronts) instead of in k_update launches */
     int64_t chain_launches, chain_items;   /* number of those launches per factorisation and the items (update tiles, diagonal blocks, solve strips, reductions) they hold */

@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PROBLEM = dict(nblocks=5, mk=40, nk=90, m0=14, nnz_in=3, link_prob=0.6)
+# the 64-block partition of the bench workload (BASELINE configs[3]) at reduced block size: what an 8-rank launch shards (argv[7] = "p64")
+PROBLEM64 = dict(nblocks=64, mk=30, nk=64, m0=24, nnz_in=3, link_prob=0.5)
 
 
 def main():
@@ -24,7 +26,8 @@ def main():
     from helpers import block_angular, ipm_like_data
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        A, row_block = block_angular(seed=seed, **PROBLEM)
+        problem = PROBLEM64 if (len(sys.argv) > 7 and sys.argv[7] == "p64") else PROBLEM
+        A, row_block = block_angular(seed=seed, **problem)
         m, n = A.shape
         th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
         kkt = tk.setup(A, tk.K2() if system == "K2" else tk.K1(), tk.Backend(device=-1, row_block=row_block, rank=rank, nranks=world))
@@ -63,8 +66,14 @@ def main():
                                                    (kkt.symbolic("row_local") == 1).astype(np.int64)]))
         dist.all_reduce(own)
         st = kkt.stats()
+        # factor flops of the fronts this rank owns (root excluded): what the partition balances
+        fl, fns, floc = kkt.symbolic("front_f").astype(float), kkt.symbolic("front_ns").astype(float), kkt.symbolic("front_local")
+        sel = (floc != 0); root = int(kkt.symbolic("root_front")[0])
+        if root >= 0:
+            sel[root] = False
+        lflops = float((fns[sel] ** 3 / 3 + (fl[sel] - fns[sel]) * fns[sel] ** 2 + (fl[sel] - fns[sel]) ** 2 * fns[sel]).sum())
         np.savez(out, dx=tdx.numpy(), dy=tdy.numpy(), own=own.numpy(), nloc=st["n_local_blocks"],
-                 rlen=st["root_panel_len"], dy_link=dy[link], **extra)
+                 rlen=st["root_panel_len"], dy_link=dy[link], lflops=lflops, **extra)
     finally:
         dist.destroy_process_group()
 

@@ -74,6 +74,51 @@ def test_sharded_newton_step_matches_oracle(world, tmp_path):
     assert sum(nloc) == PROBLEM["nblocks"] and all(v >= 1 for v in nloc)
 
 
+def test_eight_ranks_on_the_64_block_partition(tmp_path):
+    """The shape an 8-GPU launch of the bench shards (BASELINE configs[3]: 64 diagonal blocks + linking rows; hook
+    /root/reference/src/parameters.jl:11, src/IPM/ipmdata.jl:166), at reduced block size on 8 `gloo` processes: the ownership is a partition, every
+    rank owns 8 of the 64 blocks with factor flops within 10 % of the mean (the partition balances sum f^2-type flops over contiguous block ranges),
+    and every rank ends with the oracle's solution (update: local subtrees + all-reduce of the root panel + replicated root; solve: all-reduce of
+    the root right-hand side; one refinement step)."""
+    from dist_worker import PROBLEM64
+    from helpers import block_angular, ipm_like_data
+    from oracle_binding import OracleK1
+    world, seed = 8, 23
+    port = str(_free_port())
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", TLPK_HOST_THREADS="1")
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, str(seed), outs[r], "K1", "p64"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("distributed worker timed out")
+        logs.append(out.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    A, row_block = block_angular(seed=seed, **PROBLEM64)
+    m, n = A.shape
+    th, rp, rd, xp, xd = ipm_like_data(m, n, seed)
+    orc = OracleK1(A)
+    orc.update(th, rp, rd)
+    dxo, dyo = orc.solve(xp, xd)
+    nloc, lfl = [], []
+    for r in range(world):
+        z = np.load(outs[r])
+        assert np.abs(z["dx"] - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max())
+        assert np.abs(z["dy"] - dyo).max() <= 1e-9 * max(1, np.abs(dyo).max())
+        assert np.abs(z["dx_refined"] - dxo).max() <= 1e-9 * max(1, np.abs(dxo).max())
+        assert (z["own"] == 1).sum() == n + (row_block >= 0).sum()      # ownership is a partition
+        assert int(z["rlen"]) == PROBLEM64["m0"] ** 2
+        nloc.append(int(z["nloc"])); lfl.append(float(z["lflops"]))
+    assert sum(nloc) == 64 and all(6 <= v <= 10 for v in nloc), nloc
+    assert max(lfl) <= 1.10 * np.mean(lfl) and min(lfl) >= 0.90 * np.mean(lfl), lfl
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_augmented_system_matches_k2_oracle(world, tmp_path):
     """K2 (the reference's default linear system, KKT.jl:134-141) on sharded handles: every rank owns the variable and constraint

@@ -113,6 +113,32 @@ def test_device_loops_on_a_multi_device_handle(algo, ineq_bounds, system):
     assert one[8]["n_update"] == three[8]["n_update"] and one[8]["n_solve"] == three[8]["n_solve"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["hsd", "mpc"])
+def test_resident_refinement_on_a_multi_device_handle_walks_the_single_device_iterates(algo):
+    """Round-5 advisor finding: with refine > 0 the device-resident loops on a multi-device handle measured one linking-row residual (every shard subtracting
+    Rd dy: (N - 1) Rd |dy| too much) and corrected another (tlpk_refine_local dropping the other shards' partial xi_p).  One convention now: every shard adds
+    its partial xi_p, rank 0 alone subtracts Rd dy.  Three shards on this GPU with refine = 1 must walk the single-device refine = 1 run: same status and
+    iteration count, objectives to 1e-9, refinement steps accepted (a biased norm or a wrongly formed step shows as rejected steps or as extra iterations)."""
+    from tulip_jl_amd.hsd_device import DeviceHSD
+    from tulip_jl_amd.mpc_device import DeviceMPC
+    cls = DeviceHSD if algo == "hsd" else DeviceMPC
+    A, rb, b, c, l, u, zopt = _block_angular_lp_data(ineq_bounds=True)
+    runs = {}
+    for name, kw in (("one", dict(device=0, row_block=rb, refine=1)), ("three", dict(device=0, row_block=rb, ngpus=3, devices=[0, 0, 0], refine=1))):
+        opt = cls(A, b, c, l, u, system="K1", **kw)
+        opt.optimize()
+        runs[name] = (opt.status, opt.niter, opt.primal_objective, opt.dual_objective, opt.rho, opt._get(0, opt.n), opt._get(5, opt.m), opt.kkt.stats()["refine_rejected"])
+        opt.kkt.close()
+    one, three = runs["one"], runs["three"]
+    print(algo, "refine=1, one device:", one[:5], one[7], "| three shards:", three[:5], three[7])
+    assert one[0] == three[0] == "Trm_Optimal" and one[1] == three[1]
+    assert abs(one[2] - three[2]) <= 1e-9 * (1 + abs(one[2])) and abs(one[3] - three[3]) <= 1e-9 * (1 + abs(one[3]))
+    assert abs(three[2] - zopt) <= 1e-6 * (1 + abs(zopt)) and max(three[4]) <= SQRT_EPS
+    for k in (5, 6):
+        assert np.abs(one[k] - three[k]).max() <= 1e-6 * max(1.0, np.abs(one[k]).max()), k
+
+
 def device_hsd(lp, **kw):
     from tulip_jl_amd.hsd_device import DeviceHSD
     d = standard_form(lp)

@@ -12,6 +12,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 namespace tlpk {
 namespace {
 
@@ -100,12 +102,25 @@ int configured_workers() {
     if (hc > 0 && (unsigned)w + 1 > hc) w = (int)hc - 1;
     return w < 0 ? 0 : (w > 31 ? 31 : w);
 }
-Pool &pool() { static Pool p(configured_workers()); return p; }
+// One pool per PROCESS (round-5 advisor finding): after fork() -- Python's multiprocessing with the fork start method -- the child inherits the parent's pool
+// object but none of its threads; joining those handles at exit is undefined behaviour.  The holder remembers the pid that created the pool: a child builds its
+// own on first use and abandons the inherited object (its threads do not exist there), and only the owning process joins its workers at exit.
+struct PoolHolder {
+    Pool *p = nullptr; pid_t owner = 0; std::mutex m;
+    ~PoolHolder() { if (p && owner == getpid()) delete p; }
+};
+Pool &pool() {
+    static PoolHolder h;
+    std::lock_guard<std::mutex> lk(h.m);
+    const pid_t me = getpid();
+    if (!h.p || h.owner != me) { h.p = new Pool(configured_workers()); h.owner = me; }
+    return *h.p;
+}
 
 }  // namespace
 
 void host_parallel_for(int n, const std::function<void(int)> &fn) { pool().run(n, fn); }
-int host_copy_threads() { return (int)pool().th.size() + 1; }
+int host_copy_threads() { return configured_workers() + 1; }      // (the configured size: asking must not start the workers)
 
 void copy_to_staging(void *dst, const void *src, size_t bytes) {
     static const bool nt = [] { const char *e = std::getenv("TLPK_COPY_NT"); return !e || std::atoi(e) != 0; }();

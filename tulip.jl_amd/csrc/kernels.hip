@@ -3134,14 +3134,18 @@ __global__ void k_dx(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ 
 // a second solve with (r1, r2) gives the correction that k_axpy2 adds.
 __global__ void k_resid_rows(i64 m, const i64 *__restrict__ Tp, const i32 *__restrict__ Tj, const double *__restrict__ Tx,
                              const double *__restrict__ xi_p, const double *__restrict__ regD, const double *__restrict__ dx,
-                             const double *__restrict__ dy, const char *__restrict__ row_local, int rank, double *__restrict__ r1) {
+                             const double *__restrict__ dy, const char *__restrict__ row_local, int rank, int xip_all, double *__restrict__ r1) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     double s = 0.0;
     for (i64 q = Tp[i]; q < Tp[i + 1]; ++q) s += Tx[q] * dx[Tj[q]];
-    // sharded: dx is zero outside this rank's columns, so a linking row gets the rank's partial sum, and only rank 0 adds
-    // xi_p - Rd dy there (the reduction of the root right-hand side inside the following solve completes the row)
-    const double base = (row_local[i] == 2 && rank != 0) ? 0.0 : (xi_p[i] - regD[i] * dy[i]);
+    // sharded: dx is zero outside this rank's columns, so a linking row gets the rank's partial sum; the SUM over the ranks must be the row's
+    // residual (the reduction of the root right-hand side inside the following solve, or the host's sum of the shards' values, completes it):
+    //   xi_p: rank 0's only -- or, xip_all (device-resident loops: every shard holds its PARTIAL xi_p on the linking rows), every rank's;
+    //   - Rd dy: dy is replicated on the linking rows, so it is counted ONCE, by rank 0, in either convention (round-5 advisor finding: with
+    //   xip_all every shard subtracted it, a bias of (N - 1) Rd |dy| in the norms the refinement guard compares).
+    const bool link = row_local[i] == 2;
+    const double base = ((!link || rank == 0 || xip_all) ? xi_p[i] : 0.0) - ((!link || rank == 0) ? regD[i] * dy[i] : 0.0);
     r1[i] = base - s;
 }
 __global__ void k_resid_cols(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ Ai, const double *__restrict__ Ax,
@@ -3436,8 +3440,8 @@ void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy
     if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw + (rhs ? a.ctx.xw2 : 0), dy, dy_shared, rank);
 }
 void launch_residuals(hipStream_t st, const DevArrays &a, const double *xi_p, const double *xi_d, const double *theta, const double *regP,
-                      const double *regD, const double *dx, const double *dy, double *r1, double *r2, int rank) {
-    if (a.m > 0) hipLaunchKernelGGL(k_resid_rows, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.Tp, a.Tj, a.Tx, xi_p, regD, dx, dy, a.row_local, rank, r1);
+                      const double *regD, const double *dx, const double *dy, double *r1, double *r2, int rank, int xip_all) {
+    if (a.m > 0) hipLaunchKernelGGL(k_resid_rows, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.Tp, a.Tj, a.Tx, xi_p, regD, dx, dy, a.row_local, rank, xip_all, r1);
     if (a.n > 0) hipLaunchKernelGGL(k_resid_cols, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, xi_d, theta, regP, dx, dy, r2);
 }
 void launch_publish(hipStream_t st, const DevArrays &a, const double *dx, double *dx_job, const double *dy, double *dy_job) {

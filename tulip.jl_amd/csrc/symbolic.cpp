@@ -119,6 +119,10 @@ static void build_schedule(Symbolic &S);
 // Host threads for the embarrassingly parallel parts of the analyse phase.  fn(thread, i) is called once
 // for every i in [0, n), items handed out dynamically; the result never depends on the number of
 // threads (every item writes its own outputs).  Returns false if a worker threw (out of memory).
+// Sharded runs (round-5 review): every one of N ranks -- N processes of a multi-GPU launch, or the N per-shard threads of tlpk_create_multi -- runs this
+// analysis at the same time on the same host: the default thread count is divided by N (8 ranks would otherwise start 512 analyse threads on a host that
+// grants the job 16 - 256 CPUs).  Set at the top of analyse_common / analyse_rank from Options.nranks; an explicit TLPK_HOST_THREADS is taken as given.
+static thread_local i64 g_host_thread_div = 1;
 static unsigned host_threads(i64 n) {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     // up to a quarter of the hardware threads, at most 64 (env TLPK_HOST_THREADS overrides): the per-front / per-block phases
@@ -127,7 +131,7 @@ static unsigned host_threads(i64 n) {
     // fastest setting there (C4 281 ms against 347 with 16; north-star LP 1093 against 1258: tools/analyse_threads_probe.py) -- unlike the
     // seconds-long OpenMP teams of the CPU comparator, which the quota throttles
     static const i64 cap = [] { const char *e = std::getenv("TLPK_HOST_THREADS"); return e ? std::max<i64>(1, std::atoll(e)) : (i64)64; }();
-    const i64 mine = std::getenv("TLPK_HOST_THREADS") ? cap : std::min<i64>(cap, std::max<i64>(16, hw / 4));
+    const i64 mine = std::getenv("TLPK_HOST_THREADS") ? cap : std::max<i64>(1, std::min<i64>(cap, std::max<i64>(16, hw / 4)) / g_host_thread_div);
     return (unsigned)std::max<i64>(1, std::min<i64>({(i64)hw, mine, n}));
 }
 // `chunk` consecutive items go to the same thread (neighbouring items usually write neighbouring memory:
@@ -181,6 +185,7 @@ struct PhaseTimer {
 int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval, const double *nzval,
                    int base, const Options &opt) {
     PhaseTimer pt;
+    g_host_thread_div = opt.analyse_div > 0 ? opt.analyse_div : std::max<i32>(1, opt.nranks);
     if (m64 < 0 || n64 < 0 || (base != 0 && base != 1) || !colptr) return fail(S, TLPK_BADARG, "bad dimensions or index base");
     if (m64 >= (i64)1 << 31 || n64 >= (i64)1 << 31) return fail(S, TLPK_TOO_LARGE, "m or n exceeds int32");
     const i64 nnz = colptr[n64] - base;
@@ -717,6 +722,7 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
 
 int analyse_rank(Symbolic &S, const Options &opt) {
     PhaseTimer pt;
+    g_host_thread_div = opt.analyse_div > 0 ? opt.analyse_div : std::max<i32>(1, opt.nranks);
     const i32 m = (i32)S.m, n = (i32)S.n;
     const std::vector<i32> &row_block = S.row_block_v, &col_block = S.col_block_v, &sparent = S.sparent_v;
     const i32 nblocks = S.nblocks, nlink = S.nlink_v, ns_total = S.nsuper;

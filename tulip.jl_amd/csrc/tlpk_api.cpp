@@ -1148,14 +1148,15 @@ int tlpk_solve_device(tlpk_handle *h, double *d_dx, double *d_dy, const double *
 // replicated).  Every rank forms the residuals it owns; on the linking rows its PARTIAL sum over its own columns (rank 0 adds
 // xi_p - Rd dy), which the reduction inside the solve completes.  The buffers are allocated by the first call.
 static int refine_buffers(tlpk_handle *h) {
-    if (h->d_r1) return TLPK_OK;
+    // (every buffer is checked, not only the first: an allocation that failed half way must not leave a later call with a null d_ref / d_cy -- round-5 advisor finding)
     const i64 nn = std::max<i64>(h->S.n, 1), mm = std::max<i64>(h->S.m, 1);
     int rc = TLPK_OK;
-    if ((rc = dev_alloc(h, &h->d_r1, mm)) != TLPK_OK) return rc;
-    if ((rc = dev_alloc(h, &h->d_r2, nn)) != TLPK_OK) return rc;
-    if ((rc = dev_alloc(h, &h->d_cx, nn)) != TLPK_OK) return rc;
-    if ((rc = dev_alloc(h, &h->d_ref, 8)) != TLPK_OK) return rc;
-    return dev_alloc(h, &h->d_cy, mm);
+    if (!h->d_r1 && (rc = dev_alloc(h, &h->d_r1, mm)) != TLPK_OK) return rc;
+    if (!h->d_r2 && (rc = dev_alloc(h, &h->d_r2, nn)) != TLPK_OK) return rc;
+    if (!h->d_cx && (rc = dev_alloc(h, &h->d_cx, nn)) != TLPK_OK) return rc;
+    if (!h->d_ref && (rc = dev_alloc(h, &h->d_ref, 8)) != TLPK_OK) return rc;
+    if (!h->d_cy && (rc = dev_alloc(h, &h->d_cy, mm)) != TLPK_OK) return rc;
+    return TLPK_OK;
 }
 int tlpk_refine_local(tlpk_handle *h, const double *d_dx, const double *d_dy, const double *d_xip, const double *d_xid) {
     if (!h || !d_dx || !d_dy || !d_xip || !d_xid) return TLPK_BADARG;
@@ -1170,7 +1171,8 @@ int tlpk_refine_local(tlpk_handle *h, const double *d_dx, const double *d_dy, co
     h->solve_timed = false;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     h->solve_epoch += 1;
-    launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, d_dx, d_dy, h->d_r1, h->d_r2, h->opt.rank);
+    // (rhs_all_ranks: the device-resident loops' convention -- this shard's xi_p is its PARTIAL of the linking rows and counts whatever the rank)
+    launch_residuals(h->stream, h->d, d_xip, d_xid, h->d_theta, h->d_regP, h->d_regD, d_dx, d_dy, h->d_r1, h->d_r2, h->opt.rank, h->rhs_all_ranks ? 1 : 0);
     if (int rc = enq_solve_local(h, h->d_r1, h->d_r2, 0)) return rc;
     h->solve_local_done = true; h->refine_pending = true;
     return TLPK_OK;
@@ -1527,7 +1529,7 @@ int multi_resid_norm(tlpk_handle *h, double *const *dx, double *const *dy, const
         HIPCHK(h, hipSetDevice(c->device));
         if (int rc = refine_buffers_multi(c)) { h->last_error = c->last_error; return rc; }
         HIPCHK(h, hipMemsetAsync(c->d_ref, 0, 8 * sizeof(unsigned long long), c->stream));
-        launch_residuals(c->stream, c->d, xip[r], xid[r], c->d_theta, c->d_regP, c->d_regD, dx[r], dy[r], c->d_r1, c->d_r2, all_ranks ? 0 : c->opt.rank);
+        launch_residuals(c->stream, c->d, xip[r], xid[r], c->d_theta, c->d_regP, c->d_regD, dx[r], dy[r], c->d_r1, c->d_r2, c->opt.rank, all_ranks ? 1 : 0);
         launch_absmax2(c->stream, c->d, c->d_r1, c->d_r2, c->d_ref, 1);
     }
     double n1 = 0.0, n2 = 0.0;
@@ -1818,6 +1820,7 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
         const auto t0 = std::chrono::steady_clock::now();
         if (rc == TLPK_OK) {
             Options o; o.ordering = base.ordering; o.relax = base.relax; o.nranks = ngpus; o.row_block = base.row_block;
+            o.analyse_div = 1;                          // ONE analysis for the whole job runs here: all of the host's analyse threads (the shards' rank parts, in parallel, divide by ngpus)
             rc = (base.system == TLPK_SYSTEM_K2) ? analyse_k2_common(common, m, n, colptr, rowval, nzval, index_base, o, nullptr)
                                                  : analyse_common(common, m, n, colptr, rowval, nzval, index_base, o);
             if (rc != TLPK_OK) h->last_error = common.error;

@@ -85,7 +85,7 @@ void launch_single_solve(hipStream_t st, const DevArrays &a, int rhs = 0);
 void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank, int rhs = 0);
 void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy_shared = nullptr, int rank = 0, int rhs = 0);
 void launch_residuals(hipStream_t st, const DevArrays &a, const double *xi_p, const double *xi_d, const double *theta, const double *regP,
-                      const double *regD, const double *dx, const double *dy, double *r1, double *r2, int rank);
+                      const double *regD, const double *dx, const double *dy, double *r1, double *r2, int rank, int xip_all = 0);
 void launch_publish(hipStream_t st, const DevArrays &a, const double *dx, double *dx_job, const double *dy, double *dy_job);
 void launch_axpy2(hipStream_t st, i64 n, double *x, const double *dxc, i64 m, double *y, const double *dyc);
 // guarded refinement (kernels.hip: k_absmax2 ...): max-norm of (r1, r2) into *out (bit pattern, atomicMax: zero it first), verdict, candidate, commit

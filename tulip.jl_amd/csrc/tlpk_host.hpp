@@ -124,6 +124,8 @@ struct Options {
     i32 ordering = 0, relax = 1, rank = 0, nranks = 1, streams = 0;
     i32 system = 0;                   // 0 = K1 normal equations, 1 = K2 augmented system (signed Cholesky)
     i64 k2_n = 0;                     // K2, internal: number of variable nodes (nodes [0, k2_n) are variables, the rest constraints)
+    i32 analyse_div = 0;              // host threads of the analyse phase = default / analyse_div; 0 = nranks (N ranks analyse at the same time on one host); tlpk_create_multi: 1 for
+                                      // its ONE rank-independent analysis
     const i64 *user_perm = nullptr;   // 0-based here
     const i64 *row_block = nullptr;
 };
