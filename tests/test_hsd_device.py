@@ -151,7 +151,8 @@ def compare(lp, obj_tol=1e-8, vec_tol=1e-6, niter_tol=1):
     dev, sd = device_hsd(lp)
     hg, sh = solve_lp(lp, lambda A: HipBackend(A, device=0))
     assert sd["status"] == sh["status"]
-    assert abs(dev.niter - hg.niter) <= niter_tol
+    if niter_tol is not None:
+        assert abs(dev.niter - hg.niter) <= niter_tol
     if sh["status"] == "Trm_Optimal":
         assert abs(sd["z_primal"] - sh["z_primal"]) <= obj_tol * (1 + abs(sh["z_primal"]))
         assert abs(sd["z_dual"] - sh["z_dual"]) <= obj_tol * (1 + abs(sh["z_dual"]))
@@ -217,11 +218,16 @@ def test_device_hsd_c2_equivalent_and_highs():
     """configs[1] stand-in (tests/golden/stair25.mps): all row / bound types, centrality correctors fire."""
     from test_lp_configs import STAIR25_OPT
     lp = read_free_mps(os.path.join(GOLDEN, "stair25.mps"))
-    # niter_tol = 3 on THIS LP: it stops at a relative gap of 1.5e-8 and its last iterations move with any change of rounding (DESIGN.md section 3, C2) --
-    # round 4: two builds of the same kernels that differ by one scalar in a kernel-argument struct (hence in where the compiler fuses multiply-adds)
-    # took 26 and 29 device-loop iterations against 26 of the host-vector loop, objectives equal to 1e-10 in both; the host / device loops are
-    # the same algorithm, not the same rounding
-    dev, sd, hg, sh = compare(lp, obj_tol=1e-7, vec_tol=1e-3, niter_tol=3)
+    # No iteration-count assertion on THIS LP (rounds 4 - 5 carried niter_tol = 3): it stops at a relative gap of 1.5e-8 and its last iterations move with any change
+    # of rounding (DESIGN.md section 3, C2) -- two builds of the same kernels that differ in where the compiler fuses multiply-adds took 26 and 29 device-loop
+    # iterations against 26 of the host-vector loop, objectives equal to 1e-10 in both.  What the two loops owe each other is the RESULT: status, both objectives,
+    # the residual measures at termination, the duality gap, and the optimum HiGHS finds.
+    dev, sd, hg, sh = compare(lp, obj_tol=1e-7, vec_tol=1e-3, niter_tol=None)
+    assert sd["status"] == sh["status"] == "Trm_Optimal"
+    assert max(sd["rho"]) <= SQRT_EPS and max(sh["rho"]) <= SQRT_EPS
+    assert abs(sd["z_primal"] - sd["z_dual"]) <= 1e-7 * (1 + abs(sd["z_primal"]))
+    assert abs(sd["z_dual"] - STAIR25_OPT) <= 1e-6 * (1 + abs(STAIR25_OPT))
+    assert dev.niter <= 2 * hg.niter and hg.niter <= 2 * dev.niter          # (a loop that needs twice the iterations is not the same algorithm)
     assert abs(sd["z_primal"] - STAIR25_OPT) <= 1e-6 * (1 + abs(STAIR25_OPT))
 
 
