@@ -465,6 +465,7 @@ def main():
                 kkt1.set_profile(True)
                 newton_step(kkt1, paired=False)
                 kt = kkt1.kernel_times()
+                st1 = kkt1.stats()
                 kt_pair = None
                 if pair:
                     kkt1.update_device(P(d_th), P(d_rp), P(d_rd))          # (resets the class timers)
@@ -476,7 +477,6 @@ def main():
                 upd = kt["update"]
                 # (round 6: the tiles of the dependency-driven launches -- k_chain: the root front here -- are not k_update launches: their flops leave the numerator,
                 # their time is the `chain` class of kernel_ms)
-                st1 = kkt1.stats()
                 fl_alg, fl_exec = st1["flops_update_alg"] - st1["flops_update_alg_chain"], st1["flops_update"] - st1["flops_update_chain"]
                 sec = upd["ms"] * 1e-3
                 ach = fl_alg / sec / 1e12 if sec > 0 else 0.0

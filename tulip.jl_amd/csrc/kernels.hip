@@ -120,9 +120,10 @@ __global__ void k_single_factor(i64 n, const i64 *__restrict__ loff, const i64 *
     dinv[dinvoff[i]] = 1.0 / l;
 }
 __global__ void k_single_solve(i64 n, const i64 *__restrict__ dinvoff, const i32 *__restrict__ col,
-                               const double *__restrict__ dinv, double *__restrict__ xw) {
+                               const double *__restrict__ dinv, double *__restrict__ xw, i64 xw2) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (blockIdx.y) xw += xw2;                                    // (grid y = right-hand side of a pair)
     const double w = dinv[dinvoff[i]];
     xw[col[i]] = (xw[col[i]] * w) * w;                            // forward (x L^-1) then backward (x L^-1)
 }
@@ -2264,7 +2265,9 @@ __global__ __launch_bounds__(256, 2) void k_chain(const ChainArgs a, DevCtx c) {
 // own columns and only rank 0 adds xi_p on linking rows (the all-reduce completes the sum).
 // w = D .* xi_d on this rank's columns (0 elsewhere), once per solve: the row kernel below then gathers ONE vector per
 // entry of A instead of three (column mask, D, xi_d); the products are formed in the same order as before
-__global__ void k_rhs_scale(i64 n, const double *__restrict__ D, const double *__restrict__ xi_d, const char *__restrict__ col_local, double *__restrict__ w) {
+__global__ void k_rhs_scale(i64 n, const double *__restrict__ D, const double *__restrict__ xi_d, const char *__restrict__ col_local, double *__restrict__ w,
+                            const double *__restrict__ xi_d1) {
+    if (blockIdx.y) { xi_d = xi_d1; w += n; }                     // (grid y = right-hand side of a pair)
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) w[j] = col_local[j] ? D[j] * xi_d[j] : 0.0;
 }
@@ -2272,7 +2275,9 @@ __global__ __launch_bounds__(256) void k_rhs(i64 m, const i32 *__restrict__ perm
                       const i32 *__restrict__ Tj, const double *__restrict__ Tx,
                       const double *__restrict__ D, const double *__restrict__ xi_p,
                       const double *__restrict__ xi_d, const char *__restrict__ row_local,
-                      const char *__restrict__ col_local, int rank, double *__restrict__ xw) {
+                      const char *__restrict__ col_local, int rank, double *__restrict__ xw,
+                      const double *__restrict__ xi_p1, i64 w2, i64 xw2) {
+    if (blockIdx.y) { xi_p = xi_p1; D += w2; xw += xw2; }          // (grid y = right-hand side of a pair: its xi_p, pre-scaled vector and xw)
     // 8 lanes per row (LP rows are short: a wave per row left 7/8 of the lanes idle; a long linking
     // row just takes more trips); fixed shuffle-tree reduction inside the 8-lane group
     // Tp / Tj / Tx: the CSR copy with rows in PERMUTED order (tlpk_api.cpp: upload_all) -- row ii is contiguous with row ii + 1
@@ -2295,6 +2300,7 @@ __global__ __launch_bounds__(256) void k_rhs(i64 m, const i32 *__restrict__ perm
 // listed in gth_src (child order = summation order): pivot rows add them to xw, rows below the
 // pivot block start the front's own contribution vector uc.  One thread per row, no conflicts.
 __global__ __launch_bounds__(256) void k_fwd_gather(const SolveTask *__restrict__ tasks, DevCtx c) {
+    if (blockIdx.y) { c.xw += c.xw2; c.uc += c.uc2; }      // second right-hand side of a pair: its copies of xw / uc (one launch for both)
     const SolveTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     if (t.nb == SOLVE_ROWS / 8) {
@@ -3034,6 +3040,7 @@ __device__ __forceinline__ void fwd_small_body(const FrontDesc &fd, const DevCtx
     }
 }
 __global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
+    if (blockIdx.y) { c.xw += c.xw2; c.uc += c.uc2; }      // second right-hand side of a pair: its copies of xw / uc (one launch for both)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
@@ -3092,6 +3099,7 @@ __device__ __forceinline__ void bwd_small_body(const FrontDesc &fd, const DevCtx
     if (lane < ns) xs[lane] = x;
 }
 __global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
+    if (blockIdx.y) { c.xw += c.xw2; c.uc += c.uc2; }      // second right-hand side of a pair: its copies of xw / uc (one launch for both)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
@@ -3104,7 +3112,9 @@ __global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__
 // dy_shared != nullptr (single-process multi-device mode): the rows this rank OWNS (its block rows; the linking rows
 // on rank 0) are also written into the job-wide result vector, which may live on a peer device (P2P stores).
 __global__ void k_unpermute(i64 m, const i32 *__restrict__ perm, const char *__restrict__ row_local,
-                            const double *__restrict__ xw, double *__restrict__ dy, double *__restrict__ dy_shared, int rank) {
+                            const double *__restrict__ xw, double *__restrict__ dy, double *__restrict__ dy_shared, int rank,
+                            double *__restrict__ dy1, i64 xw2) {
+    if (blockIdx.y) { dy = dy1; xw += xw2; }                       // (grid y = right-hand side of a pair)
     const i64 ii = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (ii >= m) return;
     const i32 i = perm[ii];
@@ -3119,7 +3129,9 @@ __global__ void k_unpermute(i64 m, const i32 *__restrict__ perm, const char *__r
 __global__ void k_dx(i64 n, const i64 *__restrict__ Ap, const i32 *__restrict__ Ai,
                      const double *__restrict__ Ax, const double *__restrict__ D,
                      const double *__restrict__ dy, const double *__restrict__ xi_d,
-                     const char *__restrict__ col_local, double *__restrict__ dx, int local_only) {
+                     const char *__restrict__ col_local, double *__restrict__ dx, int local_only,
+                     const double *__restrict__ dy1, const double *__restrict__ xi_d1, double *__restrict__ dx1) {
+    if (blockIdx.y) { dy = dy1; xi_d = xi_d1; dx = dx1; }          // (grid y = right-hand side of a pair)
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     if (!col_local[j]) { if (!local_only) dx[j] = 0.0; return; }
@@ -3302,10 +3314,11 @@ void launch_single_factor(hipStream_t st, const DevArrays &a) {
         hipLaunchKernelGGL(k_single_factor, dim3(nblk(a.n_single, 256)), dim3(256), 0, st, a.n_single, a.single_loff, a.single_dinvoff,
                            a.single_col, a.ctx.Lval, a.ctx.dinv, a.ctx.info, a.ctx.csign);
 }
+// rhs: 0 / 1 = that right-hand side, 2 = both in one launch (grid y)
 void launch_single_solve(hipStream_t st, const DevArrays &a, int rhs) {
     if (a.n_single > 0)
-        hipLaunchKernelGGL(k_single_solve, dim3(nblk(a.n_single, 256)), dim3(256), 0, st, a.n_single, a.single_dinvoff, a.single_col,
-                           a.ctx.dinv, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
+        hipLaunchKernelGGL(k_single_solve, dim3(nblk(a.n_single, 256), rhs == 2 ? 2u : 1u), dim3(256), 0, st, a.n_single, a.single_dinvoff, a.single_col,
+                           a.ctx.dinv, a.ctx.xw + (rhs == 1 ? a.ctx.xw2 : 0), a.ctx.xw2);
 }
 // nrhs = 2 (solve schedules only): the two persistent sweep kernels run their two-right-hand-side instances (one pass over L for
 // both), every other solve kernel is launched once per right-hand side (the second on a context whose xw / uc point at the copies)
@@ -3316,6 +3329,16 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
     if (nrhs == 2) {
         if (L.kind == LK_FWD_SWEEP) { if (sw) hipLaunchKernelGGL(k_fwd_sweep<2>, g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw); return; }
         if (L.kind == LK_BWD_SWEEP) { if (sw) hipLaunchKernelGGL(k_bwd_sweep<2>, g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw); return; }
+        // round 6: the kernels of a pair that are not sweeps run BOTH right-hand sides in one launch (grid y = right-hand side; round 5 measured that launching
+        // them once per right-hand side was the whole 1.13 - 1.21 x of a pair over a single solve, profiles/r05_solve_one_group.txt).  Same arithmetic per
+        // right-hand side: the pair stays bit-identical to two solves.
+        const dim3 g2((unsigned)L.count, 2u);
+        switch (L.kind) {
+        case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g2, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); return;
+        case LK_FWD_SMALL: hipLaunchKernelGGL(k_fwd_small, g2, dim3(256), 0, st, a.fwd_small_tasks + L.first, a.ctx); return;
+        case LK_BWD_SMALL: hipLaunchKernelGGL(k_bwd_small, g2, dim3(256), 0, st, a.bwd_small_tasks + L.first, a.ctx); return;
+        default: break;
+        }
         launch_tasks(st, a, L, sw, 1);
         DevArrays b = a;
         b.ctx.xw += a.ctx.xw2; b.ctx.uc += a.ctx.uc2;
@@ -3416,10 +3439,25 @@ void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const doubl
     if (a.m > 0)
     {
         double *w = a.rhs_w + (rhs ? a.n : 0);
-        if (a.n > 0) hipLaunchKernelGGL(k_rhs_scale, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, D, xi_d, a.col_local, w);
+        if (a.n > 0) hipLaunchKernelGGL(k_rhs_scale, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, D, xi_d, a.col_local, w, xi_d);
         hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256)), dim3(256), 0, st, a.m, a.perm, a.Pp, a.Pj, a.Px, w, xi_p, xi_d,
-                           a.row_local, a.col_local, rank, a.ctx.xw + (rhs ? a.ctx.xw2 : 0));
+                           a.row_local, a.col_local, rank, a.ctx.xw + (rhs ? a.ctx.xw2 : 0), xi_p, (i64)0, (i64)0);
     }
+}
+// both right-hand sides of a pair in one launch each (grid y)
+void launch_rhs2(hipStream_t st, const DevArrays &a, const double *D, const double *const *xi_p, const double *const *xi_d, int rank) {
+    if (a.m > 0)
+    {
+        if (a.n > 0) hipLaunchKernelGGL(k_rhs_scale, dim3(nblk(a.n, 256), 2), dim3(256), 0, st, a.n, D, xi_d[0], a.col_local, a.rhs_w, xi_d[1]);
+        hipLaunchKernelGGL(k_rhs, dim3(nblk(a.m * 8, 256), 2), dim3(256), 0, st, a.m, a.perm, a.Pp, a.Pj, a.Px, a.rhs_w, xi_p[0], xi_d[0],
+                           a.row_local, a.col_local, rank, a.ctx.xw, xi_p[1], a.n, a.ctx.xw2);
+    }
+}
+void launch_unpermute2(hipStream_t st, const DevArrays &a, double *const *dy, int rank) {
+    if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256), 2), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw, dy[0], (double *)nullptr, rank, dy[1], a.ctx.xw2);
+}
+void launch_dx2(hipStream_t st, const DevArrays &a, const double *D, double *const *dy, const double *const *xi_d, double *const *dx) {
+    if (a.n > 0) hipLaunchKernelGGL(k_dx, dim3(nblk(a.n, 256), 2), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, D, dy[0], xi_d[0], a.col_local, dx[0], 0, dy[1], xi_d[1], dx[1]);
 }
 // reduce-scatter step of the multi-device reductions: this shard's slice, summed over ALL ranks in rank order (its own contribution at position
 // own_rank, the peers' slices from the staging area: rank s at slot s, or s - 1 behind own_rank) -- every slice gets the same order whoever owns it
@@ -3437,7 +3475,7 @@ void launch_sum_to(hipStream_t st, i64 len, double *out, const double *own, cons
     if (len > 0) hipLaunchKernelGGL(k_sum_to, dim3(nblk(len, 256)), dim3(256), 0, st, len, out, own, src, nsrc, stride);
 }
 void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy_shared, int rank, int rhs) {
-    if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw + (rhs ? a.ctx.xw2 : 0), dy, dy_shared, rank);
+    if (a.m > 0) hipLaunchKernelGGL(k_unpermute, dim3(nblk(a.m, 256)), dim3(256), 0, st, a.m, a.perm, a.row_local, a.ctx.xw + (rhs ? a.ctx.xw2 : 0), dy, dy_shared, rank, dy, (i64)0);
 }
 void launch_residuals(hipStream_t st, const DevArrays &a, const double *xi_p, const double *xi_d, const double *theta, const double *regP,
                       const double *regD, const double *dx, const double *dy, double *r1, double *r2, int rank, int xip_all) {
@@ -3467,7 +3505,7 @@ void launch_refine_commit(hipStream_t st, i64 n, double *x, const double *cx, i6
     if (len > 0) hipLaunchKernelGGL(k_refine_commit, dim3(nblk(len, 256)), dim3(256), 0, st, n, x, cx, m, y, cy, ref);
 }
 void launch_dx(hipStream_t st, const DevArrays &a, const double *D, const double *dy, const double *xi_d, double *dx, int local_only) {
-    if (a.n > 0) hipLaunchKernelGGL(k_dx, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, D, dy, xi_d, a.col_local, dx, local_only);
+    if (a.n > 0) hipLaunchKernelGGL(k_dx, dim3(nblk(a.n, 256)), dim3(256), 0, st, a.n, a.Ap, a.Ai, a.Ax, D, dy, xi_d, a.col_local, dx, local_only, dy, xi_d, dx);
 }
 
 }  // namespace tlpk

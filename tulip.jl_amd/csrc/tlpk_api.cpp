@@ -1204,11 +1204,10 @@ static int enq_solve2_local(tlpk_handle *h, const double *const *xip, const doub
     {
         ProfScope ps(h, TLPK_KC_SPMV);
         if (h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes2, h->stream));
-        for (int r = 0; r < 2; ++r) {
-            if (k2) launch_k2_rhs(h->stream, h->d, h->S.k2_n, xip[r], xid[r], r, rank);
-            else launch_rhs(h->stream, h->d, h->d_D, xip[r], xid[r], rank, r);
-            launch_single_solve(h->stream, h->d, r);
-        }
+        if (k2) {
+            for (int r = 0; r < 2; ++r) launch_k2_rhs(h->stream, h->d, h->S.k2_n, xip[r], xid[r], r, rank);
+        } else launch_rhs2(h->stream, h->d, h->d_D, xip, xid, rank);          // both right-hand sides in one launch each (round 6)
+        launch_single_solve(h->stream, h->d, 2);
     }
     run_launches(h, h->S.fwd_launches, 0, h->fwd_marker, 0, 2);
     HIPCHK(h, hipGetLastError());
@@ -1220,12 +1219,17 @@ static int enq_solve2_finish(tlpk_handle *h, double *const *dx, double *const *d
     run_launches(h, h->S.fwd_launches, h->fwd_marker, h->S.fwd_launches.size(), 0, 2);
     if (k2) { ProfScope ps(h, TLPK_KC_SPMV); launch_apply_signs(h->stream, h->d, 0); launch_apply_signs(h->stream, h->d, 1); }
     run_launches(h, h->S.bwd_launches, 0, h->S.bwd_launches.size(), 1, 2);
-    for (int r = 0; r < 2; ++r) {
+    {
         ProfScope ps(h, TLPK_KC_SPMV);
-        if (k2) launch_k2_out(h->stream, h->d, h->S.k2_n, dx[r], dy[r], r, h->opt.rank, 0);
-        else {
-            launch_unpermute(h->stream, h->d, dy[r], nullptr, h->opt.rank, r);
-            launch_dx(h->stream, h->d, h->d_D, dy[r], xid[r], dx[r], 0);
+        if (k2) { for (int r = 0; r < 2; ++r) launch_k2_out(h->stream, h->d, h->S.k2_n, dx[r], dy[r], r, h->opt.rank, 0); }
+        else if (h->shared_dy || h->dx_local_only) {                              // (shards of a multi-device handle publish into the lead's vectors: per right-hand side)
+            for (int r = 0; r < 2; ++r) {
+                launch_unpermute(h->stream, h->d, dy[r], nullptr, h->opt.rank, r);
+                launch_dx(h->stream, h->d, h->d_D, dy[r], xid[r], dx[r], 0);
+            }
+        } else {
+            launch_unpermute2(h->stream, h->d, dy, h->opt.rank);
+            launch_dx2(h->stream, h->d, h->d_D, dy, xid, dx);
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->h_info + 1, h->d.ctx.info + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -84,6 +84,10 @@ void launch_single_factor(hipStream_t st, const DevArrays &a);
 void launch_single_solve(hipStream_t st, const DevArrays &a, int rhs = 0);
 void launch_rhs(hipStream_t st, const DevArrays &a, const double *D, const double *xi_p, const double *xi_d, int rank, int rhs = 0);
 void launch_unpermute(hipStream_t st, const DevArrays &a, double *dy, double *dy_shared = nullptr, int rank = 0, int rhs = 0);
+// the pair's per-right-hand-side kernels, both right-hand sides in ONE launch each (grid y = right-hand side): single-rank handles
+void launch_rhs2(hipStream_t st, const DevArrays &a, const double *D, const double *const *xi_p, const double *const *xi_d, int rank);
+void launch_unpermute2(hipStream_t st, const DevArrays &a, double *const *dy, int rank);
+void launch_dx2(hipStream_t st, const DevArrays &a, const double *D, double *const *dy, const double *const *xi_d, double *const *dx);
 void launch_residuals(hipStream_t st, const DevArrays &a, const double *xi_p, const double *xi_d, const double *theta, const double *regP,
                       const double *regD, const double *dx, const double *dy, double *r1, double *r2, int rank, int xip_all = 0);
 void launch_publish(hipStream_t st, const DevArrays &a, const double *dx, double *dx_job, const double *dy, double *dy_job);
