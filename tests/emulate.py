@@ -49,7 +49,7 @@ class Emulator:
             LK["FRONT_ASSEMBLE"]: g("fa_tasks").reshape(-1, 4),
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
             LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),
-            LK["UPDATE"]: g("update_tasks").reshape(-1, 10),
+            LK["UPDATE"]: np.concatenate([g("update_tasks").reshape(-1, 10), g("update_tile64").reshape(-1, 1)], axis=1),      # + 1 = a 64 x 64 tile
             LK["UPDATE_REDUCE"]: g("reduce_tasks").reshape(-1, 8),
             LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 6),
             LK["FWD_DIAG"]: g("fwd_diag_tasks").reshape(-1, 6),
@@ -337,8 +337,9 @@ class Emulator:
             P[row0:r1, k0:k0 + nb] = X
 
     def _k3(self, T):      # update
-        TILE = 128
-        for front, k0, kw, i0, j0, jlim, beta0, slot1, seg, nsl in T:
+        for front, k0, kw, i0, j0, jlim, beta0, slot1, seg, nsl, t64 in T:
+            TILE = 64 if t64 else 128
+            assert not (t64 and slot1), "64 x 64 tiles are never split-K parts"
             P = self.panel(front)
             f, ns = int(self.f[front]), int(self.ns[front])
             i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)

@@ -57,6 +57,7 @@ def test_chain_schedule_bits_equal_launch_schedule_and_any_order(case, monkeypat
     assert 22 in kinds, "no dependency-driven launch on this LP"
     items = kkt.symbolic("chain_items").reshape(-1, 12)
     assert set(items[:, 0].tolist()) >= {0, 1, 2}, "update tiles, diagonal blocks and solve strips are all items"
+    assert kkt.symbolic("update_tile64").any(), "the diagonal blocks' short updates run as 64 x 64 tiles"
     st = kkt.stats()
     assert st["chain_launches"] == kinds.count(22) and st["chain_items"] == len(items) and 0 < st["flops_update_alg_chain"] <= st["flops_update_alg"]
     em = _factor(kkt, 3)

@@ -2037,6 +2037,114 @@ epilogue:
         }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// A 64 x 64 update tile per 4-wave workgroup (round 6): the diagonal-block tiles of the dependency-driven launches (UpdateTask.pad2 = 1).  Behind a solved block
+// column only K = 256 columns are left to apply to the next 256 x 256 diagonal block, and that update sits ON the chain potrf -> strips -> update -> potrf:
+// three 128 x 128 tiles took ~50 us there, the ten 64 x 64 tiles of the block's lower triangle run side by side on ten CUs.  Wave (wr, wc) owns the 32 x 32
+// sub-tile: 2 x 2 accumulator blocks, the operand conventions of update_tile (D[i][j] = T[I0 + j, J0 + i]: coalesced column-major targets).  Every entry sums
+// its K columns in the order of the 128 x 128 tile -- slab by slab, four columns per v_mfma_f64_16x16x4_f64 -- so the result is the same bit for bit.
+// Plain K range or K-segment list; no split-K parts (the schedule gives this shape to K <= 256 only).
+// ------------------------------------------------------------------------------------------
+constexpr int U64 = 64;                      // tile edge
+constexpr int U64_LD = U64 + 16;             // LDS row stride (doubles), == 16 mod 32: conflict-free b64 reads
+template <bool SIGNED>
+__device__ __forceinline__ void update_tile64(const UpdateTask t, const FrontDesc &fd, const DevCtx &c, double *lds) {
+    double (*As)[UPD_KT * U64_LD] = reinterpret_cast<double (*)[UPD_KT * U64_LD]>(lds);          // As[buf][k][row]: rows i0 .. of the panel (row tile)
+    double (*Bs)[UPD_KT * U64_LD] = As + 2;                                                       // Bs[buf][k][row]: rows j0 .. (column tile)
+    const i32 f = fd.f, ns = fd.ns, rs = f - ns, lda = fd.lda;
+    const double *P = c.Lval + fd.loff;
+    const double *sgf = SIGNED ? c.csign + fd.col0 : nullptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4;
+    const i32 ibase = t.i0 + wr * 32, jbase = t.j0 + wc * 32;
+    const int sr = tid & 63;
+    const int sk0 = __builtin_amdgcn_readfirstlane(tid >> 6);                                     // staging: row sr, K columns sk0 + 4 it of the slab (wave-uniform)
+    const i64 ra = min(t.i0 + sr, f - 1), rb = min(t.j0 + sr, f - 1);                            // clamped, the epilogue masks
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const i32 *segp = t.seg ? c.upd_seg + (t.seg - 1) : nullptr;
+    const i32 nseg = segp ? segp[0] : 1;
+    const i32 nfull = t.kw / UPD_KT, ktail = t.kw % UPD_KT;
+    // slab iterator over the (first column, slabs) pairs of the K-segment list, or the one plain range; a partial last slab follows
+    i32 seg_i = 0, k_slab = segp ? segp[1] : t.k0, k_rem = segp ? segp[2] : nfull;
+    const i32 nrounds = (segp ? t.nsl : nfull) + (ktail ? 1 : 0);
+    double pa[4], pb[4];
+    auto load_slab = [&](const bool tail) {
+        const i32 kbase = tail ? t.k0 + nfull * UPD_KT : k_slab;
+        const i32 klim = tail ? ktail : UPD_KT;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const i32 kk = sk0 + 4 * it;
+            const double *Pk = P + pk_off(lda, kbase + min(kk, klim - 1));
+            const double va = Pk[ra], vb = Pk[rb];
+            pa[it] = (kk < klim) ? va : 0.0;
+            pb[it] = (kk < klim) ? (SIGNED ? vb * sgf[kbase + min(kk, klim - 1)] : vb) : 0.0;
+        }
+        if (!tail) {
+            k_slab += UPD_KT;
+            if (--k_rem == 0 && ++seg_i < nseg) { k_slab = segp[1 + 2 * seg_i]; k_rem = segp[2 + 2 * seg_i]; }
+        }
+    };
+    auto store_slab = [&](const int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { As[buf][(sk0 + 4 * it) * U64_LD + sr] = pa[it]; Bs[buf][(sk0 + 4 * it) * U64_LD + sr] = pb[it]; }
+    };
+    const i32 nfull_rounds = nrounds - (ktail ? 1 : 0);
+    if (nrounds > 0) {
+        load_slab(nfull_rounds == 0);
+        store_slab(0);
+        __syncthreads();
+        int cur = 0;
+        for (i32 rd = 0; rd < nrounds; ++rd) {
+            const bool more = rd + 1 < nrounds;
+            if (more) load_slab(rd + 1 >= nfull_rounds);                                         // in flight during the products
+            const double *At = As[cur] + wr * 32 + lr + lk * U64_LD;
+            const double *Bt = Bs[cur] + wc * 32 + lr + lk * U64_LD;
+#pragma unroll
+            for (int k4 = 0; k4 < UPD_KT; k4 += 4) {
+                double av[2], bv[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) av[a] = Bt[k4 * U64_LD + a * 16];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bv[b] = At[k4 * U64_LD + b * 16];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+            if (more) store_slab(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // epilogue: as update_tile (fire-and-forget L2 adds; one adder per entry at a time: the schedule orders the adders of a target)
+    double *Pw = c.Lval + fd.loff;
+    double *Uw = front_u(c, fd);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const i32 row = ibase + b * 16 + lr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i32 col = jbase + a * 16 + lk + 4 * q;
+                if (row < f && col < t.jlim && row >= col && row < t.i0 + U64 && col < t.j0 + U64) {
+                    if (col < ns) unsafeAtomicAdd(Pw + (i64)row + pk_off(lda, col), -acc[a][b][q]);
+                    else {
+                        double *dst = Uw + (i64)(row - ns) + (i64)(col - ns) * rs;
+                        if (t.beta0) *dst = -acc[a][b][q];
+                        else unsafeAtomicAdd(dst, -acc[a][b][q]);
+                    }
+                }
+            }
+        }
+}
+
 template <bool SIGNED, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_update(const UpdateTask *__restrict__ tasks, DevCtx c) {
     // double-buffered K-slabs: slab t+1 travels global -> registers while slab t is multiplied
@@ -2185,8 +2293,9 @@ __device__ __forceinline__ DevCtx uni_ctx(const DevCtx &c) {
 template <bool SIGNED>
 __device__ __noinline__ void chain_role_update(const UpdateTask *tp_, const DevCtx &c_, lds_double *lds_) {
     const UpdateTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); double *lds = uni_lds(lds_);
-    const UpdateTask t{tp->front, tp->k0, tp->kw, tp->i0, tp->j0, tp->jlim, tp->beta0, tp->pad1, tp->seg, tp->nsl, 0, 0};
+    const UpdateTask t{tp->front, tp->k0, tp->kw, tp->i0, tp->j0, tp->jlim, tp->beta0, tp->pad1, tp->seg, tp->nsl, tp->pad2, 0};
     const FrontDesc fd = c.fronts[t.front];
+    if (t.pad2) { update_tile64<SIGNED>(t, fd, c, lds); return; }          // (workgroup-uniform) a 64 x 64 tile of the next diagonal block
     double (*As)[UPD_KT * UPD_LD] = reinterpret_cast<double (*)[UPD_KT * UPD_LD]>(lds);
     const bool full = (t.i0 + TILE <= fd.f) && (t.j0 + TILE <= t.jlim) && (t.i0 >= t.j0 + TILE);
     if (full) update_tile<true, SIGNED, 4>(t, fd, c, As, As + 2);

@@ -1423,6 +1423,7 @@ static void build_schedule(Symbolic &S) {
         // The decisions that look at the whole level (split-K, macro columns, look-ahead) see all of the rank's fronts in every pass: a tile is the same
         // tile whichever way it is launched.
         int pass = 0;
+        const bool chain_tile64 = [] { const char *e = std::getenv("TLPK_CHAIN_TILE64"); return !e || std::atoi(e) != 0; }();
         std::vector<char> chain_front(S.fronts.size(), 0);       // (only the entries of this level's fronts are ever set)
         struct Cap { i32 kind; i64 first, count; };
         std::vector<Cap> cap;
@@ -1433,14 +1434,56 @@ static void build_schedule(Symbolic &S) {
             if (pass == 2) cap.push_back(Cap{kind, first, count}); else push_launch(S.factor_launches, kind, first, count);
         };
         // entries of a tile that are targets: row >= column, row < f, column < c1
-        auto tile_entries = [&](const FrontDesc &w, i32 i0, i32 j0, i32 c1) {
+        auto tile_entries = [&](const FrontDesc &w, i32 i0, i32 j0, i32 c1, i32 ts = TILE) {
             double e = 0;
-            const i32 r1 = std::min(i0 + TILE, w.f);
-            for (i32 col = j0; col < std::min(j0 + TILE, c1); ++col) e += std::max(0, r1 - std::max(i0, col));
+            const i32 r1 = std::min(i0 + ts, w.f);
+            for (i32 col = j0; col < std::min(j0 + ts, c1); ++col) e += std::max(0, r1 - std::max(i0, col));
             return e;
         };
-        auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0, int part) {
+        // ts = 64 (chain launches only, part 0, K <= 256): the diagonal block's tiles as 64 x 64 tiles (UpdateTask.pad2 = 1, kernels.hip: update_tile64) -- the
+        // short update that is left on the chain behind a solved block column runs on ten CUs instead of three.  Same sums in the same order per entry.
+        auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0, int part, i32 ts = TILE) {
             if (kw <= 0 || c0 >= c1) return;
+            if (ts == 64) {
+                for (i32 j0 = c0; j0 < c1; j0 += 64)
+                    for (i32 i0 = j0; i0 < std::min(c0 + NB_OUT, w.f); i0 += 64) {
+                        i32 seg = 0, nsl = 0;
+                        double kexec = kw;
+                        const i32 nfull = kw / 16;
+                        if (allow_skip && S.skip_off[(size_t)s] >= 0 && nfull >= 2) {
+                            const char *fi = window_flags(s, i0), *fj = window_flags(s, j0);      // (the 128-row windows that hold the tile's rows: never skips a needed slab)
+                            const i32 sl0 = k0 / 16;
+                            i32 cnt = 0;
+                            for (i32 k = 0; k < nfull; ++k) cnt += (fi[sl0 + k] & fj[sl0 + k]);
+                            if (cnt == 0 && !beta0 && kw % 16 == 0) { if (!dry) S.flops_update_skipped += 2.0 * kw * tile_entries(w, i0, j0, c1, 64); continue; }
+                            if (cnt < nfull) {
+                                need_tmp.assign((size_t)nfull, 0);
+                                for (i32 k = 0; k < nfull; ++k) need_tmp[(size_t)k] = fi[sl0 + k] & fj[sl0 + k];
+                                nsl = cnt; kexec = 16.0 * cnt + kw % 16;
+                                if (!dry) {
+                                    seg = (i32)S.upd_seg.size() + 1;
+                                    S.upd_seg.push_back(0);
+                                    i32 nseg = 0;
+                                    for (i32 k = 0; k < nfull;) {
+                                        if (!need_tmp[(size_t)k]) { ++k; continue; }
+                                        i32 e = k; while (e < nfull && need_tmp[(size_t)e]) ++e;
+                                        S.upd_seg.push_back(k0 + 16 * k); S.upd_seg.push_back(e - k); ++nseg;
+                                        k = e;
+                                    }
+                                    S.upd_seg[(size_t)seg - 1] = nseg;
+                                }
+                            }
+                        }
+                        if (dry) { ++*dry; ++canon_count[(size_t)s]; }
+                        else {
+                            const double ent = tile_entries(w, i0, j0, c1, 64);
+                            S.flops_update += 2.0 * kexec * ent; S.flops_update_skipped += 2.0 * (kw - kexec) * ent;
+                            if (pass == 2) S.flops_update_chain += 2.0 * kexec * ent;
+                            S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0, seg, nsl, 1, 0}); task_canon.push_back(canon_next[(size_t)s]++);
+                        }
+                    }
+                return;
+            }
             // tiles in super-tile order (UPD_SUPER x UPD_SUPER tiles): tasks that are neighbours in the list
             // read the same row / column slabs of the panel, and k_update deals runs of 64 consecutive
             // tasks to one XCD (one L2)
@@ -1672,7 +1715,7 @@ static void build_schedule(Symbolic &S) {
             if (overlap)
                 emit_update_launch([&]() {
                     for_fronts([&](i32 s, const FrontDesc &w) {
-                        if (ko < w.ns) push_update_region(s, w, kd, ko - kd, ko, std::min(ko + NB_OUT, w.ns), 0, 0);
+                        if (ko < w.ns) push_update_region(s, w, kd, ko - kd, ko, std::min(ko + NB_OUT, w.ns), 0, 0, (pass == 2 && chain_tile64 && !dry && ko - kd <= NB_OUT) ? 64 : TILE);
                     });
                 });
             if (io < nouter) {
@@ -1753,6 +1796,9 @@ static void build_schedule(Symbolic &S) {
         // tile's counter in that order: exactly the order of the launches, so the factor is bit-identical to the launch form (TLPK_CHAIN=0).
         auto build_chain = [&]() {
             if (cap.empty()) return;
+            // (TLPK_CHAIN_DEFER=1; OFF by default: measured neutral on the 8-block rank-local work and 0.5 ms WORSE on the pds-class LP, profiles/r06_chain_variants.txt --
+            // the stalls at the macro-column starts are the long-K tiles themselves, not their place in the ticket order)
+            const bool chain_defer = [] { const char *e = std::getenv("TLPK_CHAIN_DEFER"); return e && std::atoi(e) != 0; }();
             struct FC { i64 base; i32 nbc, ntr, nsl, stride; };
             std::unordered_map<i32, FC> fc;
             i64 ncnt = 0;
@@ -1761,7 +1807,7 @@ static void build_schedule(Symbolic &S) {
                 if (!in_scope(s) || !chain_front[(size_t)s]) continue;
                 const FrontDesc &w = S.fronts[s];
                 FC c; c.base = ncnt; c.nbc = (w.ns + NB_OUT - 1) / NB_OUT; c.ntr = (w.f + TILE - 1) / TILE; c.nsl = (w.f + 63) / 64;
-                c.stride = 4 + 2 * c.ntr + c.nsl;
+                c.stride = 5 + 2 * c.ntr + c.nsl;
                 ncnt += (i64)c.nbc * c.stride;
                 fc[s] = c;
             }
@@ -1770,8 +1816,10 @@ static void build_schedule(Symbolic &S) {
             auto new_counter = [&]() { expect.push_back(0); return (i64)expect.size() - 1; };
             auto c_dg = [&](const FC &c, i32 io, i32 pos) { return c.base + (i64)io * c.stride + pos; };                  // diagonal block of io: tiles (ko, ko) | (ko + 128, ko) | (ko + 128, ko + 128)
             auto c_pf = [&](const FC &c, i32 io) { return c.base + (i64)io * c.stride + 3; };                             // the diagonal block is factored
-            auto c_tg = [&](const FC &c, i32 io, i32 tr, i32 cj) { return c.base + (i64)io * c.stride + 4 + 2 * tr + cj; };     // target tile (rows 128 tr .., column tile cj of block column io)
-            auto c_ts = [&](const FC &c, i32 io, i32 sl) { return c.base + (i64)io * c.stride + 4 + 2 * c.ntr + sl; };    // rows [64 sl, 64 sl + 64) are solved in block column io
+            auto c_dq = [&](const FC &c, i32 io) { return c.base + (i64)io * c.stride + 4; };                             // the 64 x 64 tiles of the diagonal block's last (short) update
+            auto c_tg = [&](const FC &c, i32 io, i32 tr, i32 cj) { return c.base + (i64)io * c.stride + 5 + 2 * tr + cj; };     // target tile (rows 128 tr .., column tile cj of block column io)
+            auto c_ts = [&](const FC &c, i32 io, i32 sl) { return c.base + (i64)io * c.stride + 5 + 2 * c.ntr + sl; };    // rows [64 sl, 64 sl + 64) are solved in block column io
+            std::unordered_map<i64, char> covered;                // target tiles of a diagonal block that a 64 x 64 tile waits for (the diagonal block then needs not)
             const i64 first_item = (i64)S.chain_items.size();
             bool bad = false;
             auto G = [&](i64 q) { return (i32)(cbase + q); };
@@ -1788,6 +1836,45 @@ static void build_schedule(Symbolic &S) {
                 for (i32 sl = s0; sl <= s1; ++sl) if (expect[(size_t)c_ts(c, io_k, sl)] != 1) bad = true;      // no strip (or two) for these rows: a bug
                 wq = G(c_ts(c, io_k, s0)); nq = s1 - s0 + 1;
             };
+            // Macro-column tiles wait their turn BEHIND the strips of the block column they were launched with: they feed LATER block columns (K = [0, kM),
+            // hundreds of microseconds each), and tickets are priorities -- drawn before the strips, as in the launch order, they kept every workgroup busy while
+            // the chain's next link (40 us of strips) waited for a free one (profiles/r06_chain_trace_*.txt: 300 - 400 us stalls at every macro column start).
+            // Deferred: the update tiles of a captured launch whose target block column lies beyond the current one, except the tiles of the NEXT diagonal block.
+            // Every adder of a target tile is still created before the later adders of that tile: same order of the sums, same bits.
+            std::vector<i64> deferred;
+            i32 io_cur = -1;                                             // block column of the last diagonal block seen
+            auto update_item = [&](i64 q, const std::unordered_map<i32, i64> &slot_red) {
+                        const UpdateTask &u = S.update_tasks[(size_t)q];
+                        const FrontDesc &w = S.fronts[u.front];
+                        const FC &c = fc.at(u.front);
+                        ChainItem it{CR_UPDATE, (i32)q, 0, 0, 0, 0, 0, 0, 0, -1, 0, -1};
+                        const i32 io_k = (u.k0 + u.kw - 1) / NB_OUT;
+                        operand_wait(c, w, io_k, u.i0, it.w0, it.n0); it.need0 = 1;
+                        if (u.j0 != u.i0) { operand_wait(c, w, io_k, u.j0, it.w1, it.n1); it.need1 = 1; }
+                        if (u.pad1) {
+                            const auto f = slot_red.find(u.pad1 - 1);
+                            if (f == slot_red.end()) { bad = true; return; }
+                            it.sig = G(f->second); ++expect[(size_t)f->second];
+                        } else if (u.pad2) {
+                            // a 64 x 64 tile of the diagonal block: ordered behind the earlier adders of the 128 x 128 target tile that holds it (look-ahead / macro-column
+                            // tiles) through that tile's counter, which it does NOT raise -- its siblings must not wait for it --; all of them raise one counter of their own
+                            const i32 io = u.j0 / NB_OUT, ko = io * NB_OUT;
+                            const i64 tc = target_counter(c, w, ko + ((u.i0 - ko) & ~(TILE - 1)), ko + ((u.j0 - ko) & ~(TILE - 1)));
+                            if (u.j0 >= w.ns || tc < 0 || u.i0 >= ko + NB_OUT) { bad = true; return; }
+                            if (expect[(size_t)tc] > 0) { it.w2 = G(tc); it.need2 = expect[(size_t)tc]; }
+                            covered[tc] = 1;
+                            it.sig = G(c_dq(c, io)); ++expect[(size_t)c_dq(c, io)];
+                        } else {
+                            const i64 tc = target_counter(c, w, u.i0, u.j0);
+                            if (tc >= 0) {
+                                if (expect[(size_t)tc] > 0) { it.w2 = G(tc); it.need2 = expect[(size_t)tc]; }     // the earlier adder(s) of this tile
+                                it.sig = G(tc); ++expect[(size_t)tc];
+                            }
+                        }
+                        S.chain_items.push_back(it);
+            };
+            const std::unordered_map<i32, i64> no_slots;
+            auto flush_deferred = [&]() { for (const i64 q : deferred) { if (bad) break; update_item(q, no_slots); } deferred.clear(); };
             for (size_t ci = 0; ci < cap.size() && !bad; ++ci) {
                 const Cap &L = cap[ci];
                 if (L.kind == LK_UPDATE) {
@@ -1803,26 +1890,12 @@ static void build_schedule(Symbolic &S) {
                             for (i32 sp = 0; sp < r.kw; ++sp) slot_red[r.k0 + sp] = rc;
                         }
                     }
-                    for (i64 q = L.first; q < L.first + L.count; ++q) {
+                    for (i64 q = L.first; q < L.first + L.count && !bad; ++q) {
                         const UpdateTask &u = S.update_tasks[(size_t)q];
-                        const FrontDesc &w = S.fronts[u.front];
-                        const FC &c = fc.at(u.front);
-                        ChainItem it{CR_UPDATE, (i32)q, 0, 0, 0, 0, 0, 0, 0, -1, 0, -1};
-                        const i32 io_k = (u.k0 + u.kw - 1) / NB_OUT;
-                        operand_wait(c, w, io_k, u.i0, it.w0, it.n0); it.need0 = 1;
-                        if (u.j0 != u.i0) { operand_wait(c, w, io_k, u.j0, it.w1, it.n1); it.need1 = 1; }
-                        if (u.pad1) {
-                            const auto f = slot_red.find(u.pad1 - 1);
-                            if (f == slot_red.end()) { bad = true; break; }
-                            it.sig = G(f->second); ++expect[(size_t)f->second];
-                        } else {
-                            const i64 tc = target_counter(c, w, u.i0, u.j0);
-                            if (tc >= 0) {
-                                if (expect[(size_t)tc] > 0) { it.w2 = G(tc); it.need2 = expect[(size_t)tc]; }     // the earlier adder(s) of this tile
-                                it.sig = G(tc); ++expect[(size_t)tc];
-                            }
-                        }
-                        S.chain_items.push_back(it);
+                        const i32 io_t = (u.j0 < S.fronts[u.front].ns) ? u.j0 / NB_OUT : -1;
+                        const bool next_diag = io_t == io_cur + 1 && u.i0 < (io_t + 1) * NB_OUT;
+                        if (chain_defer && !u.pad1 && io_t > io_cur && io_cur >= 0 && !next_diag) { deferred.push_back(q); continue; }
+                        update_item(q, slot_red);
                     }
                     if (!red_counter.empty()) {
                         const Cap &R = cap[ci + 1];
@@ -1848,13 +1921,19 @@ static void build_schedule(Symbolic &S) {
                 } else if (L.kind == LK_POTRF || L.kind == LK_POTRF_WIDE) {
                     for (i64 q = L.first; q < L.first + L.count; ++q) {
                         const PotrfTask &pt = S.potrf_tasks[(size_t)q];
+                        io_cur = std::max(io_cur, pt.k0 / NB_OUT);
                         const FC &c = fc.at(pt.front);
                         const i32 io = pt.k0 / NB_OUT;
                         ChainItem it{CR_POTRF, (i32)q, 0, 0, 0, 0, 0, 0, 0, -1, 0, G(c_pf(c, io))};
-                        const i64 d0 = c_dg(c, io, 0), d1 = c_dg(c, io, 1), d2 = c_dg(c, io, 2);
-                        if (expect[(size_t)d0] > 0) { it.w0 = G(d0); it.n0 = 1; it.need0 = expect[(size_t)d0]; }
-                        if (expect[(size_t)d1] > 0) { it.w1 = G(d1); it.n1 = 1; it.need1 = expect[(size_t)d1]; }
-                        if (expect[(size_t)d2] > 0) { it.w2 = G(d2); it.need2 = expect[(size_t)d2]; }
+                        // waits: the counter of the block's 64 x 64 tiles (they waited for the adders of their target tiles themselves), and every target tile
+                        // with adders that no 64 x 64 tile stands behind -- at most three counters in all
+                        i64 wl[4]; int nw = 0;
+                        if (expect[(size_t)c_dq(c, io)] > 0) wl[nw++] = c_dq(c, io);
+                        for (int pos = 0; pos < 3; ++pos) { const i64 d = c_dg(c, io, pos); if (expect[(size_t)d] > 0 && !covered.count(d)) wl[nw++] = d; }
+                        if (nw > 3) { bad = true; break; }
+                        if (nw > 0) { it.w0 = G(wl[0]); it.n0 = 1; it.need0 = expect[(size_t)wl[0]]; }
+                        if (nw > 1) { it.w1 = G(wl[1]); it.n1 = 1; it.need1 = expect[(size_t)wl[1]]; }
+                        if (nw > 2) { it.w2 = G(wl[2]); it.need2 = expect[(size_t)wl[2]]; }
                         ++expect[(size_t)c_pf(c, io)];
                         S.chain_items.push_back(it);
                     }
@@ -1873,8 +1952,10 @@ static void build_schedule(Symbolic &S) {
                         ++expect[(size_t)c_ts(c, io, tt.row0 / 64)];
                         S.chain_items.push_back(it);
                     }
+                    flush_deferred();                                    // the macro-column tiles launched with this block column: behind its strips
                 } else bad = true;                                       // (no other kind is ever captured)
             }
+            flush_deferred();
             // the values the diagonal blocks and the strips wait for must be FINAL: nothing after them may add to their tiles
             for (i64 q = first_item; q < (i64)S.chain_items.size() && !bad; ++q) {
                 const ChainItem &it = S.chain_items[(size_t)q];
@@ -1889,10 +1970,10 @@ static void build_schedule(Symbolic &S) {
         };
         {
             // TLPK_CHAIN: 0 = off, 1 = every level that has a front with more than one block column, unset = auto: the levels the look-ahead rule above names
-            // (at most TLPK_CHAIN_MAX_FRONTS = 16 of this rank's fronts have more than one block column, none more than 12 288 pivot columns).  The chain's
+            // (at most TLPK_CHAIN_MAX_FRONTS = 8 of this rank's fronts have more than one block column, none more than 12 288 pivot columns).  The chain's
             // diagonal-block role is the round-5 DPP kernel: the older block kernels (TLPK_POTRF_MODE != 3, diagnostics) keep the launches.
             const int chain_env = [] { const char *e = std::getenv("TLPK_CHAIN"); return e ? std::atoi(e) : -1; }();
-            const i32 chain_max = [] { const char *e = std::getenv("TLPK_CHAIN_MAX_FRONTS"); return e ? std::max(1, std::atoi(e)) : 16; }();
+            const i32 chain_max = [] { const char *e = std::getenv("TLPK_CHAIN_MAX_FRONTS"); return e ? std::max(1, std::atoi(e)) : 8; }();
             const bool potrf_default = [] {
                 const char *m = std::getenv("TLPK_POTRF_MODE");
                 return (!m || (std::atoi(m) & 3) == 3) && !std::getenv("TLPK_POTRF_WAVE") && !std::getenv("TLPK_POTRF_PAIR") && !std::getenv("TLPK_POTRF_DYN");
