@@ -1089,51 +1089,47 @@ int analyse_rank(Symbolic &S, const Options &opt) {
                     if (e1 == S.nnzS) S.pair_ptr[(size_t)S.nnzS] = 0;
                 })) return fail(S, TLPK_OOM, "out of memory while building the assembly lists");
         }
+        pt.mark("assembly lists: traverse");
         auto col_is_mine = [&](i32 j) -> bool {
             if (opt.nranks == 1 || !have_blocks) return true;
             const i32 b = col_block[j];
             return (b < 0) ? (opt.rank == 0) : (block_owner[b] == opt.rank);
         };
-        // pass 1: targets + counts, pass 2: fill.  Fronts are independent (every stored entry of S belongs
-        // to exactly one pivot column of exactly one front): handed out to the host threads, each with
-        // its own scratch maps.
+        // Round 6: ONE traversal of A per pivot column instead of two (count, then fill).  Fronts are independent (every stored entry of S belongs to exactly one
+        // pivot column of exactly one front): handed out to the host threads.  A thread walks the products of a column once -- the order of the old fill pass:
+        // rows of A' in order, entries of the column of A in order --, groups them by entry of S with a stable counting sort inside the column (a few hundred
+        // products: cache-resident) and appends the column to its own stream; the counts go to pair_ptr.  After the prefix sum every column is ONE contiguous
+        // copy from its thread's stream to its final place.  The lists are the lists of the two-pass version, entry by entry (tests/test_symbolic.py: digests).
         const unsigned nthreads = host_threads(ns_total);
-        std::vector<std::vector<i32>> t_pos(nthreads);
-        std::vector<std::vector<i64>> t_epos(nthreads);
-        uvec<i64> cursor;
-        for (int pass = 0; pass < 2; ++pass) {
-            if (pass) {
-                for (i64 e = 0; e < S.nnzS; ++e) S.pair_ptr[e + 1] += S.pair_ptr[e];
-                S.pair_w.resize((size_t)S.pair_ptr[S.nnzS]); S.pair_j.resize((size_t)S.pair_ptr[S.nnzS]);      // (first touched by the threads that fill them)
-                cursor.resize((size_t)S.nnzS);
-                constexpr i64 CH = (i64)1 << 16;
-                const i64 nch = (S.nnzS + CH - 1) / CH;
-                if (!parallel_for(nch, host_threads(nch), [&](unsigned, i64 ch) {
-                        const i64 e0 = ch * CH, e1 = std::min(S.nnzS, e0 + CH);
-                        std::copy(S.pair_ptr.begin() + e0, S.pair_ptr.begin() + e1, cursor.begin() + e0);
-                    })) return fail(S, TLPK_OOM, "out of memory while building the assembly lists");
-            }
+        struct Stream { std::vector<double> w; std::vector<i32> j; std::vector<i32> le, cj, start; std::vector<double> cw; std::vector<i32> pos_in_front; std::vector<i64> epos; };
+        std::vector<Stream> st(nthreads);
+        uvec<i64> col_off((size_t)m);                     // per pivot column: offset of its products in the stream of ...
+        uvec<i32> col_thr((size_t)m);                     // ... this thread (-1: a column of a front this rank does not own)
+        {
             const bool ok = parallel_for(ns_total, nthreads, [&](unsigned tid, i64 s64) {
                 const i32 s = (i32)s64;
-                if (!S.front_local[s]) return;
-                std::vector<i32> &pos_in_front = t_pos[tid];
-                std::vector<i64> &epos = t_epos[tid];
-                if (pos_in_front.empty()) { pos_in_front.assign(m, -1); epos.assign(m, -1); }
                 const FrontDesc &w = S.fronts[s];
+                if (!S.front_local[s]) { for (i32 kk = w.col0; kk < w.col0 + w.ns; ++kk) col_thr[(size_t)kk] = -1; return; }
+                Stream &T = st[tid];
+                if (T.pos_in_front.empty()) { T.pos_in_front.assign(m, -1); T.epos.assign(m, -1); }
+                std::vector<i32> &pos_in_front = T.pos_in_front;
+                std::vector<i64> &epos = T.epos;
                 const bool is_root = (s == S.root_front);
-                if (!pass) for (i32 t = 0; t < w.f; ++t) pos_in_front[S.rowidx[w.rowoff + t]] = t;
+                for (i32 t = 0; t < w.f; ++t) pos_in_front[S.rowidx[w.rowoff + t]] = t;
                 for (i32 kk = w.col0; kk < w.col0 + w.ns; ++kk) {
                     const i32 k = S.perm[kk];
-                    for (i64 e = S.Sp[kk]; e < S.Sp[kk + 1]; ++e) epos[S.Si[e]] = e;
-                    if (!pass) {
-                        for (i64 e = S.Sp[kk]; e < S.Sp[kk + 1]; ++e) {
-                            const i32 ii = S.Si[e];
-                            S.s_target[e] = w.loff + pos_in_front[ii] + pk_off(w.lda, kk - w.col0);
-                            S.s_local[e] = 1;
-                        }
-                        if (opt.system == 1) { if (k >= opt.k2_n && (!is_root || opt.rank == 0)) S.s_diag_row[S.Sp[kk]] = k - (i32)opt.k2_n; }   // constraint node: regD
-                        else if (!is_root || opt.rank == 0) S.s_diag_row[S.Sp[kk]] = k;
+                    const i64 e0 = S.Sp[kk], ne = S.Sp[kk + 1] - e0;
+                    for (i64 e = e0; e < e0 + ne; ++e) {
+                        const i32 ii = S.Si[e];
+                        epos[ii] = e;
+                        S.s_target[e] = w.loff + pos_in_front[ii] + pk_off(w.lda, kk - w.col0);
+                        S.s_local[e] = 1;
                     }
+                    if (opt.system == 1) { if (k >= opt.k2_n && (!is_root || opt.rank == 0)) S.s_diag_row[e0] = k - (i32)opt.k2_n; }   // constraint node: regD
+                    else if (!is_root || opt.rank == 0) S.s_diag_row[e0] = k;
+                    T.le.clear(); T.cw.clear(); T.cj.clear();
+                    T.start.assign((size_t)ne + 1, 0);
+                    auto emit = [&](i64 e, double wv, i32 j) { const i32 le = (i32)(e - e0); T.le.push_back(le); T.cw.push_back(wv); T.cj.push_back(j); ++T.start[(size_t)le + 1]; };
                     if (opt.system == 1) {
                         // Augmented system: the diagonal of a variable node is -(theta + regP) = -1 * D2[k]; an
                         // off-diagonal entry is the constant A[i,j] = A[i,j] * D2[k2_n] with D2[k2_n] = 1 (the columns
@@ -1141,39 +1137,71 @@ int analyse_rank(Symbolic &S, const Options &opt) {
                         // Sharded runs: the assembled entries of the replicated root front (linking constraint nodes and the
                         // variable nodes of columns that touch linking rows only) belong to rank 0; the all-reduce of the root
                         // panel adds the ranks' extend-add contributions to them.
-                        if (is_root && opt.rank != 0) continue;
-                        if (k < opt.k2_n) {
-                            const i64 e = S.Sp[kk];
-                            if (!pass) S.pair_ptr[e + 1]++;
-                            else { const i64 c = cursor[e]++; S.pair_w[c] = -1.0; S.pair_j[c] = k; }
+                        if (!(is_root && opt.rank != 0)) {
+                            if (k < opt.k2_n) emit(e0, -1.0, k);
+                            for (i64 q = S.Tp[k]; q < S.Tp[k + 1]; ++q) {
+                                const i32 j = S.Tj[q];
+                                const double akj = S.Ax[S.Tpos[q]];
+                                for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
+                                    const i32 ii = S.iperm[S.Ai[p]];
+                                    if (ii <= kk) continue;
+                                    emit(epos[ii], akj * S.Ax[p], (i32)opt.k2_n);
+                                }
+                            }
                         }
+                    } else {
                         for (i64 q = S.Tp[k]; q < S.Tp[k + 1]; ++q) {
                             const i32 j = S.Tj[q];
+                            if (is_root && !col_is_mine(j)) continue;
                             const double akj = S.Ax[S.Tpos[q]];
                             for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
                                 const i32 ii = S.iperm[S.Ai[p]];
-                                if (ii <= kk) continue;
-                                const i64 e = epos[ii];
-                                if (!pass) S.pair_ptr[e + 1]++;
-                                else { const i64 c = cursor[e]++; S.pair_w[c] = akj * S.Ax[p]; S.pair_j[c] = (i32)opt.k2_n; }
+                                if (ii < kk) continue;
+                                emit(epos[ii], akj * S.Ax[p], j);
                             }
                         }
-                        continue;
                     }
-                    for (i64 q = S.Tp[k]; q < S.Tp[k + 1]; ++q) {
-                        const i32 j = S.Tj[q];
-                        if (is_root && !col_is_mine(j)) continue;
-                        const double akj = S.Ax[S.Tpos[q]];
-                        for (i64 p = S.Ap[j]; p < S.Ap[j + 1]; ++p) {
-                            const i32 ii = S.iperm[S.Ai[p]];
-                            if (ii < kk) continue;
-                            const i64 e = epos[ii];
-                            if (!pass) S.pair_ptr[e + 1]++;
-                            else { const i64 c = cursor[e]++; S.pair_w[c] = akj * S.Ax[p]; S.pair_j[c] = j; }
-                        }
-                    }
+                    // counts -> pair_ptr (prefix-summed below); stable counting sort of the column's products by entry into the thread's stream
+                    const size_t np = T.le.size(), base = T.w.size();
+                    for (i64 q = 0; q < ne; ++q) { S.pair_ptr[(size_t)(e0 + q) + 1] = T.start[(size_t)q + 1]; T.start[(size_t)q + 1] += T.start[(size_t)q]; }
+                    T.w.resize(base + np); T.j.resize(base + np);
+                    for (size_t q = 0; q < np; ++q) { const size_t at = base + (size_t)T.start[(size_t)T.le[q]]++; T.w[at] = T.cw[q]; T.j[at] = T.cj[q]; }
+                    col_off[(size_t)kk] = (i64)base; col_thr[(size_t)kk] = (i32)tid;
                 }
             }, 64);
+            if (!ok) return fail(S, TLPK_OOM, "out of memory while building the assembly lists");
+        }
+        pt.mark("assembly lists: prefix");
+        {
+            // prefix sum in two levels: per chunk of 65 536 entries on the host threads, the chunk totals serially
+            constexpr i64 CH = (i64)1 << 16;
+            const i64 nch = (S.nnzS + CH - 1) / CH;
+            std::vector<i64> tot((size_t)nch + 1, 0);
+            bool ok = parallel_for(nch, host_threads(nch), [&](unsigned, i64 ch) {
+                const i64 a = ch * CH, b = std::min(S.nnzS, a + CH);
+                i64 acc = 0;
+                for (i64 e = a; e < b; ++e) { acc += S.pair_ptr[(size_t)e + 1]; S.pair_ptr[(size_t)e + 1] = acc; }
+                tot[(size_t)ch + 1] = acc;
+            });
+            for (i64 ch = 0; ch < nch; ++ch) tot[(size_t)ch + 1] += tot[(size_t)ch];
+            ok = ok && parallel_for(nch, host_threads(nch), [&](unsigned, i64 ch) {
+                const i64 a = ch * CH, b = std::min(S.nnzS, a + CH), add = tot[(size_t)ch];
+                if (add) for (i64 e = a; e < b; ++e) S.pair_ptr[(size_t)e + 1] += add;
+            });
+            if (!ok) return fail(S, TLPK_OOM, "out of memory while building the assembly lists");
+            S.pair_ptr[0] = 0;
+        }
+        pt.mark("assembly lists: place");
+        {
+            S.pair_w.resize((size_t)S.pair_ptr[S.nnzS]); S.pair_j.resize((size_t)S.pair_ptr[S.nnzS]);      // (first touched by the threads that fill them)
+            const bool ok = parallel_for(m, host_threads(m / 256 + 1), [&](unsigned, i64 kk) {
+                const i32 th = col_thr[(size_t)kk];
+                if (th < 0) return;
+                const i64 a = S.pair_ptr[(size_t)S.Sp[kk]], cnt = S.pair_ptr[(size_t)S.Sp[kk + 1]] - a;
+                if (cnt <= 0) return;
+                std::memcpy(S.pair_w.data() + a, st[(size_t)th].w.data() + col_off[(size_t)kk], (size_t)cnt * sizeof(double));
+                std::memcpy(S.pair_j.data() + a, st[(size_t)th].j.data() + col_off[(size_t)kk], (size_t)cnt * sizeof(i32));
+            }, 256);
             if (!ok) return fail(S, TLPK_OOM, "out of memory while building the assembly lists");
         }
     }
