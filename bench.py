@@ -307,6 +307,13 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    # one rank per GPU: LOCAL_RANK names the device (TLPK_BENCH_DEVICE overrides it -- the test of the duplicate-device refusal puts two ranks on device 0)
+    ndev = torch.cuda.device_count()
+    if os.environ.get("TLPK_BENCH_DEVICE"):
+        local_rank = int(os.environ["TLPK_BENCH_DEVICE"])
+    if local_rank >= ndev:
+        sys.stderr.write("bench.py: rank %d wants device %d but this process sees %d device(s): launch one rank per visible GPU\n" % (rank, local_rank, ndev))
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -317,6 +324,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+        # create the communicator NOW (RCCL builds it at the first collective) so that a launch it refuses -- two ranks on one device, a missing peer link --
+        # ends here with one clear line and exit code 3 instead of somewhere inside the timed loop
+        try:
+            probe = torch.ones(1, dtype=torch.float64, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("all-reduce of ones over %d ranks returned %r" % (world, probe.item()))
+        except Exception as e:
+            sys.stderr.write("bench.py: rank %d on device %d: RCCL refused the communicator (one rank per GPU is required; two ranks on one device are a duplicate): %s\n"
+                             % (rank, local_rank, str(e).splitlines()[0] if str(e) else repr(e)))
+            sys.stderr.flush()
+            os._exit(3)
         if args.workload == "c3":
             raise SystemExit("general sparse LPs run on one GPU (replicas only, SURVEY.md 8e)")
     P = lambda t: t.data_ptr()   # noqa: E731

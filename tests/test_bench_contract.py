@@ -78,3 +78,25 @@ def test_bench_multi_gpu_branch_with_a_world_of_one():
     assert "collectives" in b and b["n_gpus"] == 1
     assert max(b["config"]["residual_inf"]) <= 1e-6 and max(a["config"]["residual_inf"]) <= 1e-6
     assert b["ms_per_step"] < 3 * a["ms_per_step"] + 5.0                     # no host round trips hidden in the collective path
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_device_are_refused_cleanly():
+    """The first multi-GPU launch must fail loudly, not hang: `torchrun --nproc-per-node 2 bench.py --gpus 2 --blocks 8` with BOTH ranks on device 0 (this box
+    has one GPU; RCCL refuses duplicate devices when the communicator is created).  bench.py builds the communicator right behind init_process_group and turns
+    the refusal into one clear line on stderr and exit code 3 -- within the timeout, no JSON line on stdout."""
+    import socket
+    import subprocess
+    import time
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, TLPK_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", TORCH_NCCL_ASYNC_ERROR_HANDLING="1", NCCL_DEBUG="WARN")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--blocks", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    t0 = time.time()
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    took = time.time() - t0
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode != 0, "two ranks on one device must not produce a bench line"
+    assert "RCCL refused the communicator" in err or "Duplicate GPU" in err or "duplicate" in err.lower(), err[-3000:]
+    assert not any(line.startswith("{") for line in p.stdout.decode(errors="replace").splitlines()), "no JSON line from a refused launch"
+    assert took < 240
