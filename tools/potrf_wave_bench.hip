@@ -67,5 +67,10 @@ int main(int argc, char **argv) {
     printf("dpp stamps of workgroup 0 (10 ns units, differences):");
     for (int i = 1; i < 32 && st[i]; ++i) printf(" %llu", st[i] - st[i - 1]);
     printf("\n");
+    if (st.size() >= 24 && st[16] && st[23]) {            // k_potrf_wide, mode 3: potrf | solve | potrf | solve | potrf | solve | potrf (phase boundaries of the block column)
+        printf("block-column phases of workgroup 0 behind its first block (10 ns units: barrier, solve 0, block 1, solve 1, block 2, solve 2, block 3):");
+        for (int i = 17; i < 24; ++i) printf(" %llu", st[i] - st[i - 1]);
+        printf("\n");
+    }
     return 0;
 }

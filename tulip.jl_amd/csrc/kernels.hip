@@ -912,6 +912,13 @@ __device__ __forceinline__ void potrf_block_wave(const DevCtx &c, const FrontDes
 constexpr int PD_LD = NB_IN + 18;                  // leading dimension of Mt in potrf_block_dpp
 constexpr int PD_LP = PW_W * PW_W;                 // L_pp, column-major, for the forward substitution and the stores
 constexpr int POTRF_DPP_LDS = NB_IN * PD_LD + 4 * PW_W * PW_LDT + 4 * PW_W * PW_LDT + 2 * PD_LP + NB_IN;  // doubles: Mt | Wd[4] | Ts[4] | Lp[2] | Sg
+constexpr int TRM_LDT = NB_IN + 2;                 // trsm_rows_mt: leading dimension of the shared block of L behind Mt (== 2 mod 32: conflict-free b64 operand reads)
+constexpr int POTRF_WIDE_DPP_LDS = NB_IN * PD_LD + NB_IN * TRM_LDT;                 // doubles: Mt | Wt (>= POTRF_DPP_LDS)
+static_assert(POTRF_WIDE_DPP_LDS >= POTRF_DPP_LDS, "k_potrf_wide: the in-block solve's block of L lies behind the diagonal block's image");
+#ifndef TLPK_TRM_MT
+#define TLPK_TRM_MT 1
+#endif
+constexpr bool TRM_MT = TLPK_TRM_MT != 0;         // 0 (build-time, diagnostics): the round-5 in-block solves (trsm_rows: blocks staged one global round trip at a time)
 
 template <int J>
 __device__ __forceinline__ double bc16(const double x) {         // lane J of the caller's row of 16 lanes
@@ -1112,40 +1119,62 @@ __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc
     double pv[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) pv[q] = P[(i64)min(r, nb - 1) + (i64)min(wave + 4 * q, nb - 1) * lda];
-    if (SIGNED && tid < NB_IN) Sg[tid] = (tid < nb) ? sg[bk0 + tid] : 1.0;
-    // left-looking over the already factored 64-wide steps of this block column (all four waves; as in potrf_block)
+    // left-looking over the already factored 64-wide steps of this block column.  Round 6: the rows of this block in a solved step -- a 64 x 64 block of L, both
+    // operands of D -= X S X' -- travel global -> registers -> LDS ONCE (16 loads per thread and step, all steps' loads issued together with the block's own
+    // entries) instead of 20 operand loads per wave and 16 columns straight from the panel (a round trip per 16 columns: 12.5 us in front of the fourth block of
+    // a block column, for 5 us of matrix-core time); and the ten 16 x 16 blocks on and below the diagonal are dealt 3 + 3 + 2 + 2 to the waves (by rows a wave
+    // formed four blocks, of which wave 0 needed one).  Every entry sums its columns in ascending order, four per v_mfma_f64_16x16x4_f64: same bits as before.
+    // The shared block lies BEHIND the image (Xs[r * TRM_LDT + k], the layout of trsm_rows_mt's Wt), Ds in the image's place as before.
     const i32 Kp = bk0 - kprev;
     if (Kp > 0) {
-        v4f64 dacc[4];
+        double *Xs = scratch + NB_IN * PD_LD;
+        const int nprev = Kp / NB_IN;                            // 1 .. 3 (workgroup-uniform)
+        double st[3][16];
+        const i32 rsrc = bk0 + min(lane, nb - 1);                // row of the block this thread carries (clamped: the rows >= nb feed entries nobody reads)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) dacc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
-        const i32 rrow = 16 * wave + lr;
-        const i32 rr_c = min(rrow, nb - 1);
-        i32 cr_c[4];
+        for (int j = 0; j < 3; ++j)
+            if (j < nprev) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) cr_c[a] = min(16 * a + lr, nb - 1);
-        for (i32 ks = 0; ks < Kp; ks += 16) {
-            double bq[4], aq[4][4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double *Xc = pcol(c, fd, kprev + ks + 4 * u + lk) + bk0;
-                bq[u] = Xc[rr_c];
-                if (SIGNED) bq[u] *= sg[kprev + ks + 4 * u + lk];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) aq[u][a] = Xc[cr_c[a]];
+                for (int i = 0; i < 16; ++i) st[j][i] = pcol(c, fd, kprev + j * NB_IN + wave + 4 * i)[rsrc];
             }
+        // blocks (bi, bj) of this wave: wave 0: (0,0) (3,0) (3,1) | 1: (1,0) (1,1) (3,2) | 2: (2,0) (2,1) | 3: (2,2) (3,3)
+        const int nblk = wave < 2 ? 3 : 2;
+        int bi[3], bj[3];
+        bi[0] = wave == 3 ? 2 : wave; bj[0] = wave == 3 ? 2 : 0;
+        bi[1] = wave < 2 ? (wave == 0 ? 3 : 1) : (wave == 2 ? 2 : 3); bj[1] = wave == 0 ? 0 : (wave == 3 ? 3 : 1);
+        bi[2] = 3; bj[2] = wave == 0 ? 1 : 2;
+        v4f64 dacc[3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+        for (int t = 0; t < 3; ++t) dacc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    dacc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[u][a], bq[u], dacc[a], 0, 0, 0);
-        }
+        for (int j = 0; j < 3; ++j)
+            if (j < nprev) {
+                if (j > 0) __syncthreads();
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+                for (int i = 0; i < 16; ++i) Xs[lane * TRM_LDT + wave + 4 * i] = st[j][i];
+                __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Ds[(16 * a + lk + 4 * q) * PD_LD + rrow] = dacc[a][q];
-        __syncthreads();
+                for (int t = 0; t < 3; ++t)
+                    if (t < nblk) {
+                        const double *Xb = Xs + (16 * bi[t] + lr) * TRM_LDT + lk, *Xa = Xs + (16 * bj[t] + lr) * TRM_LDT + lk;
+#pragma unroll
+                        for (int ks = 0; ks < 16; ++ks) {
+                            double bq = Xb[4 * ks];
+                            if (SIGNED) bq *= sg[kprev + j * NB_IN + 4 * ks + lk];
+                            dacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[4 * ks], bq, dacc[t], 0, 0, 0);
+                        }
+                    }
+            }
+        __syncthreads();                                         // the last block is read: Ds (the image's place) is next, then Sg (inside Xs)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < nblk) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Ds[(16 * bj[t] + lk + 4 * q) * PD_LD + 16 * bi[t] + lr] = dacc[t][q];
+            }
     }
+    if (SIGNED && tid < NB_IN) Sg[tid] = (tid < nb) ? sg[bk0 + tid] : 1.0;
+    if (Kp > 0) __syncthreads();
     // As = block - Ds in place of Ds: the blocks below the diagonal blocks + FULL (symmetric) diagonal 16 x 16 blocks; rows / columns beyond nb: identity
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -1495,6 +1524,99 @@ __device__ __forceinline__ void trsm_rows(const DevCtx &c, const FrontDesc &fd, 
         }
 }
 
+// Round 6: trsm_rows behind potrf_block_dpp, step SI (0, 1, 2) of a block column -- the rows [row0, rowlim) below the 64 x 64 block that potrf_block_dpp has
+// just factored (all 64 columns: the caller only comes here when another step follows), SI solved steps in front of it, at most 3 - SI row blocks.
+// The arithmetic is trsm_rows's, entry by entry and in the same order (same sums, same bits); what changes is where the operands come from and when:
+//   * EVERY global load of the call is issued before the first product: the rows' own entries, their solved steps (xf), and the 64 x 64 blocks of L the
+//     left-looking products share (16 entries per thread and block, kept in registers until their turn in LDS) -- one round trip per call instead of one
+//     per staged block and one per operand (five for step 2; the block column's in-block solves were 43 of its 115 us for 13 us of matrix-core time);
+//   * the inverted diagonal block is read where potrf_block_dpp left it: Mt[r * PD_LD + c] = W[r][c] for every 16 x 16 block on or below the diagonal
+//     (the blocks above it are never multiplied).  Lane stride PD_LD = 82 doubles == 18 mod 32: the 16 x 2 lanes of a half wave hit 32 different bank pairs.
+//   * the shared blocks of L go through Wt, BEHIND Mt (Wt[cc * TRM_LDT + k] = L[k0 + cc][kprev + 64 j + k]: the transposed layout, read like Mt).
+template <bool SIGNED, int SI>
+__device__ __forceinline__ void trsm_rows_mt(const DevCtx &c, const FrontDesc &fd, const i32 k0, const i32 row0, const i32 rowlim, const i32 kprev,
+                                             const double *Mt, double *Wt) {
+    constexpr int NBR = 3 - SI, NPREV = SI;
+    const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
+    double *P0 = pcol(c, fd, k0);
+    const i32 ld0 = pld(fd, k0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const i32 rbase = row0 + wave * 16;
+    const int nact = (rbase < rowlim) ? min(NBR, (rowlim - rbase + NB_IN - 1) / NB_IN) : 0;      // (wave-uniform) 16-row groups of this wave
+    double bf[NBR][16], xf[NPREV > 0 ? NPREV : 1][NBR][16], st[NPREV > 0 ? NPREV : 1][16];
+    i32 rowc[NBR];
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) rowc[b] = min(rbase + b * NB_IN + lr, rowlim - 1);              // clamped, not guarded (trsm_rows)
+#pragma unroll
+    for (int b = 0; b < NBR; ++b)
+        if (b < nact) {
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) bf[b][ks] = P0[(i64)rowc[b] + (i64)(4 * ks + lk) * ld0];
+        }
+#pragma unroll
+    for (int j = 0; j < NPREV; ++j) {
+        const double *Pc = pcol(c, fd, kprev + j * NB_IN);
+        const i32 ldc = pld(fd, kprev + j * NB_IN);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[j][i] = Pc[(i64)(k0 + lane) + (i64)(wave + 4 * i) * ldc];         // L[k0 + cc][.. + k], cc = lane, k = wave + 4 i
+#pragma unroll
+        for (int b = 0; b < NBR; ++b)
+            if (b < nact) {
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    xf[j][b][ks] = Pc[(i64)rowc[b] + (i64)(4 * ks + lk) * ldc] * (SIGNED ? sg[kprev + j * NB_IN + 4 * ks + lk] : 1.0);
+            }
+    }
+    v4f64 acc[4];
+#pragma unroll
+    for (int j = 0; j < NPREV; ++j) {
+        if (j > 0) __syncthreads();                              // the products of block j - 1 are done with Wt
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Wt[lane * TRM_LDT + wave + 4 * i] = st[j][i];
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NBR; ++b)
+            if (b < nact) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[(a * 16 + lr) * TRM_LDT + 4 * ks + lk], xf[j][b][ks], acc[a], 0, 0, 0);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bf[b][4 * a + q] -= acc[a][q];
+            }
+    }
+#pragma unroll
+    for (int b = 0; b < NBR; ++b)
+        if (b < nact) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (4 * ks > 16 * a + 15) continue;       // Linv[c][k] = 0 for k > c: whole block is zero
+                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[(a * 16 + lr) * PD_LD + 4 * ks + lk], bf[b][ks], acc[a], 0, 0, 0);
+                }
+            }
+            const i32 row = rbase + b * NB_IN + lr;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const i32 cc = a * 16 + lk + 4 * q;
+                    if (row < rowlim) P0[(i64)row + (i64)cc * ld0] = SIGNED ? acc[a][q] * sg[k0 + cc] : acc[a][q];
+                }
+        }
+}
+
 // Diagonal block of one block column (t.nb <= NB_OUT columns from t.k0; the columns before k0 have
 // already been applied by the left-looking k_update): 64-wide steps, each a potrf of the step's
 // diagonal block followed by the trsm of the rows below it INSIDE the block -- one workgroup runs
@@ -1525,6 +1647,43 @@ __device__ __forceinline__ void potrf_wide_task(const PotrfTask t, const FrontDe
     // group's stream waits for at the join): C4 51.0 -> 50.8 ms, pds-class 15.79 -> 15.68 ms (profiles/r05_chain_overlap.txt)
     if (MODE == 3) __builtin_amdgcn_s_setprio(3);
     potrf_block_any<SIGNED, MODE>(c, fd, k0, min(w, NB_IN), k0, Ws);
+    if constexpr (MODE == 3 && TRM_MT) {                         // round 6: the in-block solves read W from potrf_block_dpp's LDS image, one round of global loads per step
+        double *Wt = Ws + NB_IN * PD_LD;
+#ifdef POTRF_TRACE   /* tools/potrf_wave_bench.hip: phase boundaries of the block column in words 16.. of the workgroup's row */
+        unsigned long long *ptw_ = (unsigned long long *)c.spart + (size_t)blockIdx.x * 32 + 16;
+#define PTW_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0) ptw_[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PTW_STAMP(i) do {} while (0)
+#endif
+        PTW_STAMP(0);
+        if (k0 + NB_IN < kend) {
+            __syncthreads();                                     // own global stores visible, the image complete, the LDS behind it free
+            PTW_STAMP(1);
+            trsm_rows_mt<SIGNED, 0>(c, fd, k0, k0 + NB_IN, kend, k0, Ws, Wt);
+            __syncthreads();
+            PTW_STAMP(2);
+            potrf_block_dpp<SIGNED>(c, fd, k0 + NB_IN, min(NB_IN, kend - (k0 + NB_IN)), k0, Ws);
+        }
+        if (k0 + 2 * NB_IN < kend) {
+            __syncthreads();
+            PTW_STAMP(3);
+            trsm_rows_mt<SIGNED, 1>(c, fd, k0 + NB_IN, k0 + 2 * NB_IN, kend, k0, Ws, Wt);
+            __syncthreads();
+            PTW_STAMP(4);
+            potrf_block_dpp<SIGNED>(c, fd, k0 + 2 * NB_IN, min(NB_IN, kend - (k0 + 2 * NB_IN)), k0, Ws);
+        }
+        if (k0 + 3 * NB_IN < kend) {
+            __syncthreads();
+            PTW_STAMP(5);
+            trsm_rows_mt<SIGNED, 2>(c, fd, k0 + 2 * NB_IN, k0 + 3 * NB_IN, kend, k0, Ws, Wt);
+            __syncthreads();
+            PTW_STAMP(6);
+            potrf_block_dpp<SIGNED>(c, fd, k0 + 3 * NB_IN, min(NB_IN, kend - (k0 + 3 * NB_IN)), k0, Ws);
+        }
+        PTW_STAMP(7);
+#undef PTW_STAMP
+        return;
+    }
     for (i32 ks = k0; ks + NB_IN < kend; ks += NB_IN) {          // step ks is factored: rows below, next diagonal block
         if constexpr (MODE == 3) {
             __syncthreads();                                     // own global stores visible, Ws free
@@ -1541,7 +1700,7 @@ __device__ __forceinline__ void potrf_wide_task(const PotrfTask t, const FrontDe
 }
 template <bool SIGNED, int MODE>
 __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restrict__ tasks, DevCtx c) {
-    __shared__ __attribute__((aligned(16))) double Ws[MODE == 3 ? POTRF_DPP_LDS : (MODE == 1 ? POTRF_WAVE_LDS : NB_IN * LDW)];
+    __shared__ __attribute__((aligned(16))) double Ws[MODE == 3 ? POTRF_WIDE_DPP_LDS : (MODE == 1 ? POTRF_WAVE_LDS : NB_IN * LDW)];
     const PotrfTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     potrf_wide_task<SIGNED, MODE>(t, fd, c, Ws);
@@ -2237,7 +2396,7 @@ struct ChainArgs {
     unsigned long long *trace;                       // TLPK_CHAIN_TRACE=1 (diagnostics): per item 4 words -- drawn, released by its counters, work done, published (100 MHz clock)
 };
 constexpr int CHAIN_LDS = 2 * NB_IN * LDW;           // doubles (81 920 bytes): the strips' two staging blocks >= the four K slabs of an update tile, >= the diagonal block's scratch
-static_assert(CHAIN_LDS >= 4 * UPD_KT * UPD_LD && CHAIN_LDS >= POTRF_DPP_LDS, "k_chain: one LDS block serves every role");
+static_assert(CHAIN_LDS >= 4 * UPD_KT * UPD_LD && CHAIN_LDS >= POTRF_WIDE_DPP_LDS, "k_chain: one LDS block serves every role");
 
 // wave 0 of the workgroup: wait for the item's counters; returns false if somebody (maybe this wave) gave up
 __device__ __forceinline__ bool chain_wait(const ChainItem &it, const unsigned *cnt, int *info, const int lane) {
