@@ -338,8 +338,8 @@ class Emulator:
 
     def _k3(self, T):      # update
         for front, k0, kw, i0, j0, jlim, beta0, slot1, seg, nsl, t64 in T:
-            TILE = 64 if t64 else 128
-            assert not (t64 and slot1), "64 x 64 tiles are never split-K parts"
+            TILE = {0: 128, 1: 64, 2: 32}[int(t64)]      # UpdateTask.pad2: 1 = a 64 x 64 tile, 2 = a 32 x 32 tile of a diagonal block's short update
+            assert not (t64 and slot1), "the small tiles are never split-K parts"
             P = self.panel(front)
             f, ns = int(self.f[front]), int(self.ns[front])
             i1, j1 = min(i0 + TILE, f), min(j0 + TILE, jlim)
@@ -351,7 +351,7 @@ class Emulator:
                 kcols = [np.arange(self.upd_seg[seg + 2 * q], self.upd_seg[seg + 2 * q] + 16 * self.upd_seg[seg + 2 * q + 1]) for q in range(nseg)]
                 kcols.append(np.arange(k0 + (kw // 16) * 16, k0 + kw))
                 kcols = np.concatenate(kcols)
-                assert kcols.size == 16 * nsl + kw % 16 and nsl >= 2 and kcols.min() >= k0 and kcols.max() < k0 + kw and np.all(np.diff(kcols) > 0)
+                assert kcols.size == 16 * nsl + kw % 16 and (nsl >= 2 or t64) and kcols.min() >= k0 and kcols.max() < k0 + kw and np.all(np.diff(kcols) > 0)
             else:
                 kcols = np.arange(k0, k0 + kw)
             Pj = P[j0:j1][:, kcols]

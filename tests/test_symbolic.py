@@ -92,6 +92,9 @@ def test_macro_columns_on_a_single_dense_front(monkeypatch):
     # the tile target is scaled down with the problem (tuning knob of the analyse phase) so that this
     # 1400-row instance gets macro columns of 3 block columns, as a 50 000-row one does by default
     monkeypatch.setenv("TLPK_MACRO_TILES", "50")
+    # (round 6: a front of at most 12 288 columns is a look-ahead level, which no longer groups block columns -- see the next test; the macro columns serve the
+    # wider fronts, the C3 shape's 48 000 columns: this scaled-down instance gets their rule with the look-ahead off)
+    monkeypatch.setenv("TLPK_LOOKAHEAD", "0")
     A = general_sparse_lp(1400)
     kkt = analyse_only(A)
     assert kkt.symbolic("front_ns").max() > 1200
@@ -106,6 +109,29 @@ def test_macro_columns_on_a_single_dense_front(monkeypatch):
     # (round 6: the single front of this LP runs as one dependency-driven launch -- kind 22 -- whose items include the reductions, role 3)
     kinds = kkt.symbolic("factor_launches").reshape(-1, 3)[:, 0].tolist()
     assert kinds.count(13) > 0 or (22 in kinds and (kkt.symbolic("chain_items").reshape(-1, 12)[:, 0] == 3).any())
+    check_against_oracle(A, kkt, 3, tol=1e-8)
+
+
+def test_lookahead_level_cuts_every_long_update_by_k_length(monkeypatch):
+    """Round 6: on a look-ahead level (here: one dense front of ~1 400 columns) no update item may hold a workgroup for longer than a link of the chain of
+    diagonal blocks: no macro columns, the long part K = [0, ko - 256) of a block column comes one block column early, and every tile with more than
+    TLPK_KSPLIT_LEN columns of K is cut into parts of at most that length whose sums a reduction applies in order.  Same factor as the oracle's."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from workloads import general_sparse_lp
+    monkeypatch.setenv("TLPK_KSPLIT_LEN", "512")
+    A = general_sparse_lp(1400)
+    kkt = analyse_only(A)
+    ns = kkt.symbolic("front_ns")
+    assert ns.max() > 1200
+    ut = kkt.symbolic("update_tasks").reshape(-1, 10)
+    big = ut[ns[ut[:, 0]] > 1200]
+    assert len(big) > 0 and big[:, 2].max() <= 512, "an update item of the look-ahead level spans more than TLPK_KSPLIT_LEN columns"
+    assert (big[:, 7] > 0).any(), "no split-K parts"
+    panel = big[big[:, 6] == 0]
+    assert not ((panel[:, 1] == 0) & (panel[:, 5] - panel[:, 4] > 256)).any(), "a macro-column update on a look-ahead level"
+    red = kkt.symbolic("reduce_tasks").reshape(-1, 8)
+    assert len(red) > 0 and red[:, 2].max() >= 2
     check_against_oracle(A, kkt, 3, tol=1e-8)
 
 

@@ -1156,13 +1156,17 @@ __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
                     if (t < nblk) {
+                        // (both operands of the block's 16 products to registers first: the reads of the next block are in flight behind this block's products)
                         const double *Xb = Xs + (16 * bi[t] + lr) * TRM_LDT + lk, *Xa = Xs + (16 * bj[t] + lr) * TRM_LDT + lk;
+                        double xa[16], xb[16];
 #pragma unroll
                         for (int ks = 0; ks < 16; ++ks) {
-                            double bq = Xb[4 * ks];
-                            if (SIGNED) bq *= sg[kprev + j * NB_IN + 4 * ks + lk];
-                            dacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[4 * ks], bq, dacc[t], 0, 0, 0);
+                            xa[ks] = Xa[4 * ks];
+                            xb[ks] = Xb[4 * ks];
+                            if (SIGNED) xb[ks] *= sg[kprev + j * NB_IN + 4 * ks + lk];
                         }
+#pragma unroll
+                        for (int ks = 0; ks < 16; ++ks) dacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], xb[ks], dacc[t], 0, 0, 0);
                     }
             }
         __syncthreads();                                         // the last block is read: Ds (the image's place) is next, then Sg (inside Xs)
@@ -1569,52 +1573,68 @@ __device__ __forceinline__ void trsm_rows_mt(const DevCtx &c, const FrontDesc &f
                     xf[j][b][ks] = Pc[(i64)rowc[b] + (i64)(4 * ks + lk) * ldc] * (SIGNED ? sg[kprev + j * NB_IN + 4 * ks + lk] : 1.0);
             }
     }
-    v4f64 acc[4];
+    // one LDS read of a shared operand serves every row block of the wave (ks, a outside, b inside: an entry still sums its columns in ascending order)
+    v4f64 acc[NBR][4];
 #pragma unroll
     for (int j = 0; j < NPREV; ++j) {
         if (j > 0) __syncthreads();                              // the products of block j - 1 are done with Wt
 #pragma unroll
         for (int i = 0; i < 16; ++i) Wt[lane * TRM_LDT + wave + 4 * i] = st[j][i];
         __syncthreads();
+        if (nact > 0) {
 #pragma unroll
-        for (int b = 0; b < NBR; ++b)
-            if (b < nact) {
+            for (int b = 0; b < NBR; ++b)
 #pragma unroll
-                for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[(a * 16 + lr) * TRM_LDT + 4 * ks + lk], xf[j][b][ks], acc[a], 0, 0, 0);
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) bf[b][4 * a + q] -= acc[a][q];
-            }
-    }
-#pragma unroll
-    for (int b = 0; b < NBR; ++b)
-        if (b < nact) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+                for (int a = 0; a < 4; ++a) acc[b][a] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    if (4 * ks > 16 * a + 15) continue;       // Linv[c][k] = 0 for k > c: whole block is zero
-                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[(a * 16 + lr) * PD_LD + 4 * ks + lk], bf[b][ks], acc[a], 0, 0, 0);
+                    const double wv = Wt[(a * 16 + lr) * TRM_LDT + 4 * ks + lk];
+#pragma unroll
+                    for (int b = 0; b < NBR; ++b)
+                        if (b < nact) acc[b][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, xf[j][b][ks], acc[b][a], 0, 0, 0);
                 }
             }
-            const i32 row = rbase + b * NB_IN + lr;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < NBR; ++b)
+                if (b < nact) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const i32 cc = a * 16 + lk + 4 * q;
-                    if (row < rowlim) P0[(i64)row + (i64)cc * ld0] = SIGNED ? acc[a][q] * sg[k0 + cc] : acc[a][q];
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bf[b][4 * a + q] -= acc[b][a][q];
                 }
         }
+    }
+    if (nact > 0) {
+#pragma unroll
+        for (int b = 0; b < NBR; ++b)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[b][a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (4 * ks > 16 * a + 15) continue;           // Linv[c][k] = 0 for k > c: whole block is zero
+                const double wv = Mt[(a * 16 + lr) * PD_LD + 4 * ks + lk];
+#pragma unroll
+                for (int b = 0; b < NBR; ++b)
+                    if (b < nact) acc[b][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, bf[b][ks], acc[b][a], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NBR; ++b)
+            if (b < nact) {
+                const i32 row = rbase + b * NB_IN + lr;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const i32 cc = a * 16 + lk + 4 * q;
+                        if (row < rowlim) P0[(i64)row + (i64)cc * ld0] = SIGNED ? acc[b][a][q] * sg[k0 + cc] : acc[b][a][q];
+                    }
+            }
+    }
 }
 
 // Diagonal block of one block column (t.nb <= NB_OUT columns from t.k0; the columns before k0 have
@@ -2304,6 +2324,79 @@ __device__ __forceinline__ void update_tile64(const UpdateTask t, const FrontDes
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// A 32 x 32 update tile per workgroup, one 16 x 16 block per WAVE (round 6, UpdateTask.pad2 = 2): the diagonal-block tiles of the dependency-driven launches.
+// The K = 256 update of the next diagonal block is a link of the chain (strips -> update -> diagonal block): as 64 x 64 tiles it cost ~28 us, of which 7 were
+// matrix-core time -- sixteen slabs, each a global load, an LDS round and a barrier.  Here a wave reads its operands straight from the panel (lane (lr, lk):
+// rows ib + lr and jb + lr, column 4 u + lk of a slab: 16 consecutive rows = one 128-byte line per column), eight slabs -- 64 loads -- in flight at a time,
+// no LDS, no barrier; the blocks above the diagonal are not formed.  36 tiles per diagonal block instead of ten.
+// Every entry sums its K columns in the order of the 128 x 128 tile -- slab by slab, four columns per v_mfma_f64_16x16x4_f64 -- the same bits.
+// ------------------------------------------------------------------------------------------
+template <bool SIGNED>
+__device__ __forceinline__ void update_tile32(const UpdateTask t, const FrontDesc &fd, const DevCtx &c) {
+    constexpr int CH = 8;                                                                         // slabs in flight
+    const i32 f = fd.f, ns = fd.ns, rs = f - ns, lda = fd.lda;
+    const double *P = c.Lval + fd.loff;
+    const double *sgf = SIGNED ? c.csign + fd.col0 : nullptr;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4;
+    const i32 ib = t.i0 + wr * 16, jb = t.j0 + wc * 16;
+    if (ib + 15 < jb || ib >= f || jb >= t.jlim) return;                                          // (wave-uniform) above the diagonal / outside: nothing to form
+    const i64 ra = min(ib + lr, f - 1), rb = min(jb + lr, f - 1);                                 // clamped, the epilogue masks
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    const i32 *segp = t.seg ? c.upd_seg + (t.seg - 1) : nullptr;
+    const i32 nseg = segp ? segp[0] : 1;
+    const i32 nfull = t.kw / UPD_KT, ktail = t.kw % UPD_KT;
+    i32 seg_i = 0, k_slab = segp ? segp[1] : t.k0, k_rem = segp ? segp[2] : nfull;
+    const i32 nfull_rounds = segp ? t.nsl : nfull;
+    const i32 nrounds = nfull_rounds + (ktail ? 1 : 0);
+    for (i32 rd0 = 0; rd0 < nrounds; rd0 += CH) {
+        double pa[CH][4], pb[CH][4];
+#pragma unroll
+        for (int sl = 0; sl < CH; ++sl)
+            if (rd0 + sl < nrounds) {
+                const bool tail = rd0 + sl >= nfull_rounds;
+                const i32 kbase = tail ? t.k0 + nfull * UPD_KT : k_slab;
+                const i32 klim = tail ? ktail : UPD_KT;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const i32 kk = 4 * u + lk, col = kbase + min(kk, klim - 1);
+                    const double *Pk = P + pk_off(lda, col);
+                    const double va = Pk[ra], vb = Pk[rb];
+                    pa[sl][u] = (kk < klim) ? va : 0.0;
+                    pb[sl][u] = (kk < klim) ? (SIGNED ? vb * sgf[col] : vb) : 0.0;
+                }
+                if (!tail) {
+                    k_slab += UPD_KT;
+                    if (--k_rem == 0 && ++seg_i < nseg) { k_slab = segp[1 + 2 * seg_i]; k_rem = segp[2 + 2 * seg_i]; }
+                }
+            }
+#pragma unroll
+        for (int sl = 0; sl < CH; ++sl)
+            if (rd0 + sl < nrounds) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[sl][u], pa[sl][u], acc, 0, 0, 0);
+            }
+    }
+    // epilogue: as update_tile64 (fire-and-forget L2 adds; one adder per entry at a time: the schedule orders the adders of a target)
+    double *Pw = c.Lval + fd.loff;
+    double *Uw = front_u(c, fd);
+    const i32 row = ib + lr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const i32 col = jb + lk + 4 * q;
+        if (row < f && col < t.jlim && row >= col) {
+            if (col < ns) unsafeAtomicAdd(Pw + (i64)row + pk_off(lda, col), -acc[q]);
+            else {
+                double *dst = Uw + (i64)(row - ns) + (i64)(col - ns) * rs;
+                if (t.beta0) *dst = -acc[q];
+                else unsafeAtomicAdd(dst, -acc[q]);
+            }
+        }
+    }
+}
+
 template <bool SIGNED, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_update(const UpdateTask *__restrict__ tasks, DevCtx c) {
     // double-buffered K-slabs: slab t+1 travels global -> registers while slab t is multiplied
@@ -2454,7 +2547,8 @@ __device__ __noinline__ void chain_role_update(const UpdateTask *tp_, const DevC
     const UpdateTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); double *lds = uni_lds(lds_);
     const UpdateTask t{tp->front, tp->k0, tp->kw, tp->i0, tp->j0, tp->jlim, tp->beta0, tp->pad1, tp->seg, tp->nsl, tp->pad2, 0};
     const FrontDesc fd = c.fronts[t.front];
-    if (t.pad2) { update_tile64<SIGNED>(t, fd, c, lds); return; }          // (workgroup-uniform) a 64 x 64 tile of the next diagonal block
+    if (t.pad2 == 2) { update_tile32<SIGNED>(t, fd, c); return; }         // (workgroup-uniform) a 32 x 32 tile of the next diagonal block: one 16 x 16 block per wave
+    if (t.pad2) { update_tile64<SIGNED>(t, fd, c, lds); return; }          // a 64 x 64 tile (TLPK_CHAIN_TILE64=1)
     double (*As)[UPD_KT * UPD_LD] = reinterpret_cast<double (*)[UPD_KT * UPD_LD]>(lds);
     const bool full = (t.i0 + TILE <= fd.f) && (t.j0 + TILE <= t.jlim) && (t.i0 >= t.j0 + TILE);
     if (full) update_tile<true, SIGNED, 4>(t, fd, c, As, As + 2);

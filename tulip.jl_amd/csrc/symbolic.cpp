@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <map>
+#include <climits>
 
 namespace tlpk {
 
@@ -1451,7 +1453,8 @@ static void build_schedule(Symbolic &S) {
         // The decisions that look at the whole level (split-K, macro columns, look-ahead) see all of the rank's fronts in every pass: a tile is the same
         // tile whichever way it is launched.
         int pass = 0;
-        const bool chain_tile64 = [] { const char *e = std::getenv("TLPK_CHAIN_TILE64"); return !e || std::atoi(e) != 0; }();
+        // TLPK_CHAIN_TILE64 (diagnostics): 0 = the diagonal block's short update as 128 x 128 tiles, 1 = 64 x 64 tiles (update_tile64), unset / 2 = 32 x 32 tiles (update_tile32)
+        const i32 chain_tile = [] { const char *e = std::getenv("TLPK_CHAIN_TILE64"); const int v = e ? std::atoi(e) : 2; return v == 0 ? TILE : (v == 1 ? 64 : 32); }();
         std::vector<char> chain_front(S.fronts.size(), 0);       // (only the entries of this level's fronts are ever set)
         struct Cap { i32 kind; i64 first, count; };
         std::vector<Cap> cap;
@@ -1468,13 +1471,14 @@ static void build_schedule(Symbolic &S) {
             for (i32 col = j0; col < std::min(j0 + ts, c1); ++col) e += std::max(0, r1 - std::max(i0, col));
             return e;
         };
-        // ts = 64 (chain launches only, part 0, K <= 256): the diagonal block's tiles as 64 x 64 tiles (UpdateTask.pad2 = 1, kernels.hip: update_tile64) -- the
-        // short update that is left on the chain behind a solved block column runs on ten CUs instead of three.  Same sums in the same order per entry.
+        // ts = 64 / 32 (chain launches only, part 0, K <= 256): the diagonal block's tiles as 64 x 64 tiles (UpdateTask.pad2 = 1, kernels.hip: update_tile64) or
+        // 32 x 32 tiles (pad2 = 2, update_tile32: one 16 x 16 block per wave, operands straight from the panel) -- the short update that is left on the chain
+        // behind a solved block column runs on ten / 36 CUs instead of three.  Same sums in the same order per entry.
         auto push_update_region = [&](i32 s, const FrontDesc &w, i32 k0, i32 kw, i32 c0, i32 c1, i32 beta0, int part, i32 ts = TILE) {
             if (kw <= 0 || c0 >= c1) return;
-            if (ts == 64) {
-                for (i32 j0 = c0; j0 < c1; j0 += 64)
-                    for (i32 i0 = j0; i0 < std::min(c0 + NB_OUT, w.f); i0 += 64) {
+            if (ts < TILE) {
+                for (i32 j0 = c0; j0 < c1; j0 += ts)
+                    for (i32 i0 = j0; i0 < std::min(c0 + NB_OUT, w.f); i0 += ts) {
                         i32 seg = 0, nsl = 0;
                         double kexec = kw;
                         const i32 nfull = kw / 16;
@@ -1483,7 +1487,7 @@ static void build_schedule(Symbolic &S) {
                             const i32 sl0 = k0 / 16;
                             i32 cnt = 0;
                             for (i32 k = 0; k < nfull; ++k) cnt += (fi[sl0 + k] & fj[sl0 + k]);
-                            if (cnt == 0 && !beta0 && kw % 16 == 0) { if (!dry) S.flops_update_skipped += 2.0 * kw * tile_entries(w, i0, j0, c1, 64); continue; }
+                            if (cnt == 0 && !beta0 && kw % 16 == 0) { if (!dry) S.flops_update_skipped += 2.0 * kw * tile_entries(w, i0, j0, c1, ts); continue; }
                             if (cnt < nfull) {
                                 need_tmp.assign((size_t)nfull, 0);
                                 for (i32 k = 0; k < nfull; ++k) need_tmp[(size_t)k] = fi[sl0 + k] & fj[sl0 + k];
@@ -1504,10 +1508,10 @@ static void build_schedule(Symbolic &S) {
                         }
                         if (dry) { ++*dry; ++canon_count[(size_t)s]; }
                         else {
-                            const double ent = tile_entries(w, i0, j0, c1, 64);
+                            const double ent = tile_entries(w, i0, j0, c1, ts);
                             S.flops_update += 2.0 * kexec * ent; S.flops_update_skipped += 2.0 * (kw - kexec) * ent;
                             if (pass == 2) S.flops_update_chain += 2.0 * kexec * ent;
-                            S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0, seg, nsl, 1, 0}); task_canon.push_back(canon_next[(size_t)s]++);
+                            S.update_tasks.push_back(UpdateTask{s, k0, kw, i0, j0, c1, beta0, 0, seg, nsl, ts == 64 ? 1 : 2, 0}); task_canon.push_back(canon_next[(size_t)s]++);
                         }
                     }
                 return;
@@ -1581,8 +1585,22 @@ static void build_schedule(Symbolic &S) {
         // workgroup that has its CU to itself runs at nearly twice the rate of two sharing the matrix pipes, so a half-empty last
         // wave is not half idle.  TLPK_TAIL_SLOTS=512 turns the split on (tiles are chosen by their canonical index over ALL of
         // the rank's fronts of the level, so that results do not depend on the number of stream groups).
+        // (the look-ahead rule: commented where the block columns are laid out, below)
+        const int la_env = [] { const char *e = std::getenv("TLPK_LOOKAHEAD"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
+        bool lookahead = la_env == 1;
+        if (la_env < 0) {
+            i32 nbig = 0, ns_max = 0;
+            for (i32 t = t0; t < t1; ++t) {
+                const i32 sf = S.level_fronts[t];
+                if (!S.front_local[sf] || S.front_single[sf]) continue;
+                if (S.fronts[sf].ns > NB_OUT) { ++nbig; ns_max = std::max(ns_max, S.fronts[sf].ns); }
+            }
+            lookahead = nbig >= 1 && nbig <= 16 && ns_max <= 12288;
+        }
         i64 UPD_SLOTS = 0;
         if (const char *e = std::getenv("TLPK_TAIL_SLOTS")) UPD_SLOTS = std::atoll(e);       // tuning knob; 0 = no tail split
+        i32 KSPLIT_LEN = 0;                                                                  // look-ahead levels: longest K range of one update item (0 = off)
+        if (const char *e = std::getenv("TLPK_KSPLIT_LEN")) KSPLIT_LEN = std::max(0, std::atoi(e));       // tuning knob (multiples of 16 keep the parts on slab boundaries)
         auto emit_update_launch = [&](auto &&gen) {
             i64 t_level = 0;
             for (i32 t = t0; t < t1; ++t) canon_count[(size_t)S.level_fronts[t]] = 0;
@@ -1601,6 +1619,21 @@ static void build_schedule(Symbolic &S) {
             const i64 f_upd = (i64)S.update_tasks.size();
             task_canon.clear();
             gen();
+            // Round 6, look-ahead levels (the levels the dependency-driven launch serves): NO item may run for longer than a link of the chain.  A tile with
+            // K = 4096 holds its workgroup for 640 us -- four block columns of the chain -- and the block column that waits for it (its strips) stalls that long
+            // whatever the number of tiles beside it.  Every tile of such a level is cut by K LENGTH, into parts of at most KSPLIT_LEN columns (<= 8 parts),
+            // whatever the number of tiles in the launch; the reduction applies the parts in order.  (Split tiles take no skip lists: regenerate without them.)
+            bool ksplit = false;
+            if (lookahead && KSPLIT_LEN > 0 && nsplit < 2 && UPD_SLOTS == 0) {
+                for (i64 q = f_upd; q < (i64)S.update_tasks.size(); ++q) if (S.update_tasks[(size_t)q].kw > KSPLIT_LEN && !S.update_tasks[(size_t)q].pad2) { ksplit = true; break; }
+                if (ksplit) {
+                    S.update_tasks.resize((size_t)f_upd);
+                    task_canon.clear();
+                    { i64 acc = 0; for (i32 t = t0; t < t1; ++t) { const i32 s = S.level_fronts[t]; canon_next[(size_t)s] = acc; acc += canon_count[(size_t)s]; } }
+                    allow_skip = false;
+                    gen();
+                }
+            }
             allow_skip = true;
             const i64 cnt = (i64)S.update_tasks.size() - f_upd;
             if (cnt == 0) return;
@@ -1632,7 +1665,7 @@ static void build_schedule(Symbolic &S) {
                 if (t_level < UPD_SLOTS) nsplit = best_parts(t_level);                    // a single, partly filled wave: cut every tile
                 else if (r > 0) { tail_parts = best_parts(r); tail_from = t_level - r; }  // the last wave
             }
-            if (nsplit < 2 && tail_parts < 2) { emit(LK_UPDATE, f_upd, cnt); return; }
+            if (nsplit < 2 && tail_parts < 2 && !ksplit) { emit(LK_UPDATE, f_upd, cnt); return; }
             std::vector<UpdateTask> orig(S.update_tasks.begin() + f_upd, S.update_tasks.end());
             S.update_tasks.resize(f_upd);
             const i64 f_red = (i64)S.reduce_tasks.size();
@@ -1640,7 +1673,7 @@ static void build_schedule(Symbolic &S) {
             for (size_t q = 0; q < orig.size(); ++q) {
                 const UpdateTask &t = orig[q];
                 const i32 limit = (nsplit >= 2) ? nsplit : (task_canon[q] >= tail_from ? tail_parts : 1);
-                const i32 parts = std::min(limit, t.kw / 256);
+                const i32 parts = ksplit ? (t.pad2 ? 1 : std::min<i32>(8, (t.kw + KSPLIT_LEN - 1) / KSPLIT_LEN)) : std::min(limit, t.kw / 256);
                 if (parts < 2) { S.update_tasks.push_back(t); continue; }
                 const i32 base = (t.kw / parts) / 16 * 16;              // multiples of the kernel's K slab
                 i32 k = 0;
@@ -1674,6 +1707,8 @@ static void build_schedule(Symbolic &S) {
         constexpr i32 G_MAX = 16;
         i64 TILES_WANTED = 2048;
         if (const char *e = std::getenv("TLPK_MACRO_TILES")) TILES_WANTED = std::atoll(e);    // tuning knob; 0 = no macro columns
+        const bool la_full = [] { const char *e = std::getenv("TLPK_LA_FULL"); return e && std::atoi(e) != 0; }();
+        const bool la_macro = [] { const char *e = std::getenv("TLPK_LA_MACRO"); return !e || std::atoi(e) != 0; }();
         auto macro_width = [&](i32 ko) {
             i64 tiles_bc = 0;
             for (i32 t = t0; t < t1; ++t) {
@@ -1684,6 +1719,10 @@ static void build_schedule(Symbolic &S) {
             // launches of >= ~1000 tiles are left alone (measured on C4: macro columns there cost 0.3 ms,
             // two stream groups already fill each other's tails)
             if (tiles_bc <= 0 || 2 * tiles_bc >= TILES_WANTED) return (i32)1;
+            // (TLPK_LA_MACRO=0, diagnostics: no macro columns on the look-ahead levels -- every block column pulls K = [0, ko - 256) one block column early.
+            // Measured WORSE, pds-class 13.8 -> 14.6 ms: in the middle of a 7 900-column front a block column's update is 130 us of the whole chip, as long as a
+            // link of the chain; the macro columns do that work early, while the chain is latency-bound, the pure left-looking form does it when it is due.)
+            if (lookahead && !la_macro) return (i32)1;
             return (i32)std::min<i64>(G_MAX, (TILES_WANTED + tiles_bc - 1) / tiles_bc);
         };
         // macro column of every block column: block columns [mac_first[io], mac_first[io] + mac_G[io])
@@ -1710,17 +1749,6 @@ static void build_schedule(Symbolic &S) {
         // one block column and none has more than 12 288 pivot columns (a pds-class top front, the root front, the few blocks of a rank of an
         // 8-GPU job; not the C3 shape's 48 000-column front, not the 32 blocks per stream group of config C4 at N = 1, whose diagonal-block chains
         // are hidden behind the bulk updates anyway).  The rule looks at the rank's fronts of the level only, never at the stream groups.
-        const int la_env = [] { const char *e = std::getenv("TLPK_LOOKAHEAD"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
-        bool lookahead = la_env == 1;
-        if (la_env < 0) {
-            i32 nbig = 0, ns_max = 0;
-            for (i32 t = t0; t < t1; ++t) {
-                const i32 sf = S.level_fronts[t];
-                if (!S.front_local[sf] || S.front_single[sf]) continue;
-                if (S.fronts[sf].ns > NB_OUT) { ++nbig; ns_max = std::max(ns_max, S.fronts[sf].ns); }
-            }
-            lookahead = nbig >= 1 && nbig <= 16 && ns_max <= 12288;
-        }
         auto block_columns = [&]() {
         i32 pmax = 0;
         for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t]) && pass_ok(S.level_fronts[t])) pmax = std::max(pmax, S.fronts[S.level_fronts[t]].ns);
@@ -1730,7 +1758,14 @@ static void build_schedule(Symbolic &S) {
             const i32 ko = io * NB_OUT;
             const i32 io_macro = mac_first[(size_t)io], G = mac_G[(size_t)io];
             const i32 gi = io - io_macro, kM = io_macro * NB_OUT;
-            const i32 ka = (gi == 0) ? 0 : kM;             // this block column still needs K = [ka, ko)
+            // Round 6, with the look-ahead: the FIRST block column of a macro column (gi == 0) used to pull all of K = [0, ko) itself -- tiles of up to 4096 columns
+            // (450 - 600 us each) between strips(io - 1) and strips(io), ON the chain (profiles/r06_chain_trace_pds.txt: one 450 us stall per macro column start).
+            // Now K = [0, ko - 256) comes with block column io - 1 (same operands, ready one block column earlier, off the chain) for the whole block column, not
+            // only for its diagonal block; behind strips(io - 1) only the short K = [ko - 256, ko) is left, as for every other block column.
+            // TLPK_LA_FULL=1 (diagnostics): the same for EVERY block column of a look-ahead level (inside the first macro column K = [0, ko) grows with ko).
+            const bool mac_la = lookahead && io >= 2 && (gi == 0 || la_full);
+            const i32 ka_base = (gi == 0) ? 0 : kM;
+            const i32 ka = mac_la ? std::max(ka_base, ko - NB_OUT) : ka_base;       // this block column still needs K = [ka, ko)
             const i32 kd = lookahead ? std::max(ka, ko - NB_OUT) : ka;      // ... its diagonal block only K = [kd, ko): the rest came with block column io - 1
             // Block column io.  The left-looking update of its DIAGONAL block and the factorisation
             // of that block (k_potrf*: a serial chain inside one workgroup per front) go to the
@@ -1743,7 +1778,7 @@ static void build_schedule(Symbolic &S) {
             if (overlap)
                 emit_update_launch([&]() {
                     for_fronts([&](i32 s, const FrontDesc &w) {
-                        if (ko < w.ns) push_update_region(s, w, kd, ko - kd, ko, std::min(ko + NB_OUT, w.ns), 0, 0, (pass == 2 && chain_tile64 && !dry && ko - kd <= NB_OUT) ? 64 : TILE);
+                        if (ko < w.ns) push_update_region(s, w, kd, ko - kd, ko, std::min(ko + NB_OUT, w.ns), 0, 0, (pass == 2 && !dry && ko - kd <= NB_OUT) ? chain_tile : TILE);
                     });
                 });
             if (io < nouter) {
@@ -1780,7 +1815,8 @@ static void build_schedule(Symbolic &S) {
                             // look-ahead: the diagonal block of block column io + 1, K = [k_first(io + 1), ko)
                             if (lookahead && io >= 1 && io + 1 < my_nouter) {
                                 const i32 k1 = k_first(io + 1);
-                                if (ko > k1) push_update_region(s, w, k1, ko - k1, ko + NB_OUT, std::min(ko + 2 * NB_OUT, w.ns), 0, 0);
+                                // (the next block column starts a macro column: the whole block column, see mac_la above)
+                                if (ko > k1) push_update_region(s, w, k1, ko - k1, ko + NB_OUT, std::min(ko + 2 * NB_OUT, w.ns), 0, (la_full || mac_first[(size_t)io + 1] == io + 1) ? 2 : 0);
                             }
                         } else if (io == my_nouter) push_update_region(s, w, 0, w.ns, w.ns, w.f, 1, 2);
                     });
@@ -1824,9 +1860,8 @@ static void build_schedule(Symbolic &S) {
         // tile's counter in that order: exactly the order of the launches, so the factor is bit-identical to the launch form (TLPK_CHAIN=0).
         auto build_chain = [&]() {
             if (cap.empty()) return;
-            // (TLPK_CHAIN_DEFER=1; OFF by default: measured neutral on the 8-block rank-local work and 0.5 ms WORSE on the pds-class LP, profiles/r06_chain_variants.txt --
-            // the stalls at the macro-column starts are the long-K tiles themselves, not their place in the ticket order)
-            const bool chain_defer = [] { const char *e = std::getenv("TLPK_CHAIN_DEFER"); return e && std::atoi(e) != 0; }();
+            // TLPK_CHAIN_JIT (default 1): the macro-column tiles take their tickets just in time, see `units` below; 0 = in the order of the launches.
+            const bool chain_jit = [] { const char *e = std::getenv("TLPK_CHAIN_JIT"); return e && std::atoi(e) != 0; }();
             struct FC { i64 base; i32 nbc, ntr, nsl, stride; };
             std::unordered_map<i32, FC> fc;
             i64 ncnt = 0;
@@ -1864,14 +1899,20 @@ static void build_schedule(Symbolic &S) {
                 for (i32 sl = s0; sl <= s1; ++sl) if (expect[(size_t)c_ts(c, io_k, sl)] != 1) bad = true;      // no strip (or two) for these rows: a bug
                 wq = G(c_ts(c, io_k, s0)); nq = s1 - s0 + 1;
             };
-            // Macro-column tiles wait their turn BEHIND the strips of the block column they were launched with: they feed LATER block columns (K = [0, kM),
-            // hundreds of microseconds each), and tickets are priorities -- drawn before the strips, as in the launch order, they kept every workgroup busy while
-            // the chain's next link (40 us of strips) waited for a free one (profiles/r06_chain_trace_*.txt: 300 - 400 us stalls at every macro column start).
-            // Deferred: the update tiles of a captured launch whose target block column lies beyond the current one, except the tiles of the NEXT diagonal block.
-            // Every adder of a target tile is still created before the later adders of that tile: same order of the sums, same bits.
-            std::vector<i64> deferred;
+            // Tickets are priorities, and a workgroup keeps the item it drew: at the start of a macro column the launch order puts ~900 tiles with K = [0, kM) --
+            // the long update of the macro column's OTHER block columns, hundreds of microseconds each even cut by K length -- in front of the chain's next links,
+            // which then wait for a free workgroup (profiles/r06_chain_trace_pds*.txt: 0.3 - 0.7 ms stalls at every macro column start; putting them all behind
+            // the strips of that block column, round 6's first try, only moved the stall to the next block column).  Just in time: the tiles that feed block
+            // column io_t are held back until block column io_t - 2 -- they take their tickets behind its rows-below tiles and in front of its strips, two links
+            // of the chain before they are needed, one block column's worth at a time.  A held tile travels with its split-K parts and its reduction.  Every
+            // adder of a target tile is still created before the later adders of that tile (the look-ahead tiles of block column io_t come with io_t - 1, its
+            // own tiles with io_t): same order of the sums, same bits as the launch form.
+            struct Unit { i64 first, count, red; };                    // update tasks [first, first + count) (one tile: itself, or its split-K parts) and its reduce task (or -1)
+            std::map<i32, std::vector<Unit>> held;                       // target block column -> units
+            std::unordered_map<i32, i64> slot_red;                       // split-K scratch slot -> the counter of the reduction that owns it (slots are unique inside a chain launch)
+            std::unordered_map<i64, i64> red_rc;                         // reduce task -> its counter
             i32 io_cur = -1;                                             // block column of the last diagonal block seen
-            auto update_item = [&](i64 q, const std::unordered_map<i32, i64> &slot_red) {
+            auto update_item = [&](i64 q) {
                         const UpdateTask &u = S.update_tasks[(size_t)q];
                         const FrontDesc &w = S.fronts[u.front];
                         const FC &c = fc.at(u.front);
@@ -1901,51 +1942,68 @@ static void build_schedule(Symbolic &S) {
                         }
                         S.chain_items.push_back(it);
             };
-            const std::unordered_map<i32, i64> no_slots;
-            auto flush_deferred = [&]() { for (const i64 q : deferred) { if (bad) break; update_item(q, no_slots); } deferred.clear(); };
+            auto reduce_items = [&](i64 q) {
+                const UpdateTask &r = S.reduce_tasks[(size_t)q];
+                const FrontDesc &w = S.fronts[r.front];
+                const FC &c = fc.at(r.front);
+                const i64 rc = red_rc.at(q);
+                if (expect[(size_t)rc] != r.kw) { bad = true; return; }
+                const i64 tc = target_counter(c, w, r.i0, r.j0);
+                for (i32 sub = 0; sub < RED_SPLIT; ++sub) {
+                    ChainItem it{CR_REDUCE, (i32)q, sub, G(rc), 1, r.kw, 0, 0, 0, -1, 0, -1};
+                    if (tc >= 0) {
+                        if (expect[(size_t)tc] > 0) { it.w2 = G(tc); it.need2 = expect[(size_t)tc]; }
+                        it.sig = G(tc);
+                    }
+                    S.chain_items.push_back(it);
+                }
+                if (tc >= 0) expect[(size_t)tc] += RED_SPLIT;
+            };
+            auto emit_units = [&](const std::vector<Unit> &us) {           // the tiles first, then their reductions (the order of a launch pair)
+                for (const Unit &u : us) for (i64 q = u.first; q < u.first + u.count && !bad; ++q) update_item(q);
+                for (const Unit &u : us) if (u.red >= 0 && !bad) reduce_items(u.red);
+            };
+            auto flush_held = [&](i32 io_upto) {                           // the held tiles of the block columns <= io_upto, in block-column order
+                while (!held.empty() && held.begin()->first <= io_upto && !bad) { emit_units(held.begin()->second); held.erase(held.begin()); }
+            };
             for (size_t ci = 0; ci < cap.size() && !bad; ++ci) {
                 const Cap &L = cap[ci];
                 if (L.kind == LK_UPDATE) {
                     // split-K parts of this launch: scratch slot -> the counter of the reduction that owns it
-                    std::unordered_map<i32, i64> slot_red;
-                    std::vector<i64> red_counter;
-                    if (ci + 1 < cap.size() && cap[ci + 1].kind == LK_UPDATE_REDUCE) {
+                    std::unordered_map<i32, i64> slot_task;                // slot -> reduce task
+                    const bool has_red = ci + 1 < cap.size() && cap[ci + 1].kind == LK_UPDATE_REDUCE;
+                    if (has_red) {
                         const Cap &R = cap[ci + 1];
                         for (i64 q = R.first; q < R.first + R.count; ++q) {
                             const UpdateTask &r = S.reduce_tasks[(size_t)q];
                             const i64 rc = new_counter();
-                            red_counter.push_back(rc);
-                            for (i32 sp = 0; sp < r.kw; ++sp) slot_red[r.k0 + sp] = rc;
+                            red_rc[q] = rc;
+                            for (i32 sp = 0; sp < r.kw; ++sp) { slot_red[r.k0 + sp] = rc; slot_task[r.k0 + sp] = q; }
                         }
                     }
-                    for (i64 q = L.first; q < L.first + L.count && !bad; ++q) {
+                    std::vector<Unit> now;
+                    i64 nred_seen = 0;
+                    for (i64 q = L.first; q < L.first + L.count && !bad;) {
                         const UpdateTask &u = S.update_tasks[(size_t)q];
-                        const i32 io_t = (u.j0 < S.fronts[u.front].ns) ? u.j0 / NB_OUT : -1;
-                        const bool next_diag = io_t == io_cur + 1 && u.i0 < (io_t + 1) * NB_OUT;
-                        if (chain_defer && !u.pad1 && io_t > io_cur && io_cur >= 0 && !next_diag) { deferred.push_back(q); continue; }
-                        update_item(q, slot_red);
-                    }
-                    if (!red_counter.empty()) {
-                        const Cap &R = cap[ci + 1];
-                        for (i64 q = R.first; q < R.first + R.count; ++q) {
-                            const UpdateTask &r = S.reduce_tasks[(size_t)q];
-                            const FrontDesc &w = S.fronts[r.front];
-                            const FC &c = fc.at(r.front);
-                            const i64 rc = red_counter[(size_t)(q - R.first)];
-                            if (expect[(size_t)rc] != r.kw) { bad = true; break; }
-                            const i64 tc = target_counter(c, w, r.i0, r.j0);
-                            for (i32 sub = 0; sub < RED_SPLIT; ++sub) {
-                                ChainItem it{CR_REDUCE, (i32)q, sub, G(rc), 1, r.kw, 0, 0, 0, -1, 0, -1};
-                                if (tc >= 0) {
-                                    if (expect[(size_t)tc] > 0) { it.w2 = G(tc); it.need2 = expect[(size_t)tc]; }
-                                    it.sig = G(tc);
-                                }
-                                S.chain_items.push_back(it);
+                        Unit un{q, 1, -1};
+                        if (u.pad1) {                                    // the consecutive parts of one tile
+                            const auto f = slot_task.find(u.pad1 - 1);
+                            if (f == slot_task.end()) { bad = true; break; }
+                            un.red = f->second; ++nred_seen;
+                            while (q + un.count < L.first + L.count) {
+                                const UpdateTask &v = S.update_tasks[(size_t)(q + un.count)];
+                                const auto g = v.pad1 ? slot_task.find(v.pad1 - 1) : slot_task.end();
+                                if (g == slot_task.end() || g->second != un.red) break;
+                                ++un.count;
                             }
-                            if (tc >= 0) expect[(size_t)tc] += RED_SPLIT;
                         }
-                        ++ci;                                            // the reduce launch is consumed
+                        const i32 io_t = (u.j0 < S.fronts[u.front].ns) ? u.j0 / NB_OUT : -1;
+                        if (chain_jit && io_cur >= 0 && io_t >= io_cur + 3) held[io_t].push_back(un); else now.push_back(un);
+                        q += un.count;
                     }
+                    if (has_red && nred_seen != cap[ci + 1].count) bad = true;      // every reduction belongs to exactly one tile of this launch
+                    emit_units(now);
+                    if (has_red) ++ci;                                   // the reduce launch is consumed
                 } else if (L.kind == LK_POTRF || L.kind == LK_POTRF_WIDE) {
                     for (i64 q = L.first; q < L.first + L.count; ++q) {
                         const PotrfTask &pt = S.potrf_tasks[(size_t)q];
@@ -1966,6 +2024,7 @@ static void build_schedule(Symbolic &S) {
                         S.chain_items.push_back(it);
                     }
                 } else if (L.kind == LK_TRSM) {
+                    flush_held(io_cur + 2);                              // just in time: behind this block column's rows-below tiles, in front of its strips
                     for (i64 q = L.first; q < L.first + L.count; ++q) {
                         const TrsmTask &tt = S.trsm_tasks[(size_t)q];
                         const FC &c = fc.at(tt.front);
@@ -1980,10 +2039,9 @@ static void build_schedule(Symbolic &S) {
                         ++expect[(size_t)c_ts(c, io, tt.row0 / 64)];
                         S.chain_items.push_back(it);
                     }
-                    flush_deferred();                                    // the macro-column tiles launched with this block column: behind its strips
                 } else bad = true;                                       // (no other kind is ever captured)
             }
-            flush_deferred();
+            flush_held(INT32_MAX);
             // the values the diagonal blocks and the strips wait for must be FINAL: nothing after them may add to their tiles
             for (i64 q = first_item; q < (i64)S.chain_items.size() && !bad; ++q) {
                 const ChainItem &it = S.chain_items[(size_t)q];
