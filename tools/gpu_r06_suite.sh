@@ -1,7 +1,7 @@
 #!/bin/bash
-# whole GPU suite + smoke
+# the whole GPU suite + smoke at the current code state -> gpurun_out/r06_final_pytest.txt
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r06_pytest_gpu.txt 2>&1
-tail -15 gpurun_out/r06_pytest_gpu.txt
-timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2
+timeout 2400 python -m pytest tests/ -q -m gpu 2>&1 | tail -15 > gpurun_out/r06_final_pytest.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/r06_final_pytest.txt 2>&1
+tail -12 gpurun_out/r06_final_pytest.txt
