@@ -41,8 +41,9 @@ CASES = {
     # one dense top front of ~1400 columns: macro columns + split-K parts + reductions inside the chain (the pds-class regime)
     "single_front": lambda: (_single_front_lp(1500), None, {"TLPK_MACRO_TILES": "50", "TLPK_CHAIN_MIN_NS": "257"}),
     # a front of eleven block columns whose second macro column is nine block columns wide: macro-column tiles cut by K length (TLPK_KSPLIT_LEN) AND held back
-    # until two block columns before their target (build_chain: just-in-time tickets), the macro column's first block column pulled one block column early
-    "macro_jit": lambda: (_single_front_lp(2700), None, {"TLPK_MACRO_TILES": "200", "TLPK_CHAIN_MIN_NS": "257", "TLPK_KSPLIT_LEN": "512"}),
+    # until two block columns before their target (build_chain: just-in-time tickets; both knobs are experiments that stay off by default, profiles/r06_chain_variants.txt), the
+    # macro column's first block column pulled one block column early
+    "macro_jit": lambda: (_single_front_lp(2700), None, {"TLPK_MACRO_TILES": "200", "TLPK_CHAIN_MIN_NS": "257", "TLPK_KSPLIT_LEN": "512", "TLPK_CHAIN_JIT": "1"}),
     # block-angular: the root front (900 columns, no rows below) and the block fronts of a rank that owns few blocks
     "block_angular": lambda: (*block_angular(nblocks=4, mk=300, nk=600, m0=700, nnz_in=3, link_prob=0.9, seed=5), {"TLPK_CHAIN_MIN_NS": "257"}),
     # a front whose last block column is narrow (ns = 2 * 256 + 40) and whose rows below are ragged
