@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 
 #include "tlpk_device.hpp"
 
@@ -2487,29 +2488,49 @@ struct ChainArgs {
     unsigned *cnt; i32 ticket;                       // counters of all chain launches; index of this launch's ticket
     const UpdateTask *upd, *red; const PotrfTask *potrf; const TrsmTask *trsm;
     unsigned long long *trace;                       // TLPK_CHAIN_TRACE=1 (diagnostics): per item 4 words -- drawn, released by its counters, work done, published (100 MHz clock)
+    unsigned spin_max;                               // milliseconds before a waiting wave gives up (TLPK_CHAIN_TIMEOUT_MS, default 2000)
 };
 constexpr int CHAIN_LDS = 2 * NB_IN * LDW;           // doubles (81 920 bytes): the strips' two staging blocks >= the four K slabs of an update tile, >= the diagonal block's scratch
 static_assert(CHAIN_LDS >= 4 * UPD_KT * UPD_LD && CHAIN_LDS >= POTRF_WIDE_DPP_LDS, "k_chain: one LDS block serves every role");
 
-// wave 0 of the workgroup: wait for the item's counters; returns false if somebody (maybe this wave) gave up
-__device__ __forceinline__ bool chain_wait(const ChainItem &it, const unsigned *cnt, int *info, const int lane) {
+// wave 0 of the workgroup: wait for the item's counters; returns false if somebody (maybe this wave) gave up.
+// ONLY the lanes that have a counter to watch poll (at most 3 + the strips of an operand range), and the polls back off: 0.2 us apart for the first 64 -- the
+// links of the chain hand over within microseconds --, then 0.8 us, then 3 us.  (Round 6, found by the eight-shards-on-one-GPU test: every one of the 64
+// lanes used to load the entry min(lane, ntot - 1), i.e. ~60 duplicate agent-scope loads of ONE word per poll and waiting workgroup; with 200 workgroups
+// waiting for the same few counters the memory channel that owns those words took 3e10 loads per second, the update tiles that shared it ran 6 000 times
+// slower -- 0.68 s for a 100 us tile, profiles/r06_chain_poll_storm.txt -- and the waits ran into their time limit: TLPK_INTERNAL in 15 % of the runs.)
+// The time limit is wall-clock time (100 MHz counter), `timeout_ms` milliseconds (TLPK_CHAIN_TIMEOUT_MS, default 2000).
+__device__ __forceinline__ bool chain_wait(const ChainItem &it, const unsigned *cnt, int *info, const int lane, const unsigned timeout_ms, const int dbg_slot) {
     const int n01 = it.n0 + it.n1, ntot = n01 + (it.w2 >= 0 ? 1 : 0);
     if (ntot == 0) return __hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-    // lane l polls wait entry min(l, ntot - 1): every lane has a valid address (no guarded loads in the loop)
+    const bool act = lane < ntot;
     const int e = min(lane, ntot - 1);
     const int idx = (e < it.n0) ? it.w0 + e : ((e < n01) ? it.w1 + (e - it.n0) : it.w2);
     const unsigned need = (unsigned)((e < it.n0) ? it.need0 : ((e < n01) ? it.need1 : it.need2));
     const unsigned *p = cnt + idx;
     bool dead = false;
     unsigned spins = 0;
-    unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    unsigned v = need;
+    if (act) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (!dead && !__all(v >= need)) {
-        __builtin_amdgcn_s_sleep(8);
-        if ((++spins & 127u) == 0u) {
-            if (__hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
-            else if (spins > (1u << 21)) { __hip_atomic_store(info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
+        if (spins < 64u) __builtin_amdgcn_s_sleep(8);
+        else if (spins < 512u) __builtin_amdgcn_s_sleep(32);
+        else __builtin_amdgcn_s_sleep(127);
+        if ((++spins & 63u) == 0u) {
+            int flag = 0;
+            if (lane == 0) flag = __hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readfirstlane(flag) != 0) dead = true;
+            else if (wall_clock64() - t0 > (unsigned long long)timeout_ms * 100000ull) {
+                // (diagnostics: who gave up on what -- words 4.. of the status block, printed by the host with TLPK_CHAIN_DEBUG=1)
+                if (v < need && __hip_atomic_exchange(info + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    info[4] = dbg_slot; info[5] = it.role; info[6] = idx; info[7] = (int)need; info[8] = (int)v; info[9] = (int)blockIdx.x; info[10] = (int)gridDim.x; info[11] = it.task;
+                }
+                if (lane == 0) __hip_atomic_store(info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+            }
         }
-        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (act) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE acquire after the match: plain loads of the producers' data from here on
@@ -2592,7 +2613,7 @@ __global__ __launch_bounds__(256, 2) void k_chain(const ChainArgs a, DevCtx c) {
         unsigned long long *tr = a.trace ? a.trace + 4 * (size_t)slot : nullptr;
         if (tr && tid == 0) tr[0] = wall_clock64();
         if (tid < 64) {
-            const bool ok = chain_wait(it, a.cnt, c.info, tid);
+            const bool ok = chain_wait(it, a.cnt, c.info, tid, a.spin_max, (int)slot);
             if (tid == 0) ctl[1] = ok ? 0u : 1u;
         }
         __syncthreads();
@@ -3361,7 +3382,11 @@ constexpr int SMALL_RPL = SMALL_ROWS / 64;       // rows below per lane
 // (round 4) The bodies are instantiated for (NSM pivot columns, RPL rows below per lane) = (4, 1), (4, 4), (16, 1), (16, 4) and chosen per front
 // (wave-uniform): most small fronts of the inequality LPs have one or two pivot columns and a handful of rows, and the single (16, 4) body
 // requested 64 + 32 clamped duplicate loads per lane for each of them -- 1.4 ms of a 7 ms solve on the north-star instance.
-template <int NSM, int RPL>
+// (round 6) The rows below the pivot block go through the wave 64 at a time in a LOOP -- one trip for 95 % of the small fronts of the north-star LP -- instead of
+// as up to four register sets loaded up front: the kernel needed 222 registers for the 5 % of tall fronts and ran two waves per SIMD for everybody
+// (k_fwd_small + k_bwd_small: 0.84 of the 6.7 ms of a north-star solve at 1.4 - 1.8 TB/s, profiles/r06_pmc_summary.md).  Per row the sum runs over the
+// columns in the same order as before: same bits.
+template <int NSM>
 __device__ __forceinline__ void fwd_small_body(const FrontDesc &fd, const DevCtx &c, const int lane) {
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
@@ -3369,23 +3394,20 @@ __device__ __forceinline__ void fwd_small_body(const FrontDesc &fd, const DevCtx
     const double *__restrict__ P = c.Lval + fd.loff;
     double *xs = c.xw + fd.col0;
     double *__restrict__ uc = c.uc + fd.ucoff;
-    // every load of the step is requested up front (clamped addresses, selects afterwards): the wave is
+    // every load of the first trip is requested up front (clamped addresses, selects afterwards): the wave is
     // alone with its front, so each dependent round trip would be paid in full
     const i32 ic = min(lane, ns - 1);
-    double wv[NSM], bv[NSM], lv[RPL][NSM], uv[RPL];
+    double wv[NSM], bv[NSM], lv[NSM];
 #pragma unroll
     for (int k = 0; k < NSM; ++k) {
         const i32 kc = min(k, ns - 1);
         wv[k] = W[(i64)ic + (i64)kc * ns];
         bv[k] = xs[kc];
     }
+    i32 rr = min(lane, max(rs - 1, 0));                            // row below, clamped (rs may be 0: stays inside the panel)
+    double uv = (rs > 0) ? uc[rr] : 0.0;
 #pragma unroll
-    for (int u = 0; u < RPL; ++u) {
-        const i32 rr = min(lane + 64 * u, max(rs - 1, 0));         // row below, clamped (rs may be 0: stays inside the panel)
-        uv[u] = (rs > 0) ? uc[rr] : 0.0;
-#pragma unroll
-        for (int k = 0; k < NSM; ++k) lv[u][k] = P[(i64)min(ns + rr, f - 1) + (i64)min(k, ns - 1) * lda];
-    }
+    for (int k = 0; k < NSM; ++k) lv[k] = P[(i64)min(ns + rr, f - 1) + (i64)min(k, ns - 1) * lda];
     double y = 0.0;
 #pragma unroll
     for (int k = 0; k < NSM; ++k) y += (k < ns && k <= lane) ? wv[k] * bv[k] : 0.0;
@@ -3393,12 +3415,17 @@ __device__ __forceinline__ void fwd_small_body(const FrontDesc &fd, const DevCtx
     double yv[NSM];
 #pragma unroll
     for (int k = 0; k < NSM; ++k) yv[k] = __shfl(y, k);        // only k < ns is used
-#pragma unroll
-    for (int u = 0; u < RPL; ++u) {
+    for (i32 r0 = 0;;) {
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < NSM; ++k) acc += (k < ns) ? lv[u][k] * yv[k] : 0.0;
-        if (lane + 64 * u < rs) uc[lane + 64 * u] = uv[u] - acc;
+        for (int k = 0; k < NSM; ++k) acc += (k < ns) ? lv[k] * yv[k] : 0.0;
+        if (r0 + lane < rs) uc[r0 + lane] = uv - acc;
+        r0 += 64;
+        if (r0 >= rs) break;                                       // (wave-uniform)
+        rr = min(r0 + lane, rs - 1);
+        uv = uc[rr];
+#pragma unroll
+        for (int k = 0; k < NSM; ++k) lv[k] = P[(i64)(ns + rr) + (i64)min(k, ns - 1) * lda];
     }
 }
 __global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
@@ -3407,12 +3434,11 @@ __global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__
     const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
-    const bool few = fd.ns <= 4 && !c.small_full, shortf = fd.f - fd.ns <= 64 && !c.small_full;      // wave-uniform
-    if (few) { if (shortf) fwd_small_body<4, 1>(fd, c, lane); else fwd_small_body<4, SMALL_RPL>(fd, c, lane); }
-    else { if (shortf) fwd_small_body<SMALL_NS, 1>(fd, c, lane); else fwd_small_body<SMALL_NS, SMALL_RPL>(fd, c, lane); }
+    const bool few = fd.ns <= 4 && !c.small_full;      // wave-uniform
+    if (few) fwd_small_body<4>(fd, c, lane); else fwd_small_body<SMALL_NS>(fd, c, lane);
 }
 
-template <int NSM, int RPL>
+template <int NSM>
 __device__ __forceinline__ void bwd_small_body(const FrontDesc &fd, const DevCtx &c, const int lane) {
     const i32 f = fd.f, ns = fd.ns, rs = f - ns;
     const i32 lda = fd.lda;                         // leading dimension of the panel (>= f, multiple of 16 for large fronts)
@@ -3421,32 +3447,30 @@ __device__ __forceinline__ void bwd_small_body(const FrontDesc &fd, const DevCtx
     const i32 *__restrict__ rows = c.rowidx + fd.rowoff;
     double *xs = c.xw + fd.col0;
     const i32 ic = min(lane, ns - 1);
-    double wv[NSM], bv[NSM], lv[RPL][NSM], xr[RPL];
-    i32 gi[RPL];
-#pragma unroll
-    for (int u = 0; u < RPL; ++u) gi[u] = rows[min(ns + lane + 64 * u, f - 1)];   // rows below: values of the ancestors
+    double wv[NSM], bv[NSM], lv[NSM], acc[NSM];
+    i32 gi = rows[min(ns + lane, f - 1)];                              // rows below: values of the ancestors
 #pragma unroll
     for (int k = 0; k < NSM; ++k) {
         const i32 kc = min(k, ns - 1);
         wv[k] = W[(i64)kc + (i64)ic * ns];                           // column `lane` of W
         bv[k] = xs[kc];
+        acc[k] = 0.0;
+    }
+    // the rows below, 64 per trip (one trip for almost every small front; see fwd_small_body): a lane adds its rows in ascending order, as before
+    for (i32 r0 = 0;;) {
+        const i32 r = min(ns + r0 + lane, f - 1);
+#pragma unroll
+        for (int k = 0; k < NSM; ++k) lv[k] = P[(i64)r + (i64)min(k, ns - 1) * lda];
+        const double xv = c.xw[gi];
+        const double xr = (r0 + lane < rs) ? xv : 0.0;
+#pragma unroll
+        for (int k = 0; k < NSM; ++k) acc[k] += lv[k] * xr;
+        r0 += 64;
+        if (r0 >= rs) break;                                           // (wave-uniform)
+        gi = rows[min(ns + r0 + lane, f - 1)];
     }
 #pragma unroll
-    for (int u = 0; u < RPL; ++u) {
-        const i32 r = min(ns + lane + 64 * u, f - 1);
-#pragma unroll
-        for (int k = 0; k < NSM; ++k) lv[u][k] = P[(i64)r + (i64)min(k, ns - 1) * lda];
-        const double xv = c.xw[gi[u]];
-        xr[u] = (lane + 64 * u < rs) ? xv : 0.0;
-    }
-    double acc[NSM];
-#pragma unroll
-    for (int k = 0; k < NSM; ++k) {
-        double a = 0.0;
-#pragma unroll
-        for (int u = 0; u < RPL; ++u) a += lv[u][k] * xr[u];
-        acc[k] = (k < ns) ? a : 0.0;
-    }
+    for (int k = 0; k < NSM; ++k) acc[k] = (k < ns) ? acc[k] : 0.0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -3455,7 +3479,7 @@ __device__ __forceinline__ void bwd_small_body(const FrontDesc &fd, const DevCtx
     double x = 0.0;                                                  // x[i] = sum_{k >= i} W[k][i] (b[k] - sum[k])
 #pragma unroll
     for (int k = 0; k < NSM; ++k) {
-        const double tk = bv[k] - __shfl(acc[k], 0);
+        const double tk = bv[k] - readlane_f64(acc[k], 0);            // (lane 0's sum through scalar registers)
         x += (k < ns && k >= lane) ? wv[k] * tk : 0.0;
     }
     if (lane < ns) xs[lane] = x;
@@ -3466,9 +3490,8 @@ __global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__
     const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
-    const bool few = fd.ns <= 4 && !c.small_full, shortf = fd.f - fd.ns <= 64 && !c.small_full;      // wave-uniform
-    if (few) { if (shortf) bwd_small_body<4, 1>(fd, c, lane); else bwd_small_body<4, SMALL_RPL>(fd, c, lane); }
-    else { if (shortf) bwd_small_body<SMALL_NS, 1>(fd, c, lane); else bwd_small_body<SMALL_NS, SMALL_RPL>(fd, c, lane); }
+    const bool few = fd.ns <= 4 && !c.small_full;      // wave-uniform
+    if (few) bwd_small_body<4>(fd, c, lane); else bwd_small_body<SMALL_NS>(fd, c, lane);
 }
 
 // dy_shared != nullptr (single-process multi-device mode): the rows this rank OWNS (its block rows; the linking rows
@@ -3765,11 +3788,33 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
         // TLPK_CHAIN_DYNLDS=0 TLPK_CHAIN_GRID=512: two per CU.  More workgroups than fit are harmless: one that starts late draws the next ticket.
         const unsigned dyn = [] { const char *e = std::getenv("TLPK_CHAIN_DYNLDS"); return e ? (unsigned)std::max(0, std::atoi(e)) : 70000u; }();
         const unsigned grid_max = [&] { const char *e = std::getenv("TLPK_CHAIN_GRID"); return e ? (unsigned)std::max(1, std::atoi(e)) : (dyn >= 70000u ? 256u : 512u); }();
+        static const unsigned spin_max = [] { const char *e = std::getenv("TLPK_CHAIN_TIMEOUT_MS"); return (unsigned)(e ? std::min(600000, std::max(1, std::atoi(e))) : 2000); }();
         const ChainArgs ca{a.chain_items + L.first, (i32)L.count, a.chain_cnt, L.pad, a.update_tasks, a.reduce_tasks, a.potrf_tasks, a.trsm_tasks,
-                           a.chain_trace ? a.chain_trace + 4 * L.first : nullptr};
+                           a.chain_trace ? a.chain_trace + 4 * L.first : nullptr, spin_max};
         const dim3 gc((unsigned)std::min<i64>(L.count, grid_max));
+        // ONE dependency-driven launch at a time per device, process-wide (TLPK_CHAIN_SERIAL=0 lifts it).  Each launch is deadlock-free by itself, but several of them
+        // side by side on ONE device -- eight shards of a multi-device handle on one GPU (the test configuration), independent handles of one process -- froze: with
+        // 8 or 16 hardware queues the eight-shards test ended TLPK_INTERNAL in 15 - 40 % of the runs (the time stamps show ~14 workgroups of one launch, all long
+        // update tiles, standing still for 0.68 s inside their role while every other workgroup of the device spins, and finishing the moment the others give up;
+        // never with GPU_MAX_HW_QUEUES <= 4; profiles/r06_chain_poll_storm.txt).  The launch therefore waits for the previous chain launch enqueued on this device
+        // (an event of its stream: dependencies only point back in enqueue order, so the streams' own event graph stays acyclic); launches of other kinds run
+        // beside it as before.  Not inside a stream capture (hipGraph replay of single-group schedules: one handle, one launch at a time by construction).
+        static const bool chain_serial = [] { const char *e = std::getenv("TLPK_CHAIN_SERIAL"); return !e || std::atoi(e) != 0; }();
+        static std::mutex chain_mu;
+        static hipEvent_t chain_ev[64] = {};
+        static bool chain_rec[64] = {};
+        int dev = 0; (void)hipGetDevice(&dev);
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone; (void)hipStreamIsCapturing(st, &cs);
+        const bool ser = chain_serial && cs == hipStreamCaptureStatusNone && dev >= 0 && dev < 64;
+        std::unique_lock<std::mutex> lk(chain_mu, std::defer_lock);
+        if (ser) {
+            lk.lock();
+            if (!chain_ev[dev] && hipEventCreateWithFlags(&chain_ev[dev], hipEventDisableTiming) != hipSuccess) chain_ev[dev] = nullptr;
+            if (chain_ev[dev] && chain_rec[dev]) (void)hipStreamWaitEvent(st, chain_ev[dev], 0);
+        }
         if (sgn) hipLaunchKernelGGL(k_chain<true>, gc, dim3(256), dyn, st, ca, a.ctx);
         else hipLaunchKernelGGL(k_chain<false>, gc, dim3(256), dyn, st, ca, a.ctx);
+        if (ser && chain_ev[dev]) { (void)hipEventRecord(chain_ev[dev], st); chain_rec[dev] = true; }
         break;
     }
     case LK_UPDATE_REDUCE: hipLaunchKernelGGL(k_update_reduce, dim3((unsigned)L.count * RED_SPLIT), dim3(256), 0, st, a.reduce_tasks + L.first, a.ctx); break;

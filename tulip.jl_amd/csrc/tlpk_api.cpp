@@ -356,7 +356,7 @@ int upload_all(tlpk_handle *h) {
     AL(d.ctx.Lval, S.lval_len); AL(d.ctx.U0, S.ubuf_len[0]); AL(d.ctx.U1, S.ubuf_len[1]);
     // debugging aid: start from NaNs everywhere, so that a read of storage the factorisation never writes would show
     if (std::getenv("TLPK_POISON") && S.lval_len > 0) { HIPCHK(h, hipMemset(d.ctx.Lval, 0xFF, (size_t)S.lval_len * 8)); HIPCHK(h, hipDeviceSynchronize()); }
-    AL(d.ctx.uc, 2 * S.uc_len); AL(d.ctx.xw, 2 * S.m); AL(d.ctx.info, 4);      // two copies: the second right-hand side of tlpk_solve2_device
+    AL(d.ctx.uc, 2 * S.uc_len); AL(d.ctx.xw, 2 * S.m); AL(d.ctx.info, 16);      // two copies: the second right-hand side of tlpk_solve2_device
     d.ctx.xw2 = S.m; d.ctx.uc2 = S.uc_len; AL(d.ctx.dinv, S.dinv_len); AL(d.ctx.spart, S.spart_len);
     const i64 nn = std::max<i64>(S.n, S.k2_n + 1);             // K2: user vectors have k2_n entries, D2 one more
     AL(h->d_theta, nn); AL(h->d_regP, nn); AL(h->d_regD, S.m); AL(h->d_D, nn);
@@ -386,7 +386,7 @@ int upload_all(tlpk_handle *h) {
         if ((rc = dev_alloc(h, &blk, nt + 4 * S.m)) != TLPK_OK) return rc;       // [forward | backward] x two right-hand sides
         d.sweep_tickets = blk; d.sweep_xh = reinterpret_cast<double *>(blk + nt);
         d.sweep_reset_bytes = (nt + 2 * S.m) * 8; d.sweep_reset_bytes2 = (nt + 4 * S.m) * 8;
-        HIPCHK(h, hipMemset(d.ctx.info, 0, 4 * sizeof(int)));
+        HIPCHK(h, hipMemset(d.ctx.info, 0, 16 * sizeof(int)));
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_info, 4 * sizeof(int), hipHostMallocDefault));
     h->h_info[0] = h->h_info[1] = h->h_info[2] = h->h_info[3] = 0;
@@ -815,7 +815,23 @@ static int update_finish_wait(tlpk_handle *h) {
     float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->ms_update = ms;
     prof_collect(h);
     h->local_done = false;
-    if (h->d.n_chain_cnt > 0 && h->h_info[1] != 0) { h->last_error = "the dependency-driven factorisation gave up waiting for a completion counter (internal scheduling error); the factor is invalid"; return TLPK_INTERNAL; }
+    if (h->d.n_chain_cnt > 0 && h->h_info[1] != 0) {
+        if (std::getenv("TLPK_CHAIN_DEBUG")) {
+            int dbg[16] = {0}; (void)hipMemcpy(dbg, h->d.ctx.info, sizeof(dbg), hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[tlpk chain] rank %d: gave up at item %d (role %d, task %d): counter %d needs %d, has %d; workgroup %d of %d\n", h->opt.rank, dbg[4], dbg[5], dbg[11], dbg[6], dbg[7], dbg[8], dbg[9], dbg[10]);
+            std::vector<unsigned> cnt((size_t)h->d.n_chain_cnt); (void)hipMemcpy(cnt.data(), h->d.chain_cnt, cnt.size() * 4, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[tlpk chain] counters:");
+            for (size_t q = 0; q < std::min<size_t>(cnt.size(), 12); ++q) std::fprintf(stderr, " %u", cnt[q]);
+            std::fprintf(stderr, " ... (%zu words)\n", cnt.size());
+            for (const Launch &L : h->S.factor_launches) if (L.kind == LK_CHAIN) std::fprintf(stderr, "[tlpk chain] launch: %lld items, ticket word %d = %u\n", (long long)L.count, L.pad, cnt[(size_t)L.pad]);
+            if (h->d.chain_trace) {                               // TLPK_CHAIN_TRACE=1 as well: the items' time stamps go to the file TLPK_CHAIN_DEBUG names (+ .rank<r>.bin)
+                std::vector<unsigned long long> tr(4 * h->S.chain_items.size());
+                (void)hipMemcpy(tr.data(), h->d.chain_trace, tr.size() * 8, hipMemcpyDeviceToHost);
+                const std::string path = std::string(std::getenv("TLPK_CHAIN_DEBUG")) + ".rank" + std::to_string(h->opt.rank) + ".bin";
+                if (FILE *f = std::fopen(path.c_str(), "wb")) { std::fwrite(tr.data(), 8, tr.size(), f); std::fclose(f); std::fprintf(stderr, "[tlpk chain] time stamps of %zu items -> %s\n", h->S.chain_items.size(), path.c_str()); }
+            }
+        }
+        h->last_error = "the dependency-driven factorisation gave up waiting for a completion counter (internal scheduling error); the factor is invalid"; return TLPK_INTERNAL; }
     if (h->h_info[0] != INT_MAX) { h->fail_col = h->h_info[0]; return TLPK_NOT_POSDEF; }
     h->factored = true;
     return TLPK_OK;
