@@ -8,7 +8,7 @@ import numpy as np
 
 LK = dict(EXTEND_ADD=0, POTRF=1, TRSM=2, UPDATE=3, FWD_GATHER=4, FWD_DIAG=5, FWD_UPDATE=6,
           BWD_UPDATE=7, BWD_DIAG=8, ALLREDUCE=9, POTRF_WIDE=10, SIDE_FORK=11, SIDE_JOIN=12,
-          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17, FWD_SWEEP=18, BWD_SWEEP=19, FRONT_ASSEMBLE=20, WAIT_UPPER=21, CHAIN=22)
+          UPDATE_REDUCE=13, TRSM_THIN=14, FWD_SMALL=15, BWD_SMALL=16, POTRF_SMALL=17, FWD_SWEEP=18, BWD_SWEEP=19, FRONT_ASSEMBLE=20, WAIT_UPPER=21, CHAIN=22, UPDATE_T64=23)
 
 
 class Emulator:
@@ -195,6 +195,11 @@ class Emulator:
                     else:
                         self._k7(np.array([[front, 0, ns, ns, f - ns, 1]]))
                 continue
+            if kind == LK["UPDATE_T64"]:                         # the last partial round of the preceding update launch as 64 x 64 tiles: same task array
+                T = self.tasks[LK["UPDATE"]][first: first + count]
+                assert (T[:, 10] == 1).all() and (T[:, 7] == 0).all()
+                self._k3(T)
+                continue
             if kind == LK["TRSM_THIN"]:                          # same tasks, 256 rows per task
                 self._k2(self.tasks[LK["TRSM"]][first: first + count], rows_per_task=256)
                 continue
@@ -357,7 +362,15 @@ class Emulator:
             Pj = P[j0:j1][:, kcols]
             if self.k2:
                 Pj = Pj * self.sign[self.col0[front] + kcols][None, :]      # X S X'
-            G = P[i0:i1][:, kcols] @ Pj.T
+            if getattr(self, "exact_k_order", False):
+                # one multiply-add per K column and entry, in K order: the sum of an entry does not depend on the SHAPE of the tile that holds it (a BLAS
+                # product rounds differently for a 64-row and a 128-row operand) -- for tests that compare schedules with different tile shapes bit for bit
+                Pi = P[i0:i1][:, kcols]
+                G = np.zeros((i1 - i0, j1 - j0))
+                for q in range(len(kcols)):
+                    G += Pi[:, q:q + 1] * Pj[:, q][None, :]
+            else:
+                G = P[i0:i1][:, kcols] @ Pj.T
             if slot1:            # split-K part: raw tile to its scratch slot (each slot written exactly once)
                 assert int(slot1) - 1 not in self.spart
                 self.spart[int(slot1) - 1] = G

@@ -1060,3 +1060,32 @@ def test_diagonal_block_kernels_agree(system, monkeypatch):
         tk.solve(dx, dy, kkt, xp, xd)
         assert np.isfinite(dx).all() and np.isfinite(dy).all()
     kkt.close()
+
+
+@pytest.mark.gpu
+def test_update_tail_as_64x64_tiles_bits_equal_on_the_device(monkeypatch):
+    """Round 6: the last partial round of an update launch runs as 64 x 64 tiles (launch kind 23, k_update64 / update_tile64) behind the 128 x 128 tiles of the full
+    rounds.  Same K ranges and segment lists, every entry sums its K columns in the same order: the factor (every stored entry) and the solution must be BIT-identical to
+    the schedule without the tail shape (TLPK_TAIL64=0).  16 blocks of the bench shape in one stream group: launches of 300 - 1100 tiles."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from workloads import block_angular_lp, kernel_inputs
+    monkeypatch.setenv("TLPK_STREAMS", "1")
+    A, rb = block_angular_lp(16)
+    m, n = A.shape
+    th, rp, rd, xp, xd = kernel_inputs(m, n, 7, "mid")
+    outs = []
+    for tail in ("288", "0"):
+        monkeypatch.setenv("TLPK_TAIL64", tail)
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb))
+        kinds = kkt.symbolic("factor_launches").reshape(-1, 3)[:, 0]
+        assert ((kinds == 23).any()) == (tail != "0"), "launch kinds do not match TLPK_TAIL64=" + tail      # (the tail shape is an experiment that is off by default)
+        tk.update(kkt, th, rp, rd)
+        dx, dy = np.zeros(n), np.zeros(m)
+        tk.solve(dx, dy, kkt, xp, xd)
+        outs.append((kkt.factor_panels().copy(), dx, dy))
+        kkt.close()
+    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True), "the 64 x 64 tail tiles changed the factor"
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, outs[0][1], outs[0][2])
+    assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp).max(), np.abs(xd).max()))

@@ -135,6 +135,34 @@ def test_lookahead_level_cuts_every_long_update_by_k_length(monkeypatch):
     check_against_oracle(A, kkt, 3, tol=1e-8)
 
 
+def test_last_round_of_an_update_launch_as_64x64_tiles_same_bits(monkeypatch):
+    """Round 6: the tiles of an update launch's last partial round are cut into their 64 x 64 quarters (launch kind 23 behind the launch, UpdateTask.pad2 = 1).  Same K
+    ranges, same order of every entry's sum: the emulated factor must equal, BIT FOR BIT, the factor of the schedule without the tail shape -- and the oracle's.
+    (TLPK_TAIL64_SLOTS scales the device's 512 resident tiles down to this LP's launches.)"""
+    from emulate import Emulator
+    from helpers import ipm_like_data
+    A, rb = block_angular(nblocks=4, mk=300, nk=600, m0=200, nnz_in=3, link_prob=0.9, seed=5)
+    monkeypatch.setenv("TLPK_CHAIN", "0")
+    monkeypatch.setenv("TLPK_TAIL64_SLOTS", "4")
+    monkeypatch.setenv("TLPK_SPLITK_TILES", "0")          # (launches this small would otherwise be cut along K: the tail shape is for launches that fill the chip)
+    monkeypatch.setenv("TLPK_TAIL64", "3")
+    kkt = analyse_only(A, row_block=rb)
+    kinds = kkt.symbolic("factor_launches").reshape(-1, 3)
+    assert (kinds[:, 0] == 23).any(), "no launch took the tail shape"
+    ut = kkt.symbolic("update_tasks").reshape(-1, 10); t64 = kkt.symbolic("update_tile64")
+    for kind, first, count in kinds[kinds[:, 0] == 23]:
+        assert (t64[first:first + count] == 1).all() and (ut[first:first + count, 7] == 0).all()      # 64 x 64 tiles, never split-K parts
+    th, rp, rd, _, _ = ipm_like_data(kkt.m, kkt.n, 3)
+    em = Emulator(kkt); em.exact_k_order = True; em.update(th, rp, rd)
+    monkeypatch.setenv("TLPK_TAIL64", "0")
+    kkt0 = analyse_only(A, row_block=rb)
+    assert not (kkt0.symbolic("factor_launches").reshape(-1, 3)[:, 0] == 23).any()
+    em0 = Emulator(kkt0); em0.exact_k_order = True; em0.update(th, rp, rd)
+    assert em.fail_col is None and em0.fail_col is None
+    assert np.array_equal(em.dense_L(), em0.dense_L()), "the tail shape changed the factor"
+    check_against_oracle(A, kkt, 3, tol=1e-8)
+
+
 def singleton_rows_matrix(m=300, n0=200, seed=4):
     """A = [A0 I] where a third of the rows of A0 are empty: those rows only hold their slack, i.e. they
     are isolated 1 x 1 fronts of the normal equations (13 % of the rows of the headline instance)."""

@@ -2434,6 +2434,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_update(const Updat
 #endif
 }
 
+// The last partial round of an update launch as 64 x 64 tiles (LK_UPDATE_T64, symbolic.cpp: emit_update_launch): one update_tile64 per 4-wave workgroup, 40 KB of
+// LDS and at most 128 registers -- four workgroups per CU, the 16 waves per CU of the 128 x 128 kernel.
+template <bool SIGNED>
+__global__ __launch_bounds__(256, 4) void k_update64(const UpdateTask *__restrict__ tasks, DevCtx c) {
+    __shared__ double lds[4 * UPD_KT * U64_LD];
+    const UpdateTask *tp = tasks + blockIdx.x;
+    const UpdateTask t{tp->front, tp->k0, tp->kw, tp->i0, tp->j0, tp->jlim, tp->beta0, tp->pad1, tp->seg, tp->nsl, tp->pad2, 0};
+    const FrontDesc fd = c.fronts[t.front];
+    update_tile64<SIGNED>(t, fd, c, lds);
+}
+
 // Split-K: when an update launch has too few tiles to fill the chip, the K range of every tile is
 // cut into parts computed by different workgroups (k_update with pad1 != 0 writes the raw
 // 128 x 128 partial products to scratch); this kernel adds the parts of one tile in fixed order
@@ -3817,6 +3828,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
         if (ser && chain_ev[dev]) { (void)hipEventRecord(chain_ev[dev], st); chain_rec[dev] = true; }
         break;
     }
+    case LK_UPDATE_T64: TLPK_LAUNCH_S(k_update64, a.update_tasks); break;
     case LK_UPDATE_REDUCE: hipLaunchKernelGGL(k_update_reduce, dim3((unsigned)L.count * RED_SPLIT), dim3(256), 0, st, a.reduce_tasks + L.first, a.ctx); break;
     case LK_FWD_GATHER: hipLaunchKernelGGL(k_fwd_gather, g, dim3(256), 0, st, a.fwd_gather_tasks + L.first, a.ctx); break;
     case LK_FWD_DIAG: hipLaunchKernelGGL(k_fwd_diag, g, dim3(256), 0, st, a.fwd_diag_tasks + L.first, a.ctx); break;

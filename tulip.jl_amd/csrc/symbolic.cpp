@@ -1599,6 +1599,10 @@ static void build_schedule(Symbolic &S) {
         }
         i64 UPD_SLOTS = 0;
         if (const char *e = std::getenv("TLPK_TAIL_SLOTS")) UPD_SLOTS = std::atoll(e);       // tuning knob; 0 = no tail split
+        i64 TAIL64 = 0;                                                                        // last round of an update launch as 64 x 64 tiles when it holds at most this many tiles (0 = off: MEASURED SLOWER, see below)
+        if (const char *e = std::getenv("TLPK_TAIL64")) TAIL64 = std::max(0, std::atoi(e));   // tuning knob
+        i64 TAIL64_SLOTS = 512;                                                                // resident 128 x 128 tiles (2 workgroups x 256 CUs); TLPK_TAIL64_SLOTS: for the CPU tests of the tail shape on small LPs
+        if (const char *e = std::getenv("TLPK_TAIL64_SLOTS")) TAIL64_SLOTS = std::max(1, std::atoi(e));
         i32 KSPLIT_LEN = 0;                                                                  // look-ahead levels: longest K range of one update item (0 = off)
         if (const char *e = std::getenv("TLPK_KSPLIT_LEN")) KSPLIT_LEN = std::max(0, std::atoi(e));       // tuning knob (multiples of 16 keep the parts on slab boundaries)
         auto emit_update_launch = [&](auto &&gen) {
@@ -1665,7 +1669,37 @@ static void build_schedule(Symbolic &S) {
                 if (t_level < UPD_SLOTS) nsplit = best_parts(t_level);                    // a single, partly filled wave: cut every tile
                 else if (r > 0) { tail_parts = best_parts(r); tail_from = t_level - r; }  // the last wave
             }
-            if (nsplit < 2 && tail_parts < 2 && !ksplit) { emit(LK_UPDATE, f_upd, cnt); return; }
+            if (nsplit < 2 && tail_parts < 2 && !ksplit) {
+                // Round 6 (the review's tail shape): the chip holds 512 of a launch's 128 x 128 tiles at a time, and the r = tiles mod 512 tiles of the last round
+                // take a whole round -- 18 % of the serialised update time of config C4 (tools/update_launch_eff.py: 5.96 of 32.96 ms).  When r is small the last
+                // round's tiles are cut into their 64 x 64 quarters (UpdateTask.pad2 = 1, update_tile64: four waves per workgroup, four workgroups per CU): 4 r
+                // quarter-length items on 1024 slots, launched right behind the full rounds.  Same K ranges / segment lists, every entry sums its K columns in the
+                // same order: same bits (CPU emulator and device: tests/test_symbolic.py, tests/test_gpu_parity.py).  MEASURED (profiles/r06_tail64.txt) and OFF by default
+                // (TLPK_TAIL64=288 turns it on): C4 52.5 vs 51.5 ms per step, north-star 138.0 vs 136.6, and the serialised `roofline.frac` FALLS (0.633 vs 0.638, north-star
+                // 0.598 vs 0.620): a 128 x 128 tile that has its CU to itself in a half-empty last round runs at nearly twice the rate of two sharing the matrix pipes, the
+                // four quarter tiles re-read the operands and pay a launch boundary.  Not for the side stream's diagonal tiles (few, and the single-stream modes merge them with the rows-below launch by task
+                // range), not inside the dependency-driven launches (pass 2: their items are already finer), not for launches of less than one round.
+                i64 r = (TAIL64 > 0 && pass != 2 && cur_side == 0 && cnt >= TAIL64_SLOTS) ? cnt % TAIL64_SLOTS : 0;
+                if (r > TAIL64) r = 0;
+                if (r > 0) {
+                    std::vector<UpdateTask> tail(S.update_tasks.end() - r, S.update_tasks.end());
+                    S.update_tasks.resize(S.update_tasks.size() - (size_t)r);
+                    const i64 f_t64 = (i64)S.update_tasks.size();
+                    for (const UpdateTask &t : tail) {
+                        const FrontDesc &w = S.fronts[t.front];
+                        for (i32 dj = 0; dj < TILE; dj += 64)
+                            for (i32 di = 0; di < TILE; di += 64) {
+                                const i32 si = t.i0 + di, sj = t.j0 + dj;
+                                if (si >= w.f || sj >= t.jlim || si + 63 < sj) continue;      // outside the front / the column range / above the diagonal
+                                S.update_tasks.push_back(UpdateTask{t.front, t.k0, t.kw, si, sj, t.jlim, t.beta0, 0, t.seg, t.nsl, 1, 0});
+                            }
+                    }
+                    emit(LK_UPDATE, f_upd, cnt - r);
+                    emit(LK_UPDATE_T64, f_t64, (i64)S.update_tasks.size() - f_t64);
+                    return;
+                }
+                emit(LK_UPDATE, f_upd, cnt); return;
+            }
             std::vector<UpdateTask> orig(S.update_tasks.begin() + f_upd, S.update_tasks.end());
             S.update_tasks.resize(f_upd);
             const i64 f_red = (i64)S.reduce_tasks.size();

@@ -106,6 +106,7 @@ enum LaunchKind : i32 {
     LK_WAIT_UPPER,      // marker: from here on the group's stream touches panels of the UPPER fronts (front_upper): wait for their zero-fill + assembly
     LK_CHAIN            // round 6: the whole blocked factorisation of a level's multi-block-column fronts in ONE persistent launch (k_chain): update tiles,
                         // diagonal blocks, triangular solves and split-K reductions are ITEMS drawn from a ticket counter, released by completion counters
+    , LK_UPDATE_T64     // round 6: the LAST partial round of the preceding LK_UPDATE launch as 64 x 64 tiles (UpdateTask.pad2 = 1; k_update64: 4 waves per workgroup)
 };
 // ---- dependency-driven factorisation (LK_CHAIN, symbolic.cpp: build_schedule / kernels.hip: k_chain) ----
 // An item is one task of the ordinary kernels (an update tile, the diagonal block of a block column, a 64-row strip of a triangular solve, one eighth of a
