@@ -18,6 +18,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <mutex>
+#include <functional>
+#include <condition_variable>
 #include <map>
 #include <climits>
 
@@ -136,6 +139,76 @@ static unsigned host_threads(i64 n) {
     const i64 mine = std::getenv("TLPK_HOST_THREADS") ? cap : std::max<i64>(1, std::min<i64>(cap, std::max<i64>(16, hw / 4)) / g_host_thread_div);
     return (unsigned)std::max<i64>(1, std::min<i64>({(i64)hw, mine, n}));
 }
+// Round 6: the worker threads of ONE analyse call.  parallel_for used to create and join its threads on every call -- ~50 calls per analyse (two per level of the
+// supernodal tree alone) x up to 63 threads: tens of milliseconds of clone / join on a 250-ms analyse.  An AnalysePool lives for the duration of an analyse_common /
+// analyse_rank call (scope object: nothing survives the call, nothing to make fork-safe), its threads are created on first use and sleep on a condition variable
+// between jobs.  A job = (worker function, number of participants); thread t of the pool runs worker(t + 1), the caller runs worker(0) and waits for the rest.
+// Nested parallel_for calls (none today) and calls outside an analyse fall back to the create-and-join form.
+struct AnalysePool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    const std::function<void(unsigned)> *job = nullptr;
+    unsigned want = 0, done = 0;
+    unsigned long long gen = 0;
+    bool stop = false, busy = false;
+    ~AnalysePool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void loop(unsigned idx) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                if (idx < want) j = job;
+            }
+            if (j) {
+                (*j)(idx + 1);
+                std::lock_guard<std::mutex> lk(mu);
+                if (++done == want) cv_done.notify_one();
+            }
+        }
+    }
+    // runs worker(0 .. nthreads - 1); false = the pool cannot serve (busy: a nested call) and the caller must use its own threads
+    bool run(unsigned nthreads, const std::function<void(unsigned)> &worker) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (busy) return false;
+            busy = true;
+        }
+        unsigned helpers = nthreads - 1;
+        try { while (th.size() < helpers) { const unsigned idx = (unsigned)th.size(); th.emplace_back([this, idx] { loop(idx); }); } }
+        catch (...) { helpers = (unsigned)th.size(); }      // thread / pid limits of a container: go on with the threads we have (the workers drain the items whoever runs them)
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = &worker; want = helpers; done = 0; ++gen;
+        }
+        cv.notify_all();
+        worker(0);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return done == want; });
+            job = nullptr; want = 0; busy = false;
+        }
+        return true;
+    }
+};
+static thread_local AnalysePool *g_analyse_pool = nullptr;      // the pool of the analyse running on this thread (TLPK_ANALYSE_POOL=0: none)
+struct AnalysePoolScope {
+    AnalysePool pool; AnalysePool *prev;
+    AnalysePoolScope() : prev(g_analyse_pool) {
+        static const bool on = [] { const char *e = std::getenv("TLPK_ANALYSE_POOL"); return !e || std::atoi(e) != 0; }();
+        if (on && !prev) g_analyse_pool = &pool;
+    }
+    ~AnalysePoolScope() { g_analyse_pool = prev; }
+};
+
 // `chunk` consecutive items go to the same thread (neighbouring items usually write neighbouring memory:
 // item-by-item hand-out made the threads fight over cache lines on instances with 400 000 small fronts).
 template <class F>
@@ -148,6 +221,11 @@ static bool parallel_for(i64 n, unsigned nthreads, F &&fn, i64 chunk = 1) {
                 for (i64 i = i0; i < std::min(n, i0 + chunk); ++i) fn(tid, i);
         } catch (...) { failed = 1; }
     };
+    if (nthreads <= 1) { worker(0); return !failed; }
+    if (g_analyse_pool) {
+        const std::function<void(unsigned)> w = worker;
+        if (g_analyse_pool->run(nthreads, w)) return !failed;
+    }
     // A thread that cannot be created (thread / pid limits of a container) is not an error: the
     // threads that did start and the calling thread drain the work.  Nothing may escape while a
     // started thread is still joinable (the vector's destructor would call std::terminate).
@@ -187,6 +265,7 @@ struct PhaseTimer {
 int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *rowval, const double *nzval,
                    int base, const Options &opt) {
     PhaseTimer pt;
+    AnalysePoolScope pool_scope;
     g_host_thread_div = opt.analyse_div > 0 ? opt.analyse_div : std::max<i32>(1, opt.nranks);
     if (m64 < 0 || n64 < 0 || (base != 0 && base != 1) || !colptr) return fail(S, TLPK_BADARG, "bad dimensions or index base");
     if (m64 >= (i64)1 << 31 || n64 >= (i64)1 << 31) return fail(S, TLPK_TOO_LARGE, "m or n exceeds int32");
@@ -724,6 +803,7 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
 
 int analyse_rank(Symbolic &S, const Options &opt) {
     PhaseTimer pt;
+    AnalysePoolScope pool_scope;
     g_host_thread_div = opt.analyse_div > 0 ? opt.analyse_div : std::max<i32>(1, opt.nranks);
     const i32 m = (i32)S.m, n = (i32)S.n;
     const std::vector<i32> &row_block = S.row_block_v, &col_block = S.col_block_v, &sparent = S.sparent_v;
