@@ -246,6 +246,16 @@ static void parallel_for_throw(i64 n, unsigned nthreads, F &&fn, i64 chunk = 1) 
     if (!parallel_for(n, nthreads, std::forward<F>(fn), chunk)) throw std::bad_alloc();
 }
 
+// independent iterations over [0, n) in chunks of 64 K on the host threads (the element-wise relabelling loops of the analyse: 2e6 scattered 4-byte accesses each on
+// the north-star LP, 5 - 10 ms apiece on one thread)
+template <class F>
+static void par_chunks(i64 n, F &&fn) {
+    constexpr i64 CH = 65536;
+    const i64 nch = (n + CH - 1) / CH;
+    if (nch <= 1) { if (n > 0) fn((i64)0, n); return; }
+    parallel_for_throw(nch, host_threads(nch), [&](unsigned, i64 ch) { fn(ch * CH, std::min(n, (ch + 1) * CH)); });
+}
+
 // TLPK_TIMING=1: wall time of the analyse phases on stderr
 struct PhaseTimer {
     bool on; std::chrono::steady_clock::time_point t0; const char *name = nullptr;
@@ -441,7 +451,7 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
     pt.mark("etree");
     // ---- 5. elimination tree, postorder ----
     std::vector<i32> iperm0(m);
-    for (i32 i = 0; i < m; ++i) iperm0[order0[i]] = i;
+    par_chunks(m, [&](i64 lo, i64 hi) { for (i64 i = lo; i < hi; ++i) iperm0[order0[i]] = (i32)i; });
     std::vector<i32> parent0;
     if (opt.row_block && nblocks >= 2 && opt.ordering != TLPK_ORDER_USER) {
         // block-angular: the ordering lists block after block, then the linking rows.  The nodes of a block
@@ -461,18 +471,22 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
         etree_of(m, xadj, adj, order0, iperm0, parent0);
     // final order: postorder of the forest without the linking nodes, then the linking nodes
     std::vector<char> skip(m, 0);
-    for (i32 i = 0; i < m; ++i) skip[i] = is_link[order0[i]];
+    par_chunks(m, [&](i64 lo, i64 hi) { for (i64 i = lo; i < hi; ++i) skip[i] = is_link[order0[i]]; });
     std::vector<i32> post0;
     postorder_forest(m, parent0, nlink ? &skip : nullptr, post0);
     for (i32 i = 0; i < m; ++i) if (skip[i]) post0.push_back(i);
     if ((i32)post0.size() != m) return fail(S, TLPK_INTERNAL, "postorder lost nodes");
     S.perm.resize(m); S.iperm.resize(m);
     std::vector<i32> relabel(m);               // order0-label -> final label
-    for (i32 k = 0; k < m; ++k) { S.perm[k] = order0[post0[k]]; relabel[post0[k]] = k; }
-    for (i32 k = 0; k < m; ++k) S.iperm[S.perm[k]] = k;
+    par_chunks(m, [&](i64 lo, i64 hi) { for (i64 k = lo; k < hi; ++k) { S.perm[k] = order0[post0[k]]; relabel[post0[k]] = (i32)k; } });
+    par_chunks(m, [&](i64 lo, i64 hi) { for (i64 k = lo; k < hi; ++k) S.iperm[S.perm[k]] = (i32)k; });
     S.parent.assign(m, -1);
-    for (i32 v = 0; v < m; ++v) if (parent0[v] != -1) S.parent[relabel[v]] = relabel[parent0[v]];
-    for (i32 k = 0; k < m; ++k) if (S.parent[k] != -1 && S.parent[k] <= k) return fail(S, TLPK_INTERNAL, "etree not topological");
+    par_chunks(m, [&](i64 lo, i64 hi) { for (i64 v = lo; v < hi; ++v) if (parent0[v] != -1) S.parent[relabel[v]] = relabel[parent0[v]]; });
+    {
+        std::atomic<int> bad_topo{0};
+        par_chunks(m, [&](i64 lo, i64 hi) { for (i64 k = lo; k < hi; ++k) if (S.parent[k] != -1 && S.parent[k] <= k) bad_topo = 1; });
+        if (bad_topo) return fail(S, TLPK_INTERNAL, "etree not topological");
+    }
     const i32 first_link = m - nlink;
 
     pt.mark("pattern of S");
@@ -578,7 +592,7 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
         ns_total = (i32)sn_start.size() - 1;
         S.nsuper = ns_total;
         S.sn_of_col.resize(m);
-        for (i32 s = 0; s < ns_total; ++s) for (i32 j = sn_start[s]; j < sn_start[s + 1]; ++j) S.sn_of_col[j] = s;
+        par_chunks(ns_total, [&](i64 lo, i64 hi) { for (i64 s = lo; s < hi; ++s) for (i32 j = sn_start[s]; j < sn_start[s + 1]; ++j) S.sn_of_col[j] = (i32)s; });
         S.fronts.assign(ns_total, FrontDesc{});
         sparent.assign(ns_total, -1);
         for (i32 s = 0; s < ns_total; ++s) {
@@ -778,14 +792,20 @@ int analyse_common(Symbolic &S, i64 m64, i64 n64, const i64 *colptr, const i64 *
             if (counter != m) return fail(S, TLPK_INTERNAL, "amalgamation re-ordering lost columns");
             new_start.push_back(m);
             std::vector<i32> perm2(m), parent2(m, -1), cc2(m);
-            for (i32 k = 0; k < m; ++k) {
-                perm2[newpos[k]] = S.perm[k];
-                cc2[newpos[k]] = S.colcount[k];
-                if (S.parent[k] != -1) parent2[newpos[k]] = newpos[S.parent[k]];
-            }
+            par_chunks(m, [&](i64 lo, i64 hi) {
+                for (i64 k = lo; k < hi; ++k) {
+                    perm2[newpos[k]] = S.perm[k];
+                    cc2[newpos[k]] = S.colcount[k];
+                    if (S.parent[k] != -1) parent2[newpos[k]] = newpos[S.parent[k]];
+                }
+            });
             S.perm.swap(perm2); S.parent.swap(parent2); S.colcount.swap(cc2);
-            for (i32 k = 0; k < m; ++k) S.iperm[S.perm[k]] = k;
-            for (i32 k = 0; k < m; ++k) if (S.parent[k] != -1 && S.parent[k] <= k) return fail(S, TLPK_INTERNAL, "re-ordered etree not topological");
+            par_chunks(m, [&](i64 lo, i64 hi) { for (i64 k = lo; k < hi; ++k) S.iperm[S.perm[k]] = (i32)k; });
+            {
+                std::atomic<int> bad_topo{0};
+                par_chunks(m, [&](i64 lo, i64 hi) { for (i64 k = lo; k < hi; ++k) if (S.parent[k] != -1 && S.parent[k] <= k) bad_topo = 1; });
+                if (bad_topo) return fail(S, TLPK_INTERNAL, "re-ordered etree not topological");
+            }
             if (nlink) for (i32 k = first_link; k < m; ++k) if (!is_link[S.perm[k]]) return fail(S, TLPK_INTERNAL, "linking rows moved");
             sn_start.swap(new_start);
             pt.mark("amalgamation: pattern");
