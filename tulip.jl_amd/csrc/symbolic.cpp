@@ -2280,9 +2280,13 @@ static void build_schedule(Symbolic &S) {
         w.flagoff = 0;                       // handled by the sweep kernels (hand-over words are indexed by column)
         S.n_sweep_flags += 1;
     }
+    // (TLPK_SOLVE_SIDE=1, experiment, OFF: measured neutral on C4 / north-star -- 51.6 vs 51.5, 136.3 vs 136.5 ms -- and SLOWER on the latency-bound LPs, 25fv47 class 1.17
+    // vs 0.99 ms, pds class 14.05 vs 13.83: a fork / join costs more than the launch it takes off the chain; profiles/r06_solve_side.txt)
+    const bool solve_side = [] { const char *e = std::getenv("TLPK_SOLVE_SIDE"); return e && std::atoi(e) != 0; }();
     auto fwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
         const bool root_level = (d == 0 && S.root_front >= 0);
+        i64 small_first = 0, small_count = 0;
         {
             const i64 first = (i64)S.fwd_gather_tasks.size();
             for (i32 t = t0; t < t1; ++t) {
@@ -2311,7 +2315,10 @@ static void build_schedule(Symbolic &S) {
                 if (in_scope(s) && is_small(s)) S.fwd_small_tasks.push_back(SolveTask{s, 0, S.fronts[s].ns, 0, 0, 0, 0, 0});
             }
             while (((i64)S.fwd_small_tasks.size() - first) % 4) S.fwd_small_tasks.push_back(SolveTask{-1, 0, 0, 0, 0, 0, 0, 0});
-            push_launch(S.fwd_launches, LK_FWD_SMALL, first, ((i64)S.fwd_small_tasks.size() - first) / 4);
+            // Round 6: the small fronts of a level beside its sweep (the group's side stream, forked behind the gather and joined in front of the next level's gather)
+            // when the level has both: different fronts of one level, nothing in common but the gathered right-hand side.  One launch off the level's chain -- what a
+            // latency-bound LP pays per launch, and on the north-star LP the small-front kernels were 0.8 of the 6.5 ms of a solve.  MEASURED and left OFF (see `solve_side`).
+            small_first = first; small_count = ((i64)S.fwd_small_tasks.size() - first) / 4;
         }
         i32 max_ns = 0;
         for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t]) && !is_small(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
@@ -2344,9 +2351,17 @@ static void build_schedule(Symbolic &S) {
                         if (r0 < w.f) S.fwd_sweep_tasks.push_back(SolveTask{s, r0, r1 - r0, 0, 0, nblk, 0, 0});
                     }
                 }
-            push_launch(S.fwd_launches, LK_FWD_SWEEP, first, (i64)S.fwd_sweep_tasks.size() - first);
+            const i64 sweep_count = (i64)S.fwd_sweep_tasks.size() - first;
+            const bool beside = solve_side && small_count > 0 && sweep_count > 0;
+            if (beside) { S.fwd_launches.push_back(Launch{LK_SIDE_FORK, cur_g, 0, 0, 0, 0}); cur_side = 1; }
+            push_launch(S.fwd_launches, LK_FWD_SMALL, small_first, small_count);
+            cur_side = 0;
+            push_launch(S.fwd_launches, LK_FWD_SWEEP, first, sweep_count);
+            if (beside) S.fwd_launches.push_back(Launch{LK_SIDE_JOIN, cur_g, 0, 0, 0, 0});
+            small_count = 0;
             max_ns = 0;        // no per-block launches
         }
+        push_launch(S.fwd_launches, LK_FWD_SMALL, small_first, small_count);      // (TLPK_SWEEP=0: in stream order)
         for (i32 kb = 0; kb < max_ns; kb += SOLVE_NB) {
             const i64 f_diag = (i64)S.fwd_diag_tasks.size(), f_upd = (i64)S.fwd_update_tasks.size();
             // pass 0: the look-ahead workgroups (first row chunk: they also solve the next diagonal
@@ -2391,6 +2406,7 @@ static void build_schedule(Symbolic &S) {
     // and number of source rows, nslot != 0 = also solve the diagonal block k0.
     auto bwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
+        i64 small_first = 0, small_count = 0;
         {
             const i64 first = (i64)S.bwd_small_tasks.size();
             for (i32 t = t0; t < t1; ++t) {
@@ -2398,7 +2414,7 @@ static void build_schedule(Symbolic &S) {
                 if (in_scope(s) && is_small(s)) S.bwd_small_tasks.push_back(SolveTask{s, 0, S.fronts[s].ns, 0, 0, 0, 0, 0});
             }
             while (((i64)S.bwd_small_tasks.size() - first) % 4) S.bwd_small_tasks.push_back(SolveTask{-1, 0, 0, 0, 0, 0, 0, 0});
-            push_launch(S.bwd_launches, LK_BWD_SMALL, first, ((i64)S.bwd_small_tasks.size() - first) / 4);
+            small_first = first; small_count = ((i64)S.bwd_small_tasks.size() - first) / 4;      // (beside the level's sweep: see fwd_level)
         }
         i32 max_ns = 0;
         for (i32 t = t0; t < t1; ++t) if (in_scope(S.level_fronts[t]) && !is_small(S.level_fronts[t])) max_ns = std::max(max_ns, S.fronts[S.level_fronts[t]].ns);
@@ -2418,9 +2434,17 @@ static void build_schedule(Symbolic &S) {
                     const i32 kb = my_nblk - 1 - dd;
                     S.bwd_sweep_tasks.push_back(SolveTask{s, kb * SWEEP_NB, std::min(SWEEP_NB, w.ns - kb * SWEEP_NB), w.ns, w.f - w.ns, dd, 0, 0});
                 }
-            push_launch(S.bwd_launches, LK_BWD_SWEEP, first, (i64)S.bwd_sweep_tasks.size() - first);
+            const i64 sweep_count = (i64)S.bwd_sweep_tasks.size() - first;
+            const bool beside = solve_side && small_count > 0 && sweep_count > 0;
+            if (beside) { S.bwd_launches.push_back(Launch{LK_SIDE_FORK, cur_g, 0, 0, 0, 0}); cur_side = 1; }
+            push_launch(S.bwd_launches, LK_BWD_SMALL, small_first, small_count);
+            cur_side = 0;
+            push_launch(S.bwd_launches, LK_BWD_SWEEP, first, sweep_count);
+            if (beside) S.bwd_launches.push_back(Launch{LK_SIDE_JOIN, cur_g, 0, 0, 0, 0});
+            small_count = 0;
             nblk = 0;
         }
+        push_launch(S.bwd_launches, LK_BWD_SMALL, small_first, small_count);      // (TLPK_SWEEP=0: in stream order)
         for (i32 b = 0; b < nblk; ++b) {
             const i64 f_upd = (i64)S.bwd_update_tasks.size();
             // pass 0: the workgroups that also solve a diagonal block (critical path) start first
