@@ -183,17 +183,7 @@ class Emulator:
             if kind in (LK["FWD_SMALL"], LK["BWD_SMALL"]):      # count = workgroups of 4 fronts (list padded with -1)
                 T = self.tasks[kind][first: first + 4 * count]
                 assert len(T) == 4 * count
-                for front, _, nb, *_r in T:
-                    if front < 0:
-                        continue
-                    f, ns = int(self.f[front]), int(self.ns[front])
-                    assert nb == ns and ns <= 16
-                    if kind == LK["FWD_SMALL"]:
-                        self._k5(np.array([[front, 0, ns, 0, 0, 0]]))
-                        for r0 in range(ns, f, 256):
-                            self._k6(np.array([[front, 0, ns, r0, 0, 0]]))
-                    else:
-                        self._k7(np.array([[front, 0, ns, ns, f - ns, 1]]))
+                self._small_groups(kind, T)
                 continue
             if kind == LK["UPDATE_T64"]:                         # the last partial round of the preceding update launch as 64 x 64 tiles: same task array
                 T = self.tasks[LK["UPDATE"]][first: first + count]
@@ -206,6 +196,20 @@ class Emulator:
             T = self.tasks[kind][first: first + count]
             getattr(self, "_k%d" % kind)(T)
         return len(launches)
+
+    def _small_groups(self, kind, T):
+        """Small fronts (<= 16 pivot columns), one wave per front: the bodies of k_fwd_small / k_bwd_small -- also the small-front items of a merged sweep launch."""
+        for front, _, nb, *_r in T:
+            if front < 0:
+                continue
+            f, ns = int(self.f[front]), int(self.ns[front])
+            assert nb == ns and ns <= 16
+            if kind == LK["FWD_SMALL"]:
+                self._k5(np.array([[front, 0, ns, 0, 0, 0]]))
+                for r0 in range(ns, f, 256):
+                    self._k6(np.array([[front, 0, ns, r0, 0, 0]]))
+            else:
+                self._k7(np.array([[front, 0, ns, ns, f - ns, 1]]))
 
     def _chain(self, items):
         """k_chain: the items of one dependency-driven launch, executed in TICKET order.  Every wait must already be satisfied when its item's turn comes:
@@ -542,6 +546,9 @@ class Emulator:
         import scipy.linalg as sla
         pub = set()
         for front, k0, nb, _r0, pivot, nin in T:
+            if pivot == 2:                                        # a group of four small fronts riding in the sweep's launch (round 6)
+                self._small_groups(LK["FWD_SMALL"], self.tasks[LK["FWD_SMALL"]][4 * k0: 4 * k0 + 4])
+                continue
             P = self.panel(front); c0 = int(self.col0[front])
             f, ns = int(self.f[front]), int(self.ns[front])
             assert self.flagoff[front] >= 0
@@ -565,6 +572,9 @@ class Emulator:
         import scipy.linalg as sla
         pub = set()
         for front, k0, nb, row0, nrows, nlater in T:
+            if nlater == -2:                                      # a group of four small fronts riding in the sweep's launch (round 6)
+                self._small_groups(LK["BWD_SMALL"], self.tasks[LK["BWD_SMALL"]][4 * k0: 4 * k0 + 4])
+                continue
             P = self.panel(front); c0 = int(self.col0[front])
             f, ns = int(self.f[front]), int(self.ns[front])
             rows = self.rows(front)

@@ -3236,13 +3236,33 @@ __device__ __forceinline__ void fwd_sweep_item(const SolveTask &t, const FrontDe
     }
 }
 
-template <int NR>
-__global__ __launch_bounds__(256, NR == 1 ? 4 : 3) void k_fwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
+template <int NSM> __device__ __forceinline__ void fwd_small_body(const FrontDesc &fd, const DevCtx &c, const int lane);      // (defined with k_fwd_small / k_bwd_small below)
+template <int NSM> __device__ __forceinline__ void bwd_small_body(const FrontDesc &fd, const DevCtx &c, const int lane);
+// WS (round 6): the launch also holds the level's SMALL fronts, as items with slot == 2 (k0 = a group of four tasks of a.small: one front per wave, the bodies of
+// k_fwd_small / k_bwd_small).  Only for levels whose sweep is a few hundred items (symbolic.cpp: TLPK_SOLVE_MERGE) -- the latency-bound LPs, where a launch costs more than
+// the fronts in it: one launch per level and direction less (25fv47 class: 19 -> 14 launches per solve).  The bandwidth-bound levels keep the two kernels: the small-front
+// body needs 136 registers, the sweeps run four waves per SIMD on 113.
+template <int NR, bool WS = false>
+__global__ __launch_bounds__(256, WS ? (NR == 1 ? 3 : 2) : (NR == 1 ? 4 : 3)) void k_fwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
     __shared__ double scratch[FWD_DIAG_SCRATCH];
     __shared__ unsigned s_item;
     if (threadIdx.x == 0) s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) + 1ULL);      // the counter starts at all ones (see SweepArgs): first ticket = 0
     __syncthreads();
     const SolveTask t = tasks[s_item];
+    if (WS && t.slot == 2) {                                     // (workgroup-uniform) four small fronts, one per wave
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const SolveTask ts = a.small[(i64)t.k0 * 4 + wave];
+        if (ts.front < 0) return;
+        const FrontDesc fs = c.fronts[ts.front];
+        const bool few = fs.ns <= 4 && !c.small_full;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            DevCtx cr = c;
+            if (r) { cr.xw += c.xw2; cr.uc += c.uc2; }
+            if (few) fwd_small_body<4>(fs, cr, lane); else fwd_small_body<SMALL_NS>(fs, cr, lane);
+        }
+        return;
+    }
     const FrontDesc fd = c.fronts[t.front];
     if (t.slot) fwd_sweep_item<true, NR>(t, fd, c, a, scratch);         // workgroup-uniform
     else fwd_sweep_item<false, NR>(t, fd, c, a, scratch);
@@ -3253,7 +3273,7 @@ __global__ __launch_bounds__(256, NR == 1 ? 4 : 3) void k_fwd_sweep(const SolveT
 // front, consumed as they are published (last block first); then x = W' t and the publish.  Lanes run along the 64
 // contiguous rows of a tile, a wave owns 16 of the columns and keeps per-lane partial sums over ALL tiles (one
 // shuffle reduction at the end).
-template <int NR>
+template <int NR, bool WS = false>
 __global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_bwd_sweep(const SolveTask *__restrict__ tasks, DevCtx c, SweepArgs a) {
     __shared__ double red[NB_IN][NB_IN + 1];        // per-lane partial sums of the 64 columns, transposed reduction
     __shared__ double ts[NB_IN], bsh[NR][NB_IN];
@@ -3264,6 +3284,19 @@ __global__ __launch_bounds__(256, NR == 1 ? 3 : 2) void k_bwd_sweep(const SolveT
     if (tid == 0) s_item = (unsigned)(atomicAdd(a.ticket, 1ULL) + 1ULL);
     __syncthreads();
     const SolveTask t = tasks[s_item];
+    if (WS && t.nslot == -2) {                                   // (workgroup-uniform) four small fronts of the level, one per wave (see k_fwd_sweep)
+        const SolveTask tsm = a.small[(i64)t.k0 * 4 + wave];
+        if (tsm.front < 0) return;
+        const FrontDesc fs = c.fronts[tsm.front];
+        const bool few = fs.ns <= 4 && !c.small_full;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            DevCtx cr = c;
+            if (r) { cr.xw += c.xw2; cr.uc += c.uc2; }
+            if (few) bwd_small_body<4>(fs, cr, lane); else bwd_small_body<SMALL_NS>(fs, cr, lane);
+        }
+        return;
+    }
     const FrontDesc fd = c.fronts[t.front];
     const i32 f = fd.f, ns = fd.ns, nb = t.nb;
     const i32 *rows = c.rowidx + fd.rowoff;
@@ -3723,8 +3756,16 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
     const dim3 g((unsigned)L.count);
     const bool sgn = a.ctx.csign != nullptr;                  // K2: signed Cholesky
     if (nrhs == 2) {
-        if (L.kind == LK_FWD_SWEEP) { if (sw) hipLaunchKernelGGL(k_fwd_sweep<2>, g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw); return; }
-        if (L.kind == LK_BWD_SWEEP) { if (sw) hipLaunchKernelGGL(k_bwd_sweep<2>, g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw); return; }
+        if (L.kind == LK_FWD_SWEEP) {
+            if (sw && L.pad) hipLaunchKernelGGL((k_fwd_sweep<2, true>), g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw);
+            else if (sw) hipLaunchKernelGGL(k_fwd_sweep<2>, g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw);
+            return;
+        }
+        if (L.kind == LK_BWD_SWEEP) {
+            if (sw && L.pad) hipLaunchKernelGGL((k_bwd_sweep<2, true>), g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw);
+            else if (sw) hipLaunchKernelGGL(k_bwd_sweep<2>, g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw);
+            return;
+        }
         // round 6: the kernels of a pair that are not sweeps run BOTH right-hand sides in one launch (grid y = right-hand side; round 5 measured that launching
         // them once per right-hand side was the whole 1.13 - 1.21 x of a pair over a single solve, profiles/r05_solve_one_group.txt).  Same arithmetic per
         // right-hand side: the pair stays bit-identical to two solves.
@@ -3836,8 +3877,14 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
     case LK_BWD_UPDATE: hipLaunchKernelGGL(k_bwd_update, g, dim3(256), 0, st, a.bwd_update_tasks + L.first, a.ctx); break;
     case LK_FWD_SMALL: hipLaunchKernelGGL(k_fwd_small, g, dim3(256), 0, st, a.fwd_small_tasks + L.first, a.ctx); break;
     case LK_BWD_SMALL: hipLaunchKernelGGL(k_bwd_small, g, dim3(256), 0, st, a.bwd_small_tasks + L.first, a.ctx); break;
-    case LK_FWD_SWEEP: if (sw) hipLaunchKernelGGL(k_fwd_sweep<1>, g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw); break;
-    case LK_BWD_SWEEP: if (sw) hipLaunchKernelGGL(k_bwd_sweep<1>, g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw); break;
+    case LK_FWD_SWEEP:
+        if (sw && L.pad) hipLaunchKernelGGL((k_fwd_sweep<1, true>), g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw);
+        else if (sw) hipLaunchKernelGGL(k_fwd_sweep<1>, g, dim3(256), 0, st, a.fwd_sweep_tasks + L.first, a.ctx, *sw);
+        break;
+    case LK_BWD_SWEEP:
+        if (sw && L.pad) hipLaunchKernelGGL((k_bwd_sweep<1, true>), g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw);
+        else if (sw) hipLaunchKernelGGL(k_bwd_sweep<1>, g, dim3(256), 0, st, a.bwd_sweep_tasks + L.first, a.ctx, *sw);
+        break;
     default: break;
     }
 #undef TLPK_LAUNCH_S

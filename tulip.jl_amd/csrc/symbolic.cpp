@@ -2282,6 +2282,7 @@ static void build_schedule(Symbolic &S) {
     }
     // (TLPK_SOLVE_SIDE=1, experiment, OFF: measured neutral on C4 / north-star -- 51.6 vs 51.5, 136.3 vs 136.5 ms -- and SLOWER on the latency-bound LPs, 25fv47 class 1.17
     // vs 0.99 ms, pds class 14.05 vs 13.83: a fork / join costs more than the launch it takes off the chain; profiles/r06_solve_side.txt)
+    const i64 solve_merge = [] { const char *e = std::getenv("TLPK_SOLVE_MERGE"); return e ? (i64)std::max(0, std::atoi(e)) : (i64)256; }();
     const bool solve_side = [] { const char *e = std::getenv("TLPK_SOLVE_SIDE"); return e && std::atoi(e) != 0; }();
     auto fwd_level = [&](i32 d) {
         const i32 t0 = S.level_ptr[d], t1 = S.level_ptr[d + 1];
@@ -2351,12 +2352,25 @@ static void build_schedule(Symbolic &S) {
                         if (r0 < w.f) S.fwd_sweep_tasks.push_back(SolveTask{s, r0, r1 - r0, 0, 0, nblk, 0, 0});
                     }
                 }
-            const i64 sweep_count = (i64)S.fwd_sweep_tasks.size() - first;
+            i64 sweep_count = (i64)S.fwd_sweep_tasks.size() - first;
+            // Round 6: on a level whose sweep is small (at most TLPK_SOLVE_MERGE = 256 items) the small fronts ride in the sweep's launch, as items of their own behind
+            // the sweep's (slot = 2, k0 = a group of four small-front tasks; no dependencies: any ticket will do) -- one launch per level and direction less where a
+            // launch costs more than the fronts in it.  Same bodies, same arithmetic.
+            bool merged = false;
+            if (solve_merge > 0 && small_count > 0 && sweep_count > 0 && sweep_count <= solve_merge) {
+                for (i64 g = 0; g < small_count; ++g) {
+                    i32 fr = -1;
+                    for (int u = 0; u < 4; ++u) if (S.fwd_small_tasks[(size_t)(small_first + 4 * g + u)].front >= 0) { fr = S.fwd_small_tasks[(size_t)(small_first + 4 * g + u)].front; break; }
+                    S.fwd_sweep_tasks.push_back(SolveTask{fr, (i32)(small_first / 4 + g), 0, 0, 2, 0, 0, 0});
+                }
+                sweep_count += small_count; small_count = 0; merged = true;
+            }
             const bool beside = solve_side && small_count > 0 && sweep_count > 0;
             if (beside) { S.fwd_launches.push_back(Launch{LK_SIDE_FORK, cur_g, 0, 0, 0, 0}); cur_side = 1; }
             push_launch(S.fwd_launches, LK_FWD_SMALL, small_first, small_count);
             cur_side = 0;
             push_launch(S.fwd_launches, LK_FWD_SWEEP, first, sweep_count);
+            if (merged) S.fwd_launches.back().pad = 1;
             if (beside) S.fwd_launches.push_back(Launch{LK_SIDE_JOIN, cur_g, 0, 0, 0, 0});
             small_count = 0;
             max_ns = 0;        // no per-block launches
@@ -2434,12 +2448,22 @@ static void build_schedule(Symbolic &S) {
                     const i32 kb = my_nblk - 1 - dd;
                     S.bwd_sweep_tasks.push_back(SolveTask{s, kb * SWEEP_NB, std::min(SWEEP_NB, w.ns - kb * SWEEP_NB), w.ns, w.f - w.ns, dd, 0, 0});
                 }
-            const i64 sweep_count = (i64)S.bwd_sweep_tasks.size() - first;
+            i64 sweep_count = (i64)S.bwd_sweep_tasks.size() - first;
+            bool merged = false;
+            if (solve_merge > 0 && small_count > 0 && sweep_count > 0 && sweep_count <= solve_merge) {      // (see fwd_level; here nslot = -2 marks the group)
+                for (i64 g = 0; g < small_count; ++g) {
+                    i32 fr = -1;
+                    for (int u = 0; u < 4; ++u) if (S.bwd_small_tasks[(size_t)(small_first + 4 * g + u)].front >= 0) { fr = S.bwd_small_tasks[(size_t)(small_first + 4 * g + u)].front; break; }
+                    S.bwd_sweep_tasks.push_back(SolveTask{fr, (i32)(small_first / 4 + g), 0, 0, 0, -2, 0, 0});
+                }
+                sweep_count += small_count; small_count = 0; merged = true;
+            }
             const bool beside = solve_side && small_count > 0 && sweep_count > 0;
             if (beside) { S.bwd_launches.push_back(Launch{LK_SIDE_FORK, cur_g, 0, 0, 0, 0}); cur_side = 1; }
             push_launch(S.bwd_launches, LK_BWD_SMALL, small_first, small_count);
             cur_side = 0;
             push_launch(S.bwd_launches, LK_BWD_SWEEP, first, sweep_count);
+            if (merged) S.bwd_launches.back().pad = 1;
             if (beside) S.bwd_launches.push_back(Launch{LK_SIDE_JOIN, cur_g, 0, 0, 0, 0});
             small_count = 0;
             nblk = 0;

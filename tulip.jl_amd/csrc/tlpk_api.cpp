@@ -227,7 +227,7 @@ void run_launches(tlpk_handle *h, const std::vector<Launch> &L, size_t from, siz
         }
         if (cur.kind == LK_FWD_SWEEP || cur.kind == LK_BWD_SWEEP) {
             const i32 slot = (dir == 0 ? h->sweep_slot_fwd : h->sweep_slot_bwd)[i];
-            SweepArgs sw{h->d.sweep_tickets + slot, h->d.sweep_xh + (dir == 0 ? 0 : h->S.m), 2 * h->S.m, h->poll[0], h->poll[1], h->poll[2]};
+            SweepArgs sw{h->d.sweep_tickets + slot, h->d.sweep_xh + (dir == 0 ? 0 : h->S.m), 2 * h->S.m, h->poll[0], h->poll[1], h->poll[2], dir == 0 ? h->d.fwd_small_tasks : h->d.bwd_small_tasks};
             launch_tasks(st, h->d, cur, &sw, nrhs);
         } else
             launch_tasks(st, h->d, cur, nullptr, nrhs);

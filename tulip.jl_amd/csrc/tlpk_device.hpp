@@ -36,6 +36,7 @@ struct SweepArgs {
     double *xh;                   // hand-over words of this direction, one per permuted column, sentinel-filled before the solve
     i64 xh2;                      // ... of the second right-hand side at xh + xh2 (two-rhs sweeps)
     int poll_fast, poll_nfast, poll_slow;   // polling back-off (units of s_sleep 1 = 64 clocks): first poll_nfast polls every poll_fast, then every poll_slow
+    const SolveTask *small = nullptr;       // round 6: the small-front tasks of this direction (items with slot == 2 of a merged launch name groups of four of them)
 };
 
 struct DevArrays {
