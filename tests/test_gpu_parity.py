@@ -1089,3 +1089,25 @@ def test_update_tail_as_64x64_tiles_bits_equal_on_the_device(monkeypatch):
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
     r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, outs[0][1], outs[0][2])
     assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp).max(), np.abs(xd).max()))
+
+
+@pytest.mark.gpu
+def test_eight_shards_on_one_device_thirty_updates_never_give_up():
+    """Regression test of the round-6 freeze (profiles/r06_chain_poll_storm.txt): eight shards of a multi-device handle on ONE GPU = eight dependency-driven launches
+    enqueued at the same moment.  Side by side they froze (workgroups standing still inside their role while the rest of the device spun) and `update!` came back with
+    TLPK_INTERNAL in 15 - 40 % of the runs of the five-update test above; a launch now waits for the previous chain launch on its device.  Thirty updates in a row,
+    every one must succeed, and the last factor must solve the system."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from workloads import block_angular_lp, kernel_inputs
+    A, rb = block_angular_lp(32)
+    m, n = A.shape
+    th, rp, rd, xp, xd = kernel_inputs(m, n, 11, "mid")
+    kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb, ngpus=8, devices=[0] * 8))
+    for _ in range(30):
+        tk.update(kkt, th, rp, rd)           # raises on TLPK_INTERNAL
+    dx, dy = np.zeros(n), np.zeros(m)
+    tk.solve(dx, dy, kkt, xp, xd)
+    r1, r2 = kkt_residuals(A, th, rp, rd, xp, xd, dx, dy)
+    assert max(r1, r2) <= 1e-8 * (1 + max(np.abs(xp).max(), np.abs(xd).max()))
+    kkt.close()
