@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_zero_panels(const i32 *__restrict__ tas
 }
 
 __global__ __launch_bounds__(256) void k_zero_small(const i32 *__restrict__ fronts, i64 n, DevCtx c) {      // one wave per small front
-    const i64 idx = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const i64 idx = (i64)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (idx >= n) return;
     const FrontDesc fd = c.fronts[fronts[idx]];
     const i64 len = (i64)fd.lda * fd.ns;
@@ -1365,7 +1365,8 @@ static_assert(NB_IN * LDW >= POTRF_SCRATCH && NB_IN * LDW >= POTRF_PAIR_SCRATCH 
 // its column and is replaced by 1.
 template <bool SIGNED>
 __global__ __launch_bounds__(256) void k_potrf_small(const PotrfTask *__restrict__ tasks, DevCtx c) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform: task and front descriptor in scalar registers)
     const PotrfTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
@@ -3250,7 +3251,8 @@ __global__ __launch_bounds__(256, WS ? (NR == 1 ? 3 : 2) : (NR == 1 ? 4 : 3)) vo
     __syncthreads();
     const SolveTask t = tasks[s_item];
     if (WS && t.slot == 2) {                                     // (workgroup-uniform) four small fronts, one per wave
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const SolveTask ts = a.small[(i64)t.k0 * 4 + wave];
         if (ts.front < 0) return;
         const FrontDesc fs = c.fronts[ts.front];
@@ -3474,7 +3476,8 @@ __device__ __forceinline__ void fwd_small_body(const FrontDesc &fd, const DevCtx
 }
 __global__ __launch_bounds__(256) void k_fwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
     if (blockIdx.y) { c.xw += c.xw2; c.uc += c.uc2; }      // second right-hand side of a pair: its copies of xw / uc (one launch for both)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform, and the compiler must know: task, front descriptor and every column base stay in scalar registers)
     const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
@@ -3515,22 +3518,27 @@ __device__ __forceinline__ void bwd_small_body(const FrontDesc &fd, const DevCtx
     }
 #pragma unroll
     for (int k = 0; k < NSM; ++k) acc[k] = (k < ns) ? acc[k] : 0.0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int k = 0; k < NSM; ++k) acc[k] += __shfl_down(acc[k], off);
-    }
+    // (four columns at a time: sixteen shuffles in flight held 60 temporaries and the kernel at two waves per SIMD)
     double x = 0.0;                                                  // x[i] = sum_{k >= i} W[k][i] (b[k] - sum[k])
 #pragma unroll
-    for (int k = 0; k < NSM; ++k) {
-        const double tk = bv[k] - readlane_f64(acc[k], 0);            // (lane 0's sum through scalar registers)
-        x += (k < ns && k >= lane) ? wv[k] * tk : 0.0;
+    for (int k0 = 0; k0 < NSM; k0 += 4) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = k0; k < k0 + 4; ++k) acc[k] += __shfl_down(acc[k], off);
+        }
+#pragma unroll
+        for (int k = k0; k < k0 + 4; ++k) {
+            const double tk = bv[k] - readlane_f64(acc[k], 0);        // (lane 0's sum through scalar registers)
+            x += (k < ns && k >= lane) ? wv[k] * tk : 0.0;
+        }
     }
     if (lane < ns) xs[lane] = x;
 }
 __global__ __launch_bounds__(256) void k_bwd_small(const SolveTask *__restrict__ tasks, DevCtx c) {
     if (blockIdx.y) { c.xw += c.xw2; c.uc += c.uc2; }      // second right-hand side of a pair: its copies of xw / uc (one launch for both)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform, and the compiler must know: task, front descriptor and every column base stay in scalar registers)
     const SolveTask t = tasks[(i64)blockIdx.x * 4 + wave];
     if (t.front < 0) return;
     const FrontDesc fd = c.fronts[t.front];
