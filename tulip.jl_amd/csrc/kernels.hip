@@ -1735,7 +1735,7 @@ __global__ __launch_bounds__(256, 2) void k_potrf_wide(const PotrfTask *__restri
 // every following step).
 // SIGNED: the registers keep B Linv' = X S (what the later steps of the block column need: B_i -= sum_j X_j S_j L_ij');
 // the stored factor block X gets its column signs only at the final store.
-template <bool SIGNED>
+template <bool SIGNED, bool FULLW>
 __device__ __forceinline__ void trsm_task(const TrsmTask t, const FrontDesc &fd, const DevCtx &c, double (*Wb)[NB_IN * LDW]) {
     // two operand buffers: the block staged for step n + 1 never overwrites what slower waves still read for step n, so a
     // step needs ONE barrier (after its stores) instead of two
@@ -1754,7 +1754,21 @@ __device__ __forceinline__ void trsm_task(const TrsmTask t, const FrontDesc &fd,
     // step's last column (in bounds) and count as zero.  The rows of step i are loaded two steps ahead of their use (not all
     // four up front: the registers of the late steps are free for the operand prefetch meanwhile, nothing is spilled while
     // the loads are in flight).
+    // (round 6) Full-width block columns (w == 256, all but a front's last): addresses as a wave-uniform base -- the step's slice, advanced by four columns per
+    // fragment in scalar registers -- plus ONE 32-bit lane offset (row + lk columns), for the loads of the rows, the fetches of the shared blocks and the stores.
+    // The general form computes a 64-bit address per lane and load (clamped columns): in a kernel that holds 16 rows x 256 columns per wave in registers that was
+    // 40 spilled registers and 164 bytes of scratch per lane (92 scratch instructions between the products).
+    constexpr bool fullw = FULLW;                                     // (the caller checks w == NB_OUT)
     auto load_step = [&](const int i) {
+        if constexpr (fullw) {
+            const i32 ldi = lda - (k0 + 64 * i);
+            const char *Pb = reinterpret_cast<const char *>(pcol(c, fd, k0 + 64 * i));      // (uniform)
+            unsigned vo = (unsigned)((i64)rowc + (i64)lk * ldi) * 8u;
+            asm volatile("" : "+v"(vo));
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) bf[i][ks] = *reinterpret_cast<const double *>(Pb + (size_t)(4 * ks) * (size_t)ldi * 8u + vo);
+            return;
+        }
         const i32 wi = min(max(w - 64 * i, 1), NB_IN);                 // columns of step i (>= 1: the address stays in bounds)
         const i32 ci = min(64 * i, w - 1) & ~63;                       // an existing slice for steps beyond w
         const double *Pi = pcol(c, fd, k0 + ci) + rowc;
@@ -1774,6 +1788,21 @@ __device__ __forceinline__ void trsm_task(const TrsmTask t, const FrontDesc &fd,
     double pre[16];
     auto fetch = [&](const int i, const int j) {        // j < i: L[k0+64i.., k0+64j..) ; j == i: Linv_i
         const i32 nbi = min(NB_IN, w - 64 * i);
+        if constexpr (fullw) {                                        // thread (cc = lane, k = wave + 4 u): a uniform column, the lane's row
+            unsigned vo = (unsigned)lane * 8u;
+            asm volatile("" : "+v"(vo));
+            if (j < i) {
+                const i32 ldj = lda - (k0 + 64 * j);
+                const char *Pb = reinterpret_cast<const char *>(pcol(c, fd, k0 + 64 * j) + (k0 + 64 * i));
+#pragma unroll
+                for (int u = 0; u < 16; ++u) pre[u] = *reinterpret_cast<const double *>(Pb + (size_t)(wave + 4 * u) * (size_t)ldj * 8u + vo);
+            } else {
+                const char *Wb_ = reinterpret_cast<const char *>(front_dinv(c, fd, k0 + 64 * i));
+#pragma unroll
+                for (int u = 0; u < 16; ++u) pre[u] = *reinterpret_cast<const double *>(Wb_ + (size_t)(wave + 4 * u) * (size_t)(NB_IN * 8) + vo);
+            }
+            return;
+        }
         if (j < i) {
             const double *Pj = pcol(c, fd, k0 + 64 * j);
             const i32 ldj = lda - (k0 + 64 * j);
@@ -1846,12 +1875,22 @@ __device__ __forceinline__ void trsm_task(const TrsmTask t, const FrontDesc &fd,
                     for (int q = 0; q < 4; ++q) bf[i][4 * a + q] = acc[a][q];
                 // the step's columns are final: store them now, the later steps of the block column run while the stores drain
                 if (rbase + lr < rlim) {
+                    if constexpr (fullw) {
+                        const i32 ldi = lda - (k0 + 64 * i);
+                        char *Pb = reinterpret_cast<char *>(pcol(c, fd, k0 + 64 * i));
+                        unsigned vo = (unsigned)((i64)(rbase + lr) + (i64)lk * ldi) * 8u;
+                        asm volatile("" : "+v"(vo));
+#pragma unroll
+                        for (int ks = 0; ks < 16; ++ks)
+                            *reinterpret_cast<double *>(Pb + (size_t)(4 * ks) * (size_t)ldi * 8u + vo) = SIGNED ? bf[i][ks] * c.csign[fd.col0 + k0 + 64 * i + 4 * ks + lk] : bf[i][ks];
+                    } else {
                     double *Pi = pcol(c, fd, k0 + 64 * i) + rbase + lr;
                     const i32 ldi = lda - (k0 + 64 * i);
 #pragma unroll
                     for (int ks = 0; ks < 16; ++ks) {
                         const i32 col = 64 * i + 4 * ks + lk;
                         if (col < w) Pi[(i64)(4 * ks + lk) * ldi] = SIGNED ? bf[i][ks] * c.csign[fd.col0 + k0 + col] : bf[i][ks];
+                    }
                     }
                 }
             }
@@ -1863,7 +1902,8 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     __shared__ double Wb[2][NB_IN * LDW];           // staged operand: Wb[.][k*LDW + c]
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    trsm_task<SIGNED>(t, fd, c, Wb);
+    if (t.nb == NB_OUT) trsm_task<SIGNED, true>(t, fd, c, Wb);      // (workgroup-uniform)
+    else trsm_task<SIGNED, false>(t, fd, c, Wb);
 }
 
 // Thin block columns (w <= TRSM_THIN_W: the small fronts of the leaf levels): X = B * L11^{-T} with
@@ -2600,7 +2640,8 @@ __device__ __noinline__ void chain_role_trsm(const TrsmTask *tp_, const DevCtx &
     const TrsmTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); double *lds = uni_lds(lds_);
     const TrsmTask t{tp->front, tp->k0, tp->nb, tp->row0, tp->kprev, tp->fuse_nb, tp->pad1, tp->pad2};
     const FrontDesc fd = c.fronts[t.front];
-    trsm_task<SIGNED>(t, fd, c, reinterpret_cast<double (*)[NB_IN * LDW]>(lds));
+    if (t.nb == NB_OUT) trsm_task<SIGNED, true>(t, fd, c, reinterpret_cast<double (*)[NB_IN * LDW]>(lds));
+    else trsm_task<SIGNED, false>(t, fd, c, reinterpret_cast<double (*)[NB_IN * LDW]>(lds));
 }
 __device__ __noinline__ void chain_role_reduce(const UpdateTask *tp_, const int sub_, const DevCtx &c_) {
     const UpdateTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); const int sub = __builtin_amdgcn_readfirstlane(sub_);
