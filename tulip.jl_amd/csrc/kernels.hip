@@ -2401,6 +2401,20 @@ __device__ __forceinline__ void update_tile32(const UpdateTask t, const FrontDes
                 const bool tail = rd0 + sl >= nfull_rounds;
                 const i32 kbase = tail ? t.k0 + nfull * UPD_KT : k_slab;
                 const i32 klim = tail ? ktail : UPD_KT;
+                if (!tail) {
+                    // a full slab lies inside ONE 64-column slice of the packed panel: column kbase + kk starts kk (lda - 64 b) doubles behind column kbase -- a
+                    // wave-uniform base per fragment + one 32-bit lane offset per operand (row + lk columns) instead of a 64-bit address per lane and load
+                    const i32 ldb = lda - ((kbase >> 6) << 6);
+                    const char *Pb = reinterpret_cast<const char *>(P + pk_off(lda, kbase));
+                    unsigned voa = (unsigned)(ra + (i64)lk * ldb) * 8u, vob = (unsigned)(rb + (i64)lk * ldb) * 8u;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const char *Pu = Pb + (size_t)(4 * u) * (size_t)ldb * 8u;
+                        pa[sl][u] = *reinterpret_cast<const double *>(Pu + voa);
+                        const double vb = *reinterpret_cast<const double *>(Pu + vob);
+                        pb[sl][u] = SIGNED ? vb * sgf[kbase + 4 * u + lk] : vb;
+                    }
+                } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const i32 kk = 4 * u + lk, col = kbase + min(kk, klim - 1);
@@ -2408,6 +2422,7 @@ __device__ __forceinline__ void update_tile32(const UpdateTask t, const FrontDes
                     const double va = Pk[ra], vb = Pk[rb];
                     pa[sl][u] = (kk < klim) ? va : 0.0;
                     pb[sl][u] = (kk < klim) ? (SIGNED ? vb * sgf[col] : vb) : 0.0;
+                }
                 }
                 if (!tail) {
                     k_slab += UPD_KT;
