@@ -915,7 +915,11 @@ constexpr int PD_LP = PW_W * PW_W;                 // L_pp, column-major, for th
 constexpr int POTRF_DPP_LDS = NB_IN * PD_LD + 4 * PW_W * PW_LDT + 4 * PW_W * PW_LDT + 2 * PD_LP + NB_IN;  // doubles: Mt | Wd[4] | Ts[4] | Lp[2] | Sg
 constexpr int TRM_LDT = NB_IN + 2;                 // trsm_rows_mt: leading dimension of the shared block of L behind Mt (== 2 mod 32: conflict-free b64 operand reads)
 constexpr int POTRF_WIDE_DPP_LDS = NB_IN * PD_LD + NB_IN * TRM_LDT;                 // doubles: Mt | Wt (>= POTRF_DPP_LDS)
+static_assert(30 * 256 <= POTRF_DPP_LDS, "potrf_block_dpp: the waves' shares of the left-looking sum (30 slots of 256 doubles) lie in the image's place");
 static_assert(POTRF_WIDE_DPP_LDS >= POTRF_DPP_LDS, "k_potrf_wide: the in-block solve's block of L lies behind the diagonal block's image");
+#ifndef TLPK_PROLOGUE_KSPLIT
+#define TLPK_PROLOGUE_KSPLIT 1
+#endif
 #ifndef TLPK_TRM_MT
 #define TLPK_TRM_MT 1
 #endif
@@ -1117,6 +1121,117 @@ __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc
     int pti_ = 0;
 #endif
     PT_STAMP();
+#if TLPK_PROLOGUE_KSPLIT
+    // Round 6 (last): the block's own entries and its left-looking sum in the MATRIX-CORE layout, the sum split over the waves by COLUMNS.  The ten 16 x 16 blocks on
+    // and below the diagonal belong to the waves 3 + 3 + 2 + 2 (tables below); thread (lr, lk) of the owner holds the entries (16 bi + lr, 16 bj + lk + 4 q).
+    // Left-looking part, D -= X S X' over the 64-wide steps already factored in this block column: wave w takes the columns 16 w .. 16 w + 15 of EVERY step and forms
+    // its share of ALL ten blocks straight from global memory -- lane (lr, lk) loads L[bk0 + 16 a + lr][kprev + 64 j + 16 w + 4 g + lk], which is the operand layout of
+    // v_mfma_f64_16x16x4_f64 for both sides of the product -- so a step needs no staging block in LDS and no barrier (the staged form: two barriers, 16 LDS writes and
+    // 32 LDS reads per block and step around 48 products; 2.9 us per step for 1.3 us of matrix-core time).  The shares meet once, in LDS: a wave writes the blocks it
+    // does not own, the owner adds the four shares in wave order (fixed: deterministic; both triangles of a diagonal block stay bitwise equal, the products commute).
+    // Other summation order than the staged form (columns in ascending order there): results differ in the last bits, like any two of the block kernels.
+    const i32 Kp = bk0 - kprev;
+    const int nblk = wave < 2 ? 3 : 2, bfirst = wave < 2 ? 3 * wave : 2 * wave + 2;      // blocks 0-2 | 3-5 | 6-7 | 8-9 of the table
+    int bi[3], bj[3];                                            // wave 0: (0,0) (3,0) (3,1) | 1: (1,0) (1,1) (3,2) | 2: (2,0) (2,1) | 3: (2,2) (3,3)
+    bi[0] = wave == 3 ? 2 : wave; bj[0] = wave == 3 ? 2 : 0;
+    bi[1] = wave < 2 ? (wave == 0 ? 3 : 1) : (wave == 2 ? 2 : 3); bj[1] = wave == 0 ? 0 : (wave == 3 ? 3 : 1);
+    bi[2] = 3; bj[2] = wave == 0 ? 1 : 2;
+    v4f64 tot[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) tot[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    double pvt[3][4];
+    if (Kp > 0) {
+        constexpr int BI[10] = {0, 3, 3, 1, 1, 3, 2, 2, 2, 3}, BJ[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3}, OW[10] = {0, 0, 0, 1, 1, 1, 2, 2, 3, 3};
+        const int nprev = Kp / NB_IN;                            // 1 .. 3 (workgroup-uniform)
+        double x[3][4][4];
+        i32 rowa[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) rowa[a] = bk0 + min(16 * a + lr, nb - 1);     // clamped: the rows >= nb feed entries nobody reads
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < nprev) {
+                const double *Pc = pcol(c, fd, kprev + j * NB_IN);
+                const i32 ldc = pld(fd, kprev + j * NB_IN);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) x[j][a][g] = Pc[(i64)rowa[a] + (i64)(16 * wave + 4 * g + lk) * ldc];
+            }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < nblk) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pvt[t][q] = P[(i64)min(16 * bi[t] + lr, nb - 1) + (i64)min(16 * bj[t] + lk + 4 * q, nb - 1) * lda];
+            }
+        v4f64 dacc[10];
+#pragma unroll
+        for (int b = 0; b < 10; ++b) dacc[b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < nprev) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    double xs[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) xs[a] = SIGNED ? x[j][a][g] * sg[kprev + j * NB_IN + 16 * wave + 4 * g + lk] : x[j][a][g];
+#pragma unroll
+                    for (int b = 0; b < 10; ++b) dacc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[j][BJ[b]][g], xs[BI[b]], dacc[b], 0, 0, 0);
+                }
+            }
+        // the shares: slot 3 b + (rank of the writer among the three waves that do not own block b), 256 doubles each, [q][lane]
+        double *Ps = scratch;
+#pragma unroll
+        for (int b = 0; b < 10; ++b)
+            if (wave != OW[b]) {
+                double *slot = Ps + (3 * b + (wave < OW[b] ? wave : wave - 1)) * 256 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) slot[64 * q] = dacc[b][q];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < nblk) {
+                // the wave's own share of its t-th block
+                v4f64 own = wave == 0 ? dacc[t] : (wave == 1 ? dacc[3 + t] : (wave == 2 ? dacc[t < 2 ? 6 + t : 7] : dacc[t < 2 ? 8 + t : 9]));
+                const double *sl = Ps + 3 * (bfirst + t) * 256 + lane;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    v4f64 part;
+                    if (w == wave) part = own;
+                    else {
+                        const double *sw = sl + (w < wave ? w : w - 1) * 256;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) part[q] = sw[64 * q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tot[t][q] = (w == 0) ? part[q] : tot[t][q] + part[q];
+                }
+            }
+        __syncthreads();                                         // the shares are read: the image (same LDS) is next
+    } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < nblk) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pvt[t][q] = P[(i64)min(16 * bi[t] + lr, nb - 1) + (i64)min(16 * bj[t] + lk + 4 * q, nb - 1) * lda];
+            }
+    }
+    if (SIGNED && tid < NB_IN) Sg[tid] = (tid < nb) ? sg[bk0 + tid] : 1.0;
+    // As = block - sum: the blocks below the diagonal blocks + FULL (symmetric) diagonal 16 x 16 blocks; rows / columns beyond nb: identity
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < nblk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 16 * bi[t] + lr, col = 16 * bj[t] + lk + 4 * q;
+                const double v = (row < nb && col < nb) ? (pvt[t][q] - tot[t][q]) : ((row == col) ? 1.0 : 0.0);
+                if (row >= col) {
+                    Mt[col * PD_LD + row] = v;
+                    if (row > col && bi[t] == bj[t]) Mt[row * PD_LD + col] = v;
+                }
+            }
+        }
+#else
     double pv[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) pv[q] = P[(i64)min(r, nb - 1) + (i64)min(wave + 4 * q, nb - 1) * lda];
@@ -1191,6 +1306,7 @@ __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc
             if (r > col && (r >> 4) == (col >> 4)) Mt[r * PD_LD + col] = v;
         }
     }
+#endif
     __syncthreads();
     PT_STAMP();
     i32 failcol = NB_IN;                                         // first pivot of the wrong sign (wave 0; wave-uniform)
