@@ -1,5 +1,5 @@
 #!/bin/bash
-# K-split prologue of potrf_block_dpp: microbenchmark with phase stamps, parity tests, A/B against the staged prologue (libtlpk_ab_old.so = -DTLPK_PROLOGUE_KSPLIT=0)
+# A/B of kernel builds: microbenchmark with phase stamps, parity tests, new library against libtlpk_ab_old.so (the previous build of kernels.hip)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 O=gpurun_out/r06ao

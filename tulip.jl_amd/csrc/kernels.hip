@@ -2013,13 +2013,156 @@ __device__ __forceinline__ void trsm_task(const TrsmTask t, const FrontDesc &fd,
         }
     }
 }
+// ------------------------------------------------------------------------------------------
+// Full-width block columns (w == 256), round 6 (last): the ten 64 x 64 operand blocks of a strip -- Linv_0 | L_10 Linv_1 | L_20 L_21 Linv_2 | L_30 L_31 L_32 Linv_3 --
+// travel global -> LDS WITHOUT passing the registers (global_load_lds_dwordx4: 64 lanes x 16 bytes = two 64-entry rows per instruction, eight instructions per
+// wave and block), into a ring of NBUF buffers, NBUF - 1 blocks ahead of the products.  trsm_task above keeps ONE block in flight in 32 registers and stages it
+// with 16 LDS writes per thread: a block's latency had the ~1.7 us of the previous block's products to hide in and needed ~3 (sixty strips pull the same 32 KB
+// at the same moment) -- 30 us per strip for 14.5 us of matrix-core time, on the critical path of the dependency-driven launches.  k_trsm: NBUF = 2 (two
+// workgroups per CU: the other one covers the latency; the staging writes and the 32 registers go away); k_chain: NBUF = 4 (the CU is the workgroup's own).
+// LDS image of a block: Ws[k * 64 + (cc ^ 16 (k & 1))] -- no padding (the hardware writes lane l's 16 bytes at base + 16 l), the XOR puts the rows k, k + 1
+// that the lanes lk, lk + 1 of an operand read hit into different halves of the banks, like the stride 80 of the staged form.
+// Waiting: the loads are inline assembly, the compiler's counters do not see them; s_waitcnt vmcnt(8 x blocks that may still fly) in front of the barrier of a
+// block.  That count is exact because nothing else of this wave is in flight: the strip's own rows are all loaded up front (they are older: loads return in order)
+// and ALL stores wait for the end (a store may return before an older load: one of them in the ring would break the count); the kernel must not spill.
+// Same products in the same order as trsm_task: identical bits.
+// ------------------------------------------------------------------------------------------
+#ifndef TLPK_TRSM_DMA
+#define TLPK_TRSM_DMA 1
+#endif
+constexpr bool TRSM_DMA = TLPK_TRSM_DMA != 0;
+constexpr int TRSM_DMA_BLK = NB_IN * NB_IN;          // doubles per ring buffer
+typedef __attribute__((address_space(3))) double trsm_lds_double;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+template <int PEND> __device__ __forceinline__ void trsm_dma_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PEND) : "memory");
+}
+template <bool SIGNED, int NBUF>
+__device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc &fd, const DevCtx &c, double *b01, double *b23) {
+    static_assert(NBUF == 2 || NBUF == 4, "ring of two (k_trsm) or four (k_chain) buffers");
+    constexpr int SI[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, SJ[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+    const i32 k0 = t.k0;
+    const i32 lda = fd.lda;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const i32 rbase = t.row0 + wave * 16;
+    const i32 rlim = t.pad1;
+    const bool active = rbase < rlim;
+    const i32 rowc = min(rbase + lr, rlim - 1);
+    double *bp[NBUF];
+    unsigned la[NBUF];
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) {
+        bp[q] = q < 2 ? b01 + q * TRSM_DMA_BLK : b23 + (q - 2) * TRSM_DMA_BLK;
+        la[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(trsm_lds_double *)bp[q]);
+    }
+    double bf[4][16];                               // bf[i][ks] = B[row][k0 + 64 i + 4 ks + lk]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const i32 ldi = lda - (k0 + 64 * i);
+        const char *Pb = reinterpret_cast<const char *>(pcol(c, fd, k0 + 64 * i));
+        unsigned vo = (unsigned)((i64)rowc + (i64)lk * ldi) * 8u;
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) bf[i][ks] = *reinterpret_cast<const double *>(Pb + (size_t)(4 * ks) * (size_t)ldi * 8u + vo);
+    }
+    asm volatile("" ::: "memory");                  // the rows' loads stay in front of the ring's
+    const unsigned half = (unsigned)lane >> 5;      // lanes 0..31: row k of a pair, 32..63: row k + 1
+    const unsigned ccs = (2u * ((unsigned)lane & 31u)) ^ (16u * half);
+    auto issue = [&](const int n) {                 // block n of the sequence into buffer n % NBUF (n: a constant after unrolling)
+        const int i = SI[n], j = SJ[n];
+        const char *gb;
+        i32 ld;
+        if (j < i) { ld = lda - (k0 + 64 * j); gb = reinterpret_cast<const char *>(pcol(c, fd, k0 + 64 * j) + (k0 + 64 * i)); }       // L[k0 + 64 i + cc][k0 + 64 j + k]
+        else { ld = NB_IN; gb = reinterpret_cast<const char *>(front_dinv(c, fd, k0 + 64 * i)); }                                // Linv_i[cc][k], column-major, ld 64
+        unsigned vo = (ccs + half * (unsigned)ld) * 8u;
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const char *sb = gb + (size_t)(2 * (8 * wave + e)) * (size_t)ld * 8u;
+            const unsigned m0v = la[n % NBUF] + (unsigned)(8 * wave + e) * 1024u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(vo), "s"(sb) : "memory", "m0");
+        }
+    };
+#pragma unroll
+    for (int n = 0; n < NBUF - 1; ++n) issue(n);
+    // operand (k = 4 ks + lk, cc = 16 a + lr) of the image: k & 1 = lk & 1
+    int rd[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) rd[a] = lk * NB_IN + ((a * 16 + lr) ^ (16 * (lk & 1)));
+    v4f64 acc[4];
+#pragma unroll
+    for (int n = 0; n < 10; ++n) {
+        const int i = SI[n], j = SJ[n];
+        constexpr int AHEAD = NBUF - 2;             // blocks behind block n that may still be in flight at its barrier
+        const int pend = 10 - 1 - n < AHEAD ? 10 - 1 - n : AHEAD;
+        if (pend == 0) trsm_dma_wait_barrier<0>();
+        else if (pend == 1) trsm_dma_wait_barrier<8>();
+        else trsm_dma_wait_barrier<16>();
+        // block n has landed (every wave's share: the barrier), and every wave is done with block n - 1: its buffer takes block n + NBUF - 1
+        if (n + NBUF - 1 < 10) issue(n + NBUF - 1);
+        const double *Ws = bp[n % NBUF];
+        if (j == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        }
+        if (j < i) {                                 // solved step j: acc += X_j * L[k0 + 64 i.., k0 + 64 j..]'
+            if (active) {
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[4 * ks * NB_IN + rd[a]], bf[j][ks], acc[a], 0, 0, 0);
+            }
+            if (j == i - 1) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bf[i][4 * a + q] -= acc[a][q];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            }
+        } else if (active) {                         // X_i = B_i Linv_i'
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (4 * ks > 16 * a + 15) continue;       // Linv[c][k] = 0 for k > c: whole block is zero
+                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[4 * ks * NB_IN + rd[a]], bf[i][ks], acc[a], 0, 0, 0);
+                }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bf[i][4 * a + q] = acc[a][q];
+        }
+    }
+    if (rbase + lr < rlim) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i32 ldi = lda - (k0 + 64 * i);
+            char *Pb = reinterpret_cast<char *>(pcol(c, fd, k0 + 64 * i));
+            unsigned vo = (unsigned)((i64)(rbase + lr) + (i64)lk * ldi) * 8u;
+            asm volatile("" : "+v"(vo));
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                *reinterpret_cast<double *>(Pb + (size_t)(4 * ks) * (size_t)ldi * 8u + vo) = SIGNED ? bf[i][ks] * c.csign[fd.col0 + k0 + 64 * i + 4 * ks + lk] : bf[i][ks];
+        }
+    }
+}
+#pragma clang diagnostic pop
+static_assert(2 * TRSM_DMA_BLK <= 2 * NB_IN * LDW, "trsm_task_dma: two ring buffers in the staged form's LDS");
+
 template <bool SIGNED>
 __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
-    __shared__ double Wb[2][NB_IN * LDW];           // staged operand: Wb[.][k*LDW + c]
+    __shared__ __attribute__((aligned(16))) double Wb[2][NB_IN * LDW];           // staged operand: Wb[.][k*LDW + c]; trsm_task_dma: two 64 x 64 images
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
-    if (t.nb == NB_OUT) trsm_task<SIGNED, true>(t, fd, c, Wb);      // (workgroup-uniform)
-    else trsm_task<SIGNED, false>(t, fd, c, Wb);
+    if (t.nb == NB_OUT) {                                            // (workgroup-uniform)
+        if constexpr (TRSM_DMA) trsm_task_dma<SIGNED, 2>(t, fd, c, &Wb[0][0], nullptr);
+        else trsm_task<SIGNED, true>(t, fd, c, Wb);
+    } else trsm_task<SIGNED, false>(t, fd, c, Wb);
 }
 
 // Thin block columns (w <= TRSM_THIN_W: the small fronts of the leaf levels): X = B * L11^{-T} with
@@ -2672,6 +2815,7 @@ struct ChainArgs {
     const UpdateTask *upd, *red; const PotrfTask *potrf; const TrsmTask *trsm;
     unsigned long long *trace;                       // TLPK_CHAIN_TRACE=1 (diagnostics): per item 4 words -- drawn, released by its counters, work done, published (100 MHz clock)
     unsigned spin_max;                               // milliseconds before a waiting wave gives up (TLPK_CHAIN_TIMEOUT_MS, default 2000)
+    unsigned dyn_lds;                                // bytes of dynamic LDS of the launch (one workgroup per CU: 70 000; the strips' ring of four operand images uses 65 536 of them)
 };
 constexpr int CHAIN_LDS = 2 * NB_IN * LDW;           // doubles (81 920 bytes): the strips' two staging blocks >= the four K slabs of an update tile, >= the diagonal block's scratch
 static_assert(CHAIN_LDS >= 4 * UPD_KT * UPD_LD && CHAIN_LDS >= POTRF_WIDE_DPP_LDS, "k_chain: one LDS block serves every role");
@@ -2767,12 +2911,17 @@ __device__ __noinline__ void chain_role_potrf(const PotrfTask *tp_, const DevCtx
     __builtin_amdgcn_s_setprio(0);
 }
 template <bool SIGNED>
-__device__ __noinline__ void chain_role_trsm(const TrsmTask *tp_, const DevCtx &c_, lds_double *lds_) {
+__device__ __noinline__ void chain_role_trsm(const TrsmTask *tp_, const DevCtx &c_, lds_double *lds_, lds_double *dyn_) {
     const TrsmTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); double *lds = uni_lds(lds_);
     const TrsmTask t{tp->front, tp->k0, tp->nb, tp->row0, tp->kprev, tp->fuse_nb, tp->pad1, tp->pad2};
     const FrontDesc fd = c.fronts[t.front];
-    if (t.nb == NB_OUT) trsm_task<SIGNED, true>(t, fd, c, reinterpret_cast<double (*)[NB_IN * LDW]>(lds));
-    else trsm_task<SIGNED, false>(t, fd, c, reinterpret_cast<double (*)[NB_IN * LDW]>(lds));
+    if (t.nb == NB_OUT) {
+        if constexpr (TRSM_DMA) {
+            // (dyn_: the launch's dynamic LDS when it holds two more 64 x 64 images -- the default, one workgroup per CU --, else null: the ring of two)
+            if (dyn_) trsm_task_dma<SIGNED, 4>(t, fd, c, lds, uni_lds(dyn_));
+            else trsm_task_dma<SIGNED, 2>(t, fd, c, lds, nullptr);
+        } else trsm_task<SIGNED, true>(t, fd, c, reinterpret_cast<double (*)[NB_IN * LDW]>(lds));
+    } else trsm_task<SIGNED, false>(t, fd, c, reinterpret_cast<double (*)[NB_IN * LDW]>(lds));
 }
 __device__ __noinline__ void chain_role_reduce(const UpdateTask *tp_, const int sub_, const DevCtx &c_) {
     const UpdateTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); const int sub = __builtin_amdgcn_readfirstlane(sub_);
@@ -2784,6 +2933,8 @@ __device__ __noinline__ void chain_role_reduce(const UpdateTask *tp_, const int 
 template <bool SIGNED>
 __global__ __launch_bounds__(256, 2) void k_chain(const ChainArgs a, DevCtx c) {
     __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS];
+    extern __shared__ __attribute__((aligned(16))) double chain_dyn[];
+    lds_double *dyn = a.dyn_lds >= 2u * TRSM_DMA_BLK * sizeof(double) ? (lds_double *)chain_dyn : (lds_double *)nullptr;
     unsigned *ctl = reinterpret_cast<unsigned *>(lds);        // ctl[0] = the drawn ticket, ctl[1] = 1: skip the work (somebody gave up waiting); in the role's own LDS, between its uses
     const int tid = threadIdx.x;
     for (;;) {
@@ -2809,7 +2960,7 @@ __global__ __launch_bounds__(256, 2) void k_chain(const ChainArgs a, DevCtx c) {
             // one loop body the strips' 256-register working set pushed 125 registers of the other roles' live ranges into scratch)
             if (it.role == CR_UPDATE) chain_role_update<SIGNED>(a.upd + it.task, c, (lds_double *)lds);
             else if (it.role == CR_POTRF) chain_role_potrf<SIGNED>(a.potrf + it.task, c, (lds_double *)lds);
-            else if (it.role == CR_TRSM) chain_role_trsm<SIGNED>(a.trsm + it.task, c, (lds_double *)lds);
+            else if (it.role == CR_TRSM) chain_role_trsm<SIGNED>(a.trsm + it.task, c, (lds_double *)lds, dyn);
             else chain_role_reduce(a.red + it.task, it.sub, c);
         }
         // publish: every wave's stores (and L2 adds) have left the CU, then ONE lane writes the die's L2 back and raises the counter
@@ -4022,7 +4173,7 @@ void launch_tasks(hipStream_t st, const DevArrays &a, const Launch &L, const Swe
         const unsigned grid_max = [&] { const char *e = std::getenv("TLPK_CHAIN_GRID"); return e ? (unsigned)std::max(1, std::atoi(e)) : (dyn >= 70000u ? 256u : 512u); }();
         static const unsigned spin_max = [] { const char *e = std::getenv("TLPK_CHAIN_TIMEOUT_MS"); return (unsigned)(e ? std::min(600000, std::max(1, std::atoi(e))) : 2000); }();
         const ChainArgs ca{a.chain_items + L.first, (i32)L.count, a.chain_cnt, L.pad, a.update_tasks, a.reduce_tasks, a.potrf_tasks, a.trsm_tasks,
-                           a.chain_trace ? a.chain_trace + 4 * L.first : nullptr, spin_max};
+                           a.chain_trace ? a.chain_trace + 4 * L.first : nullptr, spin_max, dyn};
         const dim3 gc((unsigned)std::min<i64>(L.count, grid_max));
         // ONE dependency-driven launch at a time per device, process-wide (TLPK_CHAIN_SERIAL=0 lifts it).  Each launch is deadlock-free by itself, but several of them
         // side by side on ONE device -- eight shards of a multi-device handle on one GPU (the test configuration), independent handles of one process -- froze: with

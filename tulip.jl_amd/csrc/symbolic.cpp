@@ -942,6 +942,7 @@ int analyse_rank(Symbolic &S, const Options &opt) {
         if (w.lda != w.f || w.f >= LDA_PAD_MIN_F) S.lval_len = (S.lval_len + 15) / 16 * 16;
         w.loff = S.lval_len; S.lval_len += pk_len(w.lda, w.ns);
         w.ucoff = S.uc_len; S.uc_len += (w.f - w.ns);
+        if (w.ns >= NB_IN) S.dinv_len = (S.dinv_len + 15) / 16 * 16;     // the inverted 64 x 64 blocks start on 128-byte lines (trsm_task_dma loads them 16 bytes per lane)
         w.dinvoff = S.dinv_len;
         S.dinv_len += (w.ns >= NB_IN) ? (i64)((w.ns + NB_IN - 1) / NB_IN) * NB_IN * NB_IN : (i64)w.ns * w.ns;
     }
