@@ -44,11 +44,12 @@ class Emulator:
         self.pair_ptr = g("pair_ptr"); self.pair_j = g("pair_j")
         from tulip_jl_amd import _lib
         self.pair_w = _lib.symbolic_array_f64(kkt._h, "pair_w")
+        self.trsm_early = g("trsm_early")
         self.tasks = {
             LK["EXTEND_ADD"]: g("ea_tasks").reshape(-1, 6),
             LK["FRONT_ASSEMBLE"]: g("fa_tasks").reshape(-1, 4),
             LK["POTRF"]: g("potrf_tasks").reshape(-1, 4),
-            LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),
+            LK["TRSM"]: g("trsm_tasks").reshape(-1, 6),      # (early entry of a strip: self.trsm_early)
             LK["UPDATE"]: np.concatenate([g("update_tasks").reshape(-1, 10), g("update_tile64").reshape(-1, 1)], axis=1),      # + 1 = a 64 x 64 tile
             LK["UPDATE_REDUCE"]: g("reduce_tasks").reshape(-1, 8),
             LK["FWD_GATHER"]: g("fwd_gather_tasks").reshape(-1, 6),
@@ -219,6 +220,12 @@ class Emulator:
 
         def ready(it):
             _r, _t, _s, w0, n0, need0, w1, n1, need1, w2, need2, _sig = it
+            if _r == 2:
+                # early entry (TrsmTask.pad2 > 0): the strip waits INSIDE its role for the counter of its block column's diagonal block, which that role raises on
+                # its way (3 x) and at its end (+ 1).  The emulator runs roles whole: the strip is runnable once the counter is final.
+                pad2 = int(self.trsm_early[_t])
+                if pad2 > 0 and cnt[pad2 - 1] < 4:
+                    return False
             return all(cnt[w0 + q] >= need0 for q in range(n0)) and all(cnt[w1 + q] >= need1 for q in range(n1)) and (w2 < 0 or cnt[w2] >= need2)
         rng = getattr(self, "chain_rng", None)
         if rng is not None:
@@ -249,7 +256,7 @@ class Emulator:
                 assert role == 3 and 0 <= sub < 8
                 self._k13(self.tasks[LK["UPDATE_REDUCE"]][task: task + 1], sub=sub)
             if sig >= 0:
-                cnt[sig] += 1
+                cnt[sig] += 4 if (role == 1 and sub == 1) else 1      # (a diagonal block with early strips: three signals on its way + the final one)
 
     def _k0(self, T):      # extend-add
         # group tasks by front: emulation processes whole columns ranges, children in order

@@ -1098,7 +1098,7 @@ __device__ __forceinline__ void dpp_inv_steps(const double (&l)[PW_W], double (&
 
 template <bool SIGNED = false>
 __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc &fd, const i32 bk0, const i32 nb,
-                                                const i32 kprev, double *scratch) {
+                                                const i32 kprev, double *scratch, unsigned *prog = nullptr) {
     typedef double v2f64 __attribute__((ext_vector_type(2)));
     const double *sg = SIGNED ? c.csign + fd.col0 : nullptr;
     double *Mt = scratch;                                        // NB_IN x PD_LD
@@ -1307,6 +1307,9 @@ __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc
         }
     }
 #endif
+    // (prog, k_chain with early strips: everything this workgroup stored so far -- the steps in front of this block, factored and solved inside the block column --
+    //  has left the CU before the barrier; wave 1, idle beside wave 0's first panel, then publishes it: one release, the block column's counter + 1)
+    if (prog) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PT_STAMP();
     i32 failcol = NB_IN;                                         // first pivot of the wrong sign (wave 0; wave-uniform)
@@ -1435,6 +1438,13 @@ __device__ __forceinline__ void potrf_block_dpp(const DevCtx &c, const FrontDesc
             default: dpp_panel<SIGNED, 3>(Mt, Lp, Sg, lane, failcol); break;
             }
         } else if (p > 0) lazy(p - 1);                           // beside wave 0's panel p
+        else if (prog && wave == 1) {
+            if (lane == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         PT_STAMP();
         __syncthreads();                                         // panel p of L is in Mt / Lp; the lazy work of panel p - 1 is done
         PT_STAMP();
@@ -1779,7 +1789,7 @@ __global__ __launch_bounds__(256) void k_potrf(const PotrfTask *__restrict__ tas
     potrf_block_any<SIGNED, MODE>(c, fd, t.k0, t.nb, t.k0, scratch);
 }
 template <bool SIGNED, int MODE>
-__device__ __forceinline__ void potrf_wide_task(const PotrfTask t, const FrontDesc &fd, const DevCtx &c, double *Ws) {
+__device__ __forceinline__ void potrf_wide_task(const PotrfTask t, const FrontDesc &fd, const DevCtx &c, double *Ws, unsigned *prog = nullptr) {
     const i32 k0 = t.k0, w = t.nb, kend = k0 + w;
     // the chain's four waves are served before the update tiles' waves that share their SIMDs (beside k_update the chain runs on the side stream: its end is what the
     // group's stream waits for at the join): C4 51.0 -> 50.8 ms, pds-class 15.79 -> 15.68 ms (profiles/r05_chain_overlap.txt)
@@ -1800,7 +1810,7 @@ __device__ __forceinline__ void potrf_wide_task(const PotrfTask t, const FrontDe
             trsm_rows_mt<SIGNED, 0>(c, fd, k0, k0 + NB_IN, kend, k0, Ws, Wt);
             __syncthreads();
             PTW_STAMP(2);
-            potrf_block_dpp<SIGNED>(c, fd, k0 + NB_IN, min(NB_IN, kend - (k0 + NB_IN)), k0, Ws);
+            potrf_block_dpp<SIGNED>(c, fd, k0 + NB_IN, min(NB_IN, kend - (k0 + NB_IN)), k0, Ws, prog);
         }
         if (k0 + 2 * NB_IN < kend) {
             __syncthreads();
@@ -1808,7 +1818,7 @@ __device__ __forceinline__ void potrf_wide_task(const PotrfTask t, const FrontDe
             trsm_rows_mt<SIGNED, 1>(c, fd, k0 + NB_IN, k0 + 2 * NB_IN, kend, k0, Ws, Wt);
             __syncthreads();
             PTW_STAMP(4);
-            potrf_block_dpp<SIGNED>(c, fd, k0 + 2 * NB_IN, min(NB_IN, kend - (k0 + 2 * NB_IN)), k0, Ws);
+            potrf_block_dpp<SIGNED>(c, fd, k0 + 2 * NB_IN, min(NB_IN, kend - (k0 + 2 * NB_IN)), k0, Ws, prog);
         }
         if (k0 + 3 * NB_IN < kend) {
             __syncthreads();
@@ -1816,7 +1826,7 @@ __device__ __forceinline__ void potrf_wide_task(const PotrfTask t, const FrontDe
             trsm_rows_mt<SIGNED, 2>(c, fd, k0 + 2 * NB_IN, k0 + 3 * NB_IN, kend, k0, Ws, Wt);
             __syncthreads();
             PTW_STAMP(6);
-            potrf_block_dpp<SIGNED>(c, fd, k0 + 3 * NB_IN, min(NB_IN, kend - (k0 + 3 * NB_IN)), k0, Ws);
+            potrf_block_dpp<SIGNED>(c, fd, k0 + 3 * NB_IN, min(NB_IN, kend - (k0 + 3 * NB_IN)), k0, Ws, prog);
         }
         PTW_STAMP(7);
 #undef PTW_STAMP
@@ -2038,10 +2048,21 @@ typedef __attribute__((address_space(3))) double trsm_lds_double;
 template <int PEND> __device__ __forceinline__ void trsm_dma_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PEND) : "memory");
 }
-template <bool SIGNED, int NBUF>
-__device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc &fd, const DevCtx &c, double *b01, double *b23) {
+// EARLY ENTRY (k_chain, TrsmTask.pad2 > 0): the strip does not wait for the diagonal block of its block column to be COMPLETE.  The diagonal-block role raises
+// the block column's counter at three points on its way (prog: 1 = step 0 factored and solved inside the block column, 2, 3 likewise; its final signal makes 4),
+// and the strip consumes the operand blocks as they become final -- Linv_0, L_10 at 1; Linv_1, L_20, L_21 at 2; Linv_2, L_30, L_31, L_32 at 3; Linv_3 at 4 --,
+// so that behind the diagonal block's last instruction only ONE product (40 of the 544 matrix-core instructions of a strip) and the stores are left: the strips
+// were 25 us of the chain's 124 us period, all of them behind the diagonal block.
+// Wave 0 polls the counter (one lane, the back-off of chain_wait) and hands the value to the other waves through one LDS word in front of a barrier: every
+// wave takes the same decisions, the ring's bookkeeping (`issued`) is workgroup-uniform.  A poll drains the polling wave's ring (its value returns behind the
+// older loads): polls only happen while the strip is AHEAD of the diagonal block.  Giving up (time limit, or somebody else did): the word becomes 99, the
+// strip runs to its end on whatever the blocks hold -- the host reports TLPK_INTERNAL, nothing hangs.
+struct TrsmProg { const unsigned *cnt; int *info; unsigned timeout_ms; };
+template <bool SIGNED, int NBUF, bool EARLY>
+__device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc &fd, const DevCtx &c, double *b01, double *b23, const TrsmProg pg) {
     static_assert(NBUF == 2 || NBUF == 4, "ring of two (k_trsm) or four (k_chain) buffers");
     constexpr int SI[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, SJ[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+    constexpr unsigned long long ITAB = 0x3333222110ull, JTAB = 0x3210210100ull, NTAB = 0x4333322211ull;      // nibble n: step, solved step, progress needed
     const i32 k0 = t.k0;
     const i32 lda = fd.lda;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2058,6 +2079,8 @@ __device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc 
         bp[q] = q < 2 ? b01 + q * TRSM_DMA_BLK : b23 + (q - 2) * TRSM_DMA_BLK;
         la[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(trsm_lds_double *)bp[q]);
     }
+    volatile unsigned *pw = reinterpret_cast<volatile unsigned *>(b01 + 2 * TRSM_DMA_BLK);      // the progress word (behind the two images of the static block)
+    constexpr bool early = EARLY;
     double bf[4][16];                               // bf[i][ks] = B[row][k0 + 64 i + 4 ks + lk]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -2071,23 +2094,35 @@ __device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc 
     asm volatile("" ::: "memory");                  // the rows' loads stay in front of the ring's
     const unsigned half = (unsigned)lane >> 5;      // lanes 0..31: row k of a pair, 32..63: row k + 1
     const unsigned ccs = (2u * ((unsigned)lane & 31u)) ^ (16u * half);
-    auto issue = [&](const int n) {                 // block n of the sequence into buffer n % NBUF (n: a constant after unrolling)
-        const int i = SI[n], j = SJ[n];
-        const char *gb;
-        i32 ld;
-        if (j < i) { ld = lda - (k0 + 64 * j); gb = reinterpret_cast<const char *>(pcol(c, fd, k0 + 64 * j) + (k0 + 64 * i)); }       // L[k0 + 64 i + cc][k0 + 64 j + k]
-        else { ld = NB_IN; gb = reinterpret_cast<const char *>(front_dinv(c, fd, k0 + 64 * i)); }                                // Linv_i[cc][k], column-major, ld 64
+    auto issue = [&](const int m) {                 // block m of the sequence into buffer m % NBUF (m: wave-uniform)
+        const int i = (int)((ITAB >> (4 * m)) & 15u), j = (int)((JTAB >> (4 * m)) & 15u);
+        const bool below = j < i;
+        const i32 ld = below ? lda - (k0 + 64 * j) : NB_IN;
+        const char *gb = below ? reinterpret_cast<const char *>(pcol(c, fd, k0 + 64 * j) + (k0 + 64 * i))        // L[k0 + 64 i + cc][k0 + 64 j + k]
+                               : reinterpret_cast<const char *>(front_dinv(c, fd, k0 + 64 * i));                 // Linv_i[cc][k], column-major, ld 64
         unsigned vo = (ccs + half * (unsigned)ld) * 8u;
         asm volatile("" : "+v"(vo));
+        const int q = m & (NBUF - 1);
+        const unsigned lbase = NBUF == 2 ? (q ? la[1] : la[0]) : (q == 0 ? la[0] : (q == 1 ? la[1] : (q == 2 ? la[NBUF - 2] : la[NBUF - 1])));
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const char *sb = gb + (size_t)(2 * (8 * wave + e)) * (size_t)ld * 8u;
-            const unsigned m0v = la[n % NBUF] + (unsigned)(8 * wave + e) * 1024u;
+            const unsigned m0v = lbase + (unsigned)(8 * wave + e) * 1024u;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(vo), "s"(sb) : "memory", "m0");
         }
     };
-#pragma unroll
-    for (int n = 0; n < NBUF - 1; ++n) issue(n);
+    unsigned have = early ? 0u : 99u;               // progress of the diagonal block as this wave knows it (workgroup-uniform behind every barrier)
+    auto need_of = [&](const int m) { return (unsigned)((NTAB >> (4 * m)) & 15u); };
+    auto poll = [&]() {                             // wave 0
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_load(pg.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    auto publish_word = [&](const unsigned v) {     // wave 0: the producers' data first (acquire), then the word
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane == 0) *pw = v;
+    };
+    int issued = 0;
     // operand (k = 4 ks + lk, cc = 16 a + lr) of the image: k & 1 = lk & 1
     int rd[4];
 #pragma unroll
@@ -2096,13 +2131,47 @@ __device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc 
 #pragma unroll
     for (int n = 0; n < 10; ++n) {
         const int i = SI[n], j = SJ[n];
-        constexpr int AHEAD = NBUF - 2;             // blocks behind block n that may still be in flight at its barrier
-        const int pend = 10 - 1 - n < AHEAD ? 10 - 1 - n : AHEAD;
-        if (pend == 0) trsm_dma_wait_barrier<0>();
-        else if (pend == 1) trsm_dma_wait_barrier<8>();
-        else trsm_dma_wait_barrier<16>();
-        // block n has landed (every wave's share: the barrier), and every wave is done with block n - 1: its buffer takes block n + NBUF - 1
-        if (n + NBUF - 1 < 10) issue(n + NBUF - 1);
+        if (issued <= n) {                           // (workgroup-uniform) block n is not on its way yet: its operands were not final at the last look
+            if (early) {
+                if (wave == 0 && have < need_of(n)) {
+                    const unsigned long long t0 = wall_clock64();
+                    unsigned spins = 0;
+                    for (;;) {
+                        have = poll();
+                        if (have >= need_of(n)) break;
+                        if (spins < 64u) __builtin_amdgcn_s_sleep(8);
+                        else __builtin_amdgcn_s_sleep(32);
+                        if ((++spins & 63u) == 0u) {
+                            int flag = 0;
+                            if (lane == 0) flag = __hip_atomic_load(pg.info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const bool late = wall_clock64() - t0 > (unsigned long long)pg.timeout_ms * 100000ull;
+                            if (__builtin_amdgcn_readfirstlane(flag) != 0 || late) {
+                                if (late && lane == 0) __hip_atomic_store(pg.info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                have = 99u;
+                                break;
+                            }
+                        }
+                    }
+                    publish_word(have);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                have = (unsigned)__builtin_amdgcn_readfirstlane((int)*pw);
+            }
+            issue(n); ++issued;
+        }
+        // ahead, into the buffers that are free in front of this block's barrier
+        while (issued < 10 && issued <= n + NBUF - 2 && have >= need_of(issued)) { issue(issued); ++issued; }
+        if (early && wave == 0 && issued < 10 && have < need_of(issued)) {      // one look per block while the diagonal block is behind
+            const unsigned v = poll();
+            if (v > have) { have = v; publish_word(have); }
+        }
+        const int pend = issued - 1 - n;             // blocks behind block n that may still be in flight at its barrier (<= NBUF - 2)
+        if (pend <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (pend == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // block n has landed (every wave's share: the barrier), and every wave is done with block n - 1: its buffer is free
+        if (early) have = (unsigned)__builtin_amdgcn_readfirstlane((int)*pw);
+        while (issued < 10 && issued <= n + NBUF - 1 && have >= need_of(issued)) { issue(issued); ++issued; }
         const double *Ws = bp[n % NBUF];
         if (j == 0) {
 #pragma unroll
@@ -2152,7 +2221,7 @@ __device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc 
     }
 }
 #pragma clang diagnostic pop
-static_assert(2 * TRSM_DMA_BLK <= 2 * NB_IN * LDW, "trsm_task_dma: two ring buffers in the staged form's LDS");
+static_assert(2 * TRSM_DMA_BLK + 2 <= 2 * NB_IN * LDW, "trsm_task_dma: two ring buffers and the progress word in the staged form's LDS");
 
 template <bool SIGNED>
 __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ tasks, DevCtx c) {
@@ -2160,7 +2229,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm(const TrsmTask *__restrict__ ta
     const TrsmTask t = tasks[blockIdx.x];
     const FrontDesc fd = c.fronts[t.front];
     if (t.nb == NB_OUT) {                                            // (workgroup-uniform)
-        if constexpr (TRSM_DMA) trsm_task_dma<SIGNED, 2>(t, fd, c, &Wb[0][0], nullptr);
+        if constexpr (TRSM_DMA) trsm_task_dma<SIGNED, 2, false>(t, fd, c, &Wb[0][0], nullptr, TrsmProg{nullptr, nullptr, 0u});
         else trsm_task<SIGNED, true>(t, fd, c, Wb);
     } else trsm_task<SIGNED, false>(t, fd, c, Wb);
 }
@@ -2903,23 +2972,30 @@ __device__ __noinline__ void chain_role_update(const UpdateTask *tp_, const DevC
     else update_tile<false, SIGNED, 4>(t, fd, c, As, As + 2);
 }
 template <bool SIGNED>
-__device__ __noinline__ void chain_role_potrf(const PotrfTask *tp_, const DevCtx &c_, lds_double *lds_) {
+__device__ __noinline__ void chain_role_potrf(const PotrfTask *tp_, const DevCtx &c_, lds_double *lds_, unsigned *prog_) {
     const PotrfTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); double *lds = uni_lds(lds_);
     const PotrfTask t{tp->front, tp->k0, tp->nb, tp->kprev};
     const FrontDesc fd = c.fronts[t.front];
-    potrf_wide_task<SIGNED, 3>(t, fd, c, lds);
+    potrf_wide_task<SIGNED, 3>(t, fd, c, lds, prog_ ? uni(prog_) : nullptr);       // (prog_: the block column's counter when its strips enter early, see trsm_task_dma)
     __builtin_amdgcn_s_setprio(0);
 }
 template <bool SIGNED>
-__device__ __noinline__ void chain_role_trsm(const TrsmTask *tp_, const DevCtx &c_, lds_double *lds_, lds_double *dyn_) {
+__device__ __noinline__ void chain_role_trsm(const TrsmTask *tp_, const DevCtx &c_, lds_double *lds_, lds_double *dyn_, unsigned *cnt_, const unsigned timeout_ms_) {
     const TrsmTask *tp = uni(tp_); const DevCtx c = uni_ctx(c_); double *lds = uni_lds(lds_);
     const TrsmTask t{tp->front, tp->k0, tp->nb, tp->row0, tp->kprev, tp->fuse_nb, tp->pad1, tp->pad2};
     const FrontDesc fd = c.fronts[t.front];
     if (t.nb == NB_OUT) {
         if constexpr (TRSM_DMA) {
-            // (dyn_: the launch's dynamic LDS when it holds two more 64 x 64 images -- the default, one workgroup per CU --, else null: the ring of two)
-            if (dyn_) trsm_task_dma<SIGNED, 4>(t, fd, c, lds, uni_lds(dyn_));
-            else trsm_task_dma<SIGNED, 2>(t, fd, c, lds, nullptr);
+            // (dyn_: the launch's dynamic LDS when it holds two more 64 x 64 images -- the default, one workgroup per CU --, else null: the ring of two;
+            //  pad2 > 0: early entry, the counter of the block column's diagonal block is cnt[pad2 - 1], see trsm_task_dma)
+            const TrsmProg pg{t.pad2 > 0 ? uni(cnt_) + (t.pad2 - 1) : nullptr, c.info, (unsigned)__builtin_amdgcn_readfirstlane((int)timeout_ms_)};
+            if (dyn_) {
+                if (t.pad2 > 0) trsm_task_dma<SIGNED, 4, true>(t, fd, c, lds, uni_lds(dyn_), pg);
+                else trsm_task_dma<SIGNED, 4, false>(t, fd, c, lds, uni_lds(dyn_), pg);
+            } else {
+                if (t.pad2 > 0) trsm_task_dma<SIGNED, 2, true>(t, fd, c, lds, nullptr, pg);
+                else trsm_task_dma<SIGNED, 2, false>(t, fd, c, lds, nullptr, pg);
+            }
         } else trsm_task<SIGNED, true>(t, fd, c, reinterpret_cast<double (*)[NB_IN * LDW]>(lds));
     } else trsm_task<SIGNED, false>(t, fd, c, reinterpret_cast<double (*)[NB_IN * LDW]>(lds));
 }
@@ -2959,8 +3035,8 @@ __global__ __launch_bounds__(256, 2) void k_chain(const ChainArgs a, DevCtx c) {
             // (the roles are separate functions, not inlined: each gets the register allocation of the stand-alone kernel it comes from -- inlined into
             // one loop body the strips' 256-register working set pushed 125 registers of the other roles' live ranges into scratch)
             if (it.role == CR_UPDATE) chain_role_update<SIGNED>(a.upd + it.task, c, (lds_double *)lds);
-            else if (it.role == CR_POTRF) chain_role_potrf<SIGNED>(a.potrf + it.task, c, (lds_double *)lds);
-            else if (it.role == CR_TRSM) chain_role_trsm<SIGNED>(a.trsm + it.task, c, (lds_double *)lds, dyn);
+            else if (it.role == CR_POTRF) chain_role_potrf<SIGNED>(a.potrf + it.task, c, (lds_double *)lds, (it.sub && it.sig >= 0) ? a.cnt + it.sig : nullptr);
+            else if (it.role == CR_TRSM) chain_role_trsm<SIGNED>(a.trsm + it.task, c, (lds_double *)lds, dyn, a.cnt, a.spin_max);
             else chain_role_reduce(a.red + it.task, it.sub, c);
         }
         // publish: every wave's stores (and L2 adds) have left the CU, then ONE lane writes the die's L2 back and raises the counter

@@ -1997,6 +1997,11 @@ static void build_schedule(Symbolic &S) {
             if (cap.empty()) return;
             // TLPK_CHAIN_JIT (default 1): the macro-column tiles take their tickets just in time, see `units` below; 0 = in the order of the launches.
             const bool chain_jit = [] { const char *e = std::getenv("TLPK_CHAIN_JIT"); return e && std::atoi(e) != 0; }();
+            // TLPK_CHAIN_EARLY (default 1): the strips of a full-width block column do not wait for its diagonal block to be complete -- the diagonal-block role
+            // raises the block column's counter on its way (+1 behind each of its first three 64-wide steps, its final signal makes 4) and the strip role waits for
+            // the value each of its ten operand blocks needs (kernels.hip: trsm_task_dma).  Here: the strip's item drops the wait (w2), its task names the
+            // counter (pad2 = global index + 1), the diagonal block's item is marked (sub = 1).  Same tickets, same data flow, same bits.
+            const bool chain_early = [] { const char *e = std::getenv("TLPK_CHAIN_EARLY"); return !e || std::atoi(e) != 0; }();
             struct FC { i64 base; i32 nbc, ntr, nsl, stride; };
             std::unordered_map<i32, FC> fc;
             i64 ncnt = 0;
@@ -2145,7 +2150,7 @@ static void build_schedule(Symbolic &S) {
                         io_cur = std::max(io_cur, pt.k0 / NB_OUT);
                         const FC &c = fc.at(pt.front);
                         const i32 io = pt.k0 / NB_OUT;
-                        ChainItem it{CR_POTRF, (i32)q, 0, 0, 0, 0, 0, 0, 0, -1, 0, G(c_pf(c, io))};
+                        ChainItem it{CR_POTRF, (i32)q, (chain_early && pt.nb == NB_OUT) ? 1 : 0, 0, 0, 0, 0, 0, 0, -1, 0, G(c_pf(c, io))};
                         // waits: the counter of the block's 64 x 64 tiles (they waited for the adders of their target tiles themselves), and every target tile
                         // with adders that no 64 x 64 tile stands behind -- at most three counters in all
                         i64 wl[4]; int nw = 0;
@@ -2171,6 +2176,7 @@ static void build_schedule(Symbolic &S) {
                             if (expect[(size_t)g0] > 0) { it.w0 = G(g0); it.n0 = 1; it.need0 = expect[(size_t)g0]; }
                             if (expect[(size_t)g1] > 0) { it.w1 = G(g1); it.n1 = 1; it.need1 = expect[(size_t)g1]; }
                         }
+                        if (chain_early && tt.nb == NB_OUT) { it.w2 = -1; it.need2 = 0; S.trsm_tasks[(size_t)q].pad2 = G(c_pf(c, io)) + 1; }
                         ++expect[(size_t)c_ts(c, io, tt.row0 / 64)];
                         S.chain_items.push_back(it);
                     }

@@ -2058,6 +2058,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "trsm_tasks") { for (auto &t : S.trsm_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.nb); tmp.push_back(t.row0); tmp.push_back(t.kprev); tmp.push_back(t.pad1); } }
     else if (w == "update_tasks") { for (auto &t : S.update_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); tmp.push_back(t.seg); tmp.push_back(t.nsl); } }
     else if (w == "upd_seg") from32(S.upd_seg);
+    else if (w == "trsm_early") { for (auto &t : S.trsm_tasks) tmp.push_back(t.pad2); }        // > 0: early entry, the counter (global index + 1) of the block column's diagonal block
     else if (w == "update_tile64") { for (auto &t : S.update_tasks) tmp.push_back(t.pad2); }      // 1 = a 64 x 64 tile (chain launches: the diagonal block's short update)
     else if (w == "skip_off") tmp = S.skip_off;
     else if (w == "skip_bits") { tmp.resize(S.skip_bits.size()); std::memcpy(tmp.data(), S.skip_bits.data(), S.skip_bits.size() * 8); }
