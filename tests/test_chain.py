@@ -77,6 +77,43 @@ def test_chain_schedule_bits_equal_launch_schedule_and_any_order(case, monkeypat
     assert np.array_equal(em.dense_L(), em0.dense_L()), "chain form and launch form differ"
 
 
+def test_early_strips_name_the_counter_of_their_diagonal_block(monkeypatch):
+    """TLPK_CHAIN_EARLY (default): a strip of a FULL-WIDTH block column does not wait for its diagonal block in the item's wait list; its task names the counter
+    that block's role raises on its way (kernels.hip: trsm_task_dma) -- the `sig` of a diagonal-block item with a SMALLER ticket, marked sub = 1, of the same front
+    and block column.  Narrow last block columns keep the plain wait.  TLPK_CHAIN_EARLY=0: plain waits everywhere."""
+    A, rb, env = CASES["narrow_last"]()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    kkt = analyse_only(A, row_block=rb)
+    items = kkt.symbolic("chain_items").reshape(-1, 12)
+    trsm = kkt.symbolic("trsm_tasks").reshape(-1, 6)
+    potrf = kkt.symbolic("potrf_tasks").reshape(-1, 4)
+    early = kkt.symbolic("trsm_early")
+    seen_early = seen_plain = 0
+    for q, it in enumerate(items):
+        role, task, sub, *_w, w2, need2, sig = (int(v) for v in it)
+        if role != 2:
+            continue
+        front, k0, nb = (int(v) for v in trsm[task][:3])
+        if nb == 256:
+            assert early[task] > 0 and w2 == -1, "a full-width strip enters early"
+            owner = [p for p in range(q) if int(items[p][0]) == 1 and int(items[p][11]) == early[task] - 1]
+            assert len(owner) == 1, "the counter belongs to ONE diagonal-block item with a smaller ticket"
+            pt = potrf[int(items[owner[0]][1])]
+            assert int(items[owner[0]][2]) == 1 and (int(pt[0]), int(pt[1]), int(pt[2])) == (front, k0, 256)
+            seen_early += 1
+        else:
+            assert early[task] == 0 and w2 >= 0 and need2 == 1
+            seen_plain += 1
+    assert seen_early and seen_plain
+    monkeypatch.setenv("TLPK_CHAIN_EARLY", "0")
+    kkt0 = analyse_only(A, row_block=rb)
+    it0 = kkt0.symbolic("chain_items").reshape(-1, 12)
+    assert not kkt0.symbolic("trsm_early").any() and (it0[it0[:, 0] == 2][:, 9] >= 0).all() and not it0[it0[:, 0] == 1][:, 2].any()
+    # same tasks, same tickets: only the waits differ
+    assert np.array_equal(np.delete(items, [2, 9, 10], axis=1), np.delete(it0, [2, 9, 10], axis=1))
+
+
 def test_chain_only_where_it_was_measured_to_help(monkeypatch):
     """Auto rule: levels with at most 16 of the rank's fronts wider than one block column; TLPK_CHAIN=1 forces every such level, 0 none; the older diagonal-block
     kernels (TLPK_POTRF_MODE != 3) keep the launches."""
@@ -150,3 +187,22 @@ def test_chain_under_serialised_launches_and_small_grids(monkeypatch):
     monkeypatch.setenv("TLPK_SERIAL", "1")
     o, _, _ = _gpu_factor(A, rb, "K1", 7)
     assert np.array_equal(o[0][0], ref[0][0], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_strip_variants_of_the_chain_same_bits(monkeypatch):
+    """The strips of the dependency-driven launches: ring of four operand images + early entry (default), plain waits (TLPK_CHAIN_EARLY=0), ring of two images
+    (no dynamic LDS: two workgroups per CU) with and without early entry -- one arithmetic, one result."""
+    A, rb, env = CASES["single_front"]()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ref, kinds, _ = _gpu_factor(A, rb, "K1", 11)
+    assert 22 in kinds
+    for var in ({"TLPK_CHAIN_EARLY": "0"}, {"TLPK_CHAIN_DYNLDS": "0", "TLPK_CHAIN_GRID": "512"}, {"TLPK_CHAIN_DYNLDS": "0", "TLPK_CHAIN_GRID": "512", "TLPK_CHAIN_EARLY": "0"}):
+        for k, v in var.items():
+            monkeypatch.setenv(k, v)
+        o, _, _ = _gpu_factor(A, rb, "K1", 11, repeats=2)
+        for r in o:
+            assert np.array_equal(r[0], ref[0][0], equal_nan=True) and np.array_equal(r[1], ref[0][1]) and np.array_equal(r[2], ref[0][2]), var
+        for k in var:
+            monkeypatch.delenv(k)
