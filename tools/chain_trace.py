@@ -47,7 +47,8 @@ for kind, first, count in L:
     pf = np.nonzero(it[:, 0] == 1)[0]
     fronts = pt[it[pf, 1], 0]; big = np.bincount(fronts).argmax()
     prev_done = None
-    print("  block column: diag tiles (first ready -> last done) | potrf wait-after-tiles, work | first strip: wait-after-potrf, work | period")
+    print("  block column: diag tiles (first ready -> last done) | potrf wait-after-tiles, work | first strip: released (relative to the potrf's publish: negative = early entry, "
+          "the strip waits inside its role, TLPK_CHAIN_EARLY), time in its role | last strip published, and how long after the potrf | period")
     for q in pf:
         if pt[it[q, 1], 0] != big:
             continue
@@ -60,7 +61,7 @@ for kind, first, count in L:
         d_first = t[dsel, 1].min() - t0 if dsel.any() else float("nan"); d_last = t[dsel, 3].max() - t0 if dsel.any() else float("nan")
         line = f"  k0={k0:5d}: tiles {d_first:8.1f} -> {d_last:8.1f} | potrf ready {t[q,1]-t0:8.1f} (+{t[q,1]-t0-d_last:5.1f}) work {t[q,2]-t[q,1]:6.1f} pub {t[q,3]-t[q,2]:4.1f}"
         if s0 is not None:
-            line += f" | strip ready {t[s0,1]-t0:8.1f} (+{t[s0,1]-t[q,3]:5.1f}) work {t[s0,2]-t[s0,1]:5.1f}; last strip done {t[strips,3].max()-t0:8.1f}"
+            line += f" | strip ready {t[s0,1]-t0:8.1f} ({t[s0,1]-t[q,3]:+6.1f}) work {t[s0,2]-t[s0,1]:5.1f}; last strip done {t[strips,3].max()-t0:8.1f} ({t[strips,3].max()-t[q,3]:+5.1f})"
         if prev_done is not None:
             line += f" | period {t[q,3]-t0-prev_done:6.1f}"
         prev_done = t[q, 3] - t0
