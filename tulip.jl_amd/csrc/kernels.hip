@@ -2043,8 +2043,7 @@ __device__ __forceinline__ void trsm_task(const TrsmTask t, const FrontDesc &fd,
 constexpr bool TRSM_DMA = TLPK_TRSM_DMA != 0;
 constexpr int TRSM_DMA_BLK = NB_IN * NB_IN;          // doubles per ring buffer
 typedef __attribute__((address_space(3))) double trsm_lds_double;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
+#pragma clang diagnostic ignored "-Winline-asm"      /* "m0" in the clobber list of the LDS-DMA statements (here and in update_tile) */
 template <int PEND> __device__ __forceinline__ void trsm_dma_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PEND) : "memory");
 }
@@ -2220,7 +2219,6 @@ __device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc 
         }
     }
 }
-#pragma clang diagnostic pop
 static_assert(2 * TRSM_DMA_BLK + 2 <= 2 * NB_IN * LDW, "trsm_task_dma: two ring buffers and the progress word in the staged form's LDS");
 
 template <bool SIGNED>
@@ -2274,6 +2272,10 @@ __global__ __launch_bounds__(256) void k_trsm_thin(const TrsmTask *__restrict__ 
 // read-modify-write.
 // Targets with column < ns live in the panel, the others in the update matrix U.
 // ------------------------------------------------------------------------------------------
+#ifndef TLPK_UPD_DMA
+#define TLPK_UPD_DMA 1
+#endif
+constexpr bool UPD_DMA = TLPK_UPD_DMA != 0;       // k_update's slabs global -> LDS directly (update_tile, main path); 0 (build-time, diagnostics): through registers
 constexpr int UPD_KT = 16;                 // K depth staged per LDS round
 constexpr int UPD_LD = TILE + 16;          // LDS row stride (doubles), == 16 mod 32: conflict-free b64 reads
 
@@ -2456,6 +2458,67 @@ __device__ __forceinline__ void update_tile(const UpdateTask t, const FrontDesc 
                 }
             }
         };
+        int cur = 0;
+        const i32 nrounds = segp ? t.nsl : t.kw / UPD_KT;
+        // (16-byte requests, and the LDS-DMA path wants them ALIGNED -- a misaligned one does not fault, it delivers the wrong rows --: the panel, its leading dimension
+        //  and the tile's first row and column must be even.  Panels of fronts with >= 64 rows start on 128-byte lines with an even lda; tiles inside the pivot columns
+        //  start on multiples of 128; the tiles of the update matrix start at ns: those of a front with an odd number of pivot columns keep the registers)
+        const bool dma_ok = UPD_DMA && !SIGNED && NW == 8 && ((fd.loff | (i64)lda | (i64)t.i0 | (i64)t.j0) & 1) == 0;      // (workgroup-uniform)
+        if (dma_ok) {
+            // Round 6 (last): the slabs travel global -> LDS WITHOUT passing the registers (global_load_lds_dwordx4: a K column of a tile -- 128 rows = 1 024 bytes -- is ONE
+            // instruction of one wave; 16 + 16 columns per slab = four instructions per wave instead of eight loads, eight ds_write_b64 and the wait between them per
+            // THREAD).  An ablation without the staging (wrong numbers, valid timing) ran the C4 update 6 % faster: the LDS writes and their waits inside the
+            // matrix-core block were the largest single cost left in this kernel.  Slab rd + 1 is requested at the start of round rd, into the buffer every wave has
+            // finished reading at the barrier in front of it, and has the whole round (~3 us with four waves per SIMD) to land; s_waitcnt vmcnt(0) in front of the round's
+            // closing barrier (nothing else of the wave is in flight inside the loop).  Lane l carries rows 2 l, 2 l + 1 of its column; rows beyond the front are
+            // clamped inside the column's padding (lda is even and >= f): they feed outputs the epilogue masks.  Same LDS image, same products: identical bits.
+            // (SIGNED tiles multiply the column operand by the signs while staging, the 4-wave role of k_chain has one wave per SIMD and keeps its two-round
+            // prefetch through registers: both stay on the register path.)
+            typedef __attribute__((address_space(3))) double upd_lds_double;
+            const unsigned la_a0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(upd_lds_double *)&As[0][0]);
+            const unsigned la_b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(upd_lds_double *)&Bs[0][0]);
+            constexpr unsigned BUFB = UPD_KT * UPD_LD * 8;                 // bytes per buffer
+            constexpr int CPW = UPD_KT / NW;                               // K columns of a slab per wave
+            unsigned dva = (unsigned)min(t.i0 + 2 * lane, lda - 2) * 8u, dvb = (unsigned)min(t.j0 + 2 * lane, lda - 2) * 8u;
+            const char *db[CPW];                                           // address of (row 0 of) K column k_slab + wave + NW * e (scalar)
+#pragma unroll
+            for (int e = 0; e < CPW; ++e) db[e] = Pc + pk_off(lda, k_slab + wave + NW * e) * 8;
+            auto dma_slab = [&](const int buf) {
+                asm volatile("" : "+v"(dva), "+v"(dvb));
+#pragma unroll
+                for (int e = 0; e < CPW; ++e) {
+                    const unsigned ko = (unsigned)(wave + NW * e) * (unsigned)(UPD_LD * 8) + (unsigned)buf * BUFB;
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(la_a0 + ko), "v"(dva), "s"(db[e]) : "memory", "m0");
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(la_b0 + ko), "v"(dvb), "s"(db[e]) : "memory", "m0");
+                }
+                k_slab += UPD_KT;
+                const bool cross = (k_slab & 63) == 0;        // (wave-uniform) the next slab opens a new slice
+#pragma unroll
+                for (int e = 0; e < CPW; ++e) db[e] += step - (cross ? (i64)(64 * 8) * (wave + NW * e + 1) : 0);
+                step -= cross ? 64 * 8 * UPD_KT : 0;
+                if (__builtin_expect(--k_rem == 0, 0)) {      // (wave-uniform) end of the K segment: jump to the next one, if any
+                    if (++k_seg < nseg) {
+                        k_slab = __builtin_amdgcn_readfirstlane(segp[1 + 2 * k_seg]);
+                        k_rem = __builtin_amdgcn_readfirstlane(segp[2 + 2 * k_seg]);
+#pragma unroll
+                        for (int e = 0; e < CPW; ++e) db[e] = Pc + pk_off(lda, k_slab + wave + NW * e) * 8;
+                        step = (i64)UPD_KT * 8 * (lda - ((k_slab >> 6) << 6));
+                    }
+                }
+            };
+            dma_slab(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (i32 rd = 0; rd < nrounds; ++rd) {
+                const bool have_next = rd + 1 < nrounds;
+                mfma_round(cur, [&](int k4) {
+                    if (k4 == 0 && have_next) dma_slab(cur ^ 1);
+                });
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                cur ^= 1;
+            }
+        } else {
         ld_a(); ld_b();
         st_ab(0);
         ld_a(); ld_b();                                   // slab 1 in flight
@@ -2463,8 +2526,6 @@ __device__ __forceinline__ void update_tile(const UpdateTask t, const FrontDesc 
 #ifdef UPD_TRACE
         if (threadIdx.x == 0) ((unsigned long long *)c.spart)[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
 #endif
-        int cur = 0;
-        const i32 nrounds = segp ? t.nsl : t.kw / UPD_KT;
         for (i32 rd = 0; rd < nrounds; ++rd) {
             const bool have_next = rd + 1 < nrounds, have_next2 = rd + 2 < nrounds;
             mfma_round(cur, [&](int k4) {
@@ -2474,6 +2535,7 @@ __device__ __forceinline__ void update_tile(const UpdateTask t, const FrontDesc 
             });
             __syncthreads();
             cur ^= 1;
+        }
         }
         if (t.kw % UPD_KT) {                              // K tail: one zero-filled slab
             const i32 kk = (t.kw / UPD_KT) * UPD_KT;
@@ -2785,8 +2847,8 @@ __device__ __forceinline__ void update_tile32(const UpdateTask t, const FrontDes
 template <bool SIGNED, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void k_update(const UpdateTask *__restrict__ tasks, DevCtx c) {
     // double-buffered K-slabs: slab t+1 travels global -> registers while slab t is multiplied
-    __shared__ double As[2][UPD_KT * UPD_LD];  // As[.][k][r] = P[i0 + r, k0 + kk + k]  (row tile)
-    __shared__ double Bs[2][UPD_KT * UPD_LD];  // Bs[.][k][r] = P[j0 + r, k0 + kk + k]  (column tile)
+    __shared__ __attribute__((aligned(16))) double As[2][UPD_KT * UPD_LD];  // As[.][k][r] = P[i0 + r, k0 + kk + k]  (row tile)
+    __shared__ __attribute__((aligned(16))) double Bs[2][UPD_KT * UPD_LD];  // Bs[.][k][r] = P[j0 + r, k0 + kk + k]  (column tile)
     // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  upd_remap = 2: XCD x takes runs of 64
     // consecutive tasks (neighbours in the list share panel slabs: one L2 serves them); 1: one contiguous
     // eighth of the list per XCD.
