@@ -2463,7 +2463,7 @@ __device__ __forceinline__ void update_tile(const UpdateTask t, const FrontDesc 
         // (16-byte requests, and the LDS-DMA path wants them ALIGNED -- a misaligned one does not fault, it delivers the wrong rows --: the panel, its leading dimension
         //  and the tile's first row and column must be even.  Panels of fronts with >= 64 rows start on 128-byte lines with an even lda; tiles inside the pivot columns
         //  start on multiples of 128; the tiles of the update matrix start at ns: those of a front with an odd number of pivot columns keep the registers)
-        const bool dma_ok = UPD_DMA && !SIGNED && NW == 8 && ((fd.loff | (i64)lda | (i64)t.i0 | (i64)t.j0) & 1) == 0;      // (workgroup-uniform)
+        const bool dma_ok = UPD_DMA && !SIGNED && ((fd.loff | (i64)lda | (i64)t.i0 | (i64)t.j0) & 1) == 0;      // (workgroup-uniform)
         if (dma_ok) {
             // Round 6 (last): the slabs travel global -> LDS WITHOUT passing the registers (global_load_lds_dwordx4: a K column of a tile -- 128 rows = 1 024 bytes -- is ONE
             // instruction of one wave; 16 + 16 columns per slab = four instructions per wave instead of eight loads, eight ds_write_b64 and the wait between them per
@@ -2472,8 +2472,8 @@ __device__ __forceinline__ void update_tile(const UpdateTask t, const FrontDesc 
             // finished reading at the barrier in front of it, and has the whole round (~3 us with four waves per SIMD) to land; s_waitcnt vmcnt(0) in front of the round's
             // closing barrier (nothing else of the wave is in flight inside the loop).  Lane l carries rows 2 l, 2 l + 1 of its column; rows beyond the front are
             // clamped inside the column's padding (lda is even and >= f): they feed outputs the epilogue masks.  Same LDS image, same products: identical bits.
-            // (SIGNED tiles multiply the column operand by the signs while staging, the 4-wave role of k_chain has one wave per SIMD and keeps its two-round
-            // prefetch through registers: both stay on the register path.)
+            // (SIGNED tiles multiply the column operand by the signs while staging: they stay on the register path.  The 4-wave role of k_chain -- one wave per
+            // SIMD, a round of 1.7 us to hide the slab in -- gains as well: pds-class 12.8 -> 12.5 ms, rank-local N = 8 11.1 -> 10.8 ms.)
             typedef __attribute__((address_space(3))) double upd_lds_double;
             const unsigned la_a0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(upd_lds_double *)&As[0][0]);
             const unsigned la_b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(upd_lds_double *)&Bs[0][0]);
