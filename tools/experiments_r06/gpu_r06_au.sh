@@ -6,7 +6,7 @@ O=gpurun_out/r06au
 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_chain.py tests/test_k2.py -m gpu -x -q 2>&1 | tail -3
 S="--steps 8 --warmup 3 --no-cpu-baseline --no-headline --no-host-abi --no-small-lp --no-c3"
 for rep in 1 2; do
-for wl in c4 headline pds; do
+for wl in pds c4; do
 for lib in new old; do
     if [ $lib = old ]; then export TLPK_LIB=$PWD/tulip.jl_amd/libtlpk_ab_old.so; else unset TLPK_LIB; fi
     timeout 600 python bench.py --workload $wl $S > ${O}_b.json 2> ${O}_b.err

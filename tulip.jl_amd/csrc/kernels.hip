@@ -2122,6 +2122,7 @@ __device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc 
         if (lane == 0) *pw = v;
     };
     int issued = 0;
+    unsigned long long t_seen = 0;                  // (wave 0) when `have` last changed, 100 MHz clock
     // operand (k = 4 ks + lk, cc = 16 a + lr) of the image: k & 1 = lk & 1
     int rd[4];
 #pragma unroll
@@ -2135,10 +2136,18 @@ __device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc 
                 if (wave == 0 && have < need_of(n)) {
                     const unsigned long long t0 = wall_clock64();
                     unsigned spins = 0;
+                    // Lean polling (the words of a few diagonal blocks are watched by every strip of their block columns -- up to two hundred workgroups --, and a
+                    // memory channel flooded with polls starves the workgroups whose data it serves: profiles/r06_chain_poll_storm.txt).  Only the LAST value is
+                    // waited for on the critical path, and only by the strips whose rows the next diagonal block needs; it comes no sooner than ~15 us behind the
+                    // third.  So: every 3 us for the early values and for the strips further down; the critical strips stay away for 12 us behind the third value
+                    // and then look every 0.2 us (64 times), every 0.8 us after that.
+                    const bool fast = need_of(n) == 4u && t.row0 < t.k0 + 2 * NB_OUT;      // (workgroup-uniform)
+                    if (fast) while (wall_clock64() - t_seen < 1200ull) __builtin_amdgcn_s_sleep(32);
                     for (;;) {
                         have = poll();
                         if (have >= need_of(n)) break;
-                        if (spins < 64u) __builtin_amdgcn_s_sleep(8);
+                        if (!fast) __builtin_amdgcn_s_sleep(127);
+                        else if (spins < 64u) __builtin_amdgcn_s_sleep(8);
                         else __builtin_amdgcn_s_sleep(32);
                         if ((++spins & 63u) == 0u) {
                             int flag = 0;
@@ -2151,6 +2160,7 @@ __device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc 
                             }
                         }
                     }
+                    t_seen = wall_clock64();
                     publish_word(have);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -2160,9 +2170,9 @@ __device__ __forceinline__ void trsm_task_dma(const TrsmTask t, const FrontDesc 
         }
         // ahead, into the buffers that are free in front of this block's barrier
         while (issued < 10 && issued <= n + NBUF - 2 && have >= need_of(issued)) { issue(issued); ++issued; }
-        if (early && wave == 0 && issued < 10 && have < need_of(issued)) {      // one look per block while the diagonal block is behind
+        if (early && wave == 0 && issued < 10 && have < need_of(issued) && wall_clock64() - t_seen >= 1000ull) {      // one look per block while the diagonal block is behind (not within 10 us of the last change)
             const unsigned v = poll();
-            if (v > have) { have = v; publish_word(have); }
+            if (v > have) { have = v; t_seen = wall_clock64(); publish_word(have); }
         }
         const int pend = issued - 1 - n;             // blocks behind block n that may still be in flight at its barrier (<= NBUF - 2)
         if (pend <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
