@@ -1310,6 +1310,7 @@ int analyse_rank(Symbolic &S, const Options &opt) {
     }
     pt.mark("schedule");
     S.error.clear();
+    S.shared_device = opt.shared_device;
     build_schedule(S);
     if (!S.error.empty()) return TLPK_INTERNAL;
     // k_update walks its K range in slabs of 16 columns and relies on a slab lying inside ONE 64-column slice of the packed panel
@@ -2001,7 +2002,7 @@ static void build_schedule(Symbolic &S) {
             // raises the block column's counter on its way (+1 behind each of its first three 64-wide steps, its final signal makes 4) and the strip role waits for
             // the value each of its ten operand blocks needs (kernels.hip: trsm_task_dma).  Here: the strip's item drops the wait (w2), its task names the
             // counter (pad2 = global index + 1), the diagonal block's item is marked (sub = 1).  Same tickets, same data flow, same bits.
-            const bool chain_early = [] { const char *e = std::getenv("TLPK_CHAIN_EARLY"); return !e || std::atoi(e) != 0; }();
+            const bool chain_early = !S.shared_device && [] { const char *e = std::getenv("TLPK_CHAIN_EARLY"); return !e || std::atoi(e) != 0; }();
             struct FC { i64 base; i32 nbc, ntr, nsl, stride; };
             std::unordered_map<i32, FC> fc;
             i64 ncnt = 0;

@@ -537,6 +537,7 @@ static int create_host(tlpk_handle *h, const tlpk_options &def, int64_t m, int64
     if (const char *e = std::getenv("TLPK_GRAPH")) { h->use_graph = std::atoi(e) != 0; h->force_graph = std::atoi(e) >= 2; }
     if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
     if (const char *e = std::getenv("TLPK_STAGGER")) { h->stagger = std::atoi(e) != 0; if (std::atoi(e) > 1) h->stagger_min = std::atoi(e); }
+    h->opt.shared_device = h->shared_device ? 1 : 0;
     const auto t0 = std::chrono::steady_clock::now();
     if (rc == TLPK_OK) {
         if (common) { h->S = *common; h->opt.k2_n = common->k2_n; rc = analyse_rank(h->S, h->opt); }
@@ -1015,7 +1016,7 @@ void host_copy(double *dst, const double *src, i64 count, bool to_staging) {
 }
 }  // namespace
 
-int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
+static int update_once(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
     if (!h || !theta || !regP || !regD) return TLPK_BADARG;
     if (!h->sub.empty()) return multi_update(h, theta, regP, regD);
     if (!h->has_device) return TLPK_NO_DEVICE;
@@ -1032,6 +1033,26 @@ int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const d
     const int rc = tlpk_update_device(h, h->d_theta, h->d_regP, h->d_regD);
     if (timing) std::fprintf(stderr, "tlpk_update host path: stage in + H2D issued %.3f ms | factorisation (enqueue + wait) %.3f ms | device update (events) %.3f ms\n",
                              t1 - t0, now_ms() - t1, h->ms_update);
+    return rc;
+}
+
+// A dependency-driven launch that gave up waiting (the bounded spins of k_chain: TLPK_INTERNAL, nothing hangs) is REPLAYED ONCE: the caller's vectors are unchanged,
+// the counters start from zero with every update, the factorisation is deterministic.  Every such case seen so far was the stall of
+// profiles/r06_chain_poll_storm.txt -- eight shards' launches on ONE GPU, a workgroup standing still inside its role while the rest of the device spins: 1 - 3 % of the
+// runs of the eight-shards tests, never on a handle that has its device to itself --, not a schedule that cannot finish: a second failure is returned as it is.
+// TLPK_CHAIN_RETRY=0: no replay; the number of replays of a handle: symbolic array "chain_retries".
+static bool chain_gave_up(const tlpk_handle *h) {
+    if (!h->sub.empty()) { for (const tlpk_handle *c : h->sub) if (chain_gave_up(c)) return true; return false; }
+    return h->d.n_chain_cnt > 0 && h->h_info[1] != 0;
+}
+int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
+    int rc = update_once(h, theta, regP, regD);
+    static const bool retry = [] { const char *e = std::getenv("TLPK_CHAIN_RETRY"); return !e || std::atoi(e) != 0; }();
+    if (rc == TLPK_INTERNAL && retry && h && chain_gave_up(h)) {
+        ++h->chain_retries;
+        if (std::getenv("TLPK_CHAIN_DEBUG")) std::fprintf(stderr, "[tlpk chain] a launch gave up waiting: the update is replayed once (replay %d of this handle)\n", h->chain_retries);
+        rc = update_once(h, theta, regP, regD);
+    }
     return rc;
 }
 
@@ -1861,6 +1882,7 @@ int tlpk_create_multi(tlpk_handle **out, int64_t m, int64_t n, const int64_t *co
                 h->sub.push_back(c);
                 opts[(size_t)r].device = devices ? devices[r] : r;
                 opts[(size_t)r].rank = r; opts[(size_t)r].nranks = ngpus;
+                if (devices) for (int q = 0; q < ngpus; ++q) if (q != r && devices[q] == devices[r]) c->shared_device = true;
             }
         }
         if (rc == TLPK_OK) {
@@ -2015,7 +2037,7 @@ int tlpk_get_perm(const tlpk_handle *h, int64_t *perm) {
 
 int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, int64_t cap) {
     if (!h || !what) return -1;
-    if (!h->sub.empty()) return tlpk_symbolic_get(h->sub[0], what, buf, cap);
+    if (!h->sub.empty() && std::string(what) != "chain_retries") return tlpk_symbolic_get(h->sub[0], what, buf, cap);
     const Symbolic &S = h->S;
     std::vector<i64> tmp;
     const std::string w(what);
@@ -2066,6 +2088,7 @@ int64_t tlpk_symbolic_get(const tlpk_handle *h, const char *what, int64_t *buf, 
     else if (w == "reduce_tasks") { for (auto &t : S.reduce_tasks) { tmp.push_back(t.front); tmp.push_back(t.k0); tmp.push_back(t.kw); tmp.push_back(t.i0); tmp.push_back(t.j0); tmp.push_back(t.jlim); tmp.push_back(t.beta0); tmp.push_back(t.pad1); } }
     else if (w == "chain_items") { for (auto &t : S.chain_items) { for (i32 v : {t.role, t.task, t.sub, t.w0, t.n0, t.need0, t.w1, t.n1, t.need1, t.w2, t.need2, t.sig}) tmp.push_back(v); } }
     else if (w == "chain_counters") tmp.assign(1, S.chain_counters);
+    else if (w == "chain_retries") tmp.assign(1, h->chain_retries);           // updates of this handle that were replayed after a dependency-driven launch gave up waiting (tlpk_update)
     else if (w == "chain_trace") {                               // diagnostics: the time stamps of the last update (the caller has synchronised)
         if (!h->d.chain_trace) return -1;
         tmp.resize(4 * S.chain_items.size());

@@ -127,6 +127,9 @@ struct Options {
     i64 k2_n = 0;                     // K2, internal: number of variable nodes (nodes [0, k2_n) are variables, the rest constraints)
     i32 analyse_div = 0;              // host threads of the analyse phase = default / analyse_div; 0 = nranks (N ranks analyse at the same time on one host); tlpk_create_multi: 1 for
                                       // its ONE rank-independent analysis
+    i32 shared_device = 0;            // another shard of the same job runs on this shard's device (tlpk_create_multi with a device named twice: test configurations).  The
+                                      // strips of the dependency-driven launches then keep their plain waits (no early entry, see build_chain): with eight shards' launches on one
+                                      // GPU the in-role waits gave up in ~1 % of the runs of the eight-shards tests even with lean polling (profiles/r06_chain_poll_storm.txt)
     const i64 *user_perm = nullptr;   // 0-based here
     const i64 *row_block = nullptr;
 };
@@ -147,6 +150,7 @@ template <class T> using uvec = std::vector<T, NoInit<T>>;
 struct Symbolic {
     i64 m = 0, n = 0, nnzA = 0;          // K2: m = order of the augmented matrix (n_var + m_con), n / nnzA those of the incidence matrix below
     i32 system = 0; i64 k2_n = 0, k2_m = 0;   // K2: user dimensions (variables, constraints)
+    i32 shared_device = 0;               // Options::shared_device of the rank this schedule is built for
     std::vector<double> csign;           // K2: +1 / -1 per permuted column (constraint / variable node)
     // A, CSC and CSR (0-based, int32 indices); csr_pos[q] = CSC position of the CSR entry q
     std::vector<i64> Ap; std::vector<i32> Ai; std::vector<double> Ax;
