@@ -206,3 +206,35 @@ def test_strip_variants_of_the_chain_same_bits(monkeypatch):
             assert np.array_equal(r[0], ref[0][0], equal_nan=True) and np.array_equal(r[1], ref[0][1]) and np.array_equal(r[2], ref[0][2]), var
         for k in var:
             monkeypatch.delenv(k)
+
+
+@pytest.mark.gpu
+def test_an_update_that_gave_up_is_replayed_and_leaves_no_trace(monkeypatch):
+    """A dependency-driven launch that gives up waiting ends the update with TLPK_INTERNAL (bounded spins: nothing hangs).  TLPK_CHAIN_FAULT=k starts update k of a handle
+    with the give-up flag set, as if a workgroup had just given up.  Without the replay (TLPK_CHAIN_RETRY=0) that update fails and the NEXT one must work and give the bits
+    of a healthy update (the flag used to stay set on the device: every later update of the handle failed within milliseconds); with it (default) tlpk_update replays the
+    update once and the caller sees nothing but `chain_retries` = 1."""
+    import tulip_jl_amd as tk
+    A, rb, env = CASES["single_front"]()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ref, kinds, _ = _gpu_factor(A, rb, "K1", 5)
+    assert 22 in kinds
+    monkeypatch.setenv("TLPK_CHAIN_FAULT", "2")
+    monkeypatch.setenv("TLPK_GRAPH", "0")          # (the injection sits in the enqueue path: a replayed graph would not pass through it)
+    for retry in ("0", "1"):
+        monkeypatch.setenv("TLPK_CHAIN_RETRY", retry)
+        kkt = tk.setup(A, tk.K1(), tk.Backend(device=0, row_block=rb))
+        th, rp, rd, xp, xd = ipm_like_data(kkt.m, kkt.n, 5)
+        failed = []
+        for it in range(5):
+            try:
+                tk.update(kkt, th, rp, rd)
+            except RuntimeError as e:
+                assert "gave up waiting" in str(e)
+                failed.append(it)
+                continue
+            assert np.array_equal(kkt.factor_panels(), ref[0][0], equal_nan=True), (retry, it)
+        retries = int(kkt.symbolic("chain_retries")[0])
+        assert (failed, retries) == (([2], 0) if retry == "0" else ([], 1)), (retry, failed, retries)
+        kkt.close()

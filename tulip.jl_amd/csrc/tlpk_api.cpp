@@ -537,6 +537,7 @@ static int create_host(tlpk_handle *h, const tlpk_options &def, int64_t m, int64
     if (const char *e = std::getenv("TLPK_GRAPH")) { h->use_graph = std::atoi(e) != 0; h->force_graph = std::atoi(e) >= 2; }
     if (const char *e = std::getenv("TLPK_POLL")) std::sscanf(e, "%d,%d,%d", &h->poll[0], &h->poll[1], &h->poll[2]);
     if (const char *e = std::getenv("TLPK_STAGGER")) { h->stagger = std::atoi(e) != 0; if (std::atoi(e) > 1) h->stagger_min = std::atoi(e); }
+    if (const char *e = std::getenv("TLPK_CHAIN_FAULT")) h->fault_at = std::atoi(e);
     h->opt.shared_device = h->shared_device ? 1 : 0;
     const auto t0 = std::chrono::steady_clock::now();
     if (rc == TLPK_OK) {
@@ -715,6 +716,17 @@ static int update_async_wait(tlpk_handle *h);
 static int enq_update_local(tlpk_handle *h) {
     const Symbolic &S = h->S;
     HIPCHK(h, hipMemcpyAsync(h->d.ctx.info, h->h_info, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    // words 1..15: the "somebody gave up waiting" flag of the dependency-driven launches / the sweeps and its diagnostics.  They were cleared at set-up only: after ONE
+    // launch that gave up every later update of the handle saw the flag, skipped its work and came back with TLPK_INTERNAL within milliseconds (found at the end of round 6
+    // by 2 500 updates in a row on eight shards of one GPU: 2 448 failures behind the first; a replay of the update could not succeed either)
+    HIPCHK(h, hipMemsetAsync(h->d.ctx.info + 1, 0, 15 * sizeof(int), h->stream));
+    // TLPK_CHAIN_FAULT=k (testing): update number k of the handle (0-based, first attempt only) starts with the flag SET, as if a workgroup had given up waiting: every
+    // dependency-driven launch of it skips its work and the update ends TLPK_INTERNAL -- what tlpk_update's replay and the next update must recover from
+    if (h->d.n_chain_cnt > 0 && h->fault_at >= 0 && h->n_updates == h->fault_at && !h->fault_done) {
+        h->fault_done = true;
+        HIPCHK(h, hipMemsetAsync(h->d.ctx.info + 1, 1, sizeof(int), h->stream));
+    }
+    ++h->n_updates;
     if (h->d.n_chain_cnt > 0) HIPCHK(h, hipMemsetAsync(h->d.chain_cnt, 0, (size_t)h->d.n_chain_cnt * sizeof(unsigned), h->stream));     // tickets + completion counters of the chain launches
     {
         ProfScope ps(h, TLPK_KC_ASSEMBLE);
@@ -1047,8 +1059,7 @@ static bool chain_gave_up(const tlpk_handle *h) {
 }
 int tlpk_update(tlpk_handle *h, const double *theta, const double *regP, const double *regD) {
     int rc = update_once(h, theta, regP, regD);
-    static const bool retry = [] { const char *e = std::getenv("TLPK_CHAIN_RETRY"); return !e || std::atoi(e) != 0; }();
-    if (rc == TLPK_INTERNAL && retry && h && chain_gave_up(h)) {
+    if (rc == TLPK_INTERNAL && h && chain_gave_up(h) && [] { const char *e = std::getenv("TLPK_CHAIN_RETRY"); return !e || std::atoi(e) != 0; }()) {
         ++h->chain_retries;
         if (std::getenv("TLPK_CHAIN_DEBUG")) std::fprintf(stderr, "[tlpk chain] a launch gave up waiting: the update is replayed once (replay %d of this handle)\n", h->chain_retries);
         rc = update_once(h, theta, regP, regD);
@@ -1064,6 +1075,9 @@ static int enq_solve_local(tlpk_handle *h, const double *d_xip, const double *d_
         ProfScope ps(h, TLPK_KC_SPMV);
         // tickets + hand-over words of both sweeps back to all ones: the data is its own flag, ticket + 1 = 0 is the first item
         if (h->S.sweep && h->S.n_sweep_flags > 0) HIPCHK(h, hipMemsetAsync(h->d.sweep_tickets, 0xFF, (size_t)h->d.sweep_reset_bytes, h->stream));
+        // (the give-up flag of an EARLIER solve must not fail this one; while the root front of an asynchronous update is still being factorised on its own stream the
+        //  flag may be that update's: it stays)
+        if (h->S.sweep && !h->root_pending) HIPCHK(h, hipMemsetAsync(h->d.ctx.info + 1, 0, sizeof(int), h->stream));
         if (h->S.system == 1) launch_k2_rhs(h->stream, h->d, h->S.k2_n, d_xip, d_xid, 0, rhs_rank >= 0 ? rhs_rank : h->opt.rank);        // [xi_d ; xi_p] permuted (sqd.jl:62-66)
         else launch_rhs(h->stream, h->d, h->d_D, d_xip, d_xid, rhs_rank >= 0 ? rhs_rank : h->opt.rank);
         launch_single_solve(h->stream, h->d);

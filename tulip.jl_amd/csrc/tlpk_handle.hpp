@@ -22,6 +22,7 @@ struct tlpk_handle {
     int device = -1;
     bool has_device = false;
     bool profile = false;
+    int fault_at = -1, n_updates = 0; bool fault_done = false;      // TLPK_CHAIN_FAULT (testing): see enq_update_local
     int chain_retries = 0;        // tlpk_update: replays after a dependency-driven launch gave up waiting
     bool shared_device = false;   // set by tlpk_create_multi when another shard of the job names the same device (Options::shared_device)
     bool serial = false;          // TLPK_SERIAL=1: every launch on the main stream (what profile mode does), for external profilers
